@@ -1,0 +1,161 @@
+"""Generate golden input/output vectors from the *reference itself*.
+
+Runs only in the dev container (needs /root/reference, read-only).  The
+reference package is imported unmodified with two empty stub modules for the
+wheels that are not installable here (potpourri3d, robust_laplacian -- neither
+is touched by the hot path).  Each case builds the reference
+``diffusion_net.layers.DiffusionNet``, feeds seeded synthetic operators, runs
+forward and ``(out * w).sum().backward()`` on CPU fp32, and stores inputs,
+weights, output and every gradient in ``tests/golden/<case>.npz``.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The committed .npz files are what travels to the GPU box; nothing there reads
+/root/reference.
+"""
+import os
+import sys
+import types
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "diffusion-net_amd"))
+from diffusion_net import synthetic  # noqa: E402  (product-side generator, no HIP needed)
+
+
+def import_reference():
+    for name in ("potpourri3d", "robust_laplacian"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    # make sure our drop-in package of the same name is not the one imported
+    for k in [k for k in sys.modules if k == "diffusion_net" or k.startswith("diffusion_net.")]:
+        del sys.modules[k]
+    sys.path.insert(0, "/root/reference/src")
+    import diffusion_net as ref
+    sys.path.pop(0)
+    assert ref.__file__.startswith("/root/reference"), ref.__file__
+    return ref
+
+
+CASES = {
+    # BASELINE.json configs[0]: 1k-vertex mesh, C_in=3 C_out=10 C_width=32 K=32
+    "cfg1_v1000_c32_k32": dict(V=1000, K=32, B=None, ctor=dict(C_in=3, C_out=10, C_width=32, N_block=4,
+                               outputs_at="vertices", dropout=False), act=None, train=False),
+    # configs[1] shape: C_width=128 K=128, per-face log-softmax, dropout module in eval()
+    "faces_v500_c128_k128": dict(V=500, K=128, B=None, ctor=dict(C_in=3, C_out=8, C_width=128, N_block=1,
+                                 outputs_at="faces", dropout=True), act="log_softmax", train=False),
+    # configs[2] shape: batched [B,V,C], global mean, C_in=16 (hks-like), C_width=64
+    "gmean_b2_v400_c64_k64": dict(V=400, K=64, B=2, ctor=dict(C_in=16, C_out=30, C_width=64, N_block=2,
+                                  outputs_at="global_mean", dropout=False), act="log_softmax", train=False),
+    "edges_norot_v300_c32_k32": dict(V=300, K=32, B=None, ctor=dict(C_in=3, C_out=5, C_width=32, N_block=1,
+                                     outputs_at="edges", dropout=False, with_gradient_rotations=False),
+                                     act=None, train=False),
+    "nograd_v300_c32_k16": dict(V=300, K=16, B=None, ctor=dict(C_in=3, C_out=4, C_width=32, N_block=2,
+                                outputs_at="vertices", dropout=False, with_gradient_features=False),
+                                act=None, train=False),
+    # train mode: pins the placement/scale of dropout (masks recorded and replayed)
+    "train_dropout_v300_c32_k32": dict(V=300, K=32, B=None, ctor=dict(C_in=3, C_out=6, C_width=32, N_block=2,
+                                       outputs_at="vertices", dropout=True), act=None, train=True),
+    # odd sizes: K, C_width not multiples of 32, hidden dims differ from C_width
+    "odd_v257_c40_k24": dict(V=257, K=24, B=None, ctor=dict(C_in=5, C_out=7, C_width=40, N_block=1,
+                             outputs_at="vertices", dropout=False, mlp_hidden_dims=[48, 24]),
+                             act=None, train=False),
+}
+
+
+def build_inputs(case, seed):
+    V, K, B = case["V"], case["K"], case["B"]
+    C_in = case["ctor"]["C_in"]
+    g = torch.Generator().manual_seed(seed)
+    items = [synthetic.make_mesh_operators(V, K, seed=seed * 100 + b) for b in range(B or 1)]
+    feats = [torch.cat([it["verts"], torch.randn(V, max(C_in - 3, 0), generator=g)], 1)[:, :C_in] for it in items]
+    return items, feats
+
+
+def run_case(ref, name, case, seed=7):
+    torch.manual_seed(seed)
+    act = (lambda t: torch.nn.functional.log_softmax(t, dim=-1)) if case["act"] == "log_softmax" else None
+    model = ref.layers.DiffusionNet(last_activation=act, **case["ctor"])
+    sd = synthetic.randomize_times(model.state_dict(), seed=seed)
+    model.load_state_dict(sd)
+    items, feats = build_inputs(case, seed)
+    B = case["B"]
+
+    if B is None:
+        it = items[0]
+        x_in = feats[0].clone().requires_grad_(True)
+        kw = dict(mass=it["mass"], evals=it["evals"], evecs=it["evecs"], gradX=it["gradX"], gradY=it["gradY"],
+                  edges=it["edges"], faces=it["faces"])
+    else:
+        x_in = torch.stack(feats, 0).requires_grad_(True)
+        st = lambda key: torch.stack([it[key] for it in items], 0)
+        kw = dict(mass=st("mass"), evals=st("evals"), evecs=st("evecs"),
+                  gradX=torch.stack([it["gradX"] for it in items], 0).coalesce(),
+                  gradY=torch.stack([it["gradY"] for it in items], 0).coalesce(),
+                  edges=st("edges"), faces=st("faces"))
+
+    masks = []
+    if case["train"]:
+        model.train()
+        F = torch.nn.functional
+        orig = F.dropout
+
+        def recording_dropout(inp, p=0.5, training=True, inplace=False):
+            keep = torch.bernoulli(torch.full_like(inp, 1.0 - p))
+            masks.append(keep.clone())
+            return inp * keep / (1.0 - p)
+        F.dropout = recording_dropout
+    else:
+        model.eval()
+    try:
+        out = model(x_in, kw["mass"], L=None, evals=kw["evals"], evecs=kw["evecs"], gradX=kw["gradX"],
+                    gradY=kw["gradY"], edges=kw["edges"], faces=kw["faces"])
+    finally:
+        if case["train"]:
+            F.dropout = orig
+    wgen = torch.Generator().manual_seed(seed + 1)
+    w = torch.randn(out.shape, generator=wgen)
+    (out * w).sum().backward()
+
+    arrays = {"out": out.detach().numpy(), "loss_w": w.numpy(), "x_in": x_in.detach().numpy(),
+              "grad.x_in": x_in.grad.numpy()}
+    for k, v in model.state_dict().items():            # includes the clamped diffusion_time
+        arrays["param." + k] = v.detach().numpy()
+    for k, p in model.named_parameters():
+        arrays["grad." + k] = p.grad.numpy()
+    for b, it in enumerate(items):
+        pre = f"mesh{b}."
+        arrays[pre + "mass"] = it["mass"].numpy()
+        arrays[pre + "evals"] = it["evals"].numpy()
+        arrays[pre + "evecs"] = it["evecs"].numpy()
+        arrays[pre + "grad_idx"] = it["gradX"].indices().numpy().astype(np.int32)
+        assert torch.equal(it["gradX"].indices(), it["gradY"].indices())
+        arrays[pre + "gradX_val"] = it["gradX"].values().numpy()
+        arrays[pre + "gradY_val"] = it["gradY"].values().numpy()
+        arrays[pre + "faces"] = it["faces"].numpy().astype(np.int32)
+        arrays[pre + "edges"] = it["edges"].numpy().astype(np.int32)
+    for i, m in enumerate(masks):
+        arrays[f"mask{i}"] = m.numpy().astype(np.uint8)
+    meta = dict(case)
+    meta["ctor"] = dict(case["ctor"])
+    arrays["meta"] = np.array(repr(meta))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: out{tuple(out.shape)} |out|max={out.abs().max():.3g} "
+          f"masks={len(masks)} -> {os.path.getsize(path)/1e3:.0f} kB")
+
+
+def main():
+    ref = import_reference()
+    print("reference imported from", ref.__file__, "torch", torch.__version__)
+    for name, case in CASES.items():
+        run_case(ref, name, case)
+
+
+if __name__ == "__main__":
+    main()

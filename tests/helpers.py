@@ -1,0 +1,73 @@
+"""Shared test helpers: golden-fixture loader and error metrics."""
+import ast
+import glob
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name, dtype=torch.float32, device="cpu"):
+    """Returns (meta, params, inputs, masks, expect) with torch tensors.
+
+    inputs: x_in, mass, evals, evecs, gradX, gradY (torch sparse COO, [V,V] or list for batches),
+            edges, faces -- shaped exactly as the reference forward received them."""
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    meta = ast.literal_eval(str(z["meta"]))
+    fl = lambda a: torch.from_numpy(np.asarray(a)).to(dtype).to(device)
+    params = {k[len("param."):]: fl(z[k]) for k in z.files if k.startswith("param.")}
+    grads = {k[len("grad."):]: fl(z[k]) for k in z.files if k.startswith("grad.")}
+    B = meta["B"]
+    meshes = []
+    for b in range(B or 1):
+        pre = f"mesh{b}."
+        V = z[pre + "mass"].shape[0]
+        idx = torch.from_numpy(z[pre + "grad_idx"].astype(np.int64)).to(device)
+        meshes.append(dict(
+            mass=fl(z[pre + "mass"]), evals=fl(z[pre + "evals"]), evecs=fl(z[pre + "evecs"]),
+            gradX=torch.sparse_coo_tensor(idx, fl(z[pre + "gradX_val"]), (V, V)).coalesce(),
+            gradY=torch.sparse_coo_tensor(idx, fl(z[pre + "gradY_val"]), (V, V)).coalesce(),
+            faces=torch.from_numpy(z[pre + "faces"].astype(np.int64)).to(device),
+            edges=torch.from_numpy(z[pre + "edges"].astype(np.int64)).to(device)))
+    if B is None:
+        m = meshes[0]
+        inputs = dict(x_in=fl(z["x_in"]), **m)
+    else:
+        st = lambda key: torch.stack([m[key] for m in meshes], 0)
+        inputs = dict(x_in=fl(z["x_in"]), mass=st("mass"), evals=st("evals"), evecs=st("evecs"),
+                      gradX=[m["gradX"] for m in meshes], gradY=[m["gradY"] for m in meshes],
+                      faces=st("faces"), edges=st("edges"))
+    masks = [fl(z[k]) for k in sorted((k for k in z.files if k.startswith("mask")), key=lambda s: int(s[4:]))]
+    expect = dict(out=fl(z["out"]), loss_w=fl(z["loss_w"]), grads=grads)
+    return meta, params, inputs, masks, expect
+
+
+def activation_of(meta):
+    if meta["act"] == "log_softmax":
+        return lambda t: torch.nn.functional.log_softmax(t, dim=-1)
+    return None
+
+
+def group_masks(meta, params, masks):
+    """Flat recorded dropout masks -> per-block lists (one mask per MLP layer i>0)."""
+    if not masks:
+        return None
+    n_block = meta["ctor"].get("N_block", 4)
+    per = len(masks) // n_block
+    return [masks[i * per:(i + 1) * per] for i in range(n_block)]
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def rel_max(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
