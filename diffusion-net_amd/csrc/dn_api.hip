@@ -1,0 +1,452 @@
+// dn_api.hip -- extern "C" entry points of libdiffnet_hip.so (see include/diffnet_hip.h).
+// Host-side orchestration only: every function enqueues kernels of dn_gemm / dn_sparse /
+// dn_pointwise on the caller's stream; nothing here allocates, frees or synchronises.
+#include "dn_common.h"
+#include "../../include/diffnet_hip.h"
+#include <string.h>
+
+static_assert(sizeof(dn_tile_t) == sizeof(DnTile), "tile layout");
+#define DN_ERR_INVALID 1   /* hipErrorInvalidValue */
+#define DN_CHECK(expr) do { int _e = (expr); if (_e) return _e; } while (0)
+
+namespace {
+struct Bump {
+    char* p; size_t left; bool ok;
+    Bump(void* ws, size_t n) : p((char*)ws), left(n), ok(true) {
+        size_t mis = (256 - ((uintptr_t)p & 255)) & 255;
+        if (mis > left) { ok = false; left = 0; } else { p += mis; left -= mis; }
+    }
+    float* f(size_t nfloat) {
+        size_t bytes = (nfloat * sizeof(float) + 255) & ~(size_t)255;
+        if (bytes > left) { ok = false; return nullptr; }
+        float* r = (float*)p; p += bytes; left -= bytes; return r;
+    }
+};
+inline size_t pad256(size_t nfloat) { return ((nfloat * sizeof(float) + 255) & ~(size_t)255); }
+inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+inline const DnTile* T(const dn_tile_t* t) { return reinterpret_cast<const DnTile*>(t); }
+inline hipStream_t S(void* s) { return (hipStream_t)s; }
+
+RgArgs rg_new(const dn_mesh_batch_t* mb) {
+    RgArgs g;
+    memset(&g, 0, sizeof(g));
+    g.tiles = T(mb->tiles);
+    for (int o = 0; o < 2; ++o) for (int s = 0; s < 3; ++s) g.bsign[o][s] = 1.f;
+    g.scale = 1.f;
+    return g;
+}
+void rg_seg(RgArgs& g, const float* p, const float* q, int w, int ld) {
+    RgSeg& s = g.a[g.nseg++];
+    s.p = p; s.q = q; s.w = w; s.ld = ld;
+}
+void rg_finish(RgArgs& g, int nout) {
+    bool ok = (g.ldb % 4 == 0) && (g.b_mesh_stride % 4 == 0) && (g.b_colk || g.N % 4 == 0);
+    for (int s = 0; s < g.nseg; ++s) {
+        ok = ok && (g.a[s].w % 32 == 0) && (g.a[s].ld % 4 == 0) && al16(g.a[s].p) && al16(g.a[s].q);
+        for (int o = 0; o < nout; ++o) ok = ok && al16(g.b[o][s]);
+    }
+    g.aligned = ok ? 1 : 0;
+}
+TnArgs tn_new(const dn_mesh_batch_t* mb) {
+    TnArgs g;
+    memset(&g, 0, sizeof(g));
+    g.chunks = T(mb->chunks);
+    return g;
+}
+void tn_a(TnArgs& g, const float* p, const float* q, int w, int ld) {
+    TnSeg& s = g.a[g.na++]; s.p = p; s.q = q; s.w = w; s.ld = ld; g.M += w;
+}
+void tn_b(TnArgs& g, const float* p, const float* q, int w, int ld) {
+    TnSeg& s = g.b[g.nb++]; s.p = p; s.q = q; s.w = w; s.ld = ld; g.N += w;
+}
+void tn_finish(TnArgs& g) {
+    bool ok = true;
+    for (int i = 0; i < g.na; ++i) ok = ok && g.a[i].w % 4 == 0 && g.a[i].ld % 4 == 0 && al16(g.a[i].p) && al16(g.a[i].q);
+    for (int i = 0; i < g.nb; ++i) ok = ok && g.b[i].w % 4 == 0 && g.b[i].ld % 4 == 0 && al16(g.b[i].p) && al16(g.b[i].q);
+    g.aligned = ok ? 1 : 0;
+}
+
+// ---- building blocks shared by the per-op and the fused-block entry points ----
+int to_basis_partials(const dn_mesh_batch_t* mb, const float* x, int C, bool use_mass, float* partial, hipStream_t st) {
+    TnArgs g = tn_new(mb);
+    tn_a(g, mb->evecs, nullptr, mb->k_eig, mb->k_eig);
+    tn_b(g, x, nullptr, C, C);
+    g.b_rowscale = use_mass ? mb->mass : nullptr;
+    g.partial = partial;
+    tn_finish(g);
+    return dn_launch_tngemm(g, mb->n_chunks, st);
+}
+int from_basis(const dn_mesh_batch_t* mb, const float* spec, int C, float* out, const float* add, bool mass_epi, hipStream_t st) {
+    RgArgs g = rg_new(mb);
+    rg_seg(g, mb->evecs, nullptr, mb->k_eig, mb->k_eig);
+    g.b[0][0] = spec; g.ldb = C; g.b_colk = 0; g.b_mesh_stride = (long long)mb->k_eig * C; g.N = C;
+    g.o0 = out; g.ldo = C; g.ldr = C;
+    if (mass_epi) { g.mode = DN_EPI_MASS_ADD; g.r0 = add; g.rowv = mb->mass; }
+    else g.mode = DN_EPI_STORE;
+    rg_finish(g, 1);
+    return dn_launch_rowgemm(g, mb->n_tiles, 1, st);
+}
+int grad_apply_fwd(const dn_mesh_batch_t* mb, const float* x, int C, float* gx, float* gy, hipStream_t st) {
+    SpArgs s; memset(&s, 0, sizeof(s));
+    s.rowptr = mb->g_rowptr; s.col = mb->g_col; s.va = mb->g_vx; s.vb = mb->g_vy;
+    s.x1 = x; s.o1 = gx; s.o2 = gy; s.nrows = mb->v_total; s.C = C; s.ldx = C; s.ldo = C; s.mode = DN_SP_FWD2; s.div = 1.f;
+    return dn_launch_spmm(s, st);
+}
+int grad_apply_bwd(const dn_mesh_batch_t* mb, const float* dgx, const float* dgy, const float* add, int C, float* dx, hipStream_t st) {
+    SpArgs s; memset(&s, 0, sizeof(s));
+    s.rowptr = mb->gt_rowptr; s.col = mb->gt_col; s.va = mb->gt_vx; s.vb = mb->gt_vy;
+    s.x1 = dgx; s.x2 = dgy; s.add = add; s.o1 = dx; s.nrows = mb->v_total; s.C = C; s.ldx = C; s.ldo = C; s.mode = DN_SP_BWD2; s.div = 1.f;
+    return dn_launch_spmm(s, st);
+}
+int gradfeat_fwd(const dn_mesh_batch_t* mb, const float* gx, const float* gy, const float* A_re, const float* A_im, int C,
+                 float* g_out, float* bre, float* bim, hipStream_t st) {
+    RgArgs g = rg_new(mb);
+    rg_seg(g, gx, nullptr, C, C);
+    rg_seg(g, gy, nullptr, C, C);
+    if (A_im) {   // Bre = gx A_re^T - gy A_im^T ; Bim = gx A_im^T + gy A_re^T   (layers.py:122-123)
+        g.b[0][0] = A_re; g.bsign[0][0] = 1.f;  g.b[0][1] = A_im; g.bsign[0][1] = -1.f;
+        g.b[1][0] = A_im; g.bsign[1][0] = 1.f;  g.b[1][1] = A_re; g.bsign[1][1] = 1.f;
+    } else {      // Bre = gx A^T ; Bim = gy A^T                                 (layers.py:125-126)
+        g.b[0][0] = A_re; g.bsign[0][0] = 1.f;  g.b[0][1] = A_re; g.bsign[0][1] = 0.f;
+        g.b[1][0] = A_re; g.bsign[1][0] = 0.f;  g.b[1][1] = A_re; g.bsign[1][1] = 1.f;
+    }
+    g.ldb = C; g.b_colk = 1; g.N = C;
+    g.mode = DN_EPI_GRADFEAT; g.r0 = gx; g.r1 = gy; g.ldr = C;
+    g.o0 = g_out; g.o1 = bre; g.o2 = bim; g.ldo = C;
+    if (!bre || !bim) { g.o1 = nullptr; g.o2 = nullptr; }
+    rg_finish(g, 2);
+    return dn_launch_rowgemm(g, mb->n_tiles, 2, st);
+}
+// d_dots = d(pre-tanh inner product).  d_gx = d_dots*Bre + dBre A_re + dBim A_im ; d_gy = d_dots*Bim - dBre A_im + dBim A_re
+int gradfeat_bwd_inputs(const dn_mesh_batch_t* mb, const float* ddots, const float* gx, const float* gy, const float* bre,
+                        const float* bim, const float* A_re, const float* A_im, int C, float* dgx, float* dgy, hipStream_t st) {
+    RgArgs g = rg_new(mb);
+    rg_seg(g, ddots, gx, C, C);   // dBre = d_dots * gx
+    rg_seg(g, ddots, gy, C, C);   // dBim = d_dots * gy
+    if (A_im) {
+        g.b[0][0] = A_re; g.bsign[0][0] = 1.f;   g.b[0][1] = A_im; g.bsign[0][1] = 1.f;
+        g.b[1][0] = A_im; g.bsign[1][0] = -1.f;  g.b[1][1] = A_re; g.bsign[1][1] = 1.f;
+    } else {
+        g.b[0][0] = A_re; g.bsign[0][0] = 1.f;   g.b[0][1] = A_re; g.bsign[0][1] = 0.f;
+        g.b[1][0] = A_re; g.bsign[1][0] = 0.f;   g.b[1][1] = A_re; g.bsign[1][1] = 1.f;
+    }
+    g.ldb = C; g.b_colk = 0; g.N = C;
+    g.mode = DN_EPI_GRADFEAT_BWD; g.r0 = ddots; g.r1 = bre; g.r2 = bim; g.ldr = C;
+    g.o0 = dgx; g.o1 = dgy; g.ldo = C;
+    rg_finish(g, 2);
+    return dn_launch_rowgemm(g, mb->n_tiles, 2, st);
+}
+int gradfeat_bwd_weights(const dn_mesh_batch_t* mb, const float* ddots, const float* gx, const float* gy, int C,
+                         float* dA_re, float* dA_im, float* partial, hipStream_t st) {
+    TnArgs g = tn_new(mb);
+    tn_a(g, ddots, gx, C, C);
+    tn_a(g, ddots, gy, C, C);
+    tn_b(g, gx, nullptr, C, C);
+    tn_b(g, gy, nullptr, C, C);
+    g.partial = partial;
+    tn_finish(g);
+    DN_CHECK(dn_launch_tngemm(g, mb->n_chunks, st));
+    return dn_launch_reduce_dA(partial, dA_re, dA_im, mb->n_chunks, C, st);
+}
+// y = act(sum_s x_s W[:, off_s:off_s+w_s]^T + b)
+int linear_fwd(const dn_mesh_batch_t* mb, const float* const* xs, const int* ws_, int nseg, const float* W, int ldw,
+               const float* b, int C_out, int mode, const uint8_t* mask, const float* resid, float* out, hipStream_t st) {
+    RgArgs g = rg_new(mb);
+    int off = 0;
+    for (int s = 0; s < nseg; ++s) {
+        rg_seg(g, xs[s], nullptr, ws_[s], ws_[s]);
+        g.b[0][s] = W + off;
+        off += ws_[s];
+    }
+    g.ldb = ldw; g.b_colk = 1; g.N = C_out;
+    g.mode = mode; g.bias = b; g.mask = mask; g.scale = mask ? 2.f : 1.f; g.r0 = resid; g.ldr = C_out;
+    g.o0 = out; g.ldo = C_out;
+    rg_finish(g, 1);
+    return dn_launch_rowgemm(g, mb->n_tiles, 1, st);
+}
+// d_in[:, n-range] = epi( d_a W[:, col_off : col_off+N] )
+int linear_bwd_input(const dn_mesh_batch_t* mb, const float* d_a, int C_out, const float* W, int ldw, int col_off, int N,
+                     int mode, const float* r0, float scale, float* out, hipStream_t st) {
+    RgArgs g = rg_new(mb);
+    rg_seg(g, d_a, nullptr, C_out, C_out);
+    g.b[0][0] = W + col_off; g.ldb = ldw; g.b_colk = 0; g.N = N;
+    g.mode = mode; g.r0 = r0; g.ldr = N; g.scale = scale;
+    g.o0 = out; g.ldo = N;
+    rg_finish(g, 1);
+    return dn_launch_rowgemm(g, mb->n_tiles, 1, st);
+}
+// dW[o][i] = sum_r d_a[r,o] in[r,i] ; db[o] = sum_r d_a[r,o]
+int linear_bwd_weights(const dn_mesh_batch_t* mb, const float* d_a, int C_out, const float* const* ins, const int* ws_, int nseg,
+                       float* dW, float* db, float* partial, float* colsum, hipStream_t st) {
+    TnArgs g = tn_new(mb);
+    tn_a(g, d_a, nullptr, C_out, C_out);
+    for (int s = 0; s < nseg; ++s) tn_b(g, ins[s], nullptr, ws_[s], ws_[s]);
+    g.partial = partial; g.colsum = db ? colsum : nullptr;
+    tn_finish(g);
+    DN_CHECK(dn_launch_tngemm(g, mb->n_chunks, st));
+    DN_CHECK(dn_launch_reduce(partial, dW, mb->n_chunks, (long long)g.M * g.N, (long long)g.M * g.N, st));
+    if (db) DN_CHECK(dn_launch_reduce(colsum, db, mb->n_chunks, g.M, g.M, st));
+    return 0;
+}
+int max_width(const dn_block_params_t* p) {
+    int m = p->C;
+    for (int i = 1; i <= p->n_mlp; ++i) if (p->widths[i] > m) m = p->widths[i];
+    return m;
+}
+size_t max_wgrad_elems(const dn_mesh_batch_t* mb, const dn_block_params_t* p) {
+    size_t m = (size_t)mb->k_eig * p->C;
+    for (int i = 0; i < p->n_mlp; ++i) {
+        size_t e = (size_t)p->widths[i] * p->widths[i + 1];
+        if (e > m) m = e;
+    }
+    if (p->with_grad) { size_t e = (size_t)4 * p->C * p->C; if (e > m) m = e; }
+    return m;
+}
+bool block_params_ok(const dn_block_params_t* p) {
+    if (!p || p->C <= 0 || p->n_mlp < 1 || p->n_mlp > DN_MAX_MLP_LAYERS) return false;
+    const int in0 = (p->with_grad ? 3 : 2) * p->C;
+    return p->widths[0] == in0 && p->widths[p->n_mlp] == p->C;
+}
+}  // namespace
+
+extern "C" {
+
+int dn_version(void) { return 100; }
+int dn_tile_rows(void) { return DN_TM; }
+
+// ------------------------------------------------------------------ to_basis / from_basis
+size_t dn_to_basis_workspace_bytes(const dn_mesh_batch_t* mb, int C) {
+    return pad256((size_t)mb->n_chunks * mb->k_eig * C) + 512;
+}
+int dn_to_basis_f32(const dn_mesh_batch_t* mb, const float* x, int C, int use_mass, float* spec, void* ws, size_t ws_bytes,
+                    void* stream) {
+    Bump b(ws, ws_bytes);
+    float* partial = b.f((size_t)mb->n_chunks * mb->k_eig * C);
+    if (!b.ok) return DN_ERR_INVALID;
+    DN_CHECK(to_basis_partials(mb, x, C, use_mass != 0, partial, S(stream)));
+    return dn_launch_spec_fwd(partial, mb->mesh_chunk_off, mb->evals, nullptr, spec, nullptr, mb->n_mesh, mb->k_eig, C, S(stream));
+}
+int dn_from_basis_f32(const dn_mesh_batch_t* mb, const float* spec, int C, int scale_rows_by_mass, float* out, void* stream) {
+    return from_basis(mb, spec, C, out, nullptr, scale_rows_by_mass != 0, S(stream));
+}
+
+// ------------------------------------------------------------------ learned-time diffusion
+size_t dn_diffusion_workspace_bytes(const dn_mesh_batch_t* mb, int C) {
+    return pad256((size_t)mb->n_chunks * mb->k_eig * C) + pad256((size_t)mb->n_mesh * mb->k_eig * C) +
+           pad256((size_t)mb->n_mesh * C) + 512;
+}
+int dn_diffusion_fwd_f32(const dn_mesh_batch_t* mb, const float* x, const float* time, int C, float* xs, float* xd,
+                         void* ws, size_t ws_bytes, void* stream) {
+    Bump b(ws, ws_bytes);
+    float* partial = b.f((size_t)mb->n_chunks * mb->k_eig * C);
+    float* ys = b.f((size_t)mb->n_mesh * mb->k_eig * C);
+    if (!b.ok) return DN_ERR_INVALID;
+    DN_CHECK(to_basis_partials(mb, x, C, true, partial, S(stream)));
+    DN_CHECK(dn_launch_spec_fwd(partial, mb->mesh_chunk_off, mb->evals, time, xs, ys, mb->n_mesh, mb->k_eig, C, S(stream)));
+    return from_basis(mb, ys, C, xd, nullptr, false, S(stream));
+}
+int dn_diffusion_bwd_f32(const dn_mesh_batch_t* mb, const float* d_xd, const float* xs, const float* time, int C,
+                         const float* d_x_add, float* d_x, float* d_time, void* ws, size_t ws_bytes, void* stream) {
+    Bump b(ws, ws_bytes);
+    float* partial = b.f((size_t)mb->n_chunks * mb->k_eig * C);
+    float* dxs = b.f((size_t)mb->n_mesh * mb->k_eig * C);
+    float* dtp = b.f((size_t)mb->n_mesh * C);
+    if (!b.ok) return DN_ERR_INVALID;
+    DN_CHECK(to_basis_partials(mb, d_xd, C, false, partial, S(stream)));
+    DN_CHECK(dn_launch_spec_bwd(partial, mb->mesh_chunk_off, mb->evals, time, xs, dxs, dtp, mb->n_mesh, mb->k_eig, C, S(stream)));
+    DN_CHECK(dn_launch_reduce(dtp, d_time, mb->n_mesh, C, C, S(stream)));
+    return from_basis(mb, dxs, C, d_x, d_x_add, true, S(stream));   // d_x_add may be NULL
+}
+
+// ------------------------------------------------------------------ gradient apply
+int dn_grad_apply_fwd_f32(const dn_mesh_batch_t* mb, const float* x, int C, float* gx, float* gy, void* stream) {
+    return grad_apply_fwd(mb, x, C, gx, gy, S(stream));
+}
+int dn_grad_apply_bwd_f32(const dn_mesh_batch_t* mb, const float* d_gx, const float* d_gy, const float* add, int C,
+                          float* d_x, void* stream) {
+    return grad_apply_bwd(mb, d_gx, d_gy, add, C, d_x, S(stream));
+}
+
+// ------------------------------------------------------------------ gradient features
+size_t dn_gradfeat_workspace_bytes(const dn_mesh_batch_t* mb, int C) {
+    return pad256((size_t)mb->n_chunks * 4 * C * C) + pad256((size_t)mb->v_total * C) + 512;
+}
+int dn_gradfeat_fwd_f32(const dn_mesh_batch_t* mb, const float* gx, const float* gy, const float* A_re, const float* A_im,
+                        int C, float* g, float* bre, float* bim, void* stream) {
+    return gradfeat_fwd(mb, gx, gy, A_re, A_im, C, g, bre, bim, S(stream));
+}
+int dn_gradfeat_bwd_f32(const dn_mesh_batch_t* mb, const float* d_g, const float* g, const float* gx, const float* gy,
+                        const float* bre, const float* bim, const float* A_re, const float* A_im, int C,
+                        float* d_gx, float* d_gy, float* dA_re, float* dA_im, void* ws, size_t ws_bytes, void* stream) {
+    Bump b(ws, ws_bytes);
+    float* partial = b.f((size_t)mb->n_chunks * 4 * C * C);
+    float* ddots = b.f((size_t)mb->v_total * C);
+    if (!b.ok) return DN_ERR_INVALID;
+    // d_dots = d_g * (1 - g^2)   (the fused block folds this into the epilogue of the d_h0 product)
+    DN_CHECK(dn_launch_dtanh(d_g, g, ddots, (long long)mb->v_total * C, S(stream)));
+    DN_CHECK(gradfeat_bwd_weights(mb, ddots, gx, gy, C, dA_re, A_im ? dA_im : nullptr, partial, S(stream)));
+    return gradfeat_bwd_inputs(mb, ddots, gx, gy, bre, bim, A_re, A_im, C, d_gx, d_gy, S(stream));
+}
+
+// ------------------------------------------------------------------ nn.Linear
+size_t dn_linear_workspace_bytes(const dn_mesh_batch_t* mb, int C_in, int C_out) {
+    return pad256((size_t)mb->n_chunks * C_in * C_out) + pad256((size_t)mb->n_chunks * C_out) + 512;
+}
+int dn_linear_fwd_f32(const dn_mesh_batch_t* mb, const float* x, int C_in, const float* W, const float* b, int C_out,
+                      int relu, const uint8_t* mask, float* out, void* stream) {
+    const float* xs[1] = {x};
+    const int ws_[1] = {C_in};
+    return linear_fwd(mb, xs, ws_, 1, W, C_in, b, C_out, relu ? DN_EPI_BIAS_RELU : DN_EPI_STORE, mask, nullptr, out, S(stream));
+}
+int dn_linear_bwd_f32(const dn_mesh_batch_t* mb, const float* d_out, const float* x, const float* W, int C_in, int C_out,
+                      float* d_x, float* dW, float* db, void* ws, size_t ws_bytes, void* stream) {
+    Bump b(ws, ws_bytes);
+    float* partial = b.f((size_t)mb->n_chunks * C_in * C_out);
+    float* colsum = b.f((size_t)mb->n_chunks * C_out);
+    if (!b.ok) return DN_ERR_INVALID;
+    const float* ins[1] = {x};
+    const int ws_[1] = {C_in};
+    DN_CHECK(linear_bwd_weights(mb, d_out, C_out, ins, ws_, 1, dW, db, partial, colsum, S(stream)));
+    if (d_x) DN_CHECK(linear_bwd_input(mb, d_out, C_out, W, C_in, 0, C_in, DN_EPI_STORE, nullptr, 1.f, d_x, S(stream)));
+    return 0;
+}
+
+// ------------------------------------------------------------------ fused DiffusionNetBlock
+size_t dn_block_fwd_workspace_bytes(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int with_saved) {
+    if (!block_params_ok(p)) return 0;
+    const size_t VC = (size_t)mb->v_total * p->C;
+    size_t n = pad256((size_t)mb->n_chunks * mb->k_eig * p->C) + pad256((size_t)mb->n_mesh * mb->k_eig * p->C) + 512;
+    if (!with_saved) {
+        n += pad256((size_t)mb->n_mesh * mb->k_eig * p->C) + 4 * pad256(VC);          // xs, xd, gx, gy, g
+        n += 2 * pad256((size_t)mb->v_total * max_width(p));                            // hidden ping-pong
+    }
+    return n;
+}
+int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, const float* x, float* out,
+                     const dn_block_saved_t* sv, void* ws, size_t ws_bytes, void* stream) {
+    if (!block_params_ok(p)) return DN_ERR_INVALID;
+    hipStream_t st = S(stream);
+    const int C = p->C, K = mb->k_eig;
+    const size_t VC = (size_t)mb->v_total * C;
+    Bump b(ws, ws_bytes);
+    float* partial = b.f((size_t)mb->n_chunks * K * C);
+    float* ys = b.f((size_t)mb->n_mesh * K * C);
+    float *xs, *xd, *gx = nullptr, *gy = nullptr, *gf = nullptr, *bre = nullptr, *bim = nullptr;
+    float* hbuf[2] = {nullptr, nullptr};
+    if (sv) {
+        xs = sv->xs; xd = sv->xd; gx = sv->gx; gy = sv->gy; gf = sv->g; bre = sv->bre; bim = sv->bim;
+    } else {
+        xs = b.f((size_t)mb->n_mesh * K * C); xd = b.f(VC);
+        gx = b.f(VC); gy = b.f(VC); gf = b.f(VC);
+        hbuf[0] = b.f((size_t)mb->v_total * max_width(p));
+        hbuf[1] = b.f((size_t)mb->v_total * max_width(p));
+    }
+    if (!b.ok) return DN_ERR_INVALID;
+
+    // diffusion (layers.py:210)
+    DN_CHECK(to_basis_partials(mb, x, C, true, partial, st));
+    DN_CHECK(dn_launch_spec_fwd(partial, mb->mesh_chunk_off, mb->evals, p->time, xs, ys, mb->n_mesh, K, C, st));
+    DN_CHECK(from_basis(mb, ys, C, xd, nullptr, false, st));
+    // gradient features (layers.py:213-226)
+    if (p->with_grad) {
+        DN_CHECK(grad_apply_fwd(mb, xd, C, gx, gy, st));
+        DN_CHECK(gradfeat_fwd(mb, gx, gy, p->A_re, p->with_rot ? p->A_im : nullptr, C, gf, bre, bim, st));
+    }
+    // MiniMLP on [x | xd | g] + residual (layers.py:229-239)
+    const float* in_ptr[3] = {x, xd, gf};
+    int in_w[3] = {C, C, C};
+    int nseg = p->with_grad ? 3 : 2;
+    for (int j = 0; j < p->n_mlp; ++j) {
+        const bool last = (j == p->n_mlp - 1);
+        float* dst = last ? out : (sv ? sv->h[j] : hbuf[j & 1]);
+        DN_CHECK(linear_fwd(mb, in_ptr, in_w, nseg, p->W[j], p->widths[j], p->b[j], p->widths[j + 1],
+                            last ? DN_EPI_BIAS_RESID : DN_EPI_BIAS_RELU, last ? nullptr : p->mask[j + 1],
+                            last ? x : nullptr, dst, st));
+        in_ptr[0] = dst; in_w[0] = p->widths[j + 1]; nseg = 1;
+    }
+    return 0;
+}
+
+size_t dn_block_bwd_workspace_bytes(const dn_mesh_batch_t* mb, const dn_block_params_t* p) {
+    if (!block_params_ok(p)) return 0;
+    const size_t VC = (size_t)mb->v_total * p->C;
+    size_t n = 2 * pad256((size_t)mb->v_total * max_width(p));     // d_a ping-pong
+    n += 5 * pad256(VC);                                            // d_xacc, d_xd, d_dots, d_gx, d_gy
+    n += pad256((size_t)mb->n_chunks * max_wgrad_elems(mb, p));     // TN partials
+    n += pad256((size_t)mb->n_chunks * max_width(p));               // bias partials
+    n += pad256((size_t)mb->n_mesh * mb->k_eig * p->C) + pad256((size_t)mb->n_mesh * p->C);
+    return n + 512;
+}
+int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, const float* x, const dn_block_saved_t* sv,
+                     const float* d_out, const dn_block_grads_t* gr, void* ws, size_t ws_bytes, void* stream) {
+    if (!block_params_ok(p) || !sv || !gr) return DN_ERR_INVALID;
+    hipStream_t st = S(stream);
+    const int C = p->C, K = mb->k_eig;
+    const size_t VC = (size_t)mb->v_total * C;
+    Bump b(ws, ws_bytes);
+    float* da[2] = {b.f((size_t)mb->v_total * max_width(p)), b.f((size_t)mb->v_total * max_width(p))};
+    float* d_xacc = b.f(VC);
+    float* d_xd = b.f(VC);
+    float* d_dots = b.f(VC);
+    float* d_gx = b.f(VC);
+    float* d_gy = b.f(VC);
+    float* partial = b.f((size_t)mb->n_chunks * max_wgrad_elems(mb, p));
+    float* colsum = b.f((size_t)mb->n_chunks * max_width(p));
+    float* dxs = b.f((size_t)mb->n_mesh * K * C);
+    float* dtp = b.f((size_t)mb->n_mesh * C);
+    if (!b.ok) return DN_ERR_INVALID;
+
+    // ---- MiniMLP backward (autograd of layers.py:236); d_a = gradient w.r.t. a layer's pre-activation output
+    const float* d_a = d_out;   // last layer has no activation; the residual branch is added into d_xacc below
+    for (int j = p->n_mlp - 1; j >= 0; --j) {
+        const int wo = p->widths[j + 1], wi = p->widths[j];
+        if (j > 0) {
+            const float* ins[1] = {sv->h[j - 1]};
+            const int iw[1] = {wi};
+            DN_CHECK(linear_bwd_weights(mb, d_a, wo, ins, iw, 1, gr->dW[j], gr->db[j], partial, colsum, st));
+            float* nxt = da[j & 1];
+            // d(pre-act of layer j-1) = (d_a W_j) * relu'(.) * dropout scale; h>0 <=> kept and active
+            DN_CHECK(linear_bwd_input(mb, d_a, wo, p->W[j], wi, 0, wi, DN_EPI_MUL_DFAC, sv->h[j - 1],
+                                      p->mask[j] ? 2.f : 1.f, nxt, st));
+            d_a = nxt;
+        } else {
+            const float* ins[3] = {x, sv->xd, sv->g};
+            const int iw[3] = {C, C, C};
+            DN_CHECK(linear_bwd_weights(mb, d_a, wo, ins, iw, p->with_grad ? 3 : 2, gr->dW[0], gr->db[0], partial, colsum, st));
+            // d_h0 = d_a W_0 split into its column groups [x | xd | g]
+            DN_CHECK(linear_bwd_input(mb, d_a, wo, p->W[0], wi, 0, C, DN_EPI_ADD, d_out, 1.f, d_xacc, st));       // + residual
+            DN_CHECK(linear_bwd_input(mb, d_a, wo, p->W[0], wi, C, C, DN_EPI_STORE, nullptr, 1.f, d_xd, st));
+            if (p->with_grad)
+                DN_CHECK(linear_bwd_input(mb, d_a, wo, p->W[0], wi, 2 * C, C, DN_EPI_DTANH, sv->g, 1.f, d_dots, st));
+        }
+    }
+    // ---- gradient features + gradient apply backward
+    if (p->with_grad) {
+        const float* A_im = p->with_rot ? p->A_im : nullptr;
+        DN_CHECK(gradfeat_bwd_weights(mb, d_dots, sv->gx, sv->gy, C, gr->dA_re, p->with_rot ? gr->dA_im : nullptr, partial, st));
+        DN_CHECK(gradfeat_bwd_inputs(mb, d_dots, sv->gx, sv->gy, sv->bre, sv->bim, p->A_re, A_im, C, d_gx, d_gy, st));
+        DN_CHECK(grad_apply_bwd(mb, d_gx, d_gy, d_xd, C, d_xd, st));   // d_xd += gradX^T d_gx + gradY^T d_gy (in place)
+    }
+    // ---- diffusion backward
+    DN_CHECK(to_basis_partials(mb, d_xd, C, false, partial, st));
+    DN_CHECK(dn_launch_spec_bwd(partial, mb->mesh_chunk_off, mb->evals, p->time, sv->xs, dxs, dtp, mb->n_mesh, K, C, st));
+    DN_CHECK(dn_launch_reduce(dtp, gr->d_time, mb->n_mesh, C, C, st));
+    return from_basis(mb, dxs, C, gr->d_x, d_xacc, true, st);
+}
+
+// ------------------------------------------------------------------ output remaps
+int dn_csr_mean_f32(const int32_t* rowptr, const int32_t* col, int n_rows, const float* x, int C, float div, float* out,
+                    void* stream) {
+    SpArgs s; memset(&s, 0, sizeof(s));
+    s.rowptr = rowptr; s.col = col; s.x1 = x; s.o1 = out; s.nrows = n_rows; s.C = C; s.ldx = C; s.ldo = C;
+    s.mode = DN_SP_ONE; s.div = div;
+    return dn_launch_spmm(s, S(stream));
+}
+int dn_mass_mean_fwd_f32(const dn_mesh_batch_t* mb, const float* x, int C, float* out, float* mass_sum, void* stream) {
+    return dn_launch_mass_mean_fwd(T(mb->mesh_rows), mb->mass, x, out, mass_sum, mb->n_mesh, C, S(stream));
+}
+int dn_mass_mean_bwd_f32(const dn_mesh_batch_t* mb, const float* mass_sum, const float* d_out, int C, float* d_x, void* stream) {
+    return dn_launch_mass_mean_bwd(T(mb->tiles), mb->n_tiles, mb->mass, mass_sum, d_out, d_x, C, S(stream));
+}
+
+}  // extern "C"

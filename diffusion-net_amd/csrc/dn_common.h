@@ -1,0 +1,158 @@
+// dn_common.h -- shared definitions for the gfx950 (MI355X / CDNA4) DiffusionNet kernels.
+//
+// The kernels are written for wave64 + exact-f32 MFMA (v_mfma_f32_32x32x2_f32).  The only
+// concession to portability is the DN_EMULATE switch, which lets tests/emu compile the same
+// sources for the host to check index logic; the product build never defines it.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef DN_EMULATE
+#include "hipemu.h"
+#define DN_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    dnemu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
+#define DN_DYN_SMEM(name) char* name = dnemu::dyn_smem()
+#define DN_RESTRICT
+#else
+#include <hip/hip_runtime.h>
+#define DN_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kernel, (grid), (block), (smem), (stream), __VA_ARGS__)
+#define DN_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define DN_RESTRICT __restrict__
+#endif
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// One 32x32x2 exact-f32 MFMA step: lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31];
+// accumulator register r of lane l is D[(r&3)+8*(r>>2)+4*(l>>5)][l&31].
+__device__ __forceinline__ f32x16 dn_mfma(float a, float b, f32x16 c) {
+#ifdef DN_EMULATE
+    return dnemu_mfma_f32_32x32x2f32(a, b, c);
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ int dn_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// A unit of row work: rows [row0,row0+nrows) of the concatenated vertex axis, all belonging to
+// mesh `mesh` (tiles/chunks never straddle meshes).  Built on the host once per mesh batch.
+struct DnTile {
+    int row0, nrows, mesh, aux;
+};
+
+__device__ __forceinline__ float4 dn_f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 dn_f4_mul(float4 a, float4 b) {
+    return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+}
+__device__ __forceinline__ float4 dn_f4_scale(float4 a, float s) {
+    return make_float4(a.x * s, a.y * s, a.z * s, a.w * s);
+}
+__device__ __forceinline__ float dn_f4_get(const float4& v, int t) {
+    return t == 0 ? v.x : (t == 1 ? v.y : (t == 2 ? v.z : v.w));
+}
+
+// LDS "COLK" tile: R rows x 32 floats (one 32-wide slice of the contraction axis per row),
+// stored row-major with the eight 16-byte slots of each 128-byte row XOR-swizzled by
+// (row>>1)&7.  A wave's ds_read_b128 of slot q for 32 consecutive rows then touches all
+// sixteen 16-byte positions of the 256-byte bank row once per 16-lane group (conflict-free),
+// and a row's eight slots written by eight consecutive lanes stay inside one 128-byte row.
+__device__ __forceinline__ int dn_colk_off(int row, int slot) { return row * 32 + ((slot ^ ((row >> 1) & 7)) << 2); }
+
+// ---------------------------------------------------------------------------------------
+// row-tile GEMM   out[r, n] = epilogue( sum_s sum_k A_s[r, k] * B_s(k, n) )    (dn_gemm.hip)
+// ---------------------------------------------------------------------------------------
+#define DN_TM 128      // rows per workgroup tile
+#define DN_KB 32       // contraction slice staged per step
+
+struct RgSeg {           // one column segment of the (virtually concatenated) A operand
+    const float* p;      // [rows, ld] row-major
+    const float* q;      // optional elementwise factor, same shape/ld (A = p*q), else null
+    int ld, w;
+};
+struct RgArgs {
+    const DnTile* tiles;
+    RgSeg a[3];
+    int nseg;
+    // B operand per output o (0/1) and segment s: sign[o][s] * Bmat[o][s]
+    const float* b[2][3];
+    float bsign[2][3];
+    int ldb;
+    int b_colk;            // 0: B[k*ldb + n] ("NN");  1: B[n*ldb + k] (nn.Linear weight, "NT")
+    long long b_mesh_stride;   // elements between consecutive meshes' B (0 = shared)
+    int N;
+    int aligned;           // 1: every width % 32 == 0, ld % 4 == 0, pointers 16-byte aligned, N % 4 == 0
+    // epilogue
+    int mode;
+    float* o0; float* o1; float* o2; int ldo;
+    const float* bias;
+    const float* r0; const float* r1; const float* r2; int ldr;
+    const float* rowv;
+    const uint8_t* mask;
+    float scale;
+};
+enum {
+    DN_EPI_STORE = 0,        // o0 = acc (+bias)
+    DN_EPI_BIAS_RELU = 1,    // o0 = relu(acc+bias) * (mask ? mask*scale : 1)
+    DN_EPI_BIAS_RESID = 2,   // o0 = acc + bias + r0
+    DN_EPI_GRADFEAT = 3,     // o0 = tanh(r0*acc0 + r1*acc1); o1 = acc0; o2 = acc1 (if non-null)
+    DN_EPI_MUL_DFAC = 4,     // o0 = acc * (r0 > 0 ? scale : 0)
+    DN_EPI_ADD = 5,          // o0 = acc + r0
+    DN_EPI_DTANH = 6,        // o0 = acc * (1 - r0^2)
+    DN_EPI_GRADFEAT_BWD = 7, // o0 = acc0 + r0*r1 ; o1 = acc1 + r0*r2
+    DN_EPI_MASS_ADD = 8,     // o0 = r0 + rowv[row]*acc
+};
+
+// ---------------------------------------------------------------------------------------
+// split-V "TN" GEMM   partial[chunk][m, n] = sum_{r in chunk} A[r, m] * B[r, n]   (dn_gemm.hip)
+// ---------------------------------------------------------------------------------------
+struct TnSeg {
+    const float* p;
+    const float* q;     // optional elementwise factor
+    int ld, w;
+};
+struct TnArgs {
+    const DnTile* chunks;
+    TnSeg a[2]; int na; int M;
+    TnSeg b[3]; int nb; int N;
+    const float* b_rowscale;    // optional per-row factor on B (lumped mass)
+    float* partial;             // [nchunks][M][N]
+    float* colsum;              // optional [nchunks][M]: column sums of A over the chunk
+    int aligned;                // widths % 4 == 0, ld % 4 == 0, 16-byte aligned pointers
+};
+
+// ---------------------------------------------------------------------------------------
+// CSR gather (dn_sparse.hip)
+// ---------------------------------------------------------------------------------------
+struct SpArgs {
+    const int* rowptr;
+    const int* col;
+    const float* va;   // values (null = 1.0)
+    const float* vb;   // second value array sharing the pattern (modes FWD2/BWD2)
+    const float* x1;
+    const float* x2;
+    const float* add;  // optional addend (ld = ldo)
+    float* o1;
+    float* o2;
+    int nrows, C, ldx, ldo, mode;
+    float div;         // DN_SP_ONE: result divided by this (exact mean of n gathered rows)
+};
+enum { DN_SP_FWD2 = 0, DN_SP_BWD2 = 1, DN_SP_ONE = 2 };
+
+// ---------------------------------------------------------------------------------------
+// small reductions / pointwise kernels (dn_pointwise.hip)
+// ---------------------------------------------------------------------------------------
+int dn_launch_spec_fwd(const float* partial, const int* mesh_chunk_off, const float* evals, const float* time,
+                       float* xs, float* ys, int n_mesh, int K, int C, hipStream_t stream);
+int dn_launch_spec_bwd(const float* partial, const int* mesh_chunk_off, const float* evals, const float* time,
+                       const float* xs, float* dxs, float* dt_part, int n_mesh, int K, int C, hipStream_t stream);
+int dn_launch_reduce(const float* partial, float* out, int n, long long stride, long long len, hipStream_t stream);
+int dn_launch_reduce_dA(const float* partial, float* dA_re, float* dA_im, int n, int C, hipStream_t stream);
+int dn_launch_mass_mean_fwd(const DnTile* meshrows, const float* mass, const float* x, float* out, float* msum,
+                            int n_mesh, int C, hipStream_t stream);
+int dn_launch_mass_mean_bwd(const DnTile* tiles, int ntiles, const float* mass, const float* msum, const float* dout,
+                            float* dx, int C, hipStream_t stream);
+int dn_launch_spmm(const SpArgs& s, hipStream_t stream);
+int dn_launch_dtanh(const float* dg, const float* g, float* out, long long n, hipStream_t stream);
+// launchers (host), defined in the .hip files; all return hipError_t as int
+int dn_launch_rowgemm(const RgArgs& g, int ntiles, int nout, hipStream_t stream);
+int dn_launch_tngemm(const TnArgs& g, int nchunks, hipStream_t stream);

@@ -1,0 +1,459 @@
+// dn_gemm.hip -- the two exact-f32 MFMA contraction engines every dense op of the
+// DiffusionNet block is built from (gfx950, wave64, v_mfma_f32_32x32x2_f32).
+//
+//  rowgemm : out[r, n] = epi( sum_k A[r, k] * B(k, n) )  over a 128-row vertex tile.  A is the
+//            long operand ([V, .] activations or the eigenbasis), B a small matrix (weights or a
+//            per-mesh spectrum).  Replaces: geometry.from_basis (geometry.py:598), every nn.Linear
+//            of the block (layers.py:122-126, :236), and their input-gradients in backward.
+//  tngemm  : partial[chunk][m, n] = sum_{r in chunk} A[r, m] * B[r, n]  -- the contraction runs over
+//            the vertex axis, split into chunks, partials reduced afterwards in fixed order
+//            (deterministic, no float atomics).  Replaces: geometry.to_basis (geometry.py:582-583)
+//            and every weight gradient dW = dY^T X of backward.
+//
+// Both engines stage 32-wide slices of the contraction axis through LDS with a register
+// prefetch of the next slice (global loads stay in flight under the MFMAs of the current one).
+// One 32x32x2 MFMA consumes lane-slot s = lane>>5; four consecutive MFMAs (t = 0..3) of a
+// k-group cover k = 8*kg + 4*s + t, which lets a "column-contraction" operand be fetched with
+// one ds_read_b128 per k-group from the swizzled COLK tile (dn_common.h) and a
+// "row-contraction" operand with four conflict-free ds_read_b32.
+#include "dn_common.h"
+
+// =======================================================================================
+// rowgemm
+// =======================================================================================
+__device__ __forceinline__ void rg_epilogue(const RgArgs& g, int row, int col, float a0, float a1) {
+    const long long io = (long long)row * g.ldo + col;
+    const long long ir = (long long)row * g.ldr + col;
+    switch (g.mode) {
+        case DN_EPI_STORE:
+            g.o0[io] = g.bias ? a0 + g.bias[col] : a0;
+            break;
+        case DN_EPI_BIAS_RELU: {
+            float h = a0 + g.bias[col];
+            h = h > 0.f ? h : 0.f;
+            if (g.mask) h = g.mask[ir] ? h * g.scale : 0.f;
+            g.o0[io] = h;
+        } break;
+        case DN_EPI_BIAS_RESID:
+            g.o0[io] = (a0 + g.bias[col]) + g.r0[ir];
+            break;
+        case DN_EPI_GRADFEAT: {
+            float d = g.r0[ir] * a0 + g.r1[ir] * a1;
+            g.o0[io] = tanhf(d);
+            if (g.o1) { g.o1[io] = a0; g.o2[io] = a1; }
+        } break;
+        case DN_EPI_MUL_DFAC:
+            g.o0[io] = g.r0[ir] > 0.f ? a0 * g.scale : 0.f;
+            break;
+        case DN_EPI_ADD:
+            g.o0[io] = a0 + g.r0[ir];
+            break;
+        case DN_EPI_DTANH: {
+            float t = g.r0[ir];
+            g.o0[io] = a0 * (1.f - t * t);
+        } break;
+        case DN_EPI_GRADFEAT_BWD: {
+            float dd = g.r0[ir];
+            g.o0[io] = a0 + dd * g.r1[ir];
+            g.o1[io] = a1 + dd * g.r2[ir];
+        } break;
+        case DN_EPI_MASS_ADD:
+            g.o0[io] = (g.r0 ? g.r0[ir] : 0.f) + g.rowv[row] * a0;
+            break;
+    }
+}
+
+template <int TN, int WR, int WC, int NOUT>
+__global__ __launch_bounds__(WR* WC * 64) void rowgemm_kernel(RgArgs g) {
+    constexpr int NTHR = WR * WC * 64;
+    constexpr int MT = DN_TM / (32 * WR);
+    constexpr int NT = TN / (32 * WC);
+    constexpr int A_IT = DN_TM * 8 / NTHR;
+    constexpr int B_IT = DN_KB * TN / 4 / NTHR;
+    constexpr int SB = DN_KB * TN;  // floats per B slice
+    static_assert(MT >= 1 && NT >= 1 && A_IT >= 1 && B_IT >= 1, "bad tile config");
+
+    DN_DYN_SMEM(smem_raw);
+    float* sA = reinterpret_cast<float*>(smem_raw);
+    float* sB = sA + DN_TM * DN_KB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WC, wc = wave % WC;
+    const int li = lane & 31, ls = lane >> 5;
+    const DnTile tile = g.tiles[blockIdx.x];
+    const int n0 = blockIdx.y * TN;
+
+    bool mt_ok[MT], nt_ok[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) mt_ok[mt] = (wr * MT + mt) * 32 < tile.nrows;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) nt_ok[nt] = n0 + (wc * NT + nt) * 32 < g.N;
+
+    f32x16 acc[NOUT][MT][NT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[o][mt][nt][r] = 0.f;
+
+    float4 ra[A_IT];
+    float4 rb[NOUT][B_IT];
+
+    int seg = 0, koff = 0;
+    bool have = g.nseg > 0;
+    bool first = true;
+    for (;;) {
+        // ---------------- global -> registers for slice (seg, koff) ----------------
+        if (have) {
+            const RgSeg sg = g.a[seg];
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int idx = tid + i * NTHR;
+                const int row = idx >> 3, q = idx & 7;
+                const bool rok = row < tile.nrows;
+                const long long base = (long long)(tile.row0 + row) * sg.ld + koff + 4 * q;
+                float4 v = dn_f4_zero();
+                if (g.aligned) {
+                    if (rok) {
+                        v = *reinterpret_cast<const float4*>(sg.p + base);
+                        if (sg.q) v = dn_f4_mul(v, *reinterpret_cast<const float4*>(sg.q + base));
+                    }
+                } else if (rok) {
+                    float e[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int k = koff + 4 * q + c;
+                        e[c] = 0.f;
+                        if (k < sg.w) {
+                            e[c] = sg.p[base + c];
+                            if (sg.q) e[c] *= sg.q[base + c];
+                        }
+                    }
+                    v = make_float4(e[0], e[1], e[2], e[3]);
+                }
+                ra[i] = v;
+            }
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                const float* bp = g.b[o][seg] + (long long)tile.mesh * g.b_mesh_stride;
+                const float sgn = g.bsign[o][seg];
+#pragma unroll
+                for (int i = 0; i < B_IT; ++i) {
+                    const int idx = tid + i * NTHR;
+                    float4 v = dn_f4_zero();
+                    if (g.b_colk) {
+                        const int nrow = idx >> 3, q = idx & 7;
+                        const int n = n0 + nrow;
+                        const long long base = (long long)n * g.ldb + koff + 4 * q;
+                        if (n < g.N) {
+                            if (g.aligned) {
+                                v = *reinterpret_cast<const float4*>(bp + base);
+                            } else {
+                                float e[4];
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) e[c] = (koff + 4 * q + c < sg.w) ? bp[base + c] : 0.f;
+                                v = make_float4(e[0], e[1], e[2], e[3]);
+                            }
+                        }
+                    } else {
+                        const int krow = idx / (TN / 4), q4 = idx % (TN / 4);
+                        const int n = n0 + 4 * q4;
+                        const long long base = (long long)(koff + krow) * g.ldb + n;
+                        if (koff + krow < sg.w) {
+                            if (g.aligned) {
+                                if (n < g.N) v = *reinterpret_cast<const float4*>(bp + base);
+                            } else {
+                                float e[4];
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) e[c] = (n + c < g.N) ? bp[base + c] : 0.f;
+                                v = make_float4(e[0], e[1], e[2], e[3]);
+                            }
+                        }
+                    }
+                    rb[o][i] = dn_f4_scale(v, sgn);
+                }
+            }
+        }
+        // ---------------- MFMAs on the slice already in LDS ----------------
+        if (!first) {
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                float4 af[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    af[mt] = *reinterpret_cast<const float4*>(&sA[dn_colk_off((wr * MT + mt) * 32 + li, 2 * kg + ls)]);
+                if (g.b_colk) {
+                    float4 bf[NOUT][NT];
+#pragma unroll
+                    for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            bf[o][nt] = *reinterpret_cast<const float4*>(
+                                &sB[o * SB + dn_colk_off((wc * NT + nt) * 32 + li, 2 * kg + ls)]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                if (mt_ok[mt] && nt_ok[nt]) {
+#pragma unroll
+                                    for (int o = 0; o < NOUT; ++o)
+                                        acc[o][mt][nt] = dn_mfma(dn_f4_get(af[mt], t), dn_f4_get(bf[o][nt], t), acc[o][mt][nt]);
+                                }
+                } else {
+                    float bs[NOUT][NT][4];
+#pragma unroll
+                    for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+                                bs[o][nt][t] = sB[o * SB + (8 * kg + 4 * ls + t) * TN + (wc * NT + nt) * 32 + li];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                if (mt_ok[mt] && nt_ok[nt]) {
+#pragma unroll
+                                    for (int o = 0; o < NOUT; ++o)
+                                        acc[o][mt][nt] = dn_mfma(dn_f4_get(af[mt], t), bs[o][nt][t], acc[o][mt][nt]);
+                                }
+                }
+            }
+            __syncthreads();  // everyone done reading the slice in LDS
+        }
+        if (!have) break;
+        // ---------------- registers -> LDS ----------------
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int idx = tid + i * NTHR;
+            *reinterpret_cast<float4*>(&sA[dn_colk_off(idx >> 3, idx & 7)]) = ra[i];
+        }
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                const int idx = tid + i * NTHR;
+                if (g.b_colk)
+                    *reinterpret_cast<float4*>(&sB[o * SB + dn_colk_off(idx >> 3, idx & 7)]) = rb[o][i];
+                else
+                    *reinterpret_cast<float4*>(&sB[o * SB + 4 * idx]) = rb[o][i];
+            }
+        __syncthreads();
+        first = false;
+        koff += DN_KB;
+        if (koff >= g.a[seg].w) { koff = 0; ++seg; }
+        have = seg < g.nseg;
+    }
+    // ---------------- epilogue ----------------
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (!(mt_ok[mt] && nt_ok[nt])) continue;
+            const int col = n0 + (wc * NT + nt) * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (wr * MT + mt) * 32 + dn_acc_row(r, lane);
+                if (rl < tile.nrows && col < g.N)
+                    rg_epilogue(g, tile.row0 + rl, col, acc[0][mt][nt][r], NOUT == 2 ? acc[NOUT - 1][mt][nt][r] : 0.f);
+            }
+        }
+}
+
+template <int TN, int WR, int WC, int NOUT>
+static int rg_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
+    const int ncol = (g.N + TN - 1) / TN;
+    const size_t smem = (size_t)(DN_TM * DN_KB + NOUT * DN_KB * TN) * sizeof(float);
+    DN_LAUNCH((rowgemm_kernel<TN, WR, WC, NOUT>), dim3(ntiles, ncol, 1), dim3(WR * WC * 64, 1, 1), smem, stream, g);
+    return (int)hipGetLastError();
+}
+
+int dn_launch_rowgemm(const RgArgs& g, int ntiles, int nout, hipStream_t stream) {
+    if (ntiles <= 0 || g.N <= 0) return 0;
+    if (nout == 1) {
+        if (g.N <= 32) return rg_launch<32, 4, 1, 1>(g, ntiles, stream);
+        if (g.N <= 64) return rg_launch<64, 2, 2, 1>(g, ntiles, stream);
+        return rg_launch<128, 2, 2, 1>(g, ntiles, stream);
+    }
+    if (g.N <= 32) return rg_launch<32, 4, 1, 2>(g, ntiles, stream);
+    if (g.N <= 64) return rg_launch<64, 2, 2, 2>(g, ntiles, stream);
+    return rg_launch<128, 2, 4, 2>(g, ntiles, stream);
+}
+
+// =======================================================================================
+// tngemm
+// =======================================================================================
+#define DN_TO 128  // output tile edge (both m and n)
+
+// value of the virtually concatenated operand at (row, col); col is resolved to its segment
+__device__ __forceinline__ float tn_elem(const TnSeg* s, int ns, long long row, int col) {
+    int c = col;
+    for (int i = 0; i < ns; ++i) {
+        if (c < s[i].w) {
+            const long long off = row * s[i].ld + c;
+            float v = s[i].p[off];
+            if (s[i].q) v *= s[i].q[off];
+            return v;
+        }
+        c -= s[i].w;
+    }
+    return 0.f;
+}
+
+__global__ __launch_bounds__(256) void tngemm_kernel(TnArgs g) {
+    DN_DYN_SMEM(smem_raw);
+    float* sA = reinterpret_cast<float*>(smem_raw);   // [32][128]  k-major
+    float* sB = sA + DN_KB * DN_TO;                   // [32][128]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, ls = lane >> 5;
+    const DnTile ch = g.chunks[blockIdx.x];
+    const int n0 = blockIdx.y * DN_TO, m0 = blockIdx.z * DN_TO;
+    const bool do_colsum = g.colsum != nullptr && blockIdx.y == 0;
+
+    bool mt_ok[2], nt_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        mt_ok[i] = m0 + (wr * 2 + i) * 32 < g.M;
+        nt_ok[i] = n0 + (wc * 2 + i) * 32 < g.N;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // each thread always stages the same 4-column group (q) of both operands
+    const int q = tid & 31, kr0 = tid >> 5;
+    const int acol = m0 + 4 * q, bcol = n0 + 4 * q;
+    // aligned fast path: resolve the segment of this thread's column group once
+    const float* ap = nullptr; const float* aq = nullptr; int ald = 0;
+    const float* bp = nullptr; const float* bq = nullptr; int bld = 0;
+    if (g.aligned) {
+        int c = acol;
+        for (int i = 0; i < g.na; ++i) {
+            if (c < g.a[i].w) { ap = g.a[i].p + c; aq = g.a[i].q ? g.a[i].q + c : nullptr; ald = g.a[i].ld; break; }
+            c -= g.a[i].w;
+        }
+        c = bcol;
+        for (int i = 0; i < g.nb; ++i) {
+            if (c < g.b[i].w) { bp = g.b[i].p + c; bq = g.b[i].q ? g.b[i].q + c : nullptr; bld = g.b[i].ld; break; }
+            c -= g.b[i].w;
+        }
+        if (acol >= g.M) ap = nullptr;
+        if (bcol >= g.N) bp = nullptr;
+    }
+    float4 csum = dn_f4_zero();
+    float4 ra[4], rb[4];
+
+    const int nsteps = (ch.nrows + DN_KB - 1) / DN_KB;
+    for (int step = 0; step <= nsteps; ++step) {
+        if (step < nsteps) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kr = step * DN_KB + kr0 + 8 * i;
+                const long long row = (long long)ch.row0 + kr;
+                float4 va = dn_f4_zero(), vb = dn_f4_zero();
+                if (kr < ch.nrows) {
+                    if (g.aligned) {
+                        if (ap) {
+                            va = *reinterpret_cast<const float4*>(ap + row * ald);
+                            if (aq) va = dn_f4_mul(va, *reinterpret_cast<const float4*>(aq + row * ald));
+                        }
+                        if (bp) {
+                            vb = *reinterpret_cast<const float4*>(bp + row * bld);
+                            if (bq) vb = dn_f4_mul(vb, *reinterpret_cast<const float4*>(bq + row * bld));
+                        }
+                    } else {
+                        float e[4], f[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            e[c] = (acol + c < g.M) ? tn_elem(g.a, g.na, row, acol + c) : 0.f;
+                            f[c] = (bcol + c < g.N) ? tn_elem(g.b, g.nb, row, bcol + c) : 0.f;
+                        }
+                        va = make_float4(e[0], e[1], e[2], e[3]);
+                        vb = make_float4(f[0], f[1], f[2], f[3]);
+                    }
+                    if (g.b_rowscale) vb = dn_f4_scale(vb, g.b_rowscale[row]);
+                }
+                ra[i] = va;
+                rb[i] = vb;
+                if (do_colsum) { csum.x += va.x; csum.y += va.y; csum.z += va.z; csum.w += va.w; }
+            }
+        }
+        if (step > 0) {
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                float af[2][4], bf[2][4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int kr = 8 * kg + 4 * ls + t;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        af[i][t] = sA[kr * DN_TO + (wr * 2 + i) * 32 + li];
+                        bf[i][t] = sB[kr * DN_TO + (wc * 2 + i) * 32 + li];
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            if (mt_ok[i] && nt_ok[j]) acc[i][j] = dn_mfma(af[i][t], bf[j][t], acc[i][j]);
+            }
+            __syncthreads();
+        }
+        if (step < nsteps) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kr = kr0 + 8 * i;
+                *reinterpret_cast<float4*>(&sA[kr * DN_TO + 4 * q]) = ra[i];
+                *reinterpret_cast<float4*>(&sB[kr * DN_TO + 4 * q]) = rb[i];
+            }
+            __syncthreads();
+        }
+    }
+    // partial tile out
+    float* out = g.partial + (long long)blockIdx.x * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (!(mt_ok[i] && nt_ok[j])) continue;
+            const int n = n0 + (wc * 2 + j) * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wr * 2 + i) * 32 + dn_acc_row(r, lane);
+                if (m < g.M && n < g.N) out[(long long)m * g.N + n] = acc[i][j][r];
+            }
+        }
+    if (do_colsum) {   // uniform per block
+        *reinterpret_cast<float4*>(&sA[kr0 * DN_TO + 4 * q]) = csum;
+        __syncthreads();
+        if (tid < DN_TO && m0 + tid < g.M) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += sA[k * DN_TO + tid];
+            g.colsum[(long long)blockIdx.x * g.M + m0 + tid] = s;
+        }
+    }
+}
+
+int dn_launch_tngemm(const TnArgs& g, int nchunks, hipStream_t stream) {
+    if (nchunks <= 0 || g.M <= 0 || g.N <= 0) return 0;
+    const size_t smem = (size_t)2 * DN_KB * DN_TO * sizeof(float);
+    dim3 grid(nchunks, (g.N + DN_TO - 1) / DN_TO, (g.M + DN_TO - 1) / DN_TO);
+    DN_LAUNCH(tngemm_kernel, grid, dim3(256, 1, 1), smem, stream, g);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,97 @@
+// dn_sparse.hip -- CSR gather kernels for the spatial-gradient operators (gfx950).
+//
+// Replaces the per-batch-item sparse COO `torch.mm(gradX[b], x)` / `torch.mm(gradY[b], x)` pair of
+// layers.py:217-223 (and their autograd transposes) and the gather+mean output remaps of
+// layers.py:379-391.  gradX and gradY share one CSR pattern (the reference builds both from one
+// complex matrix, geometry.py:381-382), so one pass over the pattern produces both products and
+// the dense operand row is fetched once.  Rows are split over 16-byte channel groups: a row of
+// C=128 floats is handled by 32 consecutive lanes, each gathering one float4 per non-zero; column
+// indices / values are wave-broadcast loads.  HBM/L2-bound (about 2 flop per byte).
+#include "dn_common.h"
+
+template <int VEC>
+__global__ __launch_bounds__(256) void spmm_kernel(SpArgs s, int tpr) {
+    const int tid = threadIdx.x;
+    const int rl = tid / tpr, cg = tid % tpr;
+    const int rows_per_block = 256 / tpr;
+    const int row = blockIdx.x * rows_per_block + rl;
+    if (row >= s.nrows) return;
+    const int beg = s.rowptr[row], end = s.rowptr[row + 1];
+    for (int c = cg * VEC; c < s.C; c += tpr * VEC) {
+        float a1[VEC], a2[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+#pragma unroll 4
+        for (int j = beg; j < end; ++j) {
+            const long long src = (long long)s.col[j] * s.ldx + c;
+            const float wa = s.va ? s.va[j] : 1.f;
+            float xv[VEC];
+            if (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(s.x1 + src);
+                xv[0] = t.x; xv[1 % VEC] = t.y; xv[2 % VEC] = t.z; xv[3 % VEC] = t.w;
+            } else {
+                xv[0] = s.x1[src];
+            }
+            if (s.mode == DN_SP_FWD2) {
+                const float wb = s.vb[j];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { a1[e] = fmaf(wa, xv[e], a1[e]); a2[e] = fmaf(wb, xv[e], a2[e]); }
+            } else if (s.mode == DN_SP_BWD2) {
+                const float wb = s.vb[j];
+                float yv[VEC];
+                if (VEC == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(s.x2 + src);
+                    yv[0] = t.x; yv[1 % VEC] = t.y; yv[2 % VEC] = t.z; yv[3 % VEC] = t.w;
+                } else {
+                    yv[0] = s.x2[src];
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) a1[e] = fmaf(wb, yv[e], fmaf(wa, xv[e], a1[e]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) a1[e] = fmaf(wa, xv[e], a1[e]);
+            }
+        }
+        const long long dst = (long long)row * s.ldo + c;
+        if (s.mode == DN_SP_ONE) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) a1[e] = a1[e] / s.div;
+        }
+        if (s.add) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) a1[e] += s.add[dst + e];
+        }
+        if (VEC == 4) {
+            *reinterpret_cast<float4*>(s.o1 + dst) = make_float4(a1[0], a1[1 % VEC], a1[2 % VEC], a1[3 % VEC]);
+            if (s.mode == DN_SP_FWD2)
+                *reinterpret_cast<float4*>(s.o2 + dst) = make_float4(a2[0], a2[1 % VEC], a2[2 % VEC], a2[3 % VEC]);
+        } else {
+            s.o1[dst] = a1[0];
+            if (s.mode == DN_SP_FWD2) s.o2[dst] = a2[0];
+        }
+    }
+}
+
+static int pow2_at_least(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+int dn_launch_spmm(const SpArgs& s, hipStream_t stream) {
+    if (s.nrows <= 0 || s.C <= 0) return 0;
+    const bool vec = (s.C % 4 == 0) && (s.ldx % 4 == 0) && (s.ldo % 4 == 0) &&
+                     ((uintptr_t)s.x1 % 16 == 0) && ((uintptr_t)s.o1 % 16 == 0) &&
+                     (!s.x2 || (uintptr_t)s.x2 % 16 == 0) && (!s.o2 || (uintptr_t)s.o2 % 16 == 0) &&
+                     (!s.add || (uintptr_t)s.add % 16 == 0);
+    int tpr = pow2_at_least(vec ? (s.C + 3) / 4 : s.C);
+    if (tpr > 256) tpr = 256;
+    const int rpb = 256 / tpr;
+    dim3 grid((s.nrows + rpb - 1) / rpb, 1, 1);
+    if (vec) {
+        DN_LAUNCH(spmm_kernel<4>, grid, dim3(256, 1, 1), 0, stream, s, tpr);
+    } else {
+        DN_LAUNCH(spmm_kernel<1>, grid, dim3(256, 1, 1), 0, stream, s, tpr);
+    }
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,152 @@
+"""ctypes binding of libdiffnet_hip.so (C ABI: include/diffnet_hip.h).
+
+The library is the product: there is no Python/torch fallback for the hot path.
+If the shared object is missing or the tensors are not on a ROCm device every
+op raises -- loudly -- instead of silently computing somewhere else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+MAX_MLP = 8
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libdiffnet_hip.so")
+
+TILE_DTYPE = np.dtype([("row0", "<i4"), ("nrows", "<i4"), ("mesh", "<i4"), ("aux", "<i4")])
+
+_vp = C.c_void_p
+
+
+class MeshBatchStruct(C.Structure):
+    _fields_ = [
+        ("n_mesh", C.c_int32), ("v_total", C.c_int32), ("k_eig", C.c_int32),
+        ("n_tiles", C.c_int32), ("n_chunks", C.c_int32), ("_pad", C.c_int32),
+        ("tiles", _vp), ("chunks", _vp), ("mesh_chunk_off", _vp), ("mesh_rows", _vp),
+        ("mass", _vp), ("evals", _vp), ("evecs", _vp),
+        ("g_rowptr", _vp), ("g_col", _vp), ("g_vx", _vp), ("g_vy", _vp),
+        ("gt_rowptr", _vp), ("gt_col", _vp), ("gt_vx", _vp), ("gt_vy", _vp),
+    ]
+
+
+class BlockParamsStruct(C.Structure):
+    _fields_ = [
+        ("C", C.c_int32), ("n_mlp", C.c_int32), ("with_grad", C.c_int32), ("with_rot", C.c_int32),
+        ("widths", C.c_int32 * (MAX_MLP + 1)),
+        ("time", _vp), ("A_re", _vp), ("A_im", _vp),
+        ("W", _vp * MAX_MLP), ("b", _vp * MAX_MLP), ("mask", _vp * MAX_MLP),
+    ]
+
+
+class BlockSavedStruct(C.Structure):
+    _fields_ = [
+        ("xs", _vp), ("xd", _vp), ("gx", _vp), ("gy", _vp), ("g", _vp), ("bre", _vp), ("bim", _vp),
+        ("h", _vp * MAX_MLP),
+    ]
+
+
+class BlockGradsStruct(C.Structure):
+    _fields_ = [
+        ("d_x", _vp), ("d_time", _vp), ("dA_re", _vp), ("dA_im", _vp),
+        ("dW", _vp * MAX_MLP), ("db", _vp * MAX_MLP),
+    ]
+
+
+_P = C.POINTER
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "dn_version": (C.c_int, []),
+    "dn_tile_rows": (C.c_int, []),
+    "dn_to_basis_workspace_bytes": (C.c_size_t, [_P(MeshBatchStruct), C.c_int]),
+    "dn_to_basis_f32": (C.c_int, [_P(MeshBatchStruct), _vp, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp]),
+    "dn_from_basis_f32": (C.c_int, [_P(MeshBatchStruct), _vp, C.c_int, C.c_int, _vp, _vp]),
+    "dn_diffusion_workspace_bytes": (C.c_size_t, [_P(MeshBatchStruct), C.c_int]),
+    "dn_diffusion_fwd_f32": (C.c_int, [_P(MeshBatchStruct), _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "dn_diffusion_bwd_f32": (C.c_int, [_P(MeshBatchStruct), _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "dn_grad_apply_fwd_f32": (C.c_int, [_P(MeshBatchStruct), _vp, C.c_int, _vp, _vp, _vp]),
+    "dn_grad_apply_bwd_f32": (C.c_int, [_P(MeshBatchStruct), _vp, _vp, _vp, C.c_int, _vp, _vp]),
+    "dn_gradfeat_workspace_bytes": (C.c_size_t, [_P(MeshBatchStruct), C.c_int]),
+    "dn_gradfeat_fwd_f32": (C.c_int, [_P(MeshBatchStruct), _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "dn_gradfeat_bwd_f32": (C.c_int, [_P(MeshBatchStruct)] + [_vp] * 8 + [C.c_int] + [_vp] * 5 + [C.c_size_t, _vp]),
+    "dn_linear_workspace_bytes": (C.c_size_t, [_P(MeshBatchStruct), C.c_int, C.c_int]),
+    "dn_linear_fwd_f32": (C.c_int, [_P(MeshBatchStruct), _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "dn_linear_bwd_f32": (C.c_int, [_P(MeshBatchStruct), _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "dn_block_fwd_workspace_bytes": (C.c_size_t, [_P(MeshBatchStruct), _P(BlockParamsStruct), C.c_int]),
+    "dn_block_bwd_workspace_bytes": (C.c_size_t, [_P(MeshBatchStruct), _P(BlockParamsStruct)]),
+    "dn_block_fwd_f32": (C.c_int, [_P(MeshBatchStruct), _P(BlockParamsStruct), _vp, _vp, _P(BlockSavedStruct), _vp, C.c_size_t, _vp]),
+    "dn_block_bwd_f32": (C.c_int, [_P(MeshBatchStruct), _P(BlockParamsStruct), _vp, _P(BlockSavedStruct), _vp,
+                                   _P(BlockGradsStruct), _vp, C.c_size_t, _vp]),
+    "dn_csr_mean_f32": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_float, _vp, _vp]),
+    "dn_mass_mean_fwd_f32": (C.c_int, [_P(MeshBatchStruct), _vp, C.c_int, _vp, _vp, _vp]),
+    "dn_mass_mean_bwd_f32": (C.c_int, [_P(MeshBatchStruct), _vp, _vp, C.c_int, _vp, _vp]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+_allow_host_tensors = False   # flipped ONLY by the CPU-emulator test fixture (tests/emu)
+
+
+def _bind(path):
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def lib():
+    """The loaded HIP library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"libdiffnet_hip.so not found at {LIB_PATH}: build it with "
+                "`make -C diffusion-net_amd/csrc` (or __graft_entry__.build()). "
+                "There is no fallback path for the DiffusionNet hot ops.")
+        _lib = _bind(LIB_PATH)
+    return _lib
+
+
+def _use_library_for_tests(path, allow_host_tensors):
+    """Test hook (tests/emu only): bind another build of the same C ABI."""
+    global _lib, _allow_host_tensors
+    _lib = _bind(path) if path else None
+    _allow_host_tensors = bool(allow_host_tensors)
+
+
+def require_device(t: torch.Tensor):
+    if not t.is_cuda and not _allow_host_tensors:
+        raise RuntimeError(
+            "diffusion_net HIP ops need tensors on a ROCm device (got %s); there is no CPU path" % t.device)
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream_of(t: torch.Tensor):
+    if t.is_cuda:
+        return torch.cuda.current_stream(t.device).cuda_stream
+    return None
+
+
+def check(err, what):
+    if err != 0:
+        raise RuntimeError(f"{what} failed with hipError {err}")
+
+
+_workspaces = {}
+
+
+def workspace(device, nbytes):
+    """Grow-only scratch buffer per device (stream-ordered reuse on the current stream)."""
+    key = str(device)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf

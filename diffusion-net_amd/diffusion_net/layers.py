@@ -1,0 +1,334 @@
+"""Drop-in ``diffusion_net.layers`` for MI355X: same classes, constructor arguments, forward
+signatures, error behaviour and ``state_dict`` keys as the reference's
+``src/diffusion_net/layers.py``, with every forward/backward op executed by hand-written HIP
+kernels (libdiffnet_hip.so) instead of ATen.
+
+Reference anchors: DiffusionNet (layers.py:244-407), DiffusionNetBlock (:167-241),
+LearnedTimeDiffusion (:17-90), SpatialGradientFeatures (:93-130), MiniMLP (:133-164).
+
+Beyond the reference API, ``DiffusionNet.forward_packed`` runs a *ragged* batch of meshes
+(different vertex counts) packed in a :class:`~diffusion_net.batch.MeshBatch` in one set of
+launches -- the unit of work the multi-GPU sharding distributes.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .batch import GatherPattern, MeshBatch
+
+_MIN_TIME = 1e-8
+
+
+def _linear_init_(weight: torch.Tensor, bias: Optional[torch.Tensor]):
+    """Same distribution as ``nn.Linear.reset_parameters`` (U(+-1/sqrt(fan_in)))."""
+    nn.init.kaiming_uniform_(weight, a=math.sqrt(5))
+    if bias is not None:
+        bound = 1.0 / math.sqrt(weight.shape[1]) if weight.shape[1] > 0 else 0.0
+        nn.init.uniform_(bias, -bound, bound)
+
+
+class _RowLinear(nn.Module):
+    """Parameters of an ``nn.Linear`` (keys ``weight``/``bias``); applied by the HIP row-GEMM."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+        _linear_init_(self.weight, self.bias)
+
+    def apply_rows(self, x2d, mb):
+        b = self.bias if self.bias is not None else torch.zeros(self.out_features, device=x2d.device)
+        return ops.LinearFn.apply(x2d, self.weight, b, mb)
+
+    def forward(self, x):
+        lead = x.shape[:-1]
+        x2d = x.reshape(-1, x.shape[-1])
+        mb = MeshBatch.rows_only(x2d.shape[0], x2d.device)
+        return self.apply_rows(x2d, mb).reshape(*lead, self.out_features)
+
+
+def _batch_of(mass, evals, evecs, gradX=None, gradY=None):
+    """MeshBatch from reference-style tensors (batched [B,..] or unbatched)."""
+    if evecs.dim() == 2:
+        mass, evals, evecs = mass[None], evals[None], evecs[None]
+        if gradX is not None and gradX.dim() == 2:
+            gradX, gradY = gradX.unsqueeze(0), gradY.unsqueeze(0)
+    return MeshBatch.from_reference_args(mass, evals, evecs, gradX, gradY)
+
+
+class LearnedTimeDiffusion(nn.Module):
+    """Per-channel learned-time heat diffusion (reference layers.py:17-90)."""
+
+    def __init__(self, C_inout, method="spectral"):
+        super().__init__()
+        self.C_inout = C_inout
+        self.diffusion_time = nn.Parameter(torch.zeros(C_inout))      # layers.py:38,41
+        self.method = method
+
+    def clamp_time_(self):
+        # same side effect as layers.py:48-49: the Parameter's data is re-bound to its clamp
+        with torch.no_grad():
+            self.diffusion_time.data = torch.clamp(self.diffusion_time, min=_MIN_TIME)
+
+    def forward(self, x, L, mass, evals, evecs):
+        self.clamp_time_()
+        if x.shape[-1] != self.C_inout:
+            raise ValueError("Tensor has wrong shape = {}. Last dim shape should have number of channels = {}".format(
+                x.shape, self.C_inout))
+        if self.method == "spectral":
+            mb = _batch_of(mass, evals, evecs)
+            out = ops.DiffusionFn.apply(x.reshape(-1, self.C_inout), self.diffusion_time, mb)
+            return out.reshape(x.shape)
+        if self.method == "implicit_dense":
+            # Toy-size dense solve (reference layers.py:69-84); not part of the accelerated path
+            # (no experiment or benchmark config uses it) -- plain torch.linalg on the tensors' device.
+            V = x.shape[-2]
+            mat = L.to_dense().unsqueeze(1).expand(-1, self.C_inout, V, V).clone()
+            mat *= self.diffusion_time[None, :, None, None]
+            mat += torch.diag_embed(mass).unsqueeze(1)
+            chol = torch.linalg.cholesky(mat)
+            rhs = (x * mass.unsqueeze(-1)).transpose(1, 2).unsqueeze(-1)
+            return torch.cholesky_solve(rhs, chol).squeeze(-1).transpose(1, 2)
+        raise ValueError("unrecognized method")
+
+
+class SpatialGradientFeatures(nn.Module):
+    """tanh(<grad, learned-rotation(grad)>) features (reference layers.py:93-130)."""
+
+    def __init__(self, C_inout, with_gradient_rotations=True):
+        super().__init__()
+        self.C_inout = C_inout
+        self.with_gradient_rotations = with_gradient_rotations
+        if with_gradient_rotations:
+            self.A_re = _RowLinear(C_inout, C_inout, bias=False)
+            self.A_im = _RowLinear(C_inout, C_inout, bias=False)
+        else:
+            self.A = _RowLinear(C_inout, C_inout, bias=False)
+
+    def matrices(self):
+        if self.with_gradient_rotations:
+            return self.A_re.weight, self.A_im.weight
+        return self.A.weight, None
+
+    def forward(self, vectors):
+        # vectors: (..., V, C, 2) as in the reference; planar copies feed the HIP op
+        lead = vectors.shape[:-2]
+        gx = vectors[..., 0].reshape(-1, self.C_inout).contiguous()
+        gy = vectors[..., 1].reshape(-1, self.C_inout).contiguous()
+        mb = MeshBatch.rows_only(gx.shape[0], gx.device)
+        A_re, A_im = self.matrices()
+        return ops.GradFeatFn.apply(gx, gy, A_re, A_im, mb).reshape(*lead, self.C_inout)
+
+
+class MiniMLP(nn.Sequential):
+    """Linear/ReLU stack with Dropout(p=.5) before every layer but the first; module names (and
+    therefore state_dict keys) follow the reference (layers.py:133-164)."""
+
+    def __init__(self, layer_sizes, dropout=False, activation=nn.ReLU, name="miniMLP"):
+        super().__init__()
+        self.layer_sizes = list(layer_sizes)
+        self.uses_dropout = bool(dropout)
+        self._hip_fusable = activation is nn.ReLU
+        n = len(layer_sizes) - 1
+        for i in range(n):
+            if dropout and i > 0:
+                self.add_module(name + "_mlp_layer_dropout_{:03d}".format(i), nn.Dropout(p=.5))
+            self.add_module(name + "_mlp_layer_{:03d}".format(i), _RowLinear(layer_sizes[i], layer_sizes[i + 1]))
+            if i + 1 < n:
+                self.add_module(name + "_mlp_act_{:03d}".format(i), activation())
+
+    def linears(self) -> List[_RowLinear]:
+        return [m for m in self if isinstance(m, _RowLinear)]
+
+
+class DiffusionNetBlock(nn.Module):
+    """diffusion -> spatial gradient features -> MiniMLP -> residual (reference layers.py:167-241),
+    executed as one fused sequence of HIP launches (``dn_block_fwd_f32`` / ``dn_block_bwd_f32``)."""
+
+    def __init__(self, C_width, mlp_hidden_dims, dropout=True, diffusion_method="spectral",
+                 with_gradient_features=True, with_gradient_rotations=True):
+        super().__init__()
+        self.C_width = C_width
+        self.mlp_hidden_dims = mlp_hidden_dims
+        self.dropout = dropout
+        self.with_gradient_features = with_gradient_features
+        self.with_gradient_rotations = with_gradient_rotations
+        self.diffusion = LearnedTimeDiffusion(C_width, method=diffusion_method)
+        self.MLP_C = 2 * C_width
+        if with_gradient_features:
+            self.gradient_features = SpatialGradientFeatures(C_width, with_gradient_rotations=with_gradient_rotations)
+            self.MLP_C += C_width
+        self.mlp = MiniMLP([self.MLP_C] + list(mlp_hidden_dims) + [C_width], dropout=dropout)
+        self._cfg = ops.BlockConfig(C_width, self.mlp.layer_sizes, with_gradient_features, with_gradient_rotations)
+        self.mask_provider = None   # test hook: callable(layer_index, shape, device) -> uint8 keep mask
+
+    def _dropout_masks(self, n_rows, device):
+        if not (self.training and self.dropout):
+            return None
+        masks = [None]
+        for i in range(1, self._cfg.n_mlp):
+            shape = (n_rows, self._cfg.widths[i])
+            if self.mask_provider is not None:
+                m = self.mask_provider(i, shape, device).to(device=device, dtype=torch.uint8).contiguous()
+            else:
+                m = torch.empty(shape, dtype=torch.uint8, device=device).bernoulli_(0.5)
+            masks.append(m)
+        return masks
+
+    def forward_packed(self, x2d: torch.Tensor, mb: MeshBatch) -> torch.Tensor:
+        """x2d: [v_total, C] on the concatenated vertex axis of ``mb``."""
+        if x2d.shape[-1] != self.C_width:
+            raise ValueError("Tensor has wrong shape = {}. Last dim shape should have number of channels = {}".format(
+                x2d.shape, self.C_width))
+        if self.diffusion.method != "spectral" or not self.mlp._hip_fusable:
+            raise NotImplementedError("the HIP block implements diffusion_method='spectral' with ReLU MLPs")
+        if self.with_gradient_features and not mb.has_grad:
+            raise ValueError("gradient features need gradX/gradY")
+        self.diffusion.clamp_time_()
+        A_re = A_im = None
+        if self.with_gradient_features:
+            A_re, A_im = self.gradient_features.matrices()
+        wb = []
+        for lin in self.mlp.linears():
+            wb += [lin.weight, lin.bias]
+        masks = self._dropout_masks(x2d.shape[0], x2d.device)
+        return ops.BlockFn.apply(mb, self._cfg, masks, x2d, self.diffusion.diffusion_time, A_re, A_im, *wb)
+
+    def forward(self, x_in, mass, L, evals, evecs, gradX, gradY):
+        # reference signature (layers.py:200): batched [B,V,C] inputs
+        if x_in.shape[-1] != self.C_width:
+            raise ValueError("Tensor has wrong shape = {}. Last dim shape should have number of channels = {}".format(
+                x_in.shape, self.C_width))
+        if self.diffusion.method != "spectral":
+            return self._forward_unfused(x_in, mass, L, evals, evecs, gradX, gradY)
+        mb = _batch_of(mass, evals, evecs, gradX if self.with_gradient_features else None,
+                       gradY if self.with_gradient_features else None)
+        return self.forward_packed(x_in.reshape(-1, self.C_width), mb).reshape(x_in.shape)
+
+    def _forward_unfused(self, x_in, mass, L, evals, evecs, gradX, gradY):
+        # only reached for diffusion_method='implicit_dense' (toy sizes, out of the accelerated scope)
+        xd = self.diffusion(x_in, L, mass, evals, evecs)
+        feats = [x_in, xd]
+        if self.with_gradient_features:
+            B, V, Cw = xd.shape
+            mbg = _batch_of(mass, mass.new_zeros(B, 1), mass.new_zeros(B, V, 1), gradX, gradY)
+            gx, gy = ops.GradApplyFn.apply(xd.reshape(-1, Cw), mbg)
+            A_re, A_im = self.gradient_features.matrices()
+            feats.append(ops.GradFeatFn.apply(gx, gy, A_re, A_im, mbg).reshape(B, V, Cw))
+        return self.mlp(torch.cat(feats, dim=-1)) + x_in
+
+
+class DiffusionNet(nn.Module):
+    """Same constructor and ``forward`` contract as the reference ``DiffusionNet`` (layers.py:244-407)."""
+
+    def __init__(self, C_in, C_out, C_width=128, N_block=4, last_activation=None, outputs_at="vertices",
+                 mlp_hidden_dims=None, dropout=True, with_gradient_features=True, with_gradient_rotations=True,
+                 diffusion_method="spectral"):
+        super().__init__()
+        self.C_in, self.C_out, self.C_width, self.N_block = C_in, C_out, C_width, N_block
+        self.last_activation = last_activation
+        self.outputs_at = outputs_at
+        if outputs_at not in ["vertices", "edges", "faces", "global_mean"]:
+            raise ValueError("invalid setting for outputs_at")
+        if mlp_hidden_dims is None:
+            mlp_hidden_dims = [C_width, C_width]
+        self.mlp_hidden_dims = mlp_hidden_dims
+        self.dropout = dropout
+        self.diffusion_method = diffusion_method
+        if diffusion_method not in ["spectral", "implicit_dense"]:
+            raise ValueError("invalid setting for diffusion_method")
+        self.with_gradient_features = with_gradient_features
+        self.with_gradient_rotations = with_gradient_rotations
+
+        self.first_lin = _RowLinear(C_in, C_width)
+        self.last_lin = _RowLinear(C_width, C_out)
+        self.blocks = []
+        for i in range(N_block):
+            blk = DiffusionNetBlock(C_width=C_width, mlp_hidden_dims=mlp_hidden_dims, dropout=dropout,
+                                    diffusion_method=diffusion_method,
+                                    with_gradient_features=with_gradient_features,
+                                    with_gradient_rotations=with_gradient_rotations)
+            self.blocks.append(blk)
+            self.add_module("block_" + str(i), blk)
+
+    # ------------------------------------------------------------------ ragged-batch entry point
+    def forward_packed(self, x2d, mb: MeshBatch, gather: Optional[GatherPattern] = None):
+        """x2d: [v_total, C_in] features on the concatenated vertex axis of ``mb``.
+
+        Returns [v_total, C_out] ('vertices'), [n_faces_or_edges_total, C_out] ('faces'/'edges',
+        ``gather`` built from global vertex ids) or [n_mesh, C_out] ('global_mean'); the last
+        activation is applied as in ``forward``."""
+        if x2d.shape[-1] != self.C_in:
+            raise ValueError("DiffusionNet was constructed with C_in={}, but x_in has last dim={}".format(
+                self.C_in, x2d.shape[-1]))
+        x = self.first_lin.apply_rows(x2d, mb)
+        for blk in self.blocks:
+            x = blk.forward_packed(x, mb)
+        x = self.last_lin.apply_rows(x, mb)
+        if self.outputs_at in ("edges", "faces"):
+            x = ops.GatherMeanFn.apply(x, gather)
+        elif self.outputs_at == "global_mean":
+            x = ops.MassMeanFn.apply(x, mb)
+        if self.last_activation is not None:
+            x = self.last_activation(x)
+        return x
+
+    # ------------------------------------------------------------------ reference entry point
+    def forward(self, x_in, mass, L=None, evals=None, evecs=None, gradX=None, gradY=None, edges=None, faces=None):
+        if x_in.shape[-1] != self.C_in:
+            raise ValueError("DiffusionNet was constructed with C_in={}, but x_in has last dim={}".format(
+                self.C_in, x_in.shape[-1]))
+        if x_in.dim() == 2:
+            squeeze = True
+            x_in, mass = x_in.unsqueeze(0), mass.unsqueeze(0)
+            L = L.unsqueeze(0) if L is not None else None
+            evals = evals.unsqueeze(0) if evals is not None else None
+            evecs = evecs.unsqueeze(0) if evecs is not None else None
+            gradX = gradX.unsqueeze(0) if gradX is not None else None
+            gradY = gradY.unsqueeze(0) if gradY is not None else None
+            edges = edges.unsqueeze(0) if edges is not None else None
+            faces = faces.unsqueeze(0) if faces is not None else None
+        elif x_in.dim() == 3:
+            squeeze = False
+        else:
+            raise ValueError("x_in should be tensor with shape [N,C] or [B,N,C]")
+
+        if self.diffusion_method != "spectral":
+            return self._forward_unfused(x_in, mass, L, evals, evecs, gradX, gradY, edges, faces, squeeze)
+
+        B, V, _ = x_in.shape
+        use_grad = self.with_gradient_features
+        mb = MeshBatch.from_reference_args(mass, evals, evecs, gradX if use_grad else None, gradY if use_grad else None)
+        gather = None
+        if self.outputs_at in ("edges", "faces"):
+            idx = edges if self.outputs_at == "edges" else faces      # AttributeError on None, as the reference
+            offs = (torch.arange(B, device=idx.device, dtype=idx.dtype) * V).view(B, 1, 1)
+            gather = GatherPattern((idx + offs).reshape(-1, idx.shape[-1]), B * V)
+            n_per_mesh = idx.shape[1]
+        out = self.forward_packed(x_in.reshape(B * V, self.C_in), mb, gather)
+        if self.outputs_at == "vertices":
+            out = out.reshape(B, V, -1)
+        elif self.outputs_at in ("edges", "faces"):
+            out = out.reshape(B, n_per_mesh, -1)
+        return out.squeeze(0) if squeeze else out
+
+    def _forward_unfused(self, x_in, mass, L, evals, evecs, gradX, gradY, edges, faces, squeeze):
+        # diffusion_method='implicit_dense' only (outside the accelerated scope; see LearnedTimeDiffusion)
+        x = self.first_lin(x_in)
+        for blk in self.blocks:
+            x = blk(x, mass, L, evals, evecs, gradX, gradY)
+        x = self.last_lin(x)
+        if self.outputs_at in ("edges", "faces"):
+            idx = edges if self.outputs_at == "edges" else faces
+            x = torch.stack([x[b][idx[b]].mean(dim=1) for b in range(x.shape[0])], 0)
+        elif self.outputs_at == "global_mean":
+            x = torch.sum(x * mass.unsqueeze(-1), dim=-2) / torch.sum(mass, dim=-1, keepdim=True)
+        if self.last_activation is not None:
+            x = self.last_activation(x)
+        return x.squeeze(0) if squeeze else x

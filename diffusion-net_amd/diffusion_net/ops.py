@@ -1,0 +1,356 @@
+"""torch.autograd bindings of the HIP hot ops (C ABI in include/diffnet_hip.h).
+
+Each Function enqueues the library's kernels on the current torch stream; forward saves the
+activations the hand-written backward needs.  No op has a torch/CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+
+from . import _hip
+from .batch import GatherPattern, MeshBatch
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise TypeError("diffusion_net HIP ops are fp32 (got %s)" % t.dtype)
+    return t.contiguous()
+
+
+def _ws(mb: MeshBatch, nbytes: int):
+    buf = _hip.workspace(mb.device, max(int(nbytes), 1024))
+    return buf, buf.numel()
+
+
+# ----------------------------------------------------------------------------------------------
+# basis transforms (geometry.py:572-598)
+# ----------------------------------------------------------------------------------------------
+def _to_basis_raw(mb, x, use_mass):
+    L = _hip.lib()
+    Cc = x.shape[1]
+    spec = torch.empty(mb.n_mesh, mb.k_eig, Cc, dtype=torch.float32, device=x.device)
+    ws, n = _ws(mb, L.dn_to_basis_workspace_bytes(mb.ref(), Cc))
+    _hip.check(L.dn_to_basis_f32(mb.ref(), x.data_ptr(), Cc, int(use_mass), spec.data_ptr(), ws.data_ptr(), n,
+                                 _hip.stream_of(x)), "dn_to_basis_f32")
+    return spec
+
+
+def _from_basis_raw(mb, spec, scale_by_mass=False):
+    L = _hip.lib()
+    Cc = spec.shape[-1]
+    out = torch.empty(mb.v_total, Cc, dtype=torch.float32, device=spec.device)
+    _hip.check(L.dn_from_basis_f32(mb.ref(), spec.data_ptr(), Cc, int(scale_by_mass), out.data_ptr(),
+                                   _hip.stream_of(spec)), "dn_from_basis_f32")
+    return out
+
+
+class ToBasisFn(torch.autograd.Function):
+    """spec[m] = evecs_m^T (x_m * mass_m)  -> [n_mesh, K, C]"""
+
+    @staticmethod
+    def forward(ctx, x, mb):
+        _hip.require_device(x)
+        ctx.mb = mb
+        return _to_basis_raw(mb, _f32c(x), True)
+
+    @staticmethod
+    def backward(ctx, d_spec):
+        return _from_basis_raw(ctx.mb, _f32c(d_spec), scale_by_mass=True), None
+
+
+class FromBasisFn(torch.autograd.Function):
+    """x_m = evecs_m spec[m]  -> [v_total, C]"""
+
+    @staticmethod
+    def forward(ctx, spec, mb):
+        _hip.require_device(spec)
+        ctx.mb = mb
+        return _from_basis_raw(mb, _f32c(spec))
+
+    @staticmethod
+    def backward(ctx, d_x):
+        return _to_basis_raw(ctx.mb, _f32c(d_x), False), None
+
+
+# ----------------------------------------------------------------------------------------------
+# learned-time spectral diffusion (layers.py:44-67)
+# ----------------------------------------------------------------------------------------------
+class DiffusionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, time, mb):
+        _hip.require_device(x)
+        L = _hip.lib()
+        x, time = _f32c(x), _f32c(time)
+        Cc = x.shape[1]
+        xs = torch.empty(mb.n_mesh, mb.k_eig, Cc, dtype=torch.float32, device=x.device)
+        xd = torch.empty_like(x)
+        ws, n = _ws(mb, L.dn_diffusion_workspace_bytes(mb.ref(), Cc))
+        _hip.check(L.dn_diffusion_fwd_f32(mb.ref(), x.data_ptr(), time.data_ptr(), Cc, xs.data_ptr(), xd.data_ptr(),
+                                          ws.data_ptr(), n, _hip.stream_of(x)), "dn_diffusion_fwd_f32")
+        ctx.mb = mb
+        ctx.save_for_backward(xs, time)
+        return xd
+
+    @staticmethod
+    def backward(ctx, d_xd):
+        L = _hip.lib()
+        mb = ctx.mb
+        xs, time = ctx.saved_tensors
+        d_xd = _f32c(d_xd)
+        Cc = d_xd.shape[1]
+        d_x = torch.empty_like(d_xd)
+        d_t = torch.empty_like(time)
+        ws, n = _ws(mb, L.dn_diffusion_workspace_bytes(mb.ref(), Cc))
+        _hip.check(L.dn_diffusion_bwd_f32(mb.ref(), d_xd.data_ptr(), xs.data_ptr(), time.data_ptr(), Cc, None,
+                                          d_x.data_ptr(), d_t.data_ptr(), ws.data_ptr(), n, _hip.stream_of(d_xd)),
+                   "dn_diffusion_bwd_f32")
+        return d_x, d_t, None
+
+
+# ----------------------------------------------------------------------------------------------
+# spatial gradients + gradient features (layers.py:217-223, 117-130)
+# ----------------------------------------------------------------------------------------------
+class GradApplyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mb):
+        _hip.require_device(x)
+        x = _f32c(x)
+        gx, gy = torch.empty_like(x), torch.empty_like(x)
+        _hip.check(_hip.lib().dn_grad_apply_fwd_f32(mb.ref(), x.data_ptr(), x.shape[1], gx.data_ptr(), gy.data_ptr(),
+                                                    _hip.stream_of(x)), "dn_grad_apply_fwd_f32")
+        ctx.mb = mb
+        return gx, gy
+
+    @staticmethod
+    def backward(ctx, d_gx, d_gy):
+        d_gx, d_gy = _f32c(d_gx), _f32c(d_gy)
+        d_x = torch.empty_like(d_gx)
+        _hip.check(_hip.lib().dn_grad_apply_bwd_f32(ctx.mb.ref(), d_gx.data_ptr(), d_gy.data_ptr(), None, d_gx.shape[1],
+                                                    d_x.data_ptr(), _hip.stream_of(d_gx)), "dn_grad_apply_bwd_f32")
+        return d_x, None
+
+
+class GradFeatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gx, gy, A_re, A_im, mb):
+        _hip.require_device(gx)
+        gx, gy, A_re = _f32c(gx), _f32c(gy), _f32c(A_re)
+        A_im = _f32c(A_im) if A_im is not None else None
+        g, bre, bim = torch.empty_like(gx), torch.empty_like(gx), torch.empty_like(gx)
+        _hip.check(_hip.lib().dn_gradfeat_fwd_f32(mb.ref(), gx.data_ptr(), gy.data_ptr(), A_re.data_ptr(), _hip.ptr(A_im),
+                                                  gx.shape[1], g.data_ptr(), bre.data_ptr(), bim.data_ptr(),
+                                                  _hip.stream_of(gx)), "dn_gradfeat_fwd_f32")
+        ctx.mb = mb
+        ctx.has_im = A_im is not None
+        ctx.save_for_backward(gx, gy, g, bre, bim, A_re, A_im if A_im is not None else A_re)
+        return g
+
+    @staticmethod
+    def backward(ctx, d_g):
+        L = _hip.lib()
+        mb = ctx.mb
+        gx, gy, g, bre, bim, A_re, A_im = ctx.saved_tensors
+        d_g = _f32c(d_g)
+        Cc = gx.shape[1]
+        d_gx, d_gy = torch.empty_like(gx), torch.empty_like(gx)
+        dA_re = torch.empty_like(A_re)
+        dA_im = torch.empty_like(A_re) if ctx.has_im else None
+        ws, n = _ws(mb, L.dn_gradfeat_workspace_bytes(mb.ref(), Cc))
+        _hip.check(L.dn_gradfeat_bwd_f32(mb.ref(), d_g.data_ptr(), g.data_ptr(), gx.data_ptr(), gy.data_ptr(), bre.data_ptr(),
+                                         bim.data_ptr(), A_re.data_ptr(), A_im.data_ptr() if ctx.has_im else None, Cc,
+                                         d_gx.data_ptr(), d_gy.data_ptr(), dA_re.data_ptr(), _hip.ptr(dA_im),
+                                         ws.data_ptr(), n, _hip.stream_of(d_g)), "dn_gradfeat_bwd_f32")
+        return d_gx, d_gy, dA_re, dA_im, None
+
+
+# ----------------------------------------------------------------------------------------------
+# nn.Linear on the row axis (first_lin / last_lin / stand-alone MiniMLP layers)
+# ----------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b, mb):
+        _hip.require_device(x)
+        x, W, b = _f32c(x), _f32c(W), _f32c(b)
+        out = torch.empty(x.shape[0], W.shape[0], dtype=torch.float32, device=x.device)
+        _hip.check(_hip.lib().dn_linear_fwd_f32(mb.ref(), x.data_ptr(), W.shape[1], W.data_ptr(), b.data_ptr(), W.shape[0],
+                                                0, None, out.data_ptr(), _hip.stream_of(x)), "dn_linear_fwd_f32")
+        ctx.mb = mb
+        ctx.save_for_backward(x, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        L = _hip.lib()
+        mb = ctx.mb
+        x, W = ctx.saved_tensors
+        d_out = _f32c(d_out)
+        C_out, C_in = W.shape
+        d_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW, db = torch.empty_like(W), torch.empty(C_out, dtype=torch.float32, device=x.device)
+        ws, n = _ws(mb, L.dn_linear_workspace_bytes(mb.ref(), C_in, C_out))
+        _hip.check(L.dn_linear_bwd_f32(mb.ref(), d_out.data_ptr(), x.data_ptr(), W.data_ptr(), C_in, C_out, _hip.ptr(d_x),
+                                       dW.data_ptr(), db.data_ptr(), ws.data_ptr(), n, _hip.stream_of(d_out)),
+                   "dn_linear_bwd_f32")
+        return d_x, dW, db, None
+
+
+# ----------------------------------------------------------------------------------------------
+# fused DiffusionNetBlock (layers.py:200-241)
+# ----------------------------------------------------------------------------------------------
+class BlockConfig:
+    """Static description of one block: channel width, MiniMLP sizes, feature switches."""
+
+    def __init__(self, C, widths, with_grad, with_rot):
+        self.C, self.widths, self.with_grad, self.with_rot = int(C), [int(w) for w in widths], bool(with_grad), bool(with_rot)
+        self.n_mlp = len(self.widths) - 1
+        if self.n_mlp > _hip.MAX_MLP:
+            raise ValueError("MiniMLP deeper than %d layers is not supported by the HIP block" % _hip.MAX_MLP)
+
+
+def _params_struct(cfg: BlockConfig, time, A_re, A_im, Ws, bs, masks):
+    p = _hip.BlockParamsStruct()
+    p.C, p.n_mlp, p.with_grad, p.with_rot = cfg.C, cfg.n_mlp, int(cfg.with_grad), int(cfg.with_rot)
+    for i, w in enumerate(cfg.widths):
+        p.widths[i] = w
+    p.time, p.A_re, p.A_im = time.data_ptr(), _hip.ptr(A_re), _hip.ptr(A_im)
+    for i in range(cfg.n_mlp):
+        p.W[i], p.b[i] = Ws[i].data_ptr(), bs[i].data_ptr()
+        p.mask[i] = _hip.ptr(masks[i]) if masks is not None else None
+    return p
+
+
+class BlockFn(torch.autograd.Function):
+    """forward(x, time, A_re, A_im, *W_and_b) with non-tensor (mb, cfg, masks) first."""
+
+    @staticmethod
+    def forward(ctx, mb, cfg, masks, x, time, A_re, A_im, *wb):
+        _hip.require_device(x)
+        L = _hip.lib()
+        x, time = _f32c(x), _f32c(time)
+        A_re = _f32c(A_re) if A_re is not None else None
+        A_im = _f32c(A_im) if A_im is not None else None
+        Ws = [_f32c(w) for w in wb[0::2]]
+        bs = [_f32c(b) for b in wb[1::2]]
+        dev, V, Cc = x.device, x.shape[0], cfg.C
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        p = _params_struct(cfg, time, A_re, A_im, Ws, bs, masks)
+        out = new(V, Cc)
+        need_grad = any(ctx.needs_input_grad)
+        if need_grad:
+            sv = _hip.BlockSavedStruct()
+            xs, xd = new(mb.n_mesh, mb.k_eig, Cc), new(V, Cc)
+            feats = [new(V, Cc) for _ in range(5)] if cfg.with_grad else []
+            hs = [new(V, cfg.widths[i + 1]) for i in range(cfg.n_mlp - 1)]
+            sv.xs, sv.xd = xs.data_ptr(), xd.data_ptr()
+            if cfg.with_grad:
+                sv.gx, sv.gy, sv.g, sv.bre, sv.bim = (t.data_ptr() for t in feats)
+            for i, h in enumerate(hs):
+                sv.h[i] = h.data_ptr()
+            sv_ref = C.byref(sv)
+        else:
+            sv_ref = None
+        ws, n = _ws(mb, L.dn_block_fwd_workspace_bytes(mb.ref(), C.byref(p), int(need_grad)))
+        _hip.check(L.dn_block_fwd_f32(mb.ref(), C.byref(p), x.data_ptr(), out.data_ptr(), sv_ref, ws.data_ptr(), n,
+                                      _hip.stream_of(x)), "dn_block_fwd_f32")
+        if need_grad:
+            ctx.mb, ctx.cfg, ctx.masks = mb, cfg, masks
+            ctx.n_feat, ctx.n_h = len(feats), len(hs)
+            ctx.has = (A_re is not None, A_im is not None)
+            ctx.save_for_backward(x, time, xs, xd, *feats, *hs, *Ws, *bs,
+                                  *([A_re] if A_re is not None else []), *([A_im] if A_im is not None else []))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        L = _hip.lib()
+        mb, cfg, masks = ctx.mb, ctx.cfg, ctx.masks
+        sav = list(ctx.saved_tensors)
+        x, time, xs, xd = sav[:4]
+        pos = 4
+        feats = sav[pos:pos + ctx.n_feat]; pos += ctx.n_feat
+        hs = sav[pos:pos + ctx.n_h]; pos += ctx.n_h
+        Ws = sav[pos:pos + cfg.n_mlp]; pos += cfg.n_mlp
+        bs = sav[pos:pos + cfg.n_mlp]; pos += cfg.n_mlp
+        A_re = A_im = None
+        if ctx.has[0]:
+            A_re = sav[pos]; pos += 1
+        if ctx.has[1]:
+            A_im = sav[pos]; pos += 1
+        d_out = _f32c(d_out)
+        p = _params_struct(cfg, time, A_re, A_im, Ws, bs, masks)
+        sv = _hip.BlockSavedStruct()
+        sv.xs, sv.xd = xs.data_ptr(), xd.data_ptr()
+        if cfg.with_grad:
+            sv.gx, sv.gy, sv.g, sv.bre, sv.bim = (t.data_ptr() for t in feats)
+        for i, h in enumerate(hs):
+            sv.h[i] = h.data_ptr()
+        gr = _hip.BlockGradsStruct()
+        d_x, d_time = torch.empty_like(x), torch.empty_like(time)
+        dA_re = torch.empty_like(A_re) if A_re is not None else None
+        dA_im = torch.empty_like(A_im) if A_im is not None else None
+        dWs, dbs = [torch.empty_like(w) for w in Ws], [torch.empty_like(b) for b in bs]
+        gr.d_x, gr.d_time, gr.dA_re, gr.dA_im = d_x.data_ptr(), d_time.data_ptr(), _hip.ptr(dA_re), _hip.ptr(dA_im)
+        for i in range(cfg.n_mlp):
+            gr.dW[i], gr.db[i] = dWs[i].data_ptr(), dbs[i].data_ptr()
+        ws, n = _ws(mb, L.dn_block_bwd_workspace_bytes(mb.ref(), C.byref(p)))
+        _hip.check(L.dn_block_bwd_f32(mb.ref(), C.byref(p), x.data_ptr(), C.byref(sv), d_out.data_ptr(), C.byref(gr),
+                                      ws.data_ptr(), n, _hip.stream_of(d_out)), "dn_block_bwd_f32")
+        wb = []
+        for dw, db in zip(dWs, dbs):
+            wb += [dw, db]
+        return (None, None, None, d_x, d_time, dA_re, dA_im, *wb)
+
+
+# ----------------------------------------------------------------------------------------------
+# output remaps (layers.py:379-397)
+# ----------------------------------------------------------------------------------------------
+class GatherMeanFn(torch.autograd.Function):
+    """out[i] = mean_j x[index[i, j]]  (faces: 3 rows, edges: 2 rows)"""
+
+    @staticmethod
+    def forward(ctx, x, pat: GatherPattern):
+        _hip.require_device(x)
+        x = _f32c(x)
+        out = torch.empty(pat.n_out, x.shape[1], dtype=torch.float32, device=x.device)
+        _hip.check(_hip.lib().dn_csr_mean_f32(pat.rowptr.data_ptr(), pat.col.data_ptr(), pat.n_out, x.data_ptr(), x.shape[1],
+                                              float(pat.n_per), out.data_ptr(), _hip.stream_of(x)), "dn_csr_mean_f32")
+        ctx.pat = pat
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        pat = ctx.pat
+        d_out = _f32c(d_out)
+        d_x = torch.empty(pat.n_src, d_out.shape[1], dtype=torch.float32, device=d_out.device)
+        _hip.check(_hip.lib().dn_csr_mean_f32(pat.t_rowptr.data_ptr(), pat.t_col.data_ptr(), pat.n_src, d_out.data_ptr(),
+                                              d_out.shape[1], float(pat.n_per), d_x.data_ptr(), _hip.stream_of(d_out)),
+                   "dn_csr_mean_f32")
+        return d_x, None
+
+
+class MassMeanFn(torch.autograd.Function):
+    """out[m] = sum_v mass_v x_v / sum_v mass_v over the vertices of mesh m (layers.py:397)"""
+
+    @staticmethod
+    def forward(ctx, x, mb):
+        _hip.require_device(x)
+        x = _f32c(x)
+        out = torch.empty(mb.n_mesh, x.shape[1], dtype=torch.float32, device=x.device)
+        msum = torch.empty(mb.n_mesh, dtype=torch.float32, device=x.device)
+        _hip.check(_hip.lib().dn_mass_mean_fwd_f32(mb.ref(), x.data_ptr(), x.shape[1], out.data_ptr(), msum.data_ptr(),
+                                                   _hip.stream_of(x)), "dn_mass_mean_fwd_f32")
+        ctx.mb = mb
+        ctx.save_for_backward(msum)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (msum,) = ctx.saved_tensors
+        d_out = _f32c(d_out)
+        d_x = torch.empty(ctx.mb.v_total, d_out.shape[1], dtype=torch.float32, device=d_out.device)
+        _hip.check(_hip.lib().dn_mass_mean_bwd_f32(ctx.mb.ref(), msum.data_ptr(), d_out.data_ptr(), d_out.shape[1],
+                                                   d_x.data_ptr(), _hip.stream_of(d_out)), "dn_mass_mean_bwd_f32")
+        return d_x, None

@@ -1,0 +1,148 @@
+/* diffnet_hip.h -- C ABI of libdiffnet_hip.so: the MI355X (gfx950) DiffusionNet hot path.
+ *
+ * The reference (nmwsharp/diffusion-net) has no native layer: its hot path is Python calling
+ * stock ATen kernels.  This header is the boundary a maintainer binds instead (ctypes stub in
+ * INTEGRATION.md).  Every entry point cites the reference interface it replaces
+ * (file:line under src/diffusion_net/).
+ *
+ * Conventions (all entry points):
+ *   - return value: hipError_t as int, 0 = success; never throws;
+ *   - never allocates, frees or synchronises; all work is enqueued on `stream` (a hipStream_t);
+ *   - every pointer inside dn_mesh_batch_t / dn_block_* and every float* / int* argument is a
+ *     DEVICE pointer owned by the caller and kept alive until the stream has drained; the structs
+ *     themselves live in host memory and are read during the call only;
+ *   - dense arrays are row-major contiguous fp32; index arrays int32; masks uint8 (1 = keep);
+ *   - `ws` is caller-provided device scratch of at least the size the matching
+ *     dn_*_workspace_bytes() reports; contents are undefined on return;
+ *   - re-entrant: no mutable global state.
+ *
+ * A "mesh batch" is a ragged batch of independent meshes whose vertex axes are concatenated:
+ * mesh m owns rows [mesh_rows[m].row0, +nrows) of every [v_total, *] array; the sparse gradient
+ * operators use global (concatenated) row/column indices, i.e. they are block-diagonal.
+ */
+#ifndef DIFFNET_HIP_H
+#define DIFFNET_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DN_MAX_MLP_LAYERS 8
+
+/* a run of rows that belongs to one mesh (tiles: <= dn_tile_rows() rows; chunks: any length) */
+typedef struct { int32_t row0, nrows, mesh, aux; } dn_tile_t;
+
+/* Per-batch geometry: what geometry.get_operators() returns per mesh (geometry.py:426-570),
+ * packed for the device.  gradX/gradY share one CSR pattern (geometry.py:381-382). */
+typedef struct dn_mesh_batch {
+    int32_t n_mesh, v_total, k_eig, n_tiles, n_chunks, _pad;
+    const dn_tile_t* tiles;          /* [n_tiles]  row tiles of <= dn_tile_rows() rows              */
+    const dn_tile_t* chunks;         /* [n_chunks] split-V chunks, grouped by mesh                   */
+    const int32_t*   mesh_chunk_off; /* [n_mesh+1] chunk range of every mesh                         */
+    const dn_tile_t* mesh_rows;      /* [n_mesh]   {row0, nrows, m, 0}                               */
+    const float* mass;               /* [v_total]            lumped vertex areas                     */
+    const float* evals;              /* [n_mesh, k_eig]      Laplacian eigenvalues                   */
+    const float* evecs;              /* [v_total, k_eig]     mass-orthonormal eigenbasis             */
+    const int32_t* g_rowptr;  const int32_t* g_col;  const float* g_vx;  const float* g_vy;   /* CSR of gradX/gradY  */
+    const int32_t* gt_rowptr; const int32_t* gt_col; const float* gt_vx; const float* gt_vy;  /* CSR of transposes   */
+} dn_mesh_batch_t;
+
+/* Weights of one DiffusionNetBlock (layers.py:167-198), nn.Linear layout: W[out][in]. */
+typedef struct dn_block_params {
+    int32_t C, n_mlp, with_grad, with_rot;
+    int32_t widths[DN_MAX_MLP_LAYERS + 1]; /* MiniMLP sizes: widths[0] = 3C (2C w/o gradient features), ..., widths[n_mlp] = C */
+    const float* time;                     /* [C] diffusion_time, already clamped to >= 1e-8 (layers.py:48-49) */
+    const float* A_re; const float* A_im;  /* [C,C] (with_rot=0: A_re holds A, A_im ignored), layers.py:110-113 */
+    const float* W[DN_MAX_MLP_LAYERS];     /* [widths[i+1], widths[i]] */
+    const float* b[DN_MAX_MLP_LAYERS];     /* [widths[i+1]] */
+    const uint8_t* mask[DN_MAX_MLP_LAYERS];/* mask[i], i>=1: dropout keep-mask of layer i's INPUT [v_total, widths[i]]
+                                              (layers.py:143-147), NULL = no dropout; kept values are scaled by 2 */
+} dn_block_params_t;
+
+/* Activations the forward saves for the backward (caller-allocated). */
+typedef struct dn_block_saved {
+    float* xs;                         /* [n_mesh, k_eig, C]  spectrum of x                     */
+    float* xd;                         /* [v_total, C]        diffused features                 */
+    float* gx; float* gy;              /* [v_total, C]        spatial gradients   (with_grad)   */
+    float* g; float* bre; float* bim;  /* [v_total, C]        tanh features, rotated gradients  */
+    float* h[DN_MAX_MLP_LAYERS];       /* h[i], i < n_mlp-1: [v_total, widths[i+1]] post-ReLU(+dropout) */
+} dn_block_saved_t;
+
+typedef struct dn_block_grads {
+    float* d_x;                        /* [v_total, C] */
+    float* d_time;                     /* [C] */
+    float* dA_re; float* dA_im;        /* [C,C] (with_rot=0: dA_re holds dA) */
+    float* dW[DN_MAX_MLP_LAYERS];
+    float* db[DN_MAX_MLP_LAYERS];
+} dn_block_grads_t;
+
+int dn_version(void);
+int dn_tile_rows(void);      /* rows per entry of dn_mesh_batch_t.tiles (128) */
+
+/* ---- geometry.to_basis (geometry.py:572-583): spec[m] = evecs_m^T (x_m * mass_m); use_mass=0 drops the mass
+ *      (the autograd transpose of from_basis).  spec: [n_mesh, k_eig, C]. */
+size_t dn_to_basis_workspace_bytes(const dn_mesh_batch_t* mb, int C);
+int dn_to_basis_f32(const dn_mesh_batch_t* mb, const float* x, int C, int use_mass, float* spec,
+                    void* ws, size_t ws_bytes, void* stream);
+/* ---- geometry.from_basis (geometry.py:586-598): out_m = evecs_m spec[m].  out: [v_total, C].
+ *      scale_rows_by_mass=1 multiplies row v by mass[v] (the autograd transpose of to_basis). */
+int dn_from_basis_f32(const dn_mesh_batch_t* mb, const float* spec, int C, int scale_rows_by_mass, float* out, void* stream);
+
+/* ---- LearnedTimeDiffusion.forward, method='spectral' (layers.py:44-67) and its gradient.
+ *      fwd: xs = to_basis(x), xd = from_basis(exp(-evals*time) * xs).
+ *      bwd: d_x = d_x_add + mass * (evecs (coef * evecs^T d_xd)), d_time[c] = -sum lambda*coef*xs*(evecs^T d_xd). */
+size_t dn_diffusion_workspace_bytes(const dn_mesh_batch_t* mb, int C);
+int dn_diffusion_fwd_f32(const dn_mesh_batch_t* mb, const float* x, const float* time, int C,
+                         float* xs, float* xd, void* ws, size_t ws_bytes, void* stream);
+int dn_diffusion_bwd_f32(const dn_mesh_batch_t* mb, const float* d_xd, const float* xs, const float* time, int C,
+                         const float* d_x_add, float* d_x, float* d_time, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- spatial gradient apply, layers.py:217-223 (gx = gradX x, gy = gradY x) and its transpose
+ *      d_x = add + gradX^T d_gx + gradY^T d_gy (add may be NULL). */
+int dn_grad_apply_fwd_f32(const dn_mesh_batch_t* mb, const float* x, int C, float* gx, float* gy, void* stream);
+int dn_grad_apply_bwd_f32(const dn_mesh_batch_t* mb, const float* d_gx, const float* d_gy, const float* add, int C,
+                          float* d_x, void* stream);
+
+/* ---- SpatialGradientFeatures.forward (layers.py:117-130): g = tanh(gx*Bre + gy*Bim).
+ *      A_im = NULL selects with_gradient_rotations=False (layers.py:125-126).  bre/bim may be NULL (inference). */
+size_t dn_gradfeat_workspace_bytes(const dn_mesh_batch_t* mb, int C);
+int dn_gradfeat_fwd_f32(const dn_mesh_batch_t* mb, const float* gx, const float* gy, const float* A_re, const float* A_im,
+                        int C, float* g, float* bre, float* bim, void* stream);
+int dn_gradfeat_bwd_f32(const dn_mesh_batch_t* mb, const float* d_g, const float* g, const float* gx, const float* gy,
+                        const float* bre, const float* bim, const float* A_re, const float* A_im, int C,
+                        float* d_gx, float* d_gy, float* dA_re, float* dA_im, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- nn.Linear (first_lin / last_lin, layers.py:297-298,366,373; MiniMLP layers, layers.py:150-164):
+ *      out = act(x W^T + b) [* 2*mask];  relu/mask as in MiniMLP.  bwd: d_x = d_out W (skipped when d_x NULL),
+ *      dW = d_out^T x, db = column sums of d_out. */
+size_t dn_linear_workspace_bytes(const dn_mesh_batch_t* mb, int C_in, int C_out);
+int dn_linear_fwd_f32(const dn_mesh_batch_t* mb, const float* x, int C_in, const float* W, const float* b, int C_out,
+                      int relu, const uint8_t* mask, float* out, void* stream);
+int dn_linear_bwd_f32(const dn_mesh_batch_t* mb, const float* d_out, const float* x, const float* W, int C_in, int C_out,
+                      float* d_x, float* dW, float* db, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- DiffusionNetBlock.forward (layers.py:200-241) and its backward, fused orchestration.
+ *      saved = NULL runs inference (intermediates live in ws). */
+size_t dn_block_fwd_workspace_bytes(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int with_saved);
+size_t dn_block_bwd_workspace_bytes(const dn_mesh_batch_t* mb, const dn_block_params_t* p);
+int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, const float* x, float* out,
+                     const dn_block_saved_t* saved, void* ws, size_t ws_bytes, void* stream);
+int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, const float* x,
+                     const dn_block_saved_t* saved, const float* d_out, const dn_block_grads_t* grads,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* ---- output remaps (layers.py:379-397).
+ *      csr_mean: out[i] = (sum_{j in row i} x[col[j]]) / div  -- faces (div=3) / edges (div=2) gather-mean, and with the
+ *      transposed pattern its gradient.  mass_mean: out[m] = sum_v mass*x / sum_v mass per mesh (global_mean). */
+int dn_csr_mean_f32(const int32_t* rowptr, const int32_t* col, int n_rows, const float* x, int C, float div,
+                    float* out, void* stream);
+int dn_mass_mean_fwd_f32(const dn_mesh_batch_t* mb, const float* x, int C, float* out, float* mass_sum, void* stream);
+int dn_mass_mean_bwd_f32(const dn_mesh_batch_t* mb, const float* mass_sum, const float* d_out, int C, float* d_x,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFNET_HIP_H */
