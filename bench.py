@@ -1,0 +1,236 @@
+#!/usr/bin/env python
+"""bench.py -- DiffusionNet training-step throughput on MI355X (BASELINE.json metric).
+
+One "step" = forward + NLL loss + backward (+ RCCL gradient all-reduce for N>1) + Adam update over
+one ragged batch of synthetic meshes per GPU (weak scaling: every rank owns its own batch).
+Workload (config.workload): BASELINE configs[1] shape (human-segmentation net: C_in=3, C_out=8,
+C_width=128, K=128, N_block=4, per-face outputs, dropout on) at the north-star size
+(>=10k-vertex meshes, batch of meshes).
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement) with two extra objects:
+  roofline     -- dominant kernel family, algorithmic flops (or bytes) / hipEvent-measured duration
+  cpu_baseline -- the CPU oracle (torch-CPU restatement of the reference) on a bounded sample
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "diffusion-net_amd"))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: exact-f32 MFMA = f32 vector peak
+PEAK_HBM_GBPS = 8000.0            # HBM3E spec (6.29 TB/s measured copy ceiling)
+
+
+def mesh_sizes(n_meshes, v_mean, rank):
+    # ragged but deterministic: +-10 % around v_mean
+    g = torch.Generator().manual_seed(1234 + rank)
+    return [int(v_mean * (0.9 + 0.2 * torch.rand(1, generator=g).item())) for _ in range(n_meshes)]
+
+
+def build_batch(sizes, K, device, seed0):
+    from diffusion_net import synthetic
+    from diffusion_net.batch import GatherPattern, MeshBatch
+    meshes = [synthetic.make_mesh_operators(v, K, seed=seed0 + i) for i, v in enumerate(sizes)]
+    mb = MeshBatch.from_operators([m["mass"] for m in meshes], [m["evals"] for m in meshes],
+                                  [m["evecs"] for m in meshes], [m["gradX"] for m in meshes],
+                                  [m["gradY"] for m in meshes], device=device)
+    offs, faces = 0, []
+    for m, v in zip(meshes, sizes):
+        faces.append(m["faces"] + offs)
+        offs += v
+    faces = torch.cat(faces, 0).to(device)
+    gather = GatherPattern(faces, sum(sizes))
+    x = torch.cat([m["verts"] for m in meshes], 0).to(device)
+    return meshes, mb, gather, x
+
+
+def cpu_baseline(args, C_out):
+    """CPU oracle (kind 'port'): fwd + loss + bwd + Adam on ONE mesh of the workload per step."""
+    import diffusion_net
+    from diffusion_net import synthetic
+    from oracle import diffusionnet_oracle as orc
+    torch.manual_seed(0)
+    V = args.verts
+    m = synthetic.make_mesh_operators(V, args.keig, seed=99)
+    model = diffusion_net.layers.DiffusionNet(3, C_out, C_width=args.cwidth, N_block=args.blocks, outputs_at="faces")
+    params = {k: v.clone().requires_grad_(True) for k, v in synthetic.randomize_times(model.state_dict(), seed=0).items()}
+    opt = torch.optim.Adam(list(params.values()), lr=1e-3)
+    labels = torch.randint(0, C_out, (m["faces"].shape[0],))
+    n_mask = 2
+
+    def step():
+        opt.zero_grad()
+        masks = [[torch.bernoulli(torch.full((V, args.cwidth), 0.5)) for _ in range(n_mask)] for _ in range(args.blocks)]
+        p = dict(params)
+        for k in p:
+            if k.endswith("diffusion_time"):
+                p[k] = orc.clamp_time(p[k])
+        out = orc.net_forward(p, m["verts"], m["mass"], m["evals"], m["evecs"], m["gradX"], m["gradY"], faces=m["faces"],
+                              outputs_at="faces", last_activation=lambda t: F.log_softmax(t, dim=-1), keep_masks=masks)
+        F.nll_loss(out, labels).backward()
+        opt.step()
+
+    for _ in range(2):
+        step()
+    t0, n = time.perf_counter(), 0
+    while n < 40 and (time.perf_counter() - t0 < 15.0 or n < 3):
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": V / dt, "unit": "vertices/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} train steps of one {V}-vertex mesh (same net/config, torch-CPU oracle, fp32)",
+            "ms_per_step": dt * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--meshes", type=int, default=16, help="meshes per GPU per step")
+    ap.add_argument("--verts", type=int, default=10000, help="mean vertices per mesh")
+    ap.add_argument("--cwidth", type=int, default=128)
+    ap.add_argument("--keig", type=int, default=128)
+    ap.add_argument("--blocks", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU path)"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import diffusion_net
+    from diffusion_net import _hip, synthetic
+    from diffusion_net.dist import FlatParams
+    lib = _hip.lib()
+
+    C_in, C_out = 3, 8
+    torch.manual_seed(0)                       # identical replicas on every rank
+    model = diffusion_net.layers.DiffusionNet(C_in, C_out, C_width=args.cwidth, N_block=args.blocks,
+                                              outputs_at="faces", dropout=True)
+    model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=0))
+    model.to(device).train()
+    flat = FlatParams(model)
+    opt = torch.optim.Adam([flat.master], lr=1e-3)
+
+    sizes = mesh_sizes(args.meshes, args.verts, rank)
+    meshes, mb, gather, x = build_batch(sizes, args.keig, device, seed0=1000 * rank)
+    labels = torch.randint(0, C_out, (gather.n_out,), device=device)
+    v_step = sum(sizes)
+
+    def step():
+        flat.zero_grad()
+        out = model.forward_packed(x, mb, gather)
+        loss = F.nll_loss(F.log_softmax(out, dim=-1), labels)
+        loss.backward()
+        flat.all_reduce_mean()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    lib.dn_prof_reset()
+    lib.dn_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    lib.dn_prof_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        vt = torch.tensor([v_step], device=device, dtype=torch.float64)
+        dist.all_reduce(vt, op=dist.ReduceOp.SUM)
+        v_all = float(vt.item())
+    else:
+        v_all = float(v_step)
+    assert torch.isfinite(loss).item()
+
+    # ---- per-kernel-family timing from the library's hipEvent brackets (this rank, timed region)
+    fam = []
+    buf = (ctypes.c_double * 4)()
+    for k in range(5):
+        lib.dn_prof_read(k, buf)
+        ms, n, fl, by = buf[0], buf[1], buf[2], buf[3]
+        if n > 0:
+            fam.append({"kernel": lib.dn_prof_kind_name(k).decode(), "ms_total": ms, "launches": int(n),
+                        "avg_us": 1e3 * ms / n, "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                        "gbps": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                        "flops_per_launch": fl / n, "bytes_per_launch": by / n})
+    dom = max(fam, key=lambda f: f["ms_total"])
+    if dom["kernel"].startswith("spmm"):
+        roof = {"bound": "hbm", "achieved": dom["gbps"], "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                "frac": dom["gbps"] / PEAK_HBM_GBPS, "traffic": None}
+    else:
+        roof = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                "frac": dom["tflops"] / PEAK_MFMA_F32_TFLOPS, "traffic": None}
+    roof.update({"kernel": dom["kernel"], "avg_launch_us": dom["avg_us"], "launches": dom["launches"],
+                 "share_of_kernel_time": dom["ms_total"] / sum(f["ms_total"] for f in fam)})
+
+    # ---- diffusion block (to_basis + exp(-lambda t) + from_basis) on the same batch: HBM GB/s of BASELINE.json
+    from diffusion_net import ops
+    Cw, K = args.cwidth, args.keig
+    xb = torch.randn(v_step, Cw, device=device)
+    tt = torch.full((Cw,), 0.05, device=device)
+    with torch.no_grad():
+        for _ in range(3):
+            ops.DiffusionFn.apply(xb, tt, mb)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        reps = 20
+        for _ in range(reps):
+            ops.DiffusionFn.apply(xb, tt, mb)
+        e1.record()
+        torch.cuda.synchronize()
+    t_diff = e0.elapsed_time(e1) * 1e-3 / reps
+    bytes_diff = sum(4.0 * (v * (2 * Cw + 2 * K + 1) + 2 * K * Cw + K + Cw) for v in sizes)
+    flops_diff = sum(4.0 * v * K * Cw for v in sizes)
+    diff = {"ms": t_diff * 1e3, "gbps": bytes_diff / t_diff / 1e9, "frac_hbm_8TBs": bytes_diff / t_diff / 1e9 / PEAK_HBM_GBPS,
+            "tflops": flops_diff / t_diff / 1e12, "frac_mfma_f32": flops_diff / t_diff / 1e12 / PEAK_MFMA_F32_TFLOPS,
+            "note": "fp32 exact: arithmetic intensity KC/(2(K+C)) = %.0f flop/B vs ridge 19.7 -> MFMA-bound" % (K * Cw / (2.0 * (K + Cw)))}
+
+    if rank == 0:
+        res = {
+            "metric": "vertices/sec fwd+bwd, C_width=%d K=%d" % (Cw, K),
+            "value": v_all * args.steps / elapsed, "unit": "vertices/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "train step (fwd+NLL+bwd+Adam%s) on a ragged batch of %d meshes x ~%d vertices per GPU, "
+                                   "DiffusionNet C_in=3 C_out=8 C_width=%d K=%d N_block=%d outputs_at=faces dropout=on"
+                                   % ("+RCCL all-reduce" if world > 1 else "", args.meshes, args.verts, Cw, K, args.blocks),
+                       "meshes_per_gpu": args.meshes, "verts_per_gpu_step": v_step, "parallelism": "dp%d" % world},
+            "roofline": roof, "kernel_families": fam, "diffusion_block": diff,
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args, C_out)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -31,6 +31,7 @@ RgArgs rg_new(const dn_mesh_batch_t* mb) {
     RgArgs g;
     memset(&g, 0, sizeof(g));
     g.tiles = T(mb->tiles);
+    g.acct_rows = mb->v_total;
     for (int o = 0; o < 2; ++o) for (int s = 0; s < 3; ++s) g.bsign[o][s] = 1.f;
     g.scale = 1.f;
     return g;
@@ -51,6 +52,7 @@ TnArgs tn_new(const dn_mesh_batch_t* mb) {
     TnArgs g;
     memset(&g, 0, sizeof(g));
     g.chunks = T(mb->chunks);
+    g.acct_rows = mb->v_total;
     return g;
 }
 void tn_a(TnArgs& g, const float* p, const float* q, int w, int ld) {
@@ -89,13 +91,13 @@ int from_basis(const dn_mesh_batch_t* mb, const float* spec, int C, float* out, 
 int grad_apply_fwd(const dn_mesh_batch_t* mb, const float* x, int C, float* gx, float* gy, hipStream_t st) {
     SpArgs s; memset(&s, 0, sizeof(s));
     s.rowptr = mb->g_rowptr; s.col = mb->g_col; s.va = mb->g_vx; s.vb = mb->g_vy;
-    s.x1 = x; s.o1 = gx; s.o2 = gy; s.nrows = mb->v_total; s.C = C; s.ldx = C; s.ldo = C; s.mode = DN_SP_FWD2; s.div = 1.f;
+    s.x1 = x; s.o1 = gx; s.o2 = gy; s.nrows = mb->v_total; s.C = C; s.ldx = C; s.ldo = C; s.mode = DN_SP_FWD2; s.div = 1.f; s.acct_nnz = mb->g_nnz;
     return dn_launch_spmm(s, st);
 }
 int grad_apply_bwd(const dn_mesh_batch_t* mb, const float* dgx, const float* dgy, const float* add, int C, float* dx, hipStream_t st) {
     SpArgs s; memset(&s, 0, sizeof(s));
     s.rowptr = mb->gt_rowptr; s.col = mb->gt_col; s.va = mb->gt_vx; s.vb = mb->gt_vy;
-    s.x1 = dgx; s.x2 = dgy; s.add = add; s.o1 = dx; s.nrows = mb->v_total; s.C = C; s.ldx = C; s.ldo = C; s.mode = DN_SP_BWD2; s.div = 1.f;
+    s.x1 = dgx; s.x2 = dgy; s.add = add; s.o1 = dx; s.nrows = mb->v_total; s.C = C; s.ldx = C; s.ldo = C; s.mode = DN_SP_BWD2; s.div = 1.f; s.acct_nnz = mb->g_nnz;
     return dn_launch_spmm(s, st);
 }
 int gradfeat_fwd(const dn_mesh_batch_t* mb, const float* gx, const float* gy, const float* A_re, const float* A_im, int C,
@@ -209,7 +211,84 @@ bool block_params_ok(const dn_block_params_t* p) {
 }
 }  // namespace
 
+// ---- opt-in per-kernel timing --------------------------------------------------------------
+#ifndef DN_EMULATE
+#include <vector>
+namespace {
+struct ProfRec { hipEvent_t e0, e1; int kind; };
+struct ProfState {
+    bool on = false;
+    std::vector<ProfRec> pool;      // reused event pairs
+    size_t used = 0;
+    double ms[DN_K_COUNT] = {0}, flops[DN_K_COUNT] = {0}, bytes[DN_K_COUNT] = {0};
+    long long launches[DN_K_COUNT] = {0};
+    bool pending = false;
+} g_prof;
+void prof_drain() {
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        float t = 0.f;
+        if (hipEventSynchronize(g_prof.pool[i].e1) == hipSuccess &&
+            hipEventElapsedTime(&t, g_prof.pool[i].e0, g_prof.pool[i].e1) == hipSuccess)
+            g_prof.ms[g_prof.pool[i].kind] += t;
+    }
+    g_prof.used = 0;
+}
+}  // namespace
+void dn_prof_begin(int kind, hipStream_t stream) {
+    if (!g_prof.on) return;
+    if (g_prof.used == g_prof.pool.size()) {
+        if (g_prof.pool.size() >= 65536) prof_drain();
+        else {
+            ProfRec r; r.kind = kind;
+            if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) { g_prof.on = false; return; }
+            g_prof.pool.push_back(r);
+        }
+    }
+    g_prof.pool[g_prof.used].kind = kind;
+    hipEventRecord(g_prof.pool[g_prof.used].e0, stream);
+    g_prof.pending = true;
+}
+void dn_prof_end(int kind, hipStream_t stream, double flops, double bytes) {
+    if (!g_prof.on || !g_prof.pending) return;
+    hipEventRecord(g_prof.pool[g_prof.used].e1, stream);
+    g_prof.used++;
+    g_prof.pending = false;
+    g_prof.launches[kind]++;
+    g_prof.flops[kind] += flops;
+    g_prof.bytes[kind] += bytes;
+}
+#endif
+
 extern "C" {
+
+int dn_prof_enable(int on) {
+#ifndef DN_EMULATE
+    g_prof.on = on != 0;
+#endif
+    return 0;
+}
+int dn_prof_reset(void) {
+#ifndef DN_EMULATE
+    prof_drain();
+    for (int k = 0; k < DN_K_COUNT; ++k) { g_prof.ms[k] = g_prof.flops[k] = g_prof.bytes[k] = 0; g_prof.launches[k] = 0; }
+#endif
+    return 0;
+}
+/* out[0..3] = {milliseconds, launches, algorithmic flops, algorithmic bytes} summed since the last reset */
+int dn_prof_read(int kind, double* out) {
+    if (kind < 0 || kind >= DN_K_COUNT || !out) return DN_ERR_INVALID;
+#ifndef DN_EMULATE
+    prof_drain();
+    out[0] = g_prof.ms[kind]; out[1] = (double)g_prof.launches[kind]; out[2] = g_prof.flops[kind]; out[3] = g_prof.bytes[kind];
+#else
+    out[0] = out[1] = out[2] = out[3] = 0;
+#endif
+    return 0;
+}
+const char* dn_prof_kind_name(int kind) {
+    static const char* names[DN_K_COUNT] = {"rowgemm_kernel<*,1>", "rowgemm_kernel<*,2>", "tngemm_kernel", "spmm_kernel", "small"};
+    return (kind >= 0 && kind < DN_K_COUNT) ? names[kind] : "";
+}
 
 int dn_version(void) { return 100; }
 int dn_tile_rows(void) { return DN_TM; }

@@ -89,6 +89,7 @@ struct RgArgs {
     const float* rowv;
     const uint8_t* mask;
     float scale;
+    int acct_rows;         // host-side accounting only (rows covered by the launch)
 };
 enum {
     DN_EPI_STORE = 0,        // o0 = acc (+bias)
@@ -118,6 +119,7 @@ struct TnArgs {
     float* partial;             // [nchunks][M][N]
     float* colsum;              // optional [nchunks][M]: column sums of A over the chunk
     int aligned;                // widths % 4 == 0, ld % 4 == 0, 16-byte aligned pointers
+    int acct_rows;              // host-side accounting only
 };
 
 // ---------------------------------------------------------------------------------------
@@ -135,6 +137,7 @@ struct SpArgs {
     float* o2;
     int nrows, C, ldx, ldo, mode;
     float div;         // DN_SP_ONE: result divided by this (exact mean of n gathered rows)
+    long long acct_nnz; // host-side accounting only
 };
 enum { DN_SP_FWD2 = 0, DN_SP_BWD2 = 1, DN_SP_ONE = 2 };
 
@@ -156,3 +159,17 @@ int dn_launch_dtanh(const float* dg, const float* g, float* out, long long n, hi
 // launchers (host), defined in the .hip files; all return hipError_t as int
 int dn_launch_rowgemm(const RgArgs& g, int ntiles, int nout, hipStream_t stream);
 int dn_launch_tngemm(const TnArgs& g, int nchunks, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------
+// opt-in per-kernel timing (bench.py's roofline leg): when enabled, every launch is bracketed by
+// hipEvents on its own stream and summed per kernel family.  Off by default; compiled out of the
+// emulator build.
+// ---------------------------------------------------------------------------------------
+enum { DN_K_ROWGEMM = 0, DN_K_ROWGEMM_DUAL = 1, DN_K_TNGEMM = 2, DN_K_SPMM = 3, DN_K_SMALL = 4, DN_K_COUNT = 5 };
+#ifdef DN_EMULATE
+static inline void dn_prof_begin(int, hipStream_t) {}
+static inline void dn_prof_end(int, hipStream_t, double, double) {}
+#else
+void dn_prof_begin(int kind, hipStream_t stream);
+void dn_prof_end(int kind, hipStream_t stream, double flops, double bytes);
+#endif

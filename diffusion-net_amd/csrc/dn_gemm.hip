@@ -277,14 +277,25 @@ static int rg_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
 
 int dn_launch_rowgemm(const RgArgs& g, int ntiles, int nout, hipStream_t stream) {
     if (ntiles <= 0 || g.N <= 0) return 0;
+    int ktot = 0;
+    for (int s = 0; s < g.nseg; ++s) ktot += g.a[s].w;
+    const double rows = g.acct_rows;
+    const double flops = 2.0 * rows * ktot * g.N * nout;
+    const double bytes = 4.0 * (rows * ktot + rows * (double)g.N * nout + (double)ktot * g.N * nout);
+    const int kind = nout == 1 ? DN_K_ROWGEMM : DN_K_ROWGEMM_DUAL;
+    dn_prof_begin(kind, stream);
+    int err;
     if (nout == 1) {
-        if (g.N <= 32) return rg_launch<32, 4, 1, 1>(g, ntiles, stream);
-        if (g.N <= 64) return rg_launch<64, 2, 2, 1>(g, ntiles, stream);
-        return rg_launch<128, 2, 2, 1>(g, ntiles, stream);
+        if (g.N <= 32) err = rg_launch<32, 4, 1, 1>(g, ntiles, stream);
+        else if (g.N <= 64) err = rg_launch<64, 2, 2, 1>(g, ntiles, stream);
+        else err = rg_launch<128, 2, 2, 1>(g, ntiles, stream);
+    } else {
+        if (g.N <= 32) err = rg_launch<32, 4, 1, 2>(g, ntiles, stream);
+        else if (g.N <= 64) err = rg_launch<64, 2, 2, 2>(g, ntiles, stream);
+        else err = rg_launch<128, 2, 4, 2>(g, ntiles, stream);
     }
-    if (g.N <= 32) return rg_launch<32, 4, 1, 2>(g, ntiles, stream);
-    if (g.N <= 64) return rg_launch<64, 2, 2, 2>(g, ntiles, stream);
-    return rg_launch<128, 2, 4, 2>(g, ntiles, stream);
+    dn_prof_end(kind, stream, flops, bytes);
+    return err;
 }
 
 // =======================================================================================
@@ -454,6 +465,10 @@ int dn_launch_tngemm(const TnArgs& g, int nchunks, hipStream_t stream) {
     if (nchunks <= 0 || g.M <= 0 || g.N <= 0) return 0;
     const size_t smem = (size_t)2 * DN_KB * DN_TO * sizeof(float);
     dim3 grid(nchunks, (g.N + DN_TO - 1) / DN_TO, (g.M + DN_TO - 1) / DN_TO);
+    const double rows = g.acct_rows;
+    dn_prof_begin(DN_K_TNGEMM, stream);
     DN_LAUNCH(tngemm_kernel, grid, dim3(256, 1, 1), smem, stream, g);
+    dn_prof_end(DN_K_TNGEMM, stream, 2.0 * rows * g.M * g.N,
+                4.0 * (rows * (g.M + g.N) + (double)nchunks * g.M * g.N));
     return (int)hipGetLastError();
 }

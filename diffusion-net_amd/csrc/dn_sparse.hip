@@ -88,10 +88,17 @@ int dn_launch_spmm(const SpArgs& s, hipStream_t stream) {
     if (tpr > 256) tpr = 256;
     const int rpb = 256 / tpr;
     dim3 grid((s.nrows + rpb - 1) / rpb, 1, 1);
+    dn_prof_begin(DN_K_SPMM, stream);
     if (vec) {
         DN_LAUNCH(spmm_kernel<4>, grid, dim3(256, 1, 1), 0, stream, s, tpr);
     } else {
         DN_LAUNCH(spmm_kernel<1>, grid, dim3(256, 1, 1), 0, stream, s, tpr);
+    }
+    {
+        const double nnz = (double)s.acct_nnz, nout = s.mode == DN_SP_FWD2 ? 2.0 : 1.0, nin = s.mode == DN_SP_BWD2 ? 2.0 : 1.0;
+        dn_prof_end(DN_K_SPMM, stream, 2.0 * nnz * s.C * (s.mode == DN_SP_ONE ? 1.0 : 2.0),
+                    4.0 * ((double)s.nrows + 1 + nnz * (s.mode == DN_SP_ONE ? 1.0 : 3.0) +
+                           (double)s.nrows * s.C * (nin + nout + (s.add ? 1.0 : 0.0))));
     }
     return (int)hipGetLastError();
 }

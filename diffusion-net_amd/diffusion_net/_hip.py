@@ -24,7 +24,7 @@ _vp = C.c_void_p
 class MeshBatchStruct(C.Structure):
     _fields_ = [
         ("n_mesh", C.c_int32), ("v_total", C.c_int32), ("k_eig", C.c_int32),
-        ("n_tiles", C.c_int32), ("n_chunks", C.c_int32), ("_pad", C.c_int32),
+        ("n_tiles", C.c_int32), ("n_chunks", C.c_int32), ("g_nnz", C.c_int32),
         ("tiles", _vp), ("chunks", _vp), ("mesh_chunk_off", _vp), ("mesh_rows", _vp),
         ("mass", _vp), ("evals", _vp), ("evecs", _vp),
         ("g_rowptr", _vp), ("g_col", _vp), ("g_vx", _vp), ("g_vy", _vp),
@@ -60,6 +60,10 @@ _SIGNATURES = {
     # name: (restype, argtypes)
     "dn_version": (C.c_int, []),
     "dn_tile_rows": (C.c_int, []),
+    "dn_prof_enable": (C.c_int, [C.c_int]),
+    "dn_prof_reset": (C.c_int, []),
+    "dn_prof_read": (C.c_int, [C.c_int, _P(C.c_double)]),
+    "dn_prof_kind_name": (C.c_char_p, [C.c_int]),
     "dn_to_basis_workspace_bytes": (C.c_size_t, [_P(MeshBatchStruct), C.c_int]),
     "dn_to_basis_f32": (C.c_int, [_P(MeshBatchStruct), _vp, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp]),
     "dn_from_basis_f32": (C.c_int, [_P(MeshBatchStruct), _vp, C.c_int, C.c_int, _vp, _vp]),

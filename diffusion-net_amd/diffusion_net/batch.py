@@ -144,6 +144,7 @@ class MeshBatch:
         s = _hip.MeshBatchStruct()
         s.n_mesh, s.v_total, s.k_eig = len(self.sizes), vt, self.k_eig
         s.n_tiles, s.n_chunks = int(self.tiles.shape[0]), int(self.chunks.shape[0])
+        s.g_nnz = int(self.g_col.shape[0]) if self.g_col is not None else 0
         for name in ("tiles", "chunks", "mesh_chunk_off", "mesh_rows", "mass", "evals", "evecs",
                      "g_rowptr", "g_col", "g_vx", "g_vy", "gt_rowptr", "gt_col", "gt_vx", "gt_vy"):
             setattr(s, name, _hip.ptr(getattr(self, name)))

@@ -72,9 +72,10 @@ class LearnedTimeDiffusion(nn.Module):
         self.method = method
 
     def clamp_time_(self):
-        # same side effect as layers.py:48-49: the Parameter's data is re-bound to its clamp
+        # same observable side effect as layers.py:48-49 (the Parameter holds its clamp afterwards, so the
+        # optimizer sees the clamped value); done in place so flat parameter buckets keep their storage
         with torch.no_grad():
-            self.diffusion_time.data = torch.clamp(self.diffusion_time, min=_MIN_TIME)
+            self.diffusion_time.clamp_(min=_MIN_TIME)
 
     def forward(self, x, L, mass, evals, evecs):
         self.clamp_time_()

@@ -37,7 +37,7 @@ typedef struct { int32_t row0, nrows, mesh, aux; } dn_tile_t;
 /* Per-batch geometry: what geometry.get_operators() returns per mesh (geometry.py:426-570),
  * packed for the device.  gradX/gradY share one CSR pattern (geometry.py:381-382). */
 typedef struct dn_mesh_batch {
-    int32_t n_mesh, v_total, k_eig, n_tiles, n_chunks, _pad;
+    int32_t n_mesh, v_total, k_eig, n_tiles, n_chunks, g_nnz;  /* g_nnz: non-zeros of the gradient pattern */
     const dn_tile_t* tiles;          /* [n_tiles]  row tiles of <= dn_tile_rows() rows              */
     const dn_tile_t* chunks;         /* [n_chunks] split-V chunks, grouped by mesh                   */
     const int32_t*   mesh_chunk_off; /* [n_mesh+1] chunk range of every mesh                         */
@@ -80,6 +80,14 @@ typedef struct dn_block_grads {
 
 int dn_version(void);
 int dn_tile_rows(void);      /* rows per entry of dn_mesh_batch_t.tiles (128) */
+
+/* ---- opt-in per-kernel timing for benchmarks (no reference counterpart; the one piece of mutable global
+ *      state, off by default): every launch is bracketed by hipEvents on its stream and summed per kernel
+ *      family kind in [0, 5).  read: out[0..3] = {ms, launches, algorithmic flops, algorithmic bytes}. */
+int dn_prof_enable(int on);
+int dn_prof_reset(void);
+int dn_prof_read(int kind, double* out);
+const char* dn_prof_kind_name(int kind);
 
 /* ---- geometry.to_basis (geometry.py:572-583): spec[m] = evecs_m^T (x_m * mass_m); use_mass=0 drops the mass
  *      (the autograd transpose of from_basis).  spec: [n_mesh, k_eig, C]. */

@@ -1,0 +1,261 @@
+"""Parity checks shared by the CPU-emulator tier (tests/test_emu_parity.py) and the GPU tier
+(tests/test_gpu_parity.py).  Every function takes the torch device the HIP path should run on and
+compares with the CPU oracle (oracle/diffusionnet_oracle.py) on the same seeded inputs.
+
+Tolerances (fp32, north_star: 1e-5 relative):
+  * a single op / forward output: rel-max <= 1e-5 against the fp32 oracle,
+  * gradients: rel-L2 <= 2e-4 (the reference's own fp32-vs-fp64 gradient floor is 1e-4..7e-4,
+    SURVEY.md section 7).
+"""
+import torch
+
+import helpers
+import diffusion_net
+from diffusion_net import ops, synthetic
+from diffusion_net.batch import GatherPattern, MeshBatch
+from oracle import diffusionnet_oracle as orc
+
+FWD_TOL = 1e-5
+GRAD_TOL = 2e-4
+
+
+def _stack_sparse(items):
+    return torch.stack(items, 0).coalesce()
+
+
+# ------------------------------------------------------------------------------------------
+# whole net vs golden vectors from the reference
+# ------------------------------------------------------------------------------------------
+def build_model(meta, params, masks, device):
+    model = diffusion_net.layers.DiffusionNet(last_activation=helpers.activation_of(meta), **meta["ctor"])
+    model.load_state_dict(params, strict=True)
+    model.train(meta["train"])
+    model.to(device)
+    if masks:
+        per = len(masks) // len(model.blocks)
+        for bi, blk in enumerate(model.blocks):
+            blk.mask_provider = (lambda b: (lambda i, shape, dev: masks[b * per + i - 1].reshape(shape)))(bi)
+    return model
+
+
+def run_golden(name, device):
+    meta, params, inputs, masks, expect = helpers.load_golden(name)
+    model = build_model(meta, params, masks, device)
+    dev = lambda t: None if t is None else t.to(device)
+    x = inputs["x_in"].to(device).requires_grad_(True)
+    gX, gY = inputs["gradX"], inputs["gradY"]
+    if isinstance(gX, list):
+        gX, gY = _stack_sparse(gX), _stack_sparse(gY)
+    out = model(x, dev(inputs["mass"]), L=None, evals=dev(inputs["evals"]), evecs=dev(inputs["evecs"]),
+                gradX=dev(gX), gradY=dev(gY), edges=dev(inputs["edges"]), faces=dev(inputs["faces"]))
+    assert out.shape == expect["out"].shape
+    err = helpers.rel_max(out.detach().cpu(), expect["out"])
+    assert err < FWD_TOL, (name, "forward", err)
+    (out * expect["loss_w"].to(device)).sum().backward()
+    errs = {"x_in": helpers.rel_l2(x.grad.cpu(), expect["grads"]["x_in"])}
+    for k, p in model.named_parameters():
+        errs[k] = helpers.rel_l2(p.grad.cpu(), expect["grads"][k])
+    bad = {k: v for k, v in errs.items() if not v < GRAD_TOL}
+    assert not bad, (name, bad)
+    # the clamp side effect on the Parameter (layers.py:48-49)
+    for k, p in model.named_parameters():
+        if k.endswith("diffusion_time"):
+            assert float(p.min()) >= 1e-8
+    return err, max(errs.values())
+
+
+# ------------------------------------------------------------------------------------------
+# ragged batch (different vertex counts) vs per-mesh oracle
+# ------------------------------------------------------------------------------------------
+def make_ragged(sizes, K, C_in, seed=0):
+    meshes = [synthetic.make_mesh_operators(v, K, seed=seed + i) for i, v in enumerate(sizes)]
+    g = torch.Generator().manual_seed(seed)
+    feats = [torch.randn(v, C_in, generator=g) for v in sizes]
+    return meshes, feats
+
+
+def pack(meshes, device, with_grad=True, chunk_rows=None):
+    return MeshBatch.from_operators(
+        [m["mass"] for m in meshes], [m["evals"] for m in meshes], [m["evecs"] for m in meshes],
+        [m["gradX"] for m in meshes] if with_grad else None, [m["gradY"] for m in meshes] if with_grad else None,
+        device=device, chunk_rows=chunk_rows)
+
+
+def run_ragged_net(device, sizes=(130, 257, 64), K=24, C=32, C_in=3, C_out=5, N_block=2, outputs_at="vertices",
+                   chunk_rows=None, seed=3):
+    torch.manual_seed(seed)
+    model = diffusion_net.layers.DiffusionNet(C_in, C_out, C_width=C, N_block=N_block, outputs_at=outputs_at, dropout=False)
+    sd = synthetic.randomize_times(model.state_dict(), seed=seed)
+    model.load_state_dict(sd)
+    params = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(device).eval()
+    meshes, feats = make_ragged(sizes, K, C_in, seed)
+    mb = pack(meshes, device, chunk_rows=chunk_rows)
+    x = torch.cat(feats, 0).to(device).requires_grad_(True)
+    gather = None
+    if outputs_at == "faces":
+        offs, rows = 0, []
+        for m, v in zip(meshes, sizes):
+            rows.append(m["faces"] + offs)
+            offs += v
+        gather = GatherPattern(torch.cat(rows, 0).to(device), sum(sizes))
+    out = model.forward_packed(x, mb, gather)
+    wgen = torch.Generator().manual_seed(seed + 1)
+    w = torch.randn(out.shape, generator=wgen)
+    (out * w.to(device)).sum().backward()
+
+    # oracle: one mesh at a time, gradients summed
+    ref_out, ref_grads, off_out = [], None, 0
+    for m, f in zip(meshes, feats):
+        n_out = {"vertices": f.shape[0], "faces": m["faces"].shape[0], "global_mean": 1}[outputs_at]
+        wi = w[off_out:off_out + n_out]
+        if outputs_at == "global_mean":
+            wi = wi[0]
+        off_out += n_out
+        o, g = orc.net_forward_backward(
+            params, dict(x_in=f, mass=m["mass"], evals=m["evals"], evecs=m["evecs"], gradX=m["gradX"], gradY=m["gradY"],
+                         faces=m["faces"]), outputs_at=outputs_at, loss_weights=wi)
+        ref_out.append(o.reshape(n_out, -1))
+        if ref_grads is None:
+            ref_grads = {k: v.clone() for k, v in g.items() if k != "x_in"}
+            ref_grads["x_in"] = [g["x_in"]]
+        else:
+            for k, v in g.items():
+                if k == "x_in":
+                    ref_grads["x_in"].append(v)
+                else:
+                    ref_grads[k] += v
+    ref_out = torch.cat(ref_out, 0)
+    assert helpers.rel_max(out.detach().cpu(), ref_out) < FWD_TOL
+    assert helpers.rel_l2(x.grad.cpu(), torch.cat(ref_grads["x_in"], 0)) < GRAD_TOL
+    for k, p in model.named_parameters():
+        e = helpers.rel_l2(p.grad.cpu(), ref_grads[k])
+        assert e < GRAD_TOL, (k, e)
+
+
+# ------------------------------------------------------------------------------------------
+# single ops vs oracle (+ autograd)
+# ------------------------------------------------------------------------------------------
+def run_ops(device, sizes=(200, 77), K=20, C=32, seed=5, chunk_rows=None):
+    meshes, _ = make_ragged(sizes, K, 3, seed)
+    mb = pack(meshes, device, chunk_rows=chunk_rows)
+    g = torch.Generator().manual_seed(seed)
+    vt = sum(sizes)
+    x = torch.randn(vt, C, generator=g)
+    time = 0.01 + 0.3 * torch.rand(C, generator=g)
+    offs = [0]
+    for v in sizes:
+        offs.append(offs[-1] + v)
+    per = lambda t: [t[offs[i]:offs[i + 1]] for i in range(len(sizes))]
+
+    # --- to_basis / from_basis
+    spec = ops.ToBasisFn.apply(x.to(device), mb).cpu()
+    for i, m in enumerate(meshes):
+        ref = orc.to_basis(per(x)[i][None], m["evecs"][None], m["mass"][None])[0]
+        assert helpers.rel_max(spec[i], ref) < FWD_TOL
+    back = ops.FromBasisFn.apply(spec.to(device), mb).cpu()
+    for i, m in enumerate(meshes):
+        ref = orc.from_basis(spec[i][None], m["evecs"][None])[0]
+        assert helpers.rel_max(per(back)[i], ref) < FWD_TOL
+
+    # --- diffusion fwd/bwd
+    xd_in = x.clone().to(device).requires_grad_(True)
+    t_in = time.clone().to(device).requires_grad_(True)
+    xd = ops.DiffusionFn.apply(xd_in, t_in, mb)
+    w = torch.randn(vt, C, generator=g)
+    (xd * w.to(device)).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    tr = time.clone().requires_grad_(True)
+    ref = torch.cat([orc.spectral_diffusion(per(xr)[i][None], m["mass"][None], m["evals"][None], m["evecs"][None], tr)[0]
+                     for i, m in enumerate(meshes)], 0)
+    (ref * w).sum().backward()
+    assert helpers.rel_max(xd.detach().cpu(), ref.detach()) < FWD_TOL
+    assert helpers.rel_l2(xd_in.grad.cpu(), xr.grad) < GRAD_TOL
+    assert helpers.rel_l2(t_in.grad.cpu(), tr.grad) < GRAD_TOL
+
+    # --- gradient apply fwd/bwd
+    xa = x.clone().to(device).requires_grad_(True)
+    gx, gy = ops.GradApplyFn.apply(xa, mb)
+    w2 = torch.randn(vt, C, generator=g)
+    (gx * w.to(device) + gy * w2.to(device)).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    rgx = torch.cat([torch.mm(m["gradX"], per(xr)[i]) for i, m in enumerate(meshes)], 0)
+    rgy = torch.cat([torch.mm(m["gradY"], per(xr)[i]) for i, m in enumerate(meshes)], 0)
+    (rgx * w + rgy * w2).sum().backward()
+    assert helpers.rel_max(gx.detach().cpu(), rgx.detach()) < FWD_TOL
+    assert helpers.rel_max(gy.detach().cpu(), rgy.detach()) < FWD_TOL
+    assert helpers.rel_l2(xa.grad.cpu(), xr.grad) < GRAD_TOL
+
+    # --- gradient features fwd/bwd (with and without rotations)
+    A_re = torch.randn(C, C, generator=g) / C ** 0.5
+    A_im = torch.randn(C, C, generator=g) / C ** 0.5
+    gxs, gys = 0.3 * torch.randn(vt, C, generator=g), 0.3 * torch.randn(vt, C, generator=g)
+    for rot in (True, False):
+        ins = [t.clone().to(device).requires_grad_(True) for t in (gxs, gys, A_re, A_im)]
+        out = ops.GradFeatFn.apply(ins[0], ins[1], ins[2], ins[3] if rot else None, mb)
+        (out * w.to(device)).sum().backward()
+        rin = [t.clone().requires_grad_(True) for t in (gxs, gys, A_re, A_im)]
+        rout = orc.gradient_features(rin[0], rin[1], A_re=rin[2], A_im=rin[3]) if rot else \
+            orc.gradient_features(rin[0], rin[1], A=rin[2])
+        (rout * w).sum().backward()
+        assert helpers.rel_max(out.detach().cpu(), rout.detach()) < FWD_TOL
+        for a, b in zip(ins[:3 + rot], rin[:3 + rot]):
+            assert helpers.rel_l2(a.grad.cpu(), b.grad) < GRAD_TOL
+
+    # --- nn.Linear on rows (odd sizes -> general path)
+    for ci, co in ((3, C), (C, 7), (C, C)):
+        W = torch.randn(co, ci, generator=g) / ci ** 0.5
+        b = torch.randn(co, generator=g)
+        xi = torch.randn(vt, ci, generator=g)
+        ins = [t.clone().to(device).requires_grad_(True) for t in (xi, W, b)]
+        out = ops.LinearFn.apply(ins[0], ins[1], ins[2], mb)
+        wl = torch.randn(vt, co, generator=g)
+        (out * wl.to(device)).sum().backward()
+        rin = [t.clone().requires_grad_(True) for t in (xi, W, b)]
+        rout = rin[0] @ rin[1].T + rin[2]
+        (rout * wl).sum().backward()
+        assert helpers.rel_max(out.detach().cpu(), rout.detach()) < FWD_TOL
+        for a, b_ in zip(ins, rin):
+            assert helpers.rel_l2(a.grad.cpu(), b_.grad) < GRAD_TOL
+
+    # --- mass-weighted mean per mesh
+    xm = x.clone().to(device).requires_grad_(True)
+    out = ops.MassMeanFn.apply(xm, mb)
+    wm = torch.randn(len(sizes), C, generator=g)
+    (out * wm.to(device)).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    rout = torch.stack([(per(xr)[i] * m["mass"][:, None]).sum(0) / m["mass"].sum() for i, m in enumerate(meshes)], 0)
+    (rout * wm).sum().backward()
+    assert helpers.rel_max(out.detach().cpu(), rout.detach()) < FWD_TOL
+    assert helpers.rel_l2(xm.grad.cpu(), xr.grad) < GRAD_TOL
+
+
+def run_mismatched_patterns(device, V=150, K=8, C=32, seed=11):
+    """gradX / gradY with different sparsity patterns -> union pattern with explicit zeros."""
+    m = synthetic.make_mesh_operators(V, K, seed=seed)
+    gx = m["gradX"]
+    idx, val = m["gradY"].indices(), m["gradY"].values()
+    keep = torch.arange(idx.shape[1]) % 5 != 0
+    gy = torch.sparse_coo_tensor(idx[:, keep], val[keep], (V, V)).coalesce()
+    mb = MeshBatch.from_operators([m["mass"]], [m["evals"]], [m["evecs"]], [gx], [gy], device=device)
+    x = torch.randn(V, C, generator=torch.Generator().manual_seed(seed))
+    ox, oy = ops.GradApplyFn.apply(x.to(device), mb)
+    assert helpers.rel_max(ox.cpu(), torch.mm(gx, x)) < FWD_TOL
+    assert helpers.rel_max(oy.cpu(), torch.mm(gy, x)) < FWD_TOL
+
+
+def run_determinism(device, V=300, K=16, C=32, seed=2):
+    """Two identical fwd+bwd runs must agree bitwise (fixed-order split-V reductions, no float atomics)."""
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(seed)
+        model = diffusion_net.layers.DiffusionNet(3, 4, C_width=C, N_block=1, dropout=False).to(device)
+        synthetic.randomize_times(model.state_dict(), seed=seed)
+        m = synthetic.make_mesh_operators(V, K, seed=seed)
+        x = m["verts"].to(device).requires_grad_(True)
+        out = model(x, m["mass"].to(device), evals=m["evals"].to(device), evecs=m["evecs"].to(device),
+                    gradX=m["gradX"].to(device), gradY=m["gradY"].to(device))
+        out.square().sum().backward()
+        outs.append([out.detach().cpu(), x.grad.cpu()] + [p.grad.cpu() for p in model.parameters()])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Runs the GPU tier group by group (separate processes: a GPU fault in one group cannot mask the others),
+# then the benchmark and a rocprofv3 kernel trace.  Outputs under gpurun_out/.
+mkdir -p gpurun_out
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd "$R"
+rocminfo 2>/dev/null | grep -m1 gfx > gpurun_out/gpu.txt; nproc >> gpurun_out/gpu.txt
+: > gpurun_out/gpu_tests.log
+for t in test_native_library_is_the_loaded_one test_golden_vectors test_single_ops test_ragged_batches \
+         test_mismatched_patterns test_bitwise_determinism test_headline_shape_against_fp32_and_fp64_oracle \
+         test_large_inference_shape test_size_independent_properties_at_full_size; do
+  echo "=== $t" >> gpurun_out/gpu_tests.log
+  timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=short -k "$t" 2>&1 | tail -40 >> gpurun_out/gpu_tests.log
+done
+grep -E "^===|passed|failed|error" gpurun_out/gpu_tests.log
+echo "=== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5
+echo "=== bench"; timeout 900 python bench.py --steps ${BENCH_STEPS:-10} --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err; tail -c 3000 gpurun_out/bench.json; tail -5 gpurun_out/bench.err
+if [ -z "$NO_PROF" ]; then
+  echo "=== rocprof"
+  (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof" -o trace -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$R/gpurun_out/prof_bench.json" 2> "$R/gpurun_out/prof.err")
+  find gpurun_out/prof -name "*stats*" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -20 "$f"
+fi

@@ -1,0 +1,127 @@
+"""GPU tier (-m gpu, real MI355X): parity of the HIP path through the C ABI against the CPU oracle
+and the committed golden vectors of the reference, plus size-independent properties at full size."""
+import os
+
+import pytest
+import torch
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tier needs a ROCm device"
+    from diffusion_net import _hip
+    _hip._use_library_for_tests(None, False)
+    lib = _hip.lib()                      # raises if libdiffnet_hip.so is missing: no fallback
+    assert lib.dn_version() >= 100
+    return torch.device("cuda:0")
+
+
+def test_native_library_is_the_loaded_one(dev):
+    from diffusion_net import _hip
+    maps = open("/proc/self/maps").read()
+    assert os.path.realpath(_hip.LIB_PATH) in maps
+
+
+@pytest.mark.parametrize("name", helpers.golden_names())
+def test_golden_vectors(dev, name):
+    import parity_cases
+    parity_cases.run_golden(name, dev)
+
+
+def test_single_ops(dev):
+    import parity_cases
+    parity_cases.run_ops(dev)
+    parity_cases.run_ops(dev, sizes=(1500, 700, 129), K=128, C=128)
+    parity_cases.run_ops(dev, sizes=(3000,), K=64, C=256, chunk_rows=512)
+
+
+@pytest.mark.parametrize("outputs_at", ["vertices", "faces", "global_mean"])
+def test_ragged_batches(dev, outputs_at):
+    import parity_cases
+    parity_cases.run_ragged_net(dev, outputs_at=outputs_at)
+    parity_cases.run_ragged_net(dev, sizes=(2100, 1900, 2500, 1601), K=128, C=64, C_out=30, outputs_at=outputs_at)
+
+
+def test_mismatched_patterns(dev):
+    import parity_cases
+    parity_cases.run_mismatched_patterns(dev)
+
+
+def test_bitwise_determinism(dev):
+    import parity_cases
+    parity_cases.run_determinism(dev, V=5000, K=64, C=128)
+
+
+def test_headline_shape_against_fp32_and_fp64_oracle(dev):
+    """BASELINE north-star shape: >=10k-vertex meshes, C_width=128, K=128, 4 blocks, ragged batch."""
+    import diffusion_net
+    import parity_cases
+    from diffusion_net import synthetic
+    from oracle import diffusionnet_oracle as orc
+    sizes, K, C = (10000, 10242), 128, 128
+    torch.manual_seed(0)
+    model = diffusion_net.layers.DiffusionNet(3, 8, C_width=C, N_block=4, dropout=False)
+    model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=0))
+    params = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(dev).eval()
+    meshes, feats = parity_cases.make_ragged(sizes, K, 3, seed=0)
+    mb = parity_cases.pack(meshes, dev)
+    x = torch.cat(feats, 0).to(dev).requires_grad_(True)
+    out = model.forward_packed(x, mb)
+    out.square().sum().backward()
+    off = 0
+    for m, f in zip(meshes, feats):
+        inp = dict(x_in=f, mass=m["mass"], evals=m["evals"], evecs=m["evecs"], gradX=m["gradX"], gradY=m["gradY"])
+        got = out[off:off + f.shape[0]].detach().cpu()
+        ref32 = orc.net_forward(params, **inp)
+        p64 = {k: v.double() for k, v in params.items()}
+        i64 = {k: (v.double() if v.is_floating_point() else v) for k, v in inp.items()}
+        ref64 = orc.net_forward(p64, **i64)
+        e_new, e_ref = helpers.rel_max(got, ref64), helpers.rel_max(ref32, ref64)
+        assert helpers.rel_max(got, ref32) < 2e-5, helpers.rel_max(got, ref32)
+        assert e_new < max(1e-5, 2 * e_ref), (e_new, e_ref)      # judged against the fp64 yard-stick
+        off += f.shape[0]
+
+
+def test_large_inference_shape(dev):
+    """BASELINE configs[3] shape (C_width=256, K=256, large V, no_grad), two blocks to bound CPU-oracle time."""
+    import diffusion_net
+    from diffusion_net import synthetic
+    from oracle import diffusionnet_oracle as orc
+    V, K, C = 60000, 256, 256
+    torch.manual_seed(1)
+    model = diffusion_net.layers.DiffusionNet(3, 16, C_width=C, N_block=2, dropout=True)
+    model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=1))
+    params = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(dev).eval()
+    m = synthetic.make_mesh_operators(V, K, seed=4)
+    with torch.no_grad():
+        out = model(m["verts"].to(dev), m["mass"].to(dev), evals=m["evals"].to(dev), evecs=m["evecs"].to(dev),
+                    gradX=m["gradX"].to(dev), gradY=m["gradY"].to(dev))
+    ref = orc.net_forward(params, m["verts"], m["mass"], m["evals"], m["evecs"], m["gradX"], m["gradY"])
+    assert helpers.rel_max(out.cpu(), ref) < 2e-5
+
+
+def test_size_independent_properties_at_full_size(dev):
+    """Round trip and linearity, no oracle needed: Phi^T M Phi = I  =>  to_basis(from_basis(S)) = S;
+    diffusion is linear in x; exp(-lambda*t) with t -> 0 is the identity on span(Phi)."""
+    import parity_cases
+    from diffusion_net import ops
+    sizes, K, C = (20000, 12345), 128, 128
+    meshes, _ = parity_cases.make_ragged(sizes, K, 3, seed=9)
+    mb = parity_cases.pack(meshes, dev)
+    g = torch.Generator().manual_seed(0)
+    S = torch.randn(len(sizes), K, C, generator=g).to(dev)
+    X = ops.FromBasisFn.apply(S, mb)
+    S2 = ops.ToBasisFn.apply(X, mb)
+    assert helpers.rel_max(S2.cpu(), S.cpu()) < 2e-5
+    t = (0.01 + 0.2 * torch.rand(C, generator=g)).to(dev)
+    x1, x2 = torch.randn(sum(sizes), C, generator=g).to(dev), torch.randn(sum(sizes), C, generator=g).to(dev)
+    d = lambda v: ops.DiffusionFn.apply(v, t, mb)
+    assert helpers.rel_max((d(x1) + 2.0 * d(x2)).cpu(), d(x1 + 2.0 * x2).cpu()) < 2e-5
+    tiny = torch.full((C,), 1e-8, device=dev)
+    assert helpers.rel_max(ops.DiffusionFn.apply(X, tiny, mb).cpu(), X.cpu()) < 2e-5
