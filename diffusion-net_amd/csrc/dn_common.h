@@ -100,8 +100,9 @@ enum {
     DN_EPI_ADD = 5,          // o0 = acc + r0
     DN_EPI_DTANH = 6,        // o0 = acc * (1 - r0^2)
     DN_EPI_GRADFEAT_BWD = 7, // o0 = acc0 + r0*r1 ; o1 = acc1 + r0*r2
-    DN_EPI_MASS_ADD = 8,     // o0 = r0 + rowv[row]*acc
+    DN_EPI_MASS_ADD = 8,     // o0 = (r0 ? r0 : 0) + rowv[row]*acc
 };
+#define DN_ERR_BAD_MODE 1
 
 // ---------------------------------------------------------------------------------------
 // split-V "TN" GEMM   partial[chunk][m, n] = sum_{r in chunk} A[r, m] * B[r, n]   (dn_gemm.hip)

@@ -21,49 +21,83 @@
 // =======================================================================================
 // rowgemm
 // =======================================================================================
-__device__ __forceinline__ void rg_epilogue(const RgArgs& g, int row, int col, float a0, float a1) {
-    const long long io = (long long)row * g.ldo + col;
-    const long long ir = (long long)row * g.ldr + col;
-    switch (g.mode) {
-        case DN_EPI_STORE:
-            g.o0[io] = g.bias ? a0 + g.bias[col] : a0;
-            break;
-        case DN_EPI_BIAS_RELU: {
-            float h = a0 + g.bias[col];
-            h = h > 0.f ? h : 0.f;
-            if (g.mask) h = g.mask[ir] ? h * g.scale : 0.f;
-            g.o0[io] = h;
-        } break;
-        case DN_EPI_BIAS_RESID:
-            g.o0[io] = (a0 + g.bias[col]) + g.r0[ir];
-            break;
-        case DN_EPI_GRADFEAT: {
-            float d = g.r0[ir] * a0 + g.r1[ir] * a1;
-            g.o0[io] = tanhf(d);
-            if (g.o1) { g.o1[io] = a0; g.o2[io] = a1; }
-        } break;
-        case DN_EPI_MUL_DFAC:
-            g.o0[io] = g.r0[ir] > 0.f ? a0 * g.scale : 0.f;
-            break;
-        case DN_EPI_ADD:
-            g.o0[io] = a0 + g.r0[ir];
-            break;
-        case DN_EPI_DTANH: {
-            float t = g.r0[ir];
-            g.o0[io] = a0 * (1.f - t * t);
-        } break;
-        case DN_EPI_GRADFEAT_BWD: {
-            float dd = g.r0[ir];
-            g.o0[io] = a0 + dd * g.r1[ir];
-            g.o1[io] = a1 + dd * g.r2[ir];
-        } break;
-        case DN_EPI_MASS_ADD:
-            g.o0[io] = (g.r0 ? g.r0[ir] : 0.f) + g.rowv[row] * a0;
-            break;
+// Epilogue of one 32x32 accumulator tile.  MODE is a compile-time constant, all auxiliary operands of the 16
+// elements a lane owns are fetched first (from clamped, always-valid addresses -> no branches between the
+// loads), then combined and stored under the validity predicate.
+template <int MODE, int NOUT>
+__device__ __forceinline__ void rg_epilogue_tile(const RgArgs& g, int row_base, int rows_valid, int col, bool col_ok,
+                                                 int lane, const f32x16& a0, const f32x16& a1) {
+    bool ok[16];
+    long long io[16], ir[16];
+    const int cc = col_ok ? col : 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rl = dn_acc_row(r, lane);
+        ok[r] = col_ok && rl < rows_valid;
+        const long long rr = row_base + (ok[r] ? rl : 0);
+        io[r] = rr * g.ldo + cc;
+        ir[r] = rr * g.ldr + cc;
+    }
+    float v0[16], v1[16], v2[16], res0[16], res1[16];
+    constexpr bool need_r0 = MODE == DN_EPI_BIAS_RESID || MODE == DN_EPI_GRADFEAT || MODE == DN_EPI_MUL_DFAC ||
+                             MODE == DN_EPI_ADD || MODE == DN_EPI_DTANH || MODE == DN_EPI_GRADFEAT_BWD ||
+                             MODE == DN_EPI_MASS_ADD;
+    constexpr bool need_r1 = MODE == DN_EPI_GRADFEAT || MODE == DN_EPI_GRADFEAT_BWD;
+    constexpr bool need_r2 = MODE == DN_EPI_GRADFEAT_BWD;
+    const bool has_r0 = g.r0 != nullptr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        v0[r] = (need_r0 && has_r0) ? g.r0[ir[r]] : 0.f;
+        v1[r] = need_r1 ? g.r1[ir[r]] : 0.f;
+        v2[r] = need_r2 ? g.r2[ir[r]] : 0.f;
+    }
+    float bias = 0.f;
+    if (MODE == DN_EPI_STORE || MODE == DN_EPI_BIAS_RELU || MODE == DN_EPI_BIAS_RESID) bias = g.bias ? g.bias[cc] : 0.f;
+    if (MODE == DN_EPI_BIAS_RELU) {
+        if (g.mask) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v1[r] = g.mask[ir[r]] ? g.scale : 0.f;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v1[r] = 1.f;
+        }
+    }
+    if (MODE == DN_EPI_MASS_ADD) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v1[r] = g.rowv[row_base + (ok[r] ? dn_acc_row(r, lane) : 0)];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float x0 = a0[r], x1 = NOUT == 2 ? a1[r] : 0.f;
+        float y0 = 0.f, y1 = 0.f;
+        if (MODE == DN_EPI_STORE) y0 = x0 + bias;
+        else if (MODE == DN_EPI_BIAS_RELU) { float h = x0 + bias; y0 = (h > 0.f ? h : 0.f) * v1[r]; }
+        else if (MODE == DN_EPI_BIAS_RESID) y0 = (x0 + bias) + v0[r];
+        else if (MODE == DN_EPI_GRADFEAT) y0 = tanhf(v0[r] * x0 + v1[r] * x1);
+        else if (MODE == DN_EPI_MUL_DFAC) y0 = v0[r] > 0.f ? x0 * g.scale : 0.f;
+        else if (MODE == DN_EPI_ADD) y0 = x0 + v0[r];
+        else if (MODE == DN_EPI_DTANH) y0 = x0 * (1.f - v0[r] * v0[r]);
+        else if (MODE == DN_EPI_GRADFEAT_BWD) { y0 = x0 + v0[r] * v1[r]; y1 = x1 + v0[r] * v2[r]; }
+        else if (MODE == DN_EPI_MASS_ADD) y0 = v0[r] + v1[r] * x0;
+        res0[r] = y0;
+        res1[r] = y1;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (ok[r]) g.o0[io[r]] = res0[r];
+    if (MODE == DN_EPI_GRADFEAT_BWD) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (ok[r]) g.o1[io[r]] = res1[r];
+    }
+    if (MODE == DN_EPI_GRADFEAT && g.o1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (ok[r]) { g.o1[io[r]] = a0[r]; g.o2[io[r]] = a1[r]; }
     }
 }
 
-template <int TN, int WR, int WC, int NOUT>
+template <int TN, int WR, int WC, int NOUT, int MODE>
 __global__ __launch_bounds__(WR* WC * 64) void rowgemm_kernel(RgArgs g) {
     constexpr int NTHR = WR * WC * 64;
     constexpr int MT = DN_TM / (32 * WR);
@@ -82,12 +116,8 @@ __global__ __launch_bounds__(WR* WC * 64) void rowgemm_kernel(RgArgs g) {
     const int li = lane & 31, ls = lane >> 5;
     const DnTile tile = g.tiles[blockIdx.x];
     const int n0 = blockIdx.y * TN;
-
-    bool mt_ok[MT], nt_ok[NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) mt_ok[mt] = (wr * MT + mt) * 32 < tile.nrows;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) nt_ok[nt] = n0 + (wc * NT + nt) * 32 < g.N;
+    // a wave whose whole sub-tile lies outside the tile's rows / the output's columns skips its MFMAs
+    const bool wave_active = (wr * MT * 32 < tile.nrows) && (n0 + wc * NT * 32 < g.N);
 
     f32x16 acc[NOUT][MT][NT];
 #pragma unroll
@@ -179,51 +209,56 @@ __global__ __launch_bounds__(WR* WC * 64) void rowgemm_kernel(RgArgs g) {
         }
         // ---------------- MFMAs on the slice already in LDS ----------------
         if (!first) {
-#pragma unroll
-            for (int kg = 0; kg < 4; ++kg) {
-                float4 af[MT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    af[mt] = *reinterpret_cast<const float4*>(&sA[dn_colk_off((wr * MT + mt) * 32 + li, 2 * kg + ls)]);
+            if (wave_active) {
                 if (g.b_colk) {
-                    float4 bf[NOUT][NT];
 #pragma unroll
-                    for (int o = 0; o < NOUT; ++o)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            bf[o][nt] = *reinterpret_cast<const float4*>(
-                                &sB[o * SB + dn_colk_off((wc * NT + nt) * 32 + li, 2 * kg + ls)]);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
+                    for (int kg = 0; kg < 4; ++kg) {
+                        float4 af[MT];
+                        float4 bf[NOUT][NT];
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
+                            af[mt] = *reinterpret_cast<const float4*>(&sA[dn_colk_off((wr * MT + mt) * 32 + li, 2 * kg + ls)]);
+#pragma unroll
+                        for (int o = 0; o < NOUT; ++o)
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                if (mt_ok[mt] && nt_ok[nt]) {
+                                bf[o][nt] = *reinterpret_cast<const float4*>(
+                                    &sB[o * SB + dn_colk_off((wc * NT + nt) * 32 + li, 2 * kg + ls)]);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                                     for (int o = 0; o < NOUT; ++o)
                                         acc[o][mt][nt] = dn_mfma(dn_f4_get(af[mt], t), dn_f4_get(bf[o][nt], t), acc[o][mt][nt]);
-                                }
+                    }
                 } else {
-                    float bs[NOUT][NT][4];
 #pragma unroll
-                    for (int o = 0; o < NOUT; ++o)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                            for (int t = 0; t < 4; ++t)
-                                bs[o][nt][t] = sB[o * SB + (8 * kg + 4 * ls + t) * TN + (wc * NT + nt) * 32 + li];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
+                    for (int kg = 0; kg < 4; ++kg) {
+                        float4 af[MT];
+                        float bs[NOUT][NT][4];
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
+                            af[mt] = *reinterpret_cast<const float4*>(&sA[dn_colk_off((wr * MT + mt) * 32 + li, 2 * kg + ls)]);
+#pragma unroll
+                        for (int o = 0; o < NOUT; ++o)
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                if (mt_ok[mt] && nt_ok[nt]) {
+#pragma unroll
+                                for (int t = 0; t < 4; ++t)
+                                    bs[o][nt][t] = sB[o * SB + (8 * kg + 4 * ls + t) * TN + (wc * NT + nt) * 32 + li];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                                     for (int o = 0; o < NOUT; ++o)
                                         acc[o][mt][nt] = dn_mfma(dn_f4_get(af[mt], t), bs[o][nt][t], acc[o][mt][nt]);
-                                }
+                    }
                 }
             }
             __syncthreads();  // everyone done reading the slice in LDS
@@ -252,27 +287,38 @@ __global__ __launch_bounds__(WR* WC * 64) void rowgemm_kernel(RgArgs g) {
         have = seg < g.nseg;
     }
     // ---------------- epilogue ----------------
+    if (wave_active) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            if (!(mt_ok[mt] && nt_ok[nt])) continue;
-            const int col = n0 + (wc * NT + nt) * 32 + li;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = (wr * MT + mt) * 32 + dn_acc_row(r, lane);
-                if (rl < tile.nrows && col < g.N)
-                    rg_epilogue(g, tile.row0 + rl, col, acc[0][mt][nt][r], NOUT == 2 ? acc[NOUT - 1][mt][nt][r] : 0.f);
+            for (int nt = 0; nt < NT; ++nt) {
+                const int rbase = (wr * MT + mt) * 32;
+                const int col = n0 + (wc * NT + nt) * 32 + li;
+                if (rbase < tile.nrows)
+                    rg_epilogue_tile<MODE, NOUT>(g, tile.row0 + rbase, tile.nrows - rbase, col, col < g.N, lane,
+                                                 acc[0][mt][nt], acc[NOUT - 1][mt][nt]);
             }
-        }
+    }
 }
 
-template <int TN, int WR, int WC, int NOUT>
+template <int TN, int WR, int WC, int NOUT, int MODE>
 static int rg_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
     const int ncol = (g.N + TN - 1) / TN;
     const size_t smem = (size_t)(DN_TM * DN_KB + NOUT * DN_KB * TN) * sizeof(float);
-    DN_LAUNCH((rowgemm_kernel<TN, WR, WC, NOUT>), dim3(ntiles, ncol, 1), dim3(WR * WC * 64, 1, 1), smem, stream, g);
+    DN_LAUNCH((rowgemm_kernel<TN, WR, WC, NOUT, MODE>), dim3(ntiles, ncol, 1), dim3(WR * WC * 64, 1, 1), smem, stream, g);
     return (int)hipGetLastError();
+}
+
+template <int NOUT, int MODE>
+static int rg_dispatch_width(const RgArgs& g, int ntiles, hipStream_t stream) {
+    if (NOUT == 1) {
+        if (g.N <= 32) return rg_launch<32, 4, 1, NOUT, MODE>(g, ntiles, stream);
+        if (g.N <= 64) return rg_launch<64, 2, 2, NOUT, MODE>(g, ntiles, stream);
+        return rg_launch<128, 2, 2, NOUT, MODE>(g, ntiles, stream);
+    }
+    if (g.N <= 32) return rg_launch<32, 4, 1, NOUT, MODE>(g, ntiles, stream);
+    if (g.N <= 64) return rg_launch<64, 2, 2, NOUT, MODE>(g, ntiles, stream);
+    return rg_launch<128, 2, 4, NOUT, MODE>(g, ntiles, stream);
 }
 
 int dn_launch_rowgemm(const RgArgs& g, int ntiles, int nout, hipStream_t stream) {
@@ -284,15 +330,24 @@ int dn_launch_rowgemm(const RgArgs& g, int ntiles, int nout, hipStream_t stream)
     const double bytes = 4.0 * (rows * ktot + rows * (double)g.N * nout + (double)ktot * g.N * nout);
     const int kind = nout == 1 ? DN_K_ROWGEMM : DN_K_ROWGEMM_DUAL;
     dn_prof_begin(kind, stream);
-    int err;
+    int err = DN_ERR_BAD_MODE;
     if (nout == 1) {
-        if (g.N <= 32) err = rg_launch<32, 4, 1, 1>(g, ntiles, stream);
-        else if (g.N <= 64) err = rg_launch<64, 2, 2, 1>(g, ntiles, stream);
-        else err = rg_launch<128, 2, 2, 1>(g, ntiles, stream);
+        switch (g.mode) {
+            case DN_EPI_STORE: err = rg_dispatch_width<1, DN_EPI_STORE>(g, ntiles, stream); break;
+            case DN_EPI_BIAS_RELU: err = rg_dispatch_width<1, DN_EPI_BIAS_RELU>(g, ntiles, stream); break;
+            case DN_EPI_BIAS_RESID: err = rg_dispatch_width<1, DN_EPI_BIAS_RESID>(g, ntiles, stream); break;
+            case DN_EPI_MUL_DFAC: err = rg_dispatch_width<1, DN_EPI_MUL_DFAC>(g, ntiles, stream); break;
+            case DN_EPI_ADD: err = rg_dispatch_width<1, DN_EPI_ADD>(g, ntiles, stream); break;
+            case DN_EPI_DTANH: err = rg_dispatch_width<1, DN_EPI_DTANH>(g, ntiles, stream); break;
+            case DN_EPI_MASS_ADD: err = rg_dispatch_width<1, DN_EPI_MASS_ADD>(g, ntiles, stream); break;
+            default: break;
+        }
     } else {
-        if (g.N <= 32) err = rg_launch<32, 4, 1, 2>(g, ntiles, stream);
-        else if (g.N <= 64) err = rg_launch<64, 2, 2, 2>(g, ntiles, stream);
-        else err = rg_launch<128, 2, 4, 2>(g, ntiles, stream);
+        switch (g.mode) {
+            case DN_EPI_GRADFEAT: err = rg_dispatch_width<2, DN_EPI_GRADFEAT>(g, ntiles, stream); break;
+            case DN_EPI_GRADFEAT_BWD: err = rg_dispatch_width<2, DN_EPI_GRADFEAT_BWD>(g, ntiles, stream); break;
+            default: break;
+        }
     }
     dn_prof_end(kind, stream, flops, bytes);
     return err;
@@ -330,12 +385,7 @@ __global__ __launch_bounds__(256) void tngemm_kernel(TnArgs g) {
     const int n0 = blockIdx.y * DN_TO, m0 = blockIdx.z * DN_TO;
     const bool do_colsum = g.colsum != nullptr && blockIdx.y == 0;
 
-    bool mt_ok[2], nt_ok[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        mt_ok[i] = m0 + (wr * 2 + i) * 32 < g.M;
-        nt_ok[i] = n0 + (wc * 2 + i) * 32 < g.N;
-    }
+    const bool wave_active = (m0 + wr * 64 < g.M) && (n0 + wc * 64 < g.N);
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -403,6 +453,7 @@ __global__ __launch_bounds__(256) void tngemm_kernel(TnArgs g) {
             }
         }
         if (step > 0) {
+            if (wave_active) {
 #pragma unroll
             for (int kg = 0; kg < 4; ++kg) {
                 float af[2][4], bf[2][4];
@@ -420,8 +471,8 @@ __global__ __launch_bounds__(256) void tngemm_kernel(TnArgs g) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            if (mt_ok[i] && nt_ok[j]) acc[i][j] = dn_mfma(af[i][t], bf[j][t], acc[i][j]);
+                        for (int j = 0; j < 2; ++j) acc[i][j] = dn_mfma(af[i][t], bf[j][t], acc[i][j]);
+            }
             }
             __syncthreads();
         }
@@ -441,7 +492,7 @@ __global__ __launch_bounds__(256) void tngemm_kernel(TnArgs g) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            if (!(mt_ok[i] && nt_ok[j])) continue;
+            if (!wave_active) continue;
             const int n = n0 + (wc * 2 + j) * 32 + li;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {

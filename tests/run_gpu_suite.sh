@@ -14,9 +14,10 @@ for t in test_native_library_is_the_loaded_one test_golden_vectors test_single_o
 done
 grep -E "^===|passed|failed|error" gpurun_out/gpu_tests.log
 echo "=== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5
+if [ -z "$NO_MICRO" ]; then echo "=== microbench"; timeout 600 python tools/microbench.py 2>&1 | grep -v Warn | tee gpurun_out/microbench.txt; fi
 echo "=== bench"; timeout 900 python bench.py --steps ${BENCH_STEPS:-10} --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err; tail -c 3000 gpurun_out/bench.json; tail -5 gpurun_out/bench.err
 if [ -z "$NO_PROF" ]; then
   echo "=== rocprof"
-  (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof" -o trace -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$R/gpurun_out/prof_bench.json" 2> "$R/gpurun_out/prof.err")
-  find gpurun_out/prof -name "*stats*" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -20 "$f"
+  (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o trace -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$R/gpurun_out/prof_bench.json" 2> "$R/gpurun_out/prof.err")
+  f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cut -c1-200 "$f" | head -30
 fi
