@@ -139,16 +139,18 @@ int gradfeat_bwd_inputs(const dn_mesh_batch_t* mb, const float* ddots, const flo
     return dn_launch_rowgemm(g, mb->n_tiles, 2, st);
 }
 int gradfeat_bwd_weights(const dn_mesh_batch_t* mb, const float* ddots, const float* gx, const float* gy, int C,
-                         float* dA_re, float* dA_im, float* partial, hipStream_t st) {
+                         float* dA_re, float* dA_im, float* partial, float* psum, hipStream_t st) {
     TnArgs g = tn_new(mb);
     tn_a(g, ddots, gx, C, C);
     tn_a(g, ddots, gy, C, C);
     tn_b(g, gx, nullptr, C, C);
     tn_b(g, gy, nullptr, C, C);
     g.partial = partial;
+    g.group = dn_tn_global_group(mb->n_chunks);
     tn_finish(g);
     DN_CHECK(dn_launch_tngemm(g, mb->n_chunks, st));
-    return dn_launch_reduce_dA(partial, dA_re, dA_im, mb->n_chunks, C, st);
+    DN_CHECK(dn_launch_reduce(partial, psum, dn_tn_npartial(mb->n_chunks, g.group), 4LL * C * C, 4LL * C * C, st));
+    return dn_launch_combine_dA(psum, dA_re, dA_im, C, st);
 }
 // y = act(sum_s x_s W[:, off_s:off_s+w_s]^T + b)
 int linear_fwd(const dn_mesh_batch_t* mb, const float* const* xs, const int* ws_, int nseg, const float* W, int ldw,
@@ -184,10 +186,12 @@ int linear_bwd_weights(const dn_mesh_batch_t* mb, const float* d_a, int C_out, c
     tn_a(g, d_a, nullptr, C_out, C_out);
     for (int s = 0; s < nseg; ++s) tn_b(g, ins[s], nullptr, ws_[s], ws_[s]);
     g.partial = partial; g.colsum = db ? colsum : nullptr;
+    g.group = dn_tn_global_group(mb->n_chunks);
     tn_finish(g);
+    const int npart = dn_tn_npartial(mb->n_chunks, g.group);
     DN_CHECK(dn_launch_tngemm(g, mb->n_chunks, st));
-    DN_CHECK(dn_launch_reduce(partial, dW, mb->n_chunks, (long long)g.M * g.N, (long long)g.M * g.N, st));
-    if (db) DN_CHECK(dn_launch_reduce(colsum, db, mb->n_chunks, g.M, g.M, st));
+    DN_CHECK(dn_launch_reduce(partial, dW, npart, (long long)g.M * g.N, (long long)g.M * g.N, st));
+    if (db) DN_CHECK(dn_launch_reduce(colsum, db, npart, g.M, g.M, st));
     return 0;
 }
 int max_width(const dn_block_params_t* p) {
@@ -332,7 +336,8 @@ int dn_diffusion_bwd_f32(const dn_mesh_batch_t* mb, const float* d_xd, const flo
     float* dtp = b.f((size_t)mb->n_mesh * C);
     if (!b.ok) return DN_ERR_INVALID;
     DN_CHECK(to_basis_partials(mb, d_xd, C, false, partial, S(stream)));
-    DN_CHECK(dn_launch_spec_bwd(partial, mb->mesh_chunk_off, mb->evals, time, xs, dxs, dtp, mb->n_mesh, mb->k_eig, C, S(stream)));
+    DN_CHECK(dn_launch_seg_reduce(partial, mb->mesh_chunk_off, mb->n_mesh, 0, dxs, (long long)mb->k_eig * C, S(stream)));
+    DN_CHECK(dn_launch_spec_bwd(dxs, mb->evals, time, xs, dtp, mb->n_mesh, mb->k_eig, C, S(stream)));
     DN_CHECK(dn_launch_reduce(dtp, d_time, mb->n_mesh, C, C, S(stream)));
     return from_basis(mb, dxs, C, d_x, d_x_add, true, S(stream));   // d_x_add may be NULL
 }
@@ -348,7 +353,7 @@ int dn_grad_apply_bwd_f32(const dn_mesh_batch_t* mb, const float* d_gx, const fl
 
 // ------------------------------------------------------------------ gradient features
 size_t dn_gradfeat_workspace_bytes(const dn_mesh_batch_t* mb, int C) {
-    return pad256((size_t)mb->n_chunks * 4 * C * C) + pad256((size_t)mb->v_total * C) + 512;
+    return pad256((size_t)mb->n_chunks * 4 * C * C) + pad256((size_t)mb->v_total * C) + pad256((size_t)4 * C * C) + 512;
 }
 int dn_gradfeat_fwd_f32(const dn_mesh_batch_t* mb, const float* gx, const float* gy, const float* A_re, const float* A_im,
                         int C, float* g, float* bre, float* bim, void* stream) {
@@ -360,10 +365,11 @@ int dn_gradfeat_bwd_f32(const dn_mesh_batch_t* mb, const float* d_g, const float
     Bump b(ws, ws_bytes);
     float* partial = b.f((size_t)mb->n_chunks * 4 * C * C);
     float* ddots = b.f((size_t)mb->v_total * C);
+    float* psum = b.f((size_t)4 * C * C);
     if (!b.ok) return DN_ERR_INVALID;
     // d_dots = d_g * (1 - g^2)   (the fused block folds this into the epilogue of the d_h0 product)
     DN_CHECK(dn_launch_dtanh(d_g, g, ddots, (long long)mb->v_total * C, S(stream)));
-    DN_CHECK(gradfeat_bwd_weights(mb, ddots, gx, gy, C, dA_re, A_im ? dA_im : nullptr, partial, S(stream)));
+    DN_CHECK(gradfeat_bwd_weights(mb, ddots, gx, gy, C, dA_re, A_im ? dA_im : nullptr, partial, psum, S(stream)));
     return gradfeat_bwd_inputs(mb, ddots, gx, gy, bre, bim, A_re, A_im, C, d_gx, d_gy, S(stream));
 }
 
@@ -454,6 +460,7 @@ size_t dn_block_bwd_workspace_bytes(const dn_mesh_batch_t* mb, const dn_block_pa
     n += pad256((size_t)mb->n_chunks * max_wgrad_elems(mb, p));     // TN partials
     n += pad256((size_t)mb->n_chunks * max_width(p));               // bias partials
     n += pad256((size_t)mb->n_mesh * mb->k_eig * p->C) + pad256((size_t)mb->n_mesh * p->C);
+    n += pad256((size_t)4 * p->C * p->C);
     return n + 512;
 }
 int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, const float* x, const dn_block_saved_t* sv,
@@ -473,6 +480,7 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     float* colsum = b.f((size_t)mb->n_chunks * max_width(p));
     float* dxs = b.f((size_t)mb->n_mesh * K * C);
     float* dtp = b.f((size_t)mb->n_mesh * C);
+    float* psum = b.f((size_t)4 * C * C);
     if (!b.ok) return DN_ERR_INVALID;
 
     // ---- MiniMLP backward (autograd of layers.py:236); d_a = gradient w.r.t. a layer's pre-activation output
@@ -502,13 +510,14 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     // ---- gradient features + gradient apply backward
     if (p->with_grad) {
         const float* A_im = p->with_rot ? p->A_im : nullptr;
-        DN_CHECK(gradfeat_bwd_weights(mb, d_dots, sv->gx, sv->gy, C, gr->dA_re, p->with_rot ? gr->dA_im : nullptr, partial, st));
+        DN_CHECK(gradfeat_bwd_weights(mb, d_dots, sv->gx, sv->gy, C, gr->dA_re, p->with_rot ? gr->dA_im : nullptr, partial, psum, st));
         DN_CHECK(gradfeat_bwd_inputs(mb, d_dots, sv->gx, sv->gy, sv->bre, sv->bim, p->A_re, A_im, C, d_gx, d_gy, st));
         DN_CHECK(grad_apply_bwd(mb, d_gx, d_gy, d_xd, C, d_xd, st));   // d_xd += gradX^T d_gx + gradY^T d_gy (in place)
     }
     // ---- diffusion backward
     DN_CHECK(to_basis_partials(mb, d_xd, C, false, partial, st));
-    DN_CHECK(dn_launch_spec_bwd(partial, mb->mesh_chunk_off, mb->evals, p->time, sv->xs, dxs, dtp, mb->n_mesh, K, C, st));
+    DN_CHECK(dn_launch_seg_reduce(partial, mb->mesh_chunk_off, mb->n_mesh, 0, dxs, (long long)K * C, st));
+    DN_CHECK(dn_launch_spec_bwd(dxs, mb->evals, p->time, sv->xs, dtp, mb->n_mesh, K, C, st));
     DN_CHECK(dn_launch_reduce(dtp, gr->d_time, mb->n_mesh, C, C, st));
     return from_basis(mb, dxs, C, gr->d_x, d_xacc, true, st);
 }

@@ -120,8 +120,14 @@ struct TnArgs {
     float* partial;             // [nchunks][M][N]
     float* colsum;              // optional [nchunks][M]: column sums of A over the chunk
     int aligned;                // widths % 4 == 0, ld % 4 == 0, 16-byte aligned pointers
+    int group;                  // consecutive chunks accumulated by one workgroup (1 for per-mesh outputs)
+    int nchunks;                // filled by the launcher
     int acct_rows;              // host-side accounting only
 };
+// number of partial results a tngemm launch over `nchunks` chunks with grouping `group` writes
+static inline int dn_tn_npartial(int nchunks, int group) { return (nchunks + (group < 1 ? 1 : group) - 1) / (group < 1 ? 1 : group); }
+// grouping for sums over ALL rows (weight gradients): about one partial per CU
+static inline int dn_tn_global_group(int nchunks) { int g = (nchunks + 255) / 256; return g < 1 ? 1 : g; }
 
 // ---------------------------------------------------------------------------------------
 // CSR gather (dn_sparse.hip)
@@ -147,10 +153,12 @@ enum { DN_SP_FWD2 = 0, DN_SP_BWD2 = 1, DN_SP_ONE = 2 };
 // ---------------------------------------------------------------------------------------
 int dn_launch_spec_fwd(const float* partial, const int* mesh_chunk_off, const float* evals, const float* time,
                        float* xs, float* ys, int n_mesh, int K, int C, hipStream_t stream);
-int dn_launch_spec_bwd(const float* partial, const int* mesh_chunk_off, const float* evals, const float* time,
-                       const float* xs, float* dxs, float* dt_part, int n_mesh, int K, int C, hipStream_t stream);
+int dn_launch_spec_bwd(float* dys_inplace, const float* evals, const float* time, const float* xs, float* dt_part,
+                       int n_mesh, int K, int C, hipStream_t stream);
 int dn_launch_reduce(const float* partial, float* out, int n, long long stride, long long len, hipStream_t stream);
-int dn_launch_reduce_dA(const float* partial, float* dA_re, float* dA_im, int n, int C, hipStream_t stream);
+// out[s][i] = sum_{ch in [seg_off[s], seg_off[s+1])} partial[ch][i]  (seg_off == nullptr: one segment [0,n))
+int dn_launch_seg_reduce(const float* partial, const int* seg_off, int nseg, int n, float* out, long long len, hipStream_t stream);
+int dn_launch_combine_dA(const float* P, float* dA_re, float* dA_im, int C, hipStream_t stream);
 int dn_launch_mass_mean_fwd(const DnTile* meshrows, const float* mass, const float* x, float* out, float* msum,
                             int n_mesh, int C, hipStream_t stream);
 int dn_launch_mass_mean_bwd(const DnTile* tiles, int ntiles, const float* mass, const float* msum, const float* dout,

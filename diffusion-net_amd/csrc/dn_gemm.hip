@@ -97,14 +97,185 @@ __device__ __forceinline__ void rg_epilogue_tile(const RgArgs& g, int row_base, 
     }
 }
 
-template <int TN, int WR, int WC, int NOUT, int MODE>
+// ---- staging helpers -------------------------------------------------------------------------------------
+// ALIGNED fast path: no branch sits between the loads (row / column guards are applied by clamping the address to
+// a valid one and zeroing the value afterwards), so every global_load of a slice is in flight at once and the
+// wait lands at the LDS store after the MFMAs of the previous slice.
+// A staged slice in registers: raw loaded values plus the factors applied when it is written to LDS.  Nothing
+// here is *used* before the MFMAs of the previous slice have been issued, so the loads stay in flight under them.
+template <int NOUT, int A_IT, int B_IT>
+struct RgRegs {
+    float4 a[A_IT];
+    float4 q[A_IT];          // optional elementwise factor of A (valid when has_q)
+    float am[A_IT];          // row guard as 0/1 factor
+    float4 b[NOUT][B_IT];
+    float bm[NOUT][B_IT];    // column guard * sign
+    bool has_q;
+};
+
+template <int TN, int NTHR, int NOUT, bool ALIGNED, bool BCOLK, int A_IT, int B_IT>
+__device__ __forceinline__ void rg_load(const RgArgs& g, const DnTile& tile, int n0, int seg, int koff, int tid,
+                                        RgRegs<NOUT, A_IT, B_IT>& R) {
+    const RgSeg sg = g.a[seg];
+    R.has_q = false;
+    if (ALIGNED) {
+        long long off[A_IT];
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int idx = tid + i * NTHR;
+            const int row = idx >> 3, q = idx & 7;
+            const bool rok = row < tile.nrows;
+            R.am[i] = rok ? 1.f : 0.f;
+            off[i] = (long long)(tile.row0 + (rok ? row : 0)) * sg.ld + koff + 4 * q;
+            R.a[i] = *reinterpret_cast<const float4*>(sg.p + off[i]);
+        }
+        if (sg.q) {   // uniform; loads only, no use
+            R.has_q = true;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) R.q[i] = *reinterpret_cast<const float4*>(sg.q + off[i]);
+        }
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            const float* bp = g.b[o][seg] + (long long)tile.mesh * g.b_mesh_stride;
+            const float sgn = g.bsign[o][seg];
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                const int idx = tid + i * NTHR;
+                long long boff;
+                bool nok;
+                if (BCOLK) {
+                    const int nrow = idx >> 3, q = idx & 7;
+                    nok = n0 + nrow < g.N;
+                    boff = (long long)(nok ? n0 + nrow : 0) * g.ldb + koff + 4 * q;
+                } else {
+                    const int krow = idx / (TN / 4), q4 = idx % (TN / 4);
+                    nok = n0 + 4 * q4 < g.N;
+                    boff = (long long)(koff + krow) * g.ldb + (nok ? n0 + 4 * q4 : 0);
+                }
+                R.b[o][i] = *reinterpret_cast<const float4*>(bp + boff);
+                R.bm[o][i] = nok ? sgn : 0.f;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int idx = tid + i * NTHR;
+            const int row = idx >> 3, q = idx & 7;
+            const long long base = (long long)(tile.row0 + row) * sg.ld + koff + 4 * q;
+            float e[4] = {0.f, 0.f, 0.f, 0.f};
+            if (row < tile.nrows) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (koff + 4 * q + c < sg.w) {
+                        e[c] = sg.p[base + c];
+                        if (sg.q) e[c] *= sg.q[base + c];
+                    }
+                }
+            }
+            R.a[i] = make_float4(e[0], e[1], e[2], e[3]);
+            R.am[i] = 1.f;
+        }
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            const float* bp = g.b[o][seg] + (long long)tile.mesh * g.b_mesh_stride;
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                const int idx = tid + i * NTHR;
+                float e[4] = {0.f, 0.f, 0.f, 0.f};
+                if (BCOLK) {
+                    const int nrow = idx >> 3, q = idx & 7;
+                    const long long base = (long long)(n0 + nrow) * g.ldb + koff + 4 * q;
+                    if (n0 + nrow < g.N) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (koff + 4 * q + c < sg.w) e[c] = bp[base + c];
+                    }
+                } else {
+                    const int krow = idx / (TN / 4), q4 = idx % (TN / 4);
+                    const long long base = (long long)(koff + krow) * g.ldb + n0 + 4 * q4;
+                    if (koff + krow < sg.w) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (n0 + 4 * q4 + c < g.N) e[c] = bp[base + c];
+                    }
+                }
+                R.b[o][i] = make_float4(e[0], e[1], e[2], e[3]);
+                R.bm[o][i] = g.bsign[o][seg];
+            }
+        }
+    }
+}
+
+template <int TN, int NTHR, int NOUT, bool BCOLK, int A_IT, int B_IT>
+__device__ __forceinline__ void rg_store(float* sA, float* sB, int tid, const RgRegs<NOUT, A_IT, B_IT>& R) {
+    constexpr int SB = DN_KB * TN;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int idx = tid + i * NTHR;
+        float4 v = dn_f4_scale(R.a[i], R.am[i]);
+        if (R.has_q) v = dn_f4_mul(v, R.q[i]);
+        *reinterpret_cast<float4*>(&sA[dn_colk_off(idx >> 3, idx & 7)]) = v;
+    }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int idx = tid + i * NTHR;
+            const float4 v = dn_f4_scale(R.b[o][i], R.bm[o][i]);
+            if (BCOLK)
+                *reinterpret_cast<float4*>(&sB[o * SB + dn_colk_off(idx >> 3, idx & 7)]) = v;
+            else
+                *reinterpret_cast<float4*>(&sB[o * SB + 4 * idx]) = v;
+        }
+}
+
+template <int TN, int MT, int NT, int NOUT, bool BCOLK>
+__device__ __forceinline__ void rg_compute(const float* sA, const float* sB, int arow0, int bcol0, int li, int ls,
+                                           f32x16 (&acc)[NOUT][MT][NT]) {
+    constexpr int SB = DN_KB * TN;
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+        float4 af[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            af[mt] = *reinterpret_cast<const float4*>(&sA[dn_colk_off(arow0 + mt * 32 + li, 2 * kg + ls)]);
+        float bv[NOUT][NT][4];
+        if (BCOLK) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(&sB[o * SB + dn_colk_off(bcol0 + nt * 32 + li, 2 * kg + ls)]);
+                    bv[o][nt][0] = t4.x; bv[o][nt][1] = t4.y; bv[o][nt][2] = t4.z; bv[o][nt][3] = t4.w;
+                }
+        } else {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        bv[o][nt][t] = sB[o * SB + (8 * kg + 4 * ls + t) * TN + bcol0 + nt * 32 + li];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int o = 0; o < NOUT; ++o)
+                        acc[o][mt][nt] = dn_mfma(dn_f4_get(af[mt], t), bv[o][nt][t], acc[o][mt][nt]);
+    }
+}
+
+template <int TN, int WR, int WC, int NOUT, int MODE, bool ALIGNED, bool BCOLK>
 __global__ __launch_bounds__(WR* WC * 64) void rowgemm_kernel(RgArgs g) {
     constexpr int NTHR = WR * WC * 64;
     constexpr int MT = DN_TM / (32 * WR);
     constexpr int NT = TN / (32 * WC);
     constexpr int A_IT = DN_TM * 8 / NTHR;
     constexpr int B_IT = DN_KB * TN / 4 / NTHR;
-    constexpr int SB = DN_KB * TN;  // floats per B slice
     static_assert(MT >= 1 && NT >= 1 && A_IT >= 1 && B_IT >= 1, "bad tile config");
 
     DN_DYN_SMEM(smem_raw);
@@ -129,163 +300,25 @@ __global__ __launch_bounds__(WR* WC * 64) void rowgemm_kernel(RgArgs g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[o][mt][nt][r] = 0.f;
 
-    float4 ra[A_IT];
-    float4 rb[NOUT][B_IT];
+    RgRegs<NOUT, A_IT, B_IT> R;
 
+    int nslices = 0;
+    for (int s = 0; s < g.nseg; ++s) nslices += (g.a[s].w + DN_KB - 1) / DN_KB;
     int seg = 0, koff = 0;
-    bool have = g.nseg > 0;
-    bool first = true;
-    for (;;) {
-        // ---------------- global -> registers for slice (seg, koff) ----------------
-        if (have) {
-            const RgSeg sg = g.a[seg];
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i) {
-                const int idx = tid + i * NTHR;
-                const int row = idx >> 3, q = idx & 7;
-                const bool rok = row < tile.nrows;
-                const long long base = (long long)(tile.row0 + row) * sg.ld + koff + 4 * q;
-                float4 v = dn_f4_zero();
-                if (g.aligned) {
-                    if (rok) {
-                        v = *reinterpret_cast<const float4*>(sg.p + base);
-                        if (sg.q) v = dn_f4_mul(v, *reinterpret_cast<const float4*>(sg.q + base));
-                    }
-                } else if (rok) {
-                    float e[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int k = koff + 4 * q + c;
-                        e[c] = 0.f;
-                        if (k < sg.w) {
-                            e[c] = sg.p[base + c];
-                            if (sg.q) e[c] *= sg.q[base + c];
-                        }
-                    }
-                    v = make_float4(e[0], e[1], e[2], e[3]);
-                }
-                ra[i] = v;
-            }
-#pragma unroll
-            for (int o = 0; o < NOUT; ++o) {
-                const float* bp = g.b[o][seg] + (long long)tile.mesh * g.b_mesh_stride;
-                const float sgn = g.bsign[o][seg];
-#pragma unroll
-                for (int i = 0; i < B_IT; ++i) {
-                    const int idx = tid + i * NTHR;
-                    float4 v = dn_f4_zero();
-                    if (g.b_colk) {
-                        const int nrow = idx >> 3, q = idx & 7;
-                        const int n = n0 + nrow;
-                        const long long base = (long long)n * g.ldb + koff + 4 * q;
-                        if (n < g.N) {
-                            if (g.aligned) {
-                                v = *reinterpret_cast<const float4*>(bp + base);
-                            } else {
-                                float e[4];
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) e[c] = (koff + 4 * q + c < sg.w) ? bp[base + c] : 0.f;
-                                v = make_float4(e[0], e[1], e[2], e[3]);
-                            }
-                        }
-                    } else {
-                        const int krow = idx / (TN / 4), q4 = idx % (TN / 4);
-                        const int n = n0 + 4 * q4;
-                        const long long base = (long long)(koff + krow) * g.ldb + n;
-                        if (koff + krow < sg.w) {
-                            if (g.aligned) {
-                                if (n < g.N) v = *reinterpret_cast<const float4*>(bp + base);
-                            } else {
-                                float e[4];
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) e[c] = (n + c < g.N) ? bp[base + c] : 0.f;
-                                v = make_float4(e[0], e[1], e[2], e[3]);
-                            }
-                        }
-                    }
-                    rb[o][i] = dn_f4_scale(v, sgn);
-                }
-            }
-        }
-        // ---------------- MFMAs on the slice already in LDS ----------------
-        if (!first) {
-            if (wave_active) {
-                if (g.b_colk) {
-#pragma unroll
-                    for (int kg = 0; kg < 4; ++kg) {
-                        float4 af[MT];
-                        float4 bf[NOUT][NT];
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-                            af[mt] = *reinterpret_cast<const float4*>(&sA[dn_colk_off((wr * MT + mt) * 32 + li, 2 * kg + ls)]);
-#pragma unroll
-                        for (int o = 0; o < NOUT; ++o)
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-                                bf[o][nt] = *reinterpret_cast<const float4*>(
-                                    &sB[o * SB + dn_colk_off((wc * NT + nt) * 32 + li, 2 * kg + ls)]);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-#pragma unroll
-                            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                                    for (int o = 0; o < NOUT; ++o)
-                                        acc[o][mt][nt] = dn_mfma(dn_f4_get(af[mt], t), dn_f4_get(bf[o][nt], t), acc[o][mt][nt]);
-                    }
-                } else {
-#pragma unroll
-                    for (int kg = 0; kg < 4; ++kg) {
-                        float4 af[MT];
-                        float bs[NOUT][NT][4];
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-                            af[mt] = *reinterpret_cast<const float4*>(&sA[dn_colk_off((wr * MT + mt) * 32 + li, 2 * kg + ls)]);
-#pragma unroll
-                        for (int o = 0; o < NOUT; ++o)
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                                for (int t = 0; t < 4; ++t)
-                                    bs[o][nt][t] = sB[o * SB + (8 * kg + 4 * ls + t) * TN + (wc * NT + nt) * 32 + li];
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-#pragma unroll
-                            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                                    for (int o = 0; o < NOUT; ++o)
-                                        acc[o][mt][nt] = dn_mfma(dn_f4_get(af[mt], t), bs[o][nt][t], acc[o][mt][nt]);
-                    }
-                }
-            }
-            __syncthreads();  // everyone done reading the slice in LDS
-        }
-        if (!have) break;
-        // ---------------- registers -> LDS ----------------
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int idx = tid + i * NTHR;
-            *reinterpret_cast<float4*>(&sA[dn_colk_off(idx >> 3, idx & 7)]) = ra[i];
-        }
-#pragma unroll
-        for (int o = 0; o < NOUT; ++o)
-#pragma unroll
-            for (int i = 0; i < B_IT; ++i) {
-                const int idx = tid + i * NTHR;
-                if (g.b_colk)
-                    *reinterpret_cast<float4*>(&sB[o * SB + dn_colk_off(idx >> 3, idx & 7)]) = rb[o][i];
-                else
-                    *reinterpret_cast<float4*>(&sB[o * SB + 4 * idx]) = rb[o][i];
-            }
-        __syncthreads();
-        first = false;
+    rg_load<TN, NTHR, NOUT, ALIGNED, BCOLK, A_IT, B_IT>(g, tile, n0, seg, koff, tid, R);
+    rg_store<TN, NTHR, NOUT, BCOLK, A_IT, B_IT>(sA, sB, tid, R);
+    __syncthreads();
+    for (int sl = 1; sl < nslices; ++sl) {
         koff += DN_KB;
         if (koff >= g.a[seg].w) { koff = 0; ++seg; }
-        have = seg < g.nseg;
+        rg_load<TN, NTHR, NOUT, ALIGNED, BCOLK, A_IT, B_IT>(g, tile, n0, seg, koff, tid, R);   // in flight during the MFMAs
+        if (wave_active) rg_compute<TN, MT, NT, NOUT, BCOLK>(sA, sB, wr * MT * 32, wc * NT * 32, li, ls, acc);
+        __syncthreads();   // everyone done reading the slice in LDS
+        rg_store<TN, NTHR, NOUT, BCOLK, A_IT, B_IT>(sA, sB, tid, R);
+        __syncthreads();
     }
+    if (wave_active) rg_compute<TN, MT, NT, NOUT, BCOLK>(sA, sB, wr * MT * 32, wc * NT * 32, li, ls, acc);
+
     // ---------------- epilogue ----------------
     if (wave_active) {
 #pragma unroll
@@ -301,28 +334,27 @@ __global__ __launch_bounds__(WR* WC * 64) void rowgemm_kernel(RgArgs g) {
     }
 }
 
-template <int TN, int WR, int WC, int NOUT, int MODE>
+template <int TN, int WR, int WC, int NOUT, int MODE, bool ALIGNED, bool BCOLK>
 static int rg_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
     const int ncol = (g.N + TN - 1) / TN;
     const size_t smem = (size_t)(DN_TM * DN_KB + NOUT * DN_KB * TN) * sizeof(float);
-    DN_LAUNCH((rowgemm_kernel<TN, WR, WC, NOUT, MODE>), dim3(ntiles, ncol, 1), dim3(WR * WC * 64, 1, 1), smem, stream, g);
+    DN_LAUNCH((rowgemm_kernel<TN, WR, WC, NOUT, MODE, ALIGNED, BCOLK>), dim3(ntiles, ncol, 1), dim3(WR * WC * 64, 1, 1), smem,
+              stream, g);
     return (int)hipGetLastError();
 }
 
-template <int NOUT, int MODE>
+// tile width by output width on the aligned path; the general (odd-size) path always uses the 128-wide tile
+template <int NOUT, int MODE, bool BCOLK>
 static int rg_dispatch_width(const RgArgs& g, int ntiles, hipStream_t stream) {
-    if (NOUT == 1) {
-        if (g.N <= 32) return rg_launch<32, 4, 1, NOUT, MODE>(g, ntiles, stream);
-        if (g.N <= 64) return rg_launch<64, 2, 2, NOUT, MODE>(g, ntiles, stream);
-        return rg_launch<128, 2, 2, NOUT, MODE>(g, ntiles, stream);
-    }
-    if (g.N <= 32) return rg_launch<32, 4, 1, NOUT, MODE>(g, ntiles, stream);
-    if (g.N <= 64) return rg_launch<64, 2, 2, NOUT, MODE>(g, ntiles, stream);
-    return rg_launch<128, 2, 4, NOUT, MODE>(g, ntiles, stream);
+    constexpr int WC128 = NOUT == 1 ? 2 : 4;
+    if (!g.aligned) return rg_launch<128, 2, WC128, NOUT, MODE, false, BCOLK>(g, ntiles, stream);
+    if (g.N <= 32) return rg_launch<32, 4, 1, NOUT, MODE, true, BCOLK>(g, ntiles, stream);
+    if (g.N <= 64) return rg_launch<64, 2, 2, NOUT, MODE, true, BCOLK>(g, ntiles, stream);
+    return rg_launch<128, 2, WC128, NOUT, MODE, true, BCOLK>(g, ntiles, stream);
 }
 
 int dn_launch_rowgemm(const RgArgs& g, int ntiles, int nout, hipStream_t stream) {
-    if (ntiles <= 0 || g.N <= 0) return 0;
+    if (ntiles <= 0 || g.N <= 0 || g.nseg <= 0) return 0;
     int ktot = 0;
     for (int s = 0; s < g.nseg; ++s) ktot += g.a[s].w;
     const double rows = g.acct_rows;
@@ -331,21 +363,25 @@ int dn_launch_rowgemm(const RgArgs& g, int ntiles, int nout, hipStream_t stream)
     const int kind = nout == 1 ? DN_K_ROWGEMM : DN_K_ROWGEMM_DUAL;
     dn_prof_begin(kind, stream);
     int err = DN_ERR_BAD_MODE;
+    const bool ck = g.b_colk != 0;
     if (nout == 1) {
         switch (g.mode) {
-            case DN_EPI_STORE: err = rg_dispatch_width<1, DN_EPI_STORE>(g, ntiles, stream); break;
-            case DN_EPI_BIAS_RELU: err = rg_dispatch_width<1, DN_EPI_BIAS_RELU>(g, ntiles, stream); break;
-            case DN_EPI_BIAS_RESID: err = rg_dispatch_width<1, DN_EPI_BIAS_RESID>(g, ntiles, stream); break;
-            case DN_EPI_MUL_DFAC: err = rg_dispatch_width<1, DN_EPI_MUL_DFAC>(g, ntiles, stream); break;
-            case DN_EPI_ADD: err = rg_dispatch_width<1, DN_EPI_ADD>(g, ntiles, stream); break;
-            case DN_EPI_DTANH: err = rg_dispatch_width<1, DN_EPI_DTANH>(g, ntiles, stream); break;
-            case DN_EPI_MASS_ADD: err = rg_dispatch_width<1, DN_EPI_MASS_ADD>(g, ntiles, stream); break;
+            case DN_EPI_STORE:
+                err = ck ? rg_dispatch_width<1, DN_EPI_STORE, true>(g, ntiles, stream)
+                         : rg_dispatch_width<1, DN_EPI_STORE, false>(g, ntiles, stream);
+                break;
+            case DN_EPI_BIAS_RELU: if (ck) err = rg_dispatch_width<1, DN_EPI_BIAS_RELU, true>(g, ntiles, stream); break;
+            case DN_EPI_BIAS_RESID: if (ck) err = rg_dispatch_width<1, DN_EPI_BIAS_RESID, true>(g, ntiles, stream); break;
+            case DN_EPI_MUL_DFAC: if (!ck) err = rg_dispatch_width<1, DN_EPI_MUL_DFAC, false>(g, ntiles, stream); break;
+            case DN_EPI_ADD: if (!ck) err = rg_dispatch_width<1, DN_EPI_ADD, false>(g, ntiles, stream); break;
+            case DN_EPI_DTANH: if (!ck) err = rg_dispatch_width<1, DN_EPI_DTANH, false>(g, ntiles, stream); break;
+            case DN_EPI_MASS_ADD: if (!ck) err = rg_dispatch_width<1, DN_EPI_MASS_ADD, false>(g, ntiles, stream); break;
             default: break;
         }
     } else {
         switch (g.mode) {
-            case DN_EPI_GRADFEAT: err = rg_dispatch_width<2, DN_EPI_GRADFEAT>(g, ntiles, stream); break;
-            case DN_EPI_GRADFEAT_BWD: err = rg_dispatch_width<2, DN_EPI_GRADFEAT_BWD>(g, ntiles, stream); break;
+            case DN_EPI_GRADFEAT: if (ck) err = rg_dispatch_width<2, DN_EPI_GRADFEAT, true>(g, ntiles, stream); break;
+            case DN_EPI_GRADFEAT_BWD: if (!ck) err = rg_dispatch_width<2, DN_EPI_GRADFEAT_BWD, false>(g, ntiles, stream); break;
             default: break;
         }
     }
@@ -381,11 +417,10 @@ __global__ __launch_bounds__(256) void tngemm_kernel(TnArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, ls = lane >> 5;
-    const DnTile ch = g.chunks[blockIdx.x];
     const int n0 = blockIdx.y * DN_TO, m0 = blockIdx.z * DN_TO;
     const bool do_colsum = g.colsum != nullptr && blockIdx.y == 0;
-
     const bool wave_active = (m0 + wr * 64 < g.M) && (n0 + wc * 64 < g.N);
+
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -397,93 +432,123 @@ __global__ __launch_bounds__(256) void tngemm_kernel(TnArgs g) {
     // each thread always stages the same 4-column group (q) of both operands
     const int q = tid & 31, kr0 = tid >> 5;
     const int acol = m0 + 4 * q, bcol = n0 + 4 * q;
-    // aligned fast path: resolve the segment of this thread's column group once
-    const float* ap = nullptr; const float* aq = nullptr; int ald = 0;
-    const float* bp = nullptr; const float* bq = nullptr; int bld = 0;
+    // aligned fast path: resolve the segment of this thread's column group once; out-of-range groups read a
+    // valid (clamped) address and are zeroed afterwards so that no branch separates the loads
+    const float* ap = g.a[0].p; const float* aq = nullptr; int ald = g.a[0].ld;
+    const float* bp = g.b[0].p; const float* bq = nullptr; int bld = g.b[0].ld;
+    const bool a_ok = acol < g.M, b_ok = bcol < g.N;
+    bool any_aq = false, any_bq = false;
     if (g.aligned) {
         int c = acol;
         for (int i = 0; i < g.na; ++i) {
-            if (c < g.a[i].w) { ap = g.a[i].p + c; aq = g.a[i].q ? g.a[i].q + c : nullptr; ald = g.a[i].ld; break; }
+            any_aq = any_aq || g.a[i].q != nullptr;
+            if (a_ok && c >= 0 && c < g.a[i].w) { ap = g.a[i].p + c; aq = g.a[i].q ? g.a[i].q + c : nullptr; ald = g.a[i].ld; }
             c -= g.a[i].w;
         }
         c = bcol;
         for (int i = 0; i < g.nb; ++i) {
-            if (c < g.b[i].w) { bp = g.b[i].p + c; bq = g.b[i].q ? g.b[i].q + c : nullptr; bld = g.b[i].ld; break; }
+            any_bq = any_bq || g.b[i].q != nullptr;
+            if (b_ok && c >= 0 && c < g.b[i].w) { bp = g.b[i].p + c; bq = g.b[i].q ? g.b[i].q + c : nullptr; bld = g.b[i].ld; }
             c -= g.b[i].w;
         }
-        if (acol >= g.M) ap = nullptr;
-        if (bcol >= g.N) bp = nullptr;
     }
     float4 csum = dn_f4_zero();
-    float4 ra[4], rb[4];
+    float4 ra[4], rb[4], rqa[4], rqb[4];
+    float ma[4], mbk[4], rs[4] = {1.f, 1.f, 1.f, 1.f};
 
-    const int nsteps = (ch.nrows + DN_KB - 1) / DN_KB;
-    for (int step = 0; step <= nsteps; ++step) {
-        if (step < nsteps) {
+    const int c_beg = blockIdx.x * g.group;
+    const int c_end = (c_beg + g.group < g.nchunks) ? c_beg + g.group : g.nchunks;
+    for (int ci = c_beg; ci < c_end; ++ci) {
+        const DnTile ch = g.chunks[ci];
+        const int nsteps = (ch.nrows + DN_KB - 1) / DN_KB;
+        for (int step = 0; step <= nsteps; ++step) {
+            // ---- raw loads of slice `step` (nothing is used before the MFMAs below) ----
+            if (step < nsteps) {
+                if (g.aligned) {
+                    long long row[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int kr = step * DN_KB + kr0 + 8 * i;
-                const long long row = (long long)ch.row0 + kr;
-                float4 va = dn_f4_zero(), vb = dn_f4_zero();
-                if (kr < ch.nrows) {
-                    if (g.aligned) {
-                        if (ap) {
-                            va = *reinterpret_cast<const float4*>(ap + row * ald);
-                            if (aq) va = dn_f4_mul(va, *reinterpret_cast<const float4*>(aq + row * ald));
-                        }
-                        if (bp) {
-                            vb = *reinterpret_cast<const float4*>(bp + row * bld);
-                            if (bq) vb = dn_f4_mul(vb, *reinterpret_cast<const float4*>(bq + row * bld));
-                        }
-                    } else {
-                        float e[4], f[4];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            e[c] = (acol + c < g.M) ? tn_elem(g.a, g.na, row, acol + c) : 0.f;
-                            f[c] = (bcol + c < g.N) ? tn_elem(g.b, g.nb, row, bcol + c) : 0.f;
-                        }
-                        va = make_float4(e[0], e[1], e[2], e[3]);
-                        vb = make_float4(f[0], f[1], f[2], f[3]);
+                    for (int i = 0; i < 4; ++i) {
+                        const int kr = step * DN_KB + kr0 + 8 * i;
+                        const bool kok = kr < ch.nrows;
+                        row[i] = (long long)ch.row0 + (kok ? kr : 0);
+                        ma[i] = (kok && a_ok) ? 1.f : 0.f;
+                        mbk[i] = (kok && b_ok) ? 1.f : 0.f;
+                        ra[i] = *reinterpret_cast<const float4*>(ap + row[i] * ald);
+                        rb[i] = *reinterpret_cast<const float4*>(bp + row[i] * bld);
                     }
-                    if (g.b_rowscale) vb = dn_f4_scale(vb, g.b_rowscale[row]);
-                }
-                ra[i] = va;
-                rb[i] = vb;
-                if (do_colsum) { csum.x += va.x; csum.y += va.y; csum.z += va.z; csum.w += va.w; }
-            }
-        }
-        if (step > 0) {
-            if (wave_active) {
+                    if (any_aq) {   // uniform
 #pragma unroll
-            for (int kg = 0; kg < 4; ++kg) {
-                float af[2][4], bf[2][4];
+                        for (int i = 0; i < 4; ++i) rqa[i] = *reinterpret_cast<const float4*>((aq ? aq : ap) + row[i] * ald);
+                    }
+                    if (any_bq) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int kr = 8 * kg + 4 * ls + t;
+                        for (int i = 0; i < 4; ++i) rqb[i] = *reinterpret_cast<const float4*>((bq ? bq : bp) + row[i] * bld);
+                    }
+                    if (g.b_rowscale) {   // raw loads only; applied at the store phase
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        af[i][t] = sA[kr * DN_TO + (wr * 2 + i) * 32 + li];
-                        bf[i][t] = sB[kr * DN_TO + (wc * 2 + i) * 32 + li];
+                        for (int i = 0; i < 4; ++i) rs[i] = g.b_rowscale[row[i]];
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int kr = step * DN_KB + kr0 + 8 * i;
+                        const long long row = (long long)ch.row0 + kr;
+                        float e[4] = {0.f, 0.f, 0.f, 0.f}, f[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (kr < ch.nrows) {
+                            const float rs = g.b_rowscale ? g.b_rowscale[row] : 1.f;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                if (acol + c < g.M) e[c] = tn_elem(g.a, g.na, row, acol + c);
+                                if (bcol + c < g.N) f[c] = tn_elem(g.b, g.nb, row, bcol + c) * rs;
+                            }
+                        }
+                        ra[i] = make_float4(e[0], e[1], e[2], e[3]);
+                        rb[i] = make_float4(f[0], f[1], f[2], f[3]);
+                        ma[i] = 1.f;
+                        mbk[i] = 1.f;
                     }
                 }
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) acc[i][j] = dn_mfma(af[i][t], bf[j][t], acc[i][j]);
             }
-            }
-            __syncthreads();
-        }
-        if (step < nsteps) {
+            // ---- MFMAs on the slice in LDS ----
+            if (step > 0) {
+                if (wave_active) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int kr = kr0 + 8 * i;
-                *reinterpret_cast<float4*>(&sA[kr * DN_TO + 4 * q]) = ra[i];
-                *reinterpret_cast<float4*>(&sB[kr * DN_TO + 4 * q]) = rb[i];
+                    for (int kg = 0; kg < 4; ++kg) {
+                        float af[2][4], bf[2][4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int kr = 8 * kg + 4 * ls + t;
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) {
+                                af[i][t] = sA[kr * DN_TO + (wr * 2 + i) * 32 + li];
+                                bf[i][t] = sB[kr * DN_TO + (wc * 2 + i) * 32 + li];
+                            }
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                                for (int j = 0; j < 2; ++j) acc[i][j] = dn_mfma(af[i][t], bf[j][t], acc[i][j]);
+                    }
+                }
+                __syncthreads();
             }
-            __syncthreads();
+            // ---- post-process the loaded slice and stage it ----
+            if (step < nsteps) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float4 va = dn_f4_scale(ra[i], ma[i]);
+                    float4 vb = dn_f4_scale(rb[i], (g.aligned && g.b_rowscale) ? mbk[i] * rs[i] : mbk[i]);
+                    if (g.aligned && any_aq && aq) va = dn_f4_mul(va, rqa[i]);
+                    if (g.aligned && any_bq && bq) vb = dn_f4_mul(vb, rqb[i]);
+                    if (do_colsum) { csum.x += va.x; csum.y += va.y; csum.z += va.z; csum.w += va.w; }
+                    const int kr = kr0 + 8 * i;
+                    *reinterpret_cast<float4*>(&sA[kr * DN_TO + 4 * q]) = va;
+                    *reinterpret_cast<float4*>(&sB[kr * DN_TO + 4 * q]) = vb;
+                }
+                __syncthreads();
+            }
         }
     }
     // partial tile out
@@ -512,14 +577,19 @@ __global__ __launch_bounds__(256) void tngemm_kernel(TnArgs g) {
     }
 }
 
-int dn_launch_tngemm(const TnArgs& g, int nchunks, hipStream_t stream) {
-    if (nchunks <= 0 || g.M <= 0 || g.N <= 0) return 0;
+// returns the number of partials written (= gridDim.x) through *npartial
+int dn_launch_tngemm(const TnArgs& g_in, int nchunks, hipStream_t stream) {
+    if (nchunks <= 0 || g_in.M <= 0 || g_in.N <= 0) return 0;
+    TnArgs g = g_in;
+    g.nchunks = nchunks;
+    if (g.group < 1) g.group = 1;
+    const int nblk = (nchunks + g.group - 1) / g.group;
     const size_t smem = (size_t)2 * DN_KB * DN_TO * sizeof(float);
-    dim3 grid(nchunks, (g.N + DN_TO - 1) / DN_TO, (g.M + DN_TO - 1) / DN_TO);
+    dim3 grid(nblk, (g.N + DN_TO - 1) / DN_TO, (g.M + DN_TO - 1) / DN_TO);
     const double rows = g.acct_rows;
     dn_prof_begin(DN_K_TNGEMM, stream);
     DN_LAUNCH(tngemm_kernel, grid, dim3(256, 1, 1), smem, stream, g);
     dn_prof_end(DN_K_TNGEMM, stream, 2.0 * rows * g.M * g.N,
-                4.0 * (rows * (g.M + g.N) + (double)nchunks * g.M * g.N));
+                4.0 * (rows * (g.M + g.N) + (double)nblk * g.M * g.N));
     return (int)hipGetLastError();
 }

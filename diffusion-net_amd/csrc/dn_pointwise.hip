@@ -28,27 +28,25 @@ int dn_launch_spec_fwd(const float* partial, const int* mesh_chunk_off, const fl
     return (int)hipGetLastError();
 }
 
-// block = 32 channels x 8 k-lanes; d_t partial per (mesh, channel)
-__global__ __launch_bounds__(256) void spec_bwd_kernel(const float* partial, const int* mco, const float* evals,
-                                                       const float* time, const float* xs, float* dxs, float* dt_part,
-                                                       int K, int C) {
+// dys: [n_mesh,K,C] = evecs^T d_xd (already reduced over chunks).  In place: dys <- exp(-lambda t) * dys (the
+// spectrum handed to from_basis), and d_t partial per (mesh, channel).  block = 32 channels x 8 k-lanes.
+__global__ __launch_bounds__(256) void spec_bwd_kernel(float* dys, const float* evals, const float* time, const float* xs,
+                                                       float* dt_part, int K, int C) {
     __shared__ float red[8][32];
     const int m = blockIdx.y;
     const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
-    const int KC = K * C;
+    const long long KC = (long long)K * C;
     float dt = 0.f;
     if (c < C) {
         const float t = time[c];
-        const int ch0 = mco[m], ch1 = mco[m + 1];
         for (int k = kl; k < K; k += 8) {
-            const int i = k * C + c;
-            float d = 0.f;
-            for (int ch = ch0; ch < ch1; ++ch) d += partial[(long long)ch * KC + i];
+            const long long i = m * KC + (long long)k * C + c;
+            const float d = dys[i];
             const float lam = evals[m * K + k];
             const float coef = expf(-lam * t);
-            dxs[(long long)m * KC + i] = coef * d;
-            dt -= lam * d * coef * xs[(long long)m * KC + i];
+            dys[i] = coef * d;
+            dt -= lam * d * coef * xs[i];
         }
     }
     red[kl][cl] = dt;
@@ -61,56 +59,109 @@ __global__ __launch_bounds__(256) void spec_bwd_kernel(const float* partial, con
     }
 }
 
-int dn_launch_spec_bwd(const float* partial, const int* mesh_chunk_off, const float* evals, const float* time,
-                       const float* xs, float* dxs, float* dt_part, int n_mesh, int K, int C, hipStream_t stream) {
+int dn_launch_spec_bwd(float* dys, const float* evals, const float* time, const float* xs, float* dt_part, int n_mesh, int K,
+                       int C, hipStream_t stream) {
     if (n_mesh <= 0 || K <= 0 || C <= 0) return 0;
     dim3 grid((C + 31) / 32, n_mesh, 1);
-    DN_LAUNCH(spec_bwd_kernel, grid, dim3(256, 1, 1), 0, stream, partial, mesh_chunk_off, evals, time, xs, dxs,
-              dt_part, K, C);
+    dn_prof_begin(DN_K_SMALL, stream);
+    DN_LAUNCH(spec_bwd_kernel, grid, dim3(256, 1, 1), 0, stream, dys, evals, time, xs, dt_part, K, C);
+    dn_prof_end(DN_K_SMALL, stream, 0.0, 0.0);
     return (int)hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void reduce_kernel(const float* partial, float* out, int n, long long stride,
-                                                     long long len) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= len) return;
-    float s = 0.f;
-    for (int ch = 0; ch < n; ++ch) s += partial[ch * stride + i];
-    out[i] = s;
+// Fixed-order segmented sum of split-V partials: out[s][i] = sum_{ch in segment s} partial[ch][i].
+// block = 32 column groups x 8 chunk lanes: lane kl sums chunks beg+kl, beg+kl+8, ... (several loads in flight),
+// the 8 lane sums are then combined in order through LDS -> bitwise reproducible, bandwidth-bound.
+template <int VEC>
+__global__ __launch_bounds__(256) void seg_reduce_kernel(const float* partial, const int* seg_off, int n, float* out,
+                                                         long long len) {
+    __shared__ float red[8][32 * VEC];
+    const int s = blockIdx.y;
+    const int beg = seg_off ? seg_off[s] : 0, end = seg_off ? seg_off[s + 1] : n;
+    const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
+    const long long i = ((long long)blockIdx.x * 32 + cl) * VEC;
+    float a[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) a[e] = 0.f;
+    if (i < len) {
+        int ch = beg + kl;
+        for (; ch + 24 < end; ch += 32) {
+            float v[4][VEC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* src = partial + (long long)(ch + 8 * u) * len + i;
+                if (VEC == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(src);
+                    v[u][0] = t.x; v[u][1 % VEC] = t.y; v[u][2 % VEC] = t.z; v[u][3 % VEC] = t.w;
+                } else {
+                    v[u][0] = src[0];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) a[e] += v[u][e];
+        }
+        for (; ch < end; ch += 8) {
+            const float* src = partial + (long long)ch * len + i;
+            if (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(src);
+                a[0] += t.x; a[1 % VEC] += t.y; a[2 % VEC] += t.z; a[3 % VEC] += t.w;
+            } else {
+                a[0] += src[0];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) red[kl][cl * VEC + e] = a[e];
+    __syncthreads();
+    if (kl == 0 && i < len) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t += red[j][cl * VEC + e];
+            out[(long long)s * len + i + e] = t;
+        }
+    }
+}
+
+int dn_launch_seg_reduce(const float* partial, const int* seg_off, int nseg, int n, float* out, long long len,
+                         hipStream_t stream) {
+    if (len <= 0 || nseg <= 0) return 0;
+    const bool vec = (len % 4 == 0) && ((uintptr_t)partial % 16 == 0) && ((uintptr_t)out % 16 == 0);
+    dn_prof_begin(DN_K_SMALL, stream);
+    if (vec) {
+        dim3 grid((unsigned)((len / 4 + 31) / 32), nseg, 1);
+        DN_LAUNCH(seg_reduce_kernel<4>, grid, dim3(256, 1, 1), 0, stream, partial, seg_off, n, out, len);
+    } else {
+        dim3 grid((unsigned)((len + 31) / 32), nseg, 1);
+        DN_LAUNCH(seg_reduce_kernel<1>, grid, dim3(256, 1, 1), 0, stream, partial, seg_off, n, out, len);
+    }
+    dn_prof_end(DN_K_SMALL, stream, 0.0, 4.0 * (double)len * ((double)(seg_off ? 0 : n) + 1.0));
+    return (int)hipGetLastError();
 }
 
 int dn_launch_reduce(const float* partial, float* out, int n, long long stride, long long len, hipStream_t stream) {
-    if (len <= 0) return 0;
-    dim3 grid((unsigned)((len + 255) / 256), 1, 1);
-    DN_LAUNCH(reduce_kernel, grid, dim3(256, 1, 1), 0, stream, partial, out, n, stride, len);
-    return (int)hipGetLastError();
+    if (stride != len) return DN_ERR_BAD_MODE;
+    return dn_launch_seg_reduce(partial, nullptr, 1, n, out, len, stream);
 }
 
-// partial: [n][2C][2C] of [dBre|dBim]^T [gx|gy];  dA_re = P00 + P11,  dA_im = P10 - P01
+// P: [2C][2C] = [dBre|dBim]^T [gx|gy] summed over all rows;  dA_re = P00 + P11,  dA_im = P10 - P01
 // (dA_im null: gradient rotations off, single matrix A, dA = P00 + P11 -> dA_re)
-__global__ __launch_bounds__(256) void reduce_dA_kernel(const float* partial, float* dA_re, float* dA_im, int n, int C) {
+__global__ __launch_bounds__(256) void combine_dA_kernel(const float* P, float* dA_re, float* dA_im, int C) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= C * C) return;
     const int o = i / C, c = i % C;
-    const long long W = 2LL * C, stride = W * W;
-    float p00 = 0.f, p11 = 0.f, p01 = 0.f, p10 = 0.f;
-    for (int ch = 0; ch < n; ++ch) {
-        const float* P = partial + ch * stride;
-        p00 += P[o * W + c];
-        p11 += P[(C + o) * W + C + c];
-        if (dA_im) {
-            p01 += P[o * W + C + c];
-            p10 += P[(C + o) * W + c];
-        }
-    }
-    dA_re[i] = p00 + p11;
-    if (dA_im) dA_im[i] = p10 - p01;
+    const long long W = 2LL * C;
+    dA_re[i] = P[o * W + c] + P[(C + o) * W + C + c];
+    if (dA_im) dA_im[i] = P[(C + o) * W + c] - P[o * W + C + c];
 }
 
-int dn_launch_reduce_dA(const float* partial, float* dA_re, float* dA_im, int n, int C, hipStream_t stream) {
+int dn_launch_combine_dA(const float* P, float* dA_re, float* dA_im, int C, hipStream_t stream) {
     if (C <= 0) return 0;
     dim3 grid((C * C + 255) / 256, 1, 1);
-    DN_LAUNCH(reduce_dA_kernel, grid, dim3(256, 1, 1), 0, stream, partial, dA_re, dA_im, n, C);
+    DN_LAUNCH(combine_dA_kernel, grid, dim3(256, 1, 1), 0, stream, P, dA_re, dA_im, C);
     return (int)hipGetLastError();
 }
 
