@@ -110,14 +110,12 @@ struct RgRegs {
     float am[A_IT];          // row guard as 0/1 factor
     float4 b[NOUT][B_IT];
     float bm[NOUT][B_IT];    // column guard * sign
-    bool has_q;
 };
 
-template <int TN, int NTHR, int NOUT, bool ALIGNED, bool BCOLK, int A_IT, int B_IT>
+template <int TN, int NTHR, int NOUT, bool ALIGNED, bool BCOLK, bool HASQ, int A_IT, int B_IT>
 __device__ __forceinline__ void rg_load(const RgArgs& g, const DnTile& tile, int n0, int seg, int koff, int tid,
                                         RgRegs<NOUT, A_IT, B_IT>& R) {
     const RgSeg sg = g.a[seg];
-    R.has_q = false;
     if (ALIGNED) {
         long long off[A_IT];
 #pragma unroll
@@ -129,8 +127,7 @@ __device__ __forceinline__ void rg_load(const RgArgs& g, const DnTile& tile, int
             off[i] = (long long)(tile.row0 + (rok ? row : 0)) * sg.ld + koff + 4 * q;
             R.a[i] = *reinterpret_cast<const float4*>(sg.p + off[i]);
         }
-        if (sg.q) {   // uniform; loads only, no use
-            R.has_q = true;
+        if (HASQ) {   // compile-time; loads only, no use
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) R.q[i] = *reinterpret_cast<const float4*>(sg.q + off[i]);
         }
@@ -174,6 +171,7 @@ __device__ __forceinline__ void rg_load(const RgArgs& g, const DnTile& tile, int
             }
             R.a[i] = make_float4(e[0], e[1], e[2], e[3]);
             R.am[i] = 1.f;
+            if (HASQ) R.q[i] = make_float4(1.f, 1.f, 1.f, 1.f);   // already folded in above
         }
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) {
@@ -206,14 +204,14 @@ __device__ __forceinline__ void rg_load(const RgArgs& g, const DnTile& tile, int
     }
 }
 
-template <int TN, int NTHR, int NOUT, bool BCOLK, int A_IT, int B_IT>
+template <int TN, int NTHR, int NOUT, bool BCOLK, bool HASQ, int A_IT, int B_IT>
 __device__ __forceinline__ void rg_store(float* sA, float* sB, int tid, const RgRegs<NOUT, A_IT, B_IT>& R) {
     constexpr int SB = DN_KB * TN;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int idx = tid + i * NTHR;
         float4 v = dn_f4_scale(R.a[i], R.am[i]);
-        if (R.has_q) v = dn_f4_mul(v, R.q[i]);
+        if (HASQ) v = dn_f4_mul(v, R.q[i]);
         *reinterpret_cast<float4*>(&sA[dn_colk_off(idx >> 3, idx & 7)]) = v;
     }
 #pragma unroll
@@ -276,18 +274,20 @@ __global__ __launch_bounds__(WR* WC * 64) void rowgemm_kernel(RgArgs g) {
     constexpr int NT = TN / (32 * WC);
     constexpr int A_IT = DN_TM * 8 / NTHR;
     constexpr int B_IT = DN_KB * TN / 4 / NTHR;
+    constexpr int SA = DN_TM * DN_KB;              // floats of one A slice
+    constexpr int SBUF = SA + NOUT * DN_KB * TN;   // floats of one (A,B) slice buffer; two buffers in LDS
+    constexpr bool HASQ = (MODE == DN_EPI_GRADFEAT_BWD);   // the only op whose A operand is an elementwise product
     static_assert(MT >= 1 && NT >= 1 && A_IT >= 1 && B_IT >= 1, "bad tile config");
 
     DN_DYN_SMEM(smem_raw);
-    float* sA = reinterpret_cast<float*>(smem_raw);
-    float* sB = sA + DN_TM * DN_KB;
+    float* smem = reinterpret_cast<float*>(smem_raw);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;
     const int li = lane & 31, ls = lane >> 5;
     const DnTile tile = g.tiles[blockIdx.x];
     const int n0 = blockIdx.y * TN;
-    // a wave whose whole sub-tile lies outside the tile's rows / the output's columns skips its MFMAs
+    // a wave whose whole sub-tile lies outside the tile's rows / the output's columns has nothing to store
     const bool wave_active = (wr * MT * 32 < tile.nrows) && (n0 + wc * NT * 32 < g.N);
 
     f32x16 acc[NOUT][MT][NT];
@@ -301,23 +301,44 @@ __global__ __launch_bounds__(WR* WC * 64) void rowgemm_kernel(RgArgs g) {
                 for (int r = 0; r < 16; ++r) acc[o][mt][nt][r] = 0.f;
 
     RgRegs<NOUT, A_IT, B_IT> R;
-
     int nslices = 0;
     for (int s = 0; s < g.nseg; ++s) nslices += (g.a[s].w + DN_KB - 1) / DN_KB;
+
+    // Software pipeline over 32-wide slices of the contraction axis, two LDS buffers, ONE barrier per slice:
+    //   iteration sl:  regs(slice sl+1) -> LDS[other] ; global loads of slice sl+2 -> regs ; MFMAs on LDS[cur] ; barrier
+    // The steady-state body has no branch, so the LDS writes and the global loads can be scheduled under the MFMAs.
     int seg = 0, koff = 0;
-    rg_load<TN, NTHR, NOUT, ALIGNED, BCOLK, A_IT, B_IT>(g, tile, n0, seg, koff, tid, R);
-    rg_store<TN, NTHR, NOUT, BCOLK, A_IT, B_IT>(sA, sB, tid, R);
-    __syncthreads();
-    for (int sl = 1; sl < nslices; ++sl) {
+    rg_load<TN, NTHR, NOUT, ALIGNED, BCOLK, HASQ, A_IT, B_IT>(g, tile, n0, seg, koff, tid, R);
+    rg_store<TN, NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>(smem, smem + SA, tid, R);
+    if (nslices > 1) {
         koff += DN_KB;
         if (koff >= g.a[seg].w) { koff = 0; ++seg; }
-        rg_load<TN, NTHR, NOUT, ALIGNED, BCOLK, A_IT, B_IT>(g, tile, n0, seg, koff, tid, R);   // in flight during the MFMAs
-        if (wave_active) rg_compute<TN, MT, NT, NOUT, BCOLK>(sA, sB, wr * MT * 32, wc * NT * 32, li, ls, acc);
-        __syncthreads();   // everyone done reading the slice in LDS
-        rg_store<TN, NTHR, NOUT, BCOLK, A_IT, B_IT>(sA, sB, tid, R);
+        rg_load<TN, NTHR, NOUT, ALIGNED, BCOLK, HASQ, A_IT, B_IT>(g, tile, n0, seg, koff, tid, R);
+    }
+    __syncthreads();
+    int sl = 0;
+    for (; sl + 2 < nslices; ++sl) {
+        float* cur = smem + (sl & 1) * SBUF;
+        float* nxt = smem + ((sl & 1) ^ 1) * SBUF;
+        rg_store<TN, NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>(nxt, nxt + SA, tid, R);
+        koff += DN_KB;
+        if (koff >= g.a[seg].w) { koff = 0; ++seg; }
+        rg_load<TN, NTHR, NOUT, ALIGNED, BCOLK, HASQ, A_IT, B_IT>(g, tile, n0, seg, koff, tid, R);
+        rg_compute<TN, MT, NT, NOUT, BCOLK>(cur, cur + SA, wr * MT * 32, wc * NT * 32, li, ls, acc);
         __syncthreads();
     }
-    if (wave_active) rg_compute<TN, MT, NT, NOUT, BCOLK>(sA, sB, wr * MT * 32, wc * NT * 32, li, ls, acc);
+    if (sl + 1 < nslices) {   // second-to-last slice: stage the last one, nothing left to load
+        float* cur = smem + (sl & 1) * SBUF;
+        float* nxt = smem + ((sl & 1) ^ 1) * SBUF;
+        rg_store<TN, NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>(nxt, nxt + SA, tid, R);
+        rg_compute<TN, MT, NT, NOUT, BCOLK>(cur, cur + SA, wr * MT * 32, wc * NT * 32, li, ls, acc);
+        __syncthreads();
+        ++sl;
+    }
+    {
+        float* cur = smem + (sl & 1) * SBUF;
+        rg_compute<TN, MT, NT, NOUT, BCOLK>(cur, cur + SA, wr * MT * 32, wc * NT * 32, li, ls, acc);
+    }
 
     // ---------------- epilogue ----------------
     if (wave_active) {
@@ -337,7 +358,15 @@ __global__ __launch_bounds__(WR* WC * 64) void rowgemm_kernel(RgArgs g) {
 template <int TN, int WR, int WC, int NOUT, int MODE, bool ALIGNED, bool BCOLK>
 static int rg_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
     const int ncol = (g.N + TN - 1) / TN;
-    const size_t smem = (size_t)(DN_TM * DN_KB + NOUT * DN_KB * TN) * sizeof(float);
+    const size_t smem = (size_t)2 * (DN_TM * DN_KB + NOUT * DN_KB * TN) * sizeof(float);
+#ifndef DN_EMULATE
+    static bool lds_opt_in = false;   // idempotent: allow > 64 KiB of dynamic LDS for this instantiation
+    if (!lds_opt_in) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_kernel<TN, WR, WC, NOUT, MODE, ALIGNED, BCOLK>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        lds_opt_in = true;
+    }
+#endif
     DN_LAUNCH((rowgemm_kernel<TN, WR, WC, NOUT, MODE, ALIGNED, BCOLK>), dim3(ntiles, ncol, 1), dim3(WR * WC * 64, 1, 1), smem,
               stream, g);
     return (int)hipGetLastError();
@@ -409,16 +438,102 @@ __device__ __forceinline__ float tn_elem(const TnSeg* s, int ns, long long row, 
     return 0.f;
 }
 
+enum { DN_TN_PLAIN = 0, DN_TN_ROWSCALE = 1, DN_TN_COLSUM = 2, DN_TN_QA = 3 };
+
+struct TnRegs {
+    float4 a[4], b[4], qa[4];
+    float ma[4], mb[4];
+};
+
+// raw loads of one 32-row step (nothing is used here, so the loads stay in flight under the MFMAs)
+template <bool ALIGNED, int FLAVOR>
+__device__ __forceinline__ void tn_load(const TnArgs& g, const DnTile& ch, int step, int kr0, int acol, int bcol, bool a_ok,
+                                        bool b_ok, const float* ap, const float* aq, int ald, const float* bp, int bld,
+                                        TnRegs& R) {
+    if (ALIGNED) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kr = step * DN_KB + kr0 + 8 * i;
+            const bool kok = kr < ch.nrows;
+            const long long row = (long long)ch.row0 + (kok ? kr : 0);
+            R.ma[i] = (kok && a_ok) ? 1.f : 0.f;
+            R.mb[i] = (kok && b_ok) ? 1.f : 0.f;
+            R.a[i] = *reinterpret_cast<const float4*>(ap + row * ald);
+            R.b[i] = *reinterpret_cast<const float4*>(bp + row * bld);
+            if (FLAVOR == DN_TN_QA) R.qa[i] = *reinterpret_cast<const float4*>(aq + row * ald);
+            if (FLAVOR == DN_TN_ROWSCALE) R.qa[i].x = g.b_rowscale[row];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kr = step * DN_KB + kr0 + 8 * i;
+            const long long row = (long long)ch.row0 + kr;
+            float e[4] = {0.f, 0.f, 0.f, 0.f}, f[4] = {0.f, 0.f, 0.f, 0.f};
+            if (kr < ch.nrows) {
+                const float rs = g.b_rowscale ? g.b_rowscale[row] : 1.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (acol + c < g.M) e[c] = tn_elem(g.a, g.na, row, acol + c);
+                    if (bcol + c < g.N) f[c] = tn_elem(g.b, g.nb, row, bcol + c) * rs;
+                }
+            }
+            R.a[i] = make_float4(e[0], e[1], e[2], e[3]);
+            R.b[i] = make_float4(f[0], f[1], f[2], f[3]);
+            R.ma[i] = 1.f;
+            R.mb[i] = 1.f;
+            if (FLAVOR == DN_TN_QA) R.qa[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (FLAVOR == DN_TN_ROWSCALE) R.qa[i].x = 1.f;
+        }
+    }
+}
+
+template <int FLAVOR>
+__device__ __forceinline__ void tn_store(float* sA, float* sB, int kr0, int q, const TnRegs& R, float4& csum) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float4 va = dn_f4_scale(R.a[i], R.ma[i]);
+        float4 vb = dn_f4_scale(R.b[i], FLAVOR == DN_TN_ROWSCALE ? R.mb[i] * R.qa[i].x : R.mb[i]);
+        if (FLAVOR == DN_TN_QA) va = dn_f4_mul(va, R.qa[i]);
+        if (FLAVOR == DN_TN_COLSUM) { csum.x += va.x; csum.y += va.y; csum.z += va.z; csum.w += va.w; }
+        const int kr = kr0 + 8 * i;
+        *reinterpret_cast<float4*>(&sA[kr * DN_TO + 4 * q]) = va;
+        *reinterpret_cast<float4*>(&sB[kr * DN_TO + 4 * q]) = vb;
+    }
+}
+
+__device__ __forceinline__ void tn_compute(const float* sA, const float* sB, int wr, int wc, int li, int ls, f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+        float af[2][4], bf[2][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int kr = 8 * kg + 4 * ls + t;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i][t] = sA[kr * DN_TO + (wr * 2 + i) * 32 + li];
+                bf[i][t] = sB[kr * DN_TO + (wc * 2 + i) * 32 + li];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = dn_mfma(af[i][t], bf[j][t], acc[i][j]);
+    }
+}
+
+template <bool ALIGNED, int FLAVOR>
 __global__ __launch_bounds__(256) void tngemm_kernel(TnArgs g) {
+    constexpr int SBUF = 2 * DN_KB * DN_TO;   // floats of one (A,B) step buffer; two buffers in LDS
     DN_DYN_SMEM(smem_raw);
-    float* sA = reinterpret_cast<float*>(smem_raw);   // [32][128]  k-major
-    float* sB = sA + DN_KB * DN_TO;                   // [32][128]
+    float* smem = reinterpret_cast<float*>(smem_raw);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, ls = lane >> 5;
     const int n0 = blockIdx.y * DN_TO, m0 = blockIdx.z * DN_TO;
-    const bool do_colsum = g.colsum != nullptr && blockIdx.y == 0;
+    const bool do_colsum = FLAVOR == DN_TN_COLSUM && blockIdx.y == 0;
     const bool wave_active = (m0 + wr * 64 < g.M) && (n0 + wc * 64 < g.N);
 
     f32x16 acc[2][2];
@@ -429,126 +544,59 @@ __global__ __launch_bounds__(256) void tngemm_kernel(TnArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // each thread always stages the same 4-column group (q) of both operands
+    // each thread always stages the same 4-column group (q) of both operands; on the aligned path its segment is
+    // resolved once, out-of-range groups read a valid (clamped) address and are zeroed by the 0/1 factor
     const int q = tid & 31, kr0 = tid >> 5;
     const int acol = m0 + 4 * q, bcol = n0 + 4 * q;
-    // aligned fast path: resolve the segment of this thread's column group once; out-of-range groups read a
-    // valid (clamped) address and are zeroed afterwards so that no branch separates the loads
-    const float* ap = g.a[0].p; const float* aq = nullptr; int ald = g.a[0].ld;
-    const float* bp = g.b[0].p; const float* bq = nullptr; int bld = g.b[0].ld;
+    const float* ap = g.a[0].p; const float* aq = g.a[0].q ? g.a[0].q : g.a[0].p; int ald = g.a[0].ld;
+    const float* bp = g.b[0].p; int bld = g.b[0].ld;
     const bool a_ok = acol < g.M, b_ok = bcol < g.N;
-    bool any_aq = false, any_bq = false;
-    if (g.aligned) {
+    if (ALIGNED) {
         int c = acol;
         for (int i = 0; i < g.na; ++i) {
-            any_aq = any_aq || g.a[i].q != nullptr;
-            if (a_ok && c >= 0 && c < g.a[i].w) { ap = g.a[i].p + c; aq = g.a[i].q ? g.a[i].q + c : nullptr; ald = g.a[i].ld; }
+            if (a_ok && c >= 0 && c < g.a[i].w) { ap = g.a[i].p + c; aq = (g.a[i].q ? g.a[i].q : g.a[i].p) + c; ald = g.a[i].ld; }
             c -= g.a[i].w;
         }
         c = bcol;
         for (int i = 0; i < g.nb; ++i) {
-            any_bq = any_bq || g.b[i].q != nullptr;
-            if (b_ok && c >= 0 && c < g.b[i].w) { bp = g.b[i].p + c; bq = g.b[i].q ? g.b[i].q + c : nullptr; bld = g.b[i].ld; }
+            if (b_ok && c >= 0 && c < g.b[i].w) { bp = g.b[i].p + c; bld = g.b[i].ld; }
             c -= g.b[i].w;
         }
     }
     float4 csum = dn_f4_zero();
-    float4 ra[4], rb[4], rqa[4], rqb[4];
-    float ma[4], mbk[4], rs[4] = {1.f, 1.f, 1.f, 1.f};
+    TnRegs R;
 
     const int c_beg = blockIdx.x * g.group;
     const int c_end = (c_beg + g.group < g.nchunks) ? c_beg + g.group : g.nchunks;
     for (int ci = c_beg; ci < c_end; ++ci) {
         const DnTile ch = g.chunks[ci];
         const int nsteps = (ch.nrows + DN_KB - 1) / DN_KB;
-        for (int step = 0; step <= nsteps; ++step) {
-            // ---- raw loads of slice `step` (nothing is used before the MFMAs below) ----
-            if (step < nsteps) {
-                if (g.aligned) {
-                    long long row[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int kr = step * DN_KB + kr0 + 8 * i;
-                        const bool kok = kr < ch.nrows;
-                        row[i] = (long long)ch.row0 + (kok ? kr : 0);
-                        ma[i] = (kok && a_ok) ? 1.f : 0.f;
-                        mbk[i] = (kok && b_ok) ? 1.f : 0.f;
-                        ra[i] = *reinterpret_cast<const float4*>(ap + row[i] * ald);
-                        rb[i] = *reinterpret_cast<const float4*>(bp + row[i] * bld);
-                    }
-                    if (any_aq) {   // uniform
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) rqa[i] = *reinterpret_cast<const float4*>((aq ? aq : ap) + row[i] * ald);
-                    }
-                    if (any_bq) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) rqb[i] = *reinterpret_cast<const float4*>((bq ? bq : bp) + row[i] * bld);
-                    }
-                    if (g.b_rowscale) {   // raw loads only; applied at the store phase
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) rs[i] = g.b_rowscale[row[i]];
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int kr = step * DN_KB + kr0 + 8 * i;
-                        const long long row = (long long)ch.row0 + kr;
-                        float e[4] = {0.f, 0.f, 0.f, 0.f}, f[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (kr < ch.nrows) {
-                            const float rs = g.b_rowscale ? g.b_rowscale[row] : 1.f;
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) {
-                                if (acol + c < g.M) e[c] = tn_elem(g.a, g.na, row, acol + c);
-                                if (bcol + c < g.N) f[c] = tn_elem(g.b, g.nb, row, bcol + c) * rs;
-                            }
-                        }
-                        ra[i] = make_float4(e[0], e[1], e[2], e[3]);
-                        rb[i] = make_float4(f[0], f[1], f[2], f[3]);
-                        ma[i] = 1.f;
-                        mbk[i] = 1.f;
-                    }
-                }
-            }
-            // ---- MFMAs on the slice in LDS ----
-            if (step > 0) {
-                if (wave_active) {
-#pragma unroll
-                    for (int kg = 0; kg < 4; ++kg) {
-                        float af[2][4], bf[2][4];
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const int kr = 8 * kg + 4 * ls + t;
-#pragma unroll
-                            for (int i = 0; i < 2; ++i) {
-                                af[i][t] = sA[kr * DN_TO + (wr * 2 + i) * 32 + li];
-                                bf[i][t] = sB[kr * DN_TO + (wc * 2 + i) * 32 + li];
-                            }
-                        }
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-#pragma unroll
-                            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                                for (int j = 0; j < 2; ++j) acc[i][j] = dn_mfma(af[i][t], bf[j][t], acc[i][j]);
-                    }
-                }
-                __syncthreads();
-            }
-            // ---- post-process the loaded slice and stage it ----
-            if (step < nsteps) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float4 va = dn_f4_scale(ra[i], ma[i]);
-                    float4 vb = dn_f4_scale(rb[i], (g.aligned && g.b_rowscale) ? mbk[i] * rs[i] : mbk[i]);
-                    if (g.aligned && any_aq && aq) va = dn_f4_mul(va, rqa[i]);
-                    if (g.aligned && any_bq && bq) vb = dn_f4_mul(vb, rqb[i]);
-                    if (do_colsum) { csum.x += va.x; csum.y += va.y; csum.z += va.z; csum.w += va.w; }
-                    const int kr = kr0 + 8 * i;
-                    *reinterpret_cast<float4*>(&sA[kr * DN_TO + 4 * q]) = va;
-                    *reinterpret_cast<float4*>(&sB[kr * DN_TO + 4 * q]) = vb;
-                }
-                __syncthreads();
-            }
+        // pipeline: regs(step+1) -> LDS[other]; loads(step+2) -> regs; MFMAs on LDS[cur]; ONE barrier per step
+        tn_load<ALIGNED, FLAVOR>(g, ch, 0, kr0, acol, bcol, a_ok, b_ok, ap, aq, ald, bp, bld, R);
+        tn_store<FLAVOR>(smem, smem + DN_KB * DN_TO, kr0, q, R, csum);
+        if (nsteps > 1) tn_load<ALIGNED, FLAVOR>(g, ch, 1, kr0, acol, bcol, a_ok, b_ok, ap, aq, ald, bp, bld, R);
+        __syncthreads();
+        int st = 0;
+        for (; st + 2 < nsteps; ++st) {
+            float* cur = smem + (st & 1) * SBUF;
+            float* nxt = smem + ((st & 1) ^ 1) * SBUF;
+            tn_store<FLAVOR>(nxt, nxt + DN_KB * DN_TO, kr0, q, R, csum);
+            tn_load<ALIGNED, FLAVOR>(g, ch, st + 2, kr0, acol, bcol, a_ok, b_ok, ap, aq, ald, bp, bld, R);
+            tn_compute(cur, cur + DN_KB * DN_TO, wr, wc, li, ls, acc);
+            __syncthreads();
+        }
+        if (st + 1 < nsteps) {
+            float* cur = smem + (st & 1) * SBUF;
+            float* nxt = smem + ((st & 1) ^ 1) * SBUF;
+            tn_store<FLAVOR>(nxt, nxt + DN_KB * DN_TO, kr0, q, R, csum);
+            tn_compute(cur, cur + DN_KB * DN_TO, wr, wc, li, ls, acc);
+            __syncthreads();
+            ++st;
+        }
+        {
+            float* cur = smem + (st & 1) * SBUF;
+            tn_compute(cur, cur + DN_KB * DN_TO, wr, wc, li, ls, acc);
+            __syncthreads();   // the next chunk's prologue overwrites buffer 0
         }
     }
     // partial tile out
@@ -566,15 +614,22 @@ __global__ __launch_bounds__(256) void tngemm_kernel(TnArgs g) {
             }
         }
     if (do_colsum) {   // uniform per block
-        *reinterpret_cast<float4*>(&sA[kr0 * DN_TO + 4 * q]) = csum;
+        *reinterpret_cast<float4*>(&smem[kr0 * DN_TO + 4 * q]) = csum;
         __syncthreads();
         if (tid < DN_TO && m0 + tid < g.M) {
-            float s = 0.f;
+            float sum = 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) s += sA[k * DN_TO + tid];
-            g.colsum[(long long)blockIdx.x * g.M + m0 + tid] = s;
+            for (int k = 0; k < 8; ++k) sum += smem[k * DN_TO + tid];
+            g.colsum[(long long)blockIdx.x * g.M + m0 + tid] = sum;
         }
     }
+}
+
+template <bool ALIGNED, int FLAVOR>
+static int tn_launch(const TnArgs& g, dim3 grid, hipStream_t stream) {
+    const size_t smem = (size_t)2 * 2 * DN_KB * DN_TO * sizeof(float);
+    DN_LAUNCH((tngemm_kernel<ALIGNED, FLAVOR>), grid, dim3(256, 1, 1), smem, stream, g);
+    return (int)hipGetLastError();
 }
 
 // returns the number of partials written (= gridDim.x) through *npartial
@@ -584,12 +639,32 @@ int dn_launch_tngemm(const TnArgs& g_in, int nchunks, hipStream_t stream) {
     g.nchunks = nchunks;
     if (g.group < 1) g.group = 1;
     const int nblk = (nchunks + g.group - 1) / g.group;
-    const size_t smem = (size_t)2 * DN_KB * DN_TO * sizeof(float);
     dim3 grid(nblk, (g.N + DN_TO - 1) / DN_TO, (g.M + DN_TO - 1) / DN_TO);
+    // flavour: which optional operand treatment the launch needs (at most one is ever combined by the callers)
+    bool has_qa = false;
+    for (int i = 0; i < g.na; ++i) has_qa = has_qa || g.a[i].q != nullptr;
+    for (int i = 0; i < g.nb; ++i) if (g.b[i].q) return DN_ERR_BAD_MODE;
+    const int flavor = has_qa ? DN_TN_QA : (g.colsum ? DN_TN_COLSUM : (g.b_rowscale ? DN_TN_ROWSCALE : DN_TN_PLAIN));
+    if ((has_qa && (g.colsum || g.b_rowscale)) || (g.colsum && g.b_rowscale)) return DN_ERR_BAD_MODE;
     const double rows = g.acct_rows;
     dn_prof_begin(DN_K_TNGEMM, stream);
-    DN_LAUNCH(tngemm_kernel, grid, dim3(256, 1, 1), smem, stream, g);
+    int err;
+    if (g.aligned) {
+        switch (flavor) {
+            case DN_TN_QA: err = tn_launch<true, DN_TN_QA>(g, grid, stream); break;
+            case DN_TN_COLSUM: err = tn_launch<true, DN_TN_COLSUM>(g, grid, stream); break;
+            case DN_TN_ROWSCALE: err = tn_launch<true, DN_TN_ROWSCALE>(g, grid, stream); break;
+            default: err = tn_launch<true, DN_TN_PLAIN>(g, grid, stream); break;
+        }
+    } else {
+        switch (flavor) {
+            case DN_TN_QA: err = tn_launch<false, DN_TN_QA>(g, grid, stream); break;
+            case DN_TN_COLSUM: err = tn_launch<false, DN_TN_COLSUM>(g, grid, stream); break;
+            case DN_TN_ROWSCALE: err = tn_launch<false, DN_TN_ROWSCALE>(g, grid, stream); break;
+            default: err = tn_launch<false, DN_TN_PLAIN>(g, grid, stream); break;
+        }
+    }
     dn_prof_end(DN_K_TNGEMM, stream, 2.0 * rows * g.M * g.N,
                 4.0 * (rows * (g.M + g.N) + (double)nblk * g.M * g.N));
-    return (int)hipGetLastError();
+    return err;
 }

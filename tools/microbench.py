@@ -14,7 +14,11 @@ import bench
 from diffusion_net import ops
 
 
-def timeit(fn, reps=20, warm=3):
+REPS = [20]
+
+
+def timeit(fn, reps=None, warm=2):
+    reps = reps or REPS[0]
     for _ in range(warm):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -33,7 +37,9 @@ def main():
     ap.add_argument("--verts", type=int, default=10000)
     ap.add_argument("--cwidth", type=int, default=128)
     ap.add_argument("--keig", type=int, default=128)
+    ap.add_argument("--reps", type=int, default=20)
     a = ap.parse_args()
+    REPS[0] = a.reps
     dev = torch.device("cuda:0")
     sizes = bench.mesh_sizes(a.meshes, a.verts, 0)
     meshes, mb, gather, x3 = bench.build_batch(sizes, a.keig, dev, 0)
@@ -76,7 +82,7 @@ def main():
     def fb():
         out = blk.forward_packed(xg, mb)
         out.backward(y)
-    rec("block fwd+bwd (train)", timeit(fb, reps=10), 3.1 * fl_f, 4.0 * V * C * 60)
+    rec("block fwd+bwd (train)", timeit(fb, reps=max(2, a.reps // 2)), 3.1 * fl_f, 4.0 * V * C * 60)
 
 
 if __name__ == "__main__":
