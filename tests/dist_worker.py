@@ -1,0 +1,48 @@
+"""Worker for tests/test_dist_gloo.py: one process per rank, gloo backend on CPU.  The HIP kernels run on the
+fiber emulator here (test infrastructure); on the GPU box the same code path runs with backend nccl (= RCCL)."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "diffusion-net_amd"), ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def run(rank, world, port, emu_so, sizes, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import diffusion_net
+    from diffusion_net import _hip, synthetic
+    from diffusion_net.dist import FlatParams, shard_by_cost
+    import parity_cases
+    _hip._use_library_for_tests(emu_so, True)
+    torch.manual_seed(0)                                   # identical replicas
+    model = diffusion_net.layers.DiffusionNet(3, 4, C_width=32, N_block=1, dropout=False)
+    model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=0))
+    flat = FlatParams(model)
+    opt = torch.optim.Adam([flat.master], lr=1e-2)
+    mine = shard_by_cost(sizes, world)[rank]
+    meshes, feats = parity_cases.make_ragged(sizes, 16, 3, seed=1)
+    mb = parity_cases.pack([meshes[i] for i in mine], "cpu")
+    x = torch.cat([feats[i] for i in mine], 0)
+    first_grad = None
+    for _ in range(2):
+        flat.zero_grad()
+        out = model.forward_packed(x, mb)
+        # per-mesh mean loss so that the rank average equals the global mean over meshes (equal mesh counts per rank)
+        off, loss = 0, 0.0
+        for i in mine:
+            loss = loss + out[off:off + sizes[i]].square().mean()
+            off += sizes[i]
+        (loss / len(mine)).backward()
+        flat.all_reduce_mean()
+        if first_grad is None:
+            first_grad = flat.grad.clone()
+        opt.step()
+    torch.save({"flat": flat.flat.clone(), "grad": first_grad, "mine": mine}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
