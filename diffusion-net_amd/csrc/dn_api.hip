@@ -7,6 +7,7 @@
 
 static_assert(sizeof(dn_tile_t) == sizeof(DnTile), "tile layout");
 #define DN_ERR_INVALID 1   /* hipErrorInvalidValue */
+#define DN_SMALLN_BLOCKS 256
 #define DN_CHECK(expr) do { int _e = (expr); if (_e) return _e; } while (0)
 
 namespace {
@@ -374,11 +375,21 @@ int dn_gradfeat_bwd_f32(const dn_mesh_batch_t* mb, const float* d_g, const float
 }
 
 // ------------------------------------------------------------------ nn.Linear
+static size_t linear_partial_elems(const dn_mesh_batch_t* mb, int C_in, int C_out) {
+    size_t part = (size_t)mb->n_chunks * C_in * C_out;
+    if (C_in <= 16) {   // thin-input route: smalln partials, and a 4-column product for the bias column sums
+        if ((size_t)DN_SMALLN_BLOCKS * C_in * C_out > part) part = (size_t)DN_SMALLN_BLOCKS * C_in * C_out;
+        if ((size_t)mb->n_chunks * C_out * 4 > part) part = (size_t)mb->n_chunks * C_out * 4;
+    }
+    return part;
+}
 size_t dn_linear_workspace_bytes(const dn_mesh_batch_t* mb, int C_in, int C_out) {
-    return pad256((size_t)mb->n_chunks * C_in * C_out) + pad256((size_t)mb->n_chunks * C_out) + 512;
+    return pad256(linear_partial_elems(mb, C_in, C_out)) + pad256((size_t)mb->n_chunks * C_out) + 512;
 }
 int dn_linear_fwd_f32(const dn_mesh_batch_t* mb, const float* x, int C_in, const float* W, const float* b, int C_out,
                       int relu, const uint8_t* mask, float* out, void* stream) {
+    if (C_in <= 16 && !relu && !mask)   // thin contraction (first_lin: xyz / hks features): bandwidth-bound VALU kernel
+        return dn_launch_smallk_rows(x, C_in, W, 0, b, C_out, out, mb->v_total, S(stream));
     const float* xs[1] = {x};
     const int ws_[1] = {C_in};
     return linear_fwd(mb, xs, ws_, 1, W, C_in, b, C_out, relu ? DN_EPI_BIAS_RELU : DN_EPI_STORE, mask, nullptr, out, S(stream));
@@ -386,13 +397,30 @@ int dn_linear_fwd_f32(const dn_mesh_batch_t* mb, const float* x, int C_in, const
 int dn_linear_bwd_f32(const dn_mesh_batch_t* mb, const float* d_out, const float* x, const float* W, int C_in, int C_out,
                       float* d_x, float* dW, float* db, void* ws, size_t ws_bytes, void* stream) {
     Bump b(ws, ws_bytes);
-    float* partial = b.f((size_t)mb->n_chunks * C_in * C_out);
+    float* partial = b.f(linear_partial_elems(mb, C_in, C_out));
     float* colsum = b.f((size_t)mb->n_chunks * C_out);
     if (!b.ok) return DN_ERR_INVALID;
     const float* ins[1] = {x};
     const int ws_[1] = {C_in};
-    DN_CHECK(linear_bwd_weights(mb, d_out, C_out, ins, ws_, 1, dW, db, partial, colsum, S(stream)));
-    if (d_x) DN_CHECK(linear_bwd_input(mb, d_out, C_out, W, C_in, 0, C_in, DN_EPI_STORE, nullptr, 1.f, d_x, S(stream)));
+    if (C_in <= 16) {
+        // thin input (first_lin): dW = d_out^T x streams d_out once on the VALU
+        DN_CHECK(dn_launch_smalln_tn(d_out, C_out, x, C_in, mb->v_total, dW, partial, DN_SMALLN_BLOCKS, S(stream)));
+        if (db) {   // db[o] = sum_r d_out[r,o]: column sums of a minimal (4-column) split-V product
+            TnArgs g = tn_new(mb);
+            tn_a(g, d_out, nullptr, C_out, C_out);
+            tn_b(g, d_out, nullptr, C_out < 4 ? C_out : 4, C_out);
+            g.partial = partial; g.colsum = colsum; g.group = dn_tn_global_group(mb->n_chunks);
+            tn_finish(g);
+            DN_CHECK(dn_launch_tngemm(g, mb->n_chunks, S(stream)));
+            DN_CHECK(dn_launch_reduce(colsum, db, dn_tn_npartial(mb->n_chunks, g.group), C_out, C_out, S(stream)));
+        }
+    } else {
+        DN_CHECK(linear_bwd_weights(mb, d_out, C_out, ins, ws_, 1, dW, db, partial, colsum, S(stream)));
+    }
+    if (d_x) {
+        if (C_out <= 16) DN_CHECK(dn_launch_smallk_rows(d_out, C_out, W, 1, nullptr, C_in, d_x, mb->v_total, S(stream)));
+        else DN_CHECK(linear_bwd_input(mb, d_out, C_out, W, C_in, 0, C_in, DN_EPI_STORE, nullptr, 1.f, d_x, S(stream)));
+    }
     return 0;
 }
 

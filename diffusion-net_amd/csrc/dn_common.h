@@ -32,6 +32,16 @@ __device__ __forceinline__ f32x16 dn_mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 #endif
 }
+__device__ __forceinline__ void dn_setprio_hi() {
+#if !defined(DN_EMULATE) && defined(DN_USE_SETPRIO)
+    __builtin_amdgcn_s_setprio(1);
+#endif
+}
+__device__ __forceinline__ void dn_setprio_lo() {
+#if !defined(DN_EMULATE) && defined(DN_USE_SETPRIO)
+    __builtin_amdgcn_s_setprio(0);
+#endif
+}
 __device__ __forceinline__ int dn_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // A unit of row work: rows [row0,row0+nrows) of the concatenated vertex axis, all belonging to
@@ -126,8 +136,11 @@ struct TnArgs {
 };
 // number of partial results a tngemm launch over `nchunks` chunks with grouping `group` writes
 static inline int dn_tn_npartial(int nchunks, int group) { return (nchunks + (group < 1 ? 1 : group) - 1) / (group < 1 ? 1 : group); }
-// grouping for sums over ALL rows (weight gradients): about one partial per CU
-static inline int dn_tn_global_group(int nchunks) { int g = (nchunks + 255) / 256; return g < 1 ? 1 : g; }
+// grouping for sums over ALL rows (weight gradients): about two workgroups per CU
+#ifndef DN_TN_TARGET_PARTIALS
+#define DN_TN_TARGET_PARTIALS 512
+#endif
+static inline int dn_tn_global_group(int nchunks) { int g = (nchunks + DN_TN_TARGET_PARTIALS - 1) / DN_TN_TARGET_PARTIALS; return g < 1 ? 1 : g; }
 
 // ---------------------------------------------------------------------------------------
 // CSR gather (dn_sparse.hip)
@@ -164,6 +177,12 @@ int dn_launch_mass_mean_fwd(const DnTile* meshrows, const float* mass, const flo
 int dn_launch_mass_mean_bwd(const DnTile* tiles, int ntiles, const float* mass, const float* msum, const float* dout,
                             float* dx, int C, hipStream_t stream);
 int dn_launch_spmm(const SpArgs& s, hipStream_t stream);
+// out[r, n] = (bias ? bias[n] : 0) + sum_{k<K} x[r,k] * (w_kn ? W[k*N+n] : W[n*K+k]),  K <= 32  (VALU, bandwidth-bound)
+int dn_launch_smallk_rows(const float* x, int K, const float* W, int w_kn, const float* bias, int N, float* out,
+                          long long rows, hipStream_t stream);
+// partial-free small-N vertex contraction: out[m, n] = sum_r A[r,m] * B[r,n], N <= 16, via per-block partials in ws
+int dn_launch_smalln_tn(const float* A, int M, const float* B, int N, long long rows, float* out, float* ws, int nblk,
+                        hipStream_t stream);
 int dn_launch_dtanh(const float* dg, const float* g, float* out, long long n, hipStream_t stream);
 // launchers (host), defined in the .hip files; all return hipError_t as int
 int dn_launch_rowgemm(const RgArgs& g, int ntiles, int nout, hipStream_t stream);

@@ -255,6 +255,7 @@ __device__ __forceinline__ void rg_compute(const float* sA, const float* sB, int
                     for (int t = 0; t < 4; ++t)
                         bv[o][nt][t] = sB[o * SB + (8 * kg + 4 * ls + t) * TN + bcol0 + nt * 32 + li];
         }
+        dn_setprio_hi();
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -264,6 +265,7 @@ __device__ __forceinline__ void rg_compute(const float* sA, const float* sB, int
 #pragma unroll
                     for (int o = 0; o < NOUT; ++o)
                         acc[o][mt][nt] = dn_mfma(dn_f4_get(af[mt], t), bv[o][nt][t], acc[o][mt][nt]);
+        dn_setprio_lo();
     }
 }
 

@@ -230,3 +230,64 @@ int dn_launch_dtanh(const float* dg, const float* g, float* out, long long n, hi
     DN_LAUNCH(dtanh_kernel, dim3((unsigned)nb, 1, 1), dim3(256, 1, 1), 0, stream, dg, g, out, n);
     return (int)hipGetLastError();
 }
+
+// ---- thin products with a tiny contraction / output width (first_lin: C_in = 3 or 16; last_lin backward) ----
+// One thread per 4 output columns of a row; the K <= 32 inputs of the row are wave-broadcast loads.
+__global__ __launch_bounds__(256) void smallk_rows_kernel(const float* x, int K, const float* W, int w_kn, const float* bias,
+                                                          int N, float* out, long long rows) {
+    const int n4 = (N + 3) / 4;
+    const long long total = rows * n4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / n4;
+        const int n = (int)(i % n4) * 4;
+        float acc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = (bias && n + e < N) ? bias[n + e] : 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float xv = x[r * K + k];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < N) acc[e] = fmaf(xv, w_kn ? W[(long long)k * N + n + e] : W[(long long)(n + e) * K + k], acc[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n + e < N) out[r * N + n + e] = acc[e];
+    }
+}
+
+int dn_launch_smallk_rows(const float* x, int K, const float* W, int w_kn, const float* bias, int N, float* out,
+                          long long rows, hipStream_t stream) {
+    if (rows <= 0 || N <= 0) return 0;
+    long long nb = (rows * ((N + 3) / 4) + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    dn_prof_begin(DN_K_SMALL, stream);
+    DN_LAUNCH(smallk_rows_kernel, dim3((unsigned)nb, 1, 1), dim3(256, 1, 1), 0, stream, x, K, W, w_kn, bias, N, out, rows);
+    dn_prof_end(DN_K_SMALL, stream, 2.0 * rows * K * N, 4.0 * rows * (K + N));
+    return (int)hipGetLastError();
+}
+
+// out[m, n] = sum_r A[r,m] B[r,n] with N <= 16: block b sums rows b, b+nblk, ... for all m (thread = one m, loops M in
+// strides of 256), writes ws[b][m][n]; a fixed-order seg_reduce finishes.  Bandwidth-bound stream over A.
+__global__ __launch_bounds__(256) void smalln_tn_kernel(const float* A, int M, const float* B, int N, long long rows, float* ws) {
+    for (int m = threadIdx.x; m < M; m += 256) {
+        float acc[16];
+#pragma unroll
+        for (int n = 0; n < 16; ++n) acc[n] = 0.f;
+        for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+            const float a = A[r * M + m];
+#pragma unroll
+            for (int n = 0; n < 16; ++n)
+                if (n < N) acc[n] = fmaf(a, B[r * N + n], acc[n]);
+        }
+        for (int n = 0; n < N; ++n) ws[((long long)blockIdx.x * M + m) * N + n] = acc[n];
+    }
+}
+
+int dn_launch_smalln_tn(const float* A, int M, const float* B, int N, long long rows, float* out, float* ws, int nblk,
+                        hipStream_t stream) {
+    if (rows <= 0 || M <= 0 || N <= 0 || N > 16) return N > 16 ? DN_ERR_BAD_MODE : 0;
+    dn_prof_begin(DN_K_SMALL, stream);
+    DN_LAUNCH(smalln_tn_kernel, dim3(nblk, 1, 1), dim3(256, 1, 1), 0, stream, A, M, B, N, rows, ws);
+    dn_prof_end(DN_K_SMALL, stream, 2.0 * rows * M * N, 4.0 * rows * (M + N));
+    return dn_launch_seg_reduce(ws, nullptr, 1, nblk, out, (long long)M * N, stream);
+}

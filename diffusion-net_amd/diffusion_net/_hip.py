@@ -14,7 +14,9 @@ import torch
 
 MAX_MLP = 8
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libdiffnet_hip.so")
+# DN_LIB_VARIANT=<tag> selects libdiffnet_hip_<tag>.so (same sources, other build flags) for A/B experiments
+_VARIANT = os.environ.get("DN_LIB_VARIANT", "")
+LIB_PATH = os.path.join(_PKG_DIR, "libdiffnet_hip%s.so" % (("_" + _VARIANT) if _VARIANT else ""))
 
 TILE_DTYPE = np.dtype([("row0", "<i4"), ("nrows", "<i4"), ("mesh", "<i4"), ("aux", "<i4")])
 
