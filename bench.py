@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--cwidth", type=int, default=128)
     ap.add_argument("--keig", type=int, default=128)
     ap.add_argument("--blocks", type=int, default=4)
+    ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch into this many sub-batches run on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -129,15 +130,40 @@ def main():
     opt = torch.optim.Adam([flat.master], lr=1e-3)
 
     sizes = mesh_sizes(args.meshes, args.verts, rank)
-    meshes, mb, gather, x = build_batch(sizes, args.keig, device, seed0=1000 * rank)
-    labels = torch.randint(0, C_out, (gather.n_out,), device=device)
+    nsub = max(1, min(args.streams, args.meshes))
+    subs = []
+    for j in range(nsub):
+        sub_sizes = sizes[j::nsub]
+        _, mb_j, gather_j, x_j = build_batch(sub_sizes, args.keig, device, seed0=1000 * rank + 100 * j)
+        labels_j = torch.randint(0, C_out, (gather_j.n_out,), device=device)
+        subs.append((mb_j, gather_j, x_j, labels_j, sum(sub_sizes)))
+    mb = subs[0][0]
     v_step = sum(sizes)
+    streams = [torch.cuda.Stream(device) for _ in range(nsub)] if nsub > 1 else [None]
 
     def step():
         flat.zero_grad()
-        out = model.forward_packed(x, mb, gather)
-        loss = F.nll_loss(F.log_softmax(out, dim=-1), labels)
-        loss.backward()
+        if nsub == 1:
+            mb_j, gather_j, x_j, labels_j, _ = subs[0]
+            out = model.forward_packed(x_j, mb_j, gather_j)
+            loss = F.nll_loss(F.log_softmax(out, dim=-1), labels_j)
+            loss.backward()
+        else:
+            # sub-batches on separate streams: the store phase of one overlaps the MFMA phase of the other;
+            # gradients of all sub-batches accumulate into the same flat bucket (mean over the whole batch)
+            cur = torch.cuda.current_stream(device)
+            losses = []
+            for st, (mb_j, gather_j, x_j, labels_j, v_j) in zip(streams, subs):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    out = model.forward_packed(x_j, mb_j, gather_j)
+                    losses.append(F.nll_loss(F.log_softmax(out, dim=-1), labels_j) * (1.0 / nsub))
+            for st, l in zip(streams, losses):
+                with torch.cuda.stream(st):
+                    l.backward()
+            for st in streams:
+                cur.wait_stream(st)
+            loss = losses[0]
         flat.all_reduce_mean()
         opt.step()
         return loss
@@ -193,7 +219,9 @@ def main():
     # ---- diffusion block (to_basis + exp(-lambda t) + from_basis) on the same batch: HBM GB/s of BASELINE.json
     from diffusion_net import ops
     Cw, K = args.cwidth, args.keig
-    xb = torch.randn(v_step, Cw, device=device)
+    v_sub0 = subs[0][4]
+    sizes = sizes[0::nsub]
+    xb = torch.randn(v_sub0, Cw, device=device)
     tt = torch.full((Cw,), 0.05, device=device)
     with torch.no_grad():
         for _ in range(3):
@@ -222,7 +250,8 @@ def main():
             "config": {"workload": "train step (fwd+NLL+bwd+Adam%s) on a ragged batch of %d meshes x ~%d vertices per GPU, "
                                    "DiffusionNet C_in=3 C_out=8 C_width=%d K=%d N_block=%d outputs_at=faces dropout=on"
                                    % ("+RCCL all-reduce" if world > 1 else "", args.meshes, args.verts, Cw, K, args.blocks),
-                       "meshes_per_gpu": args.meshes, "verts_per_gpu_step": v_step, "parallelism": "dp%d" % world},
+                       "meshes_per_gpu": args.meshes, "verts_per_gpu_step": v_step, "parallelism": "dp%d" % world,
+                       "streams_per_gpu": nsub},
             "roofline": roof, "kernel_families": fam, "diffusion_block": diff,
         }
         if not args.no_cpu_baseline:

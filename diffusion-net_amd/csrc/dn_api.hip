@@ -7,7 +7,7 @@
 
 static_assert(sizeof(dn_tile_t) == sizeof(DnTile), "tile layout");
 #define DN_ERR_INVALID 1   /* hipErrorInvalidValue */
-#define DN_SMALLN_BLOCKS 256
+#define DN_SMALLN_BLOCKS 2048
 #define DN_CHECK(expr) do { int _e = (expr); if (_e) return _e; } while (0)
 
 namespace {
@@ -388,7 +388,7 @@ size_t dn_linear_workspace_bytes(const dn_mesh_batch_t* mb, int C_in, int C_out)
 }
 int dn_linear_fwd_f32(const dn_mesh_batch_t* mb, const float* x, int C_in, const float* W, const float* b, int C_out,
                       int relu, const uint8_t* mask, float* out, void* stream) {
-    if (C_in <= 16 && !relu && !mask)   // thin contraction (first_lin: xyz / hks features): bandwidth-bound VALU kernel
+    if (C_in <= 16 && C_out <= 1024 && !relu && !mask)   // thin contraction (first_lin: xyz / hks features): bandwidth-bound VALU kernel
         return dn_launch_smallk_rows(x, C_in, W, 0, b, C_out, out, mb->v_total, S(stream));
     const float* xs[1] = {x};
     const int ws_[1] = {C_in};
@@ -418,7 +418,7 @@ int dn_linear_bwd_f32(const dn_mesh_batch_t* mb, const float* d_out, const float
         DN_CHECK(linear_bwd_weights(mb, d_out, C_out, ins, ws_, 1, dW, db, partial, colsum, S(stream)));
     }
     if (d_x) {
-        if (C_out <= 16) DN_CHECK(dn_launch_smallk_rows(d_out, C_out, W, 1, nullptr, C_in, d_x, mb->v_total, S(stream)));
+        if (C_out <= 16 && C_in <= 1024) DN_CHECK(dn_launch_smallk_rows(d_out, C_out, W, 1, nullptr, C_in, d_x, mb->v_total, S(stream)));
         else DN_CHECK(linear_bwd_input(mb, d_out, C_out, W, C_in, 0, C_in, DN_EPI_STORE, nullptr, 1.f, d_x, S(stream)));
     }
     return 0;

@@ -263,8 +263,13 @@ __device__ __forceinline__ void rg_compute(const float* sA, const float* sB, int
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int o = 0; o < NOUT; ++o)
+                    for (int o = 0; o < NOUT; ++o) {
+#if defined(DN_ABLATE_MFMA)   // development ablation: operands stay live, no matrix work
+                        acc[o][mt][nt][0] += dn_f4_get(af[mt], t) * bv[o][nt][t];
+#else
                         acc[o][mt][nt] = dn_mfma(dn_f4_get(af[mt], t), bv[o][nt][t], acc[o][mt][nt]);
+#endif
+                    }
         dn_setprio_lo();
     }
 }
@@ -343,6 +348,21 @@ __global__ __launch_bounds__(WR* WC * 64) void rowgemm_kernel(RgArgs g) {
     }
 
     // ---------------- epilogue ----------------
+#if defined(DN_ABLATE_EPILOGUE)   // development ablation: keep the accumulators live, store one value per wave
+    {
+        float keep = 0.f;
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) keep += acc[o][mt][nt][r];
+        if (lane == 0 && wave_active) g.o0[(long long)tile.row0 * g.ldo + n0 + wave] = keep;
+        return;
+    }
+#endif
     if (wave_active) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)

@@ -149,10 +149,13 @@ _workspaces = {}
 
 
 def workspace(device, nbytes):
-    """Grow-only scratch buffer per device (stream-ordered reuse on the current stream)."""
-    key = str(device)
+    """Grow-only scratch buffer per (device, current stream): reuse is stream-ordered, and concurrent streams
+    (two half-batches in flight) never share scratch."""
+    dev = torch.device(device)
+    sid = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+    key = (str(dev), sid)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)
         _workspaces[key] = buf
     return buf
