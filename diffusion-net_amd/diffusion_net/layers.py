@@ -74,8 +74,9 @@ class LearnedTimeDiffusion(nn.Module):
     def clamp_time_(self):
         # same observable side effect as layers.py:48-49 (the Parameter holds its clamp afterwards, so the
         # optimizer sees the clamped value); done in place so flat parameter buckets keep their storage
-        with torch.no_grad():
-            self.diffusion_time.clamp_(min=_MIN_TIME)
+        # (.data: the clamp is idempotent between optimizer steps and must not invalidate tensors another
+        # in-flight forward saved for its backward)
+        self.diffusion_time.data.clamp_(min=_MIN_TIME)
 
     def forward(self, x, L, mass, evals, evecs):
         self.clamp_time_()
