@@ -307,6 +307,12 @@ __global__ __launch_bounds__(WR* WC * 64) void rowgemm_kernel(RgArgs g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[o][mt][nt][r] = 0.f;
 
+#if defined(DN_STAGGER) && !defined(DN_EMULATE)
+    // development probe: de-phase the second workgroup of each CU (first dispatch wave only) by DN_STAGGER x 3.4 us
+    if (blockIdx.x >= 256 && blockIdx.x < 512) {
+        for (int i = 0; i < DN_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     RgRegs<NOUT, A_IT, B_IT> R;
     int nslices = 0;
     for (int s = 0; s < g.nseg; ++s) nslices += (g.a[s].w + DN_KB - 1) / DN_KB;
@@ -327,12 +333,18 @@ __global__ __launch_bounds__(WR* WC * 64) void rowgemm_kernel(RgArgs g) {
     for (; sl + 2 < nslices; ++sl) {
         float* cur = smem + (sl & 1) * SBUF;
         float* nxt = smem + ((sl & 1) ^ 1) * SBUF;
+#if !defined(DN_ABLATE_LOADS)
         rg_store<TN, NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>(nxt, nxt + SA, tid, R);
         koff += DN_KB;
         if (koff >= g.a[seg].w) { koff = 0; ++seg; }
         rg_load<TN, NTHR, NOUT, ALIGNED, BCOLK, HASQ, A_IT, B_IT>(g, tile, n0, seg, koff, tid, R);
+#else
+        (void)nxt;
+#endif
         rg_compute<TN, MT, NT, NOUT, BCOLK>(cur, cur + SA, wr * MT * 32, wc * NT * 32, li, ls, acc);
+#if !defined(DN_ABLATE_BARRIER)
         __syncthreads();
+#endif
     }
     if (sl + 1 < nslices) {   // second-to-last slice: stage the last one, nothing left to load
         float* cur = smem + (sl & 1) * SBUF;
@@ -404,6 +416,243 @@ static int rg_dispatch_width(const RgArgs& g, int ntiles, hipStream_t stream) {
     return rg_launch<128, 2, WC128, NOUT, MODE, true, BCOLK>(g, ntiles, stream);
 }
 
+// =======================================================================================
+// persistent single-output rowgemm (the heavy N >= 128 products)
+//
+// One 8-wave workgroup per CU walks its tiles (tile = blockIdx.x, += gridDim.x ...).  The slice pipeline runs
+// ACROSS tile boundaries (the loads of the next tile's first slices are in flight under the current tile's last
+// MFMAs), and a finished tile's accumulators are parked in a 64 KiB LDS staging area from which every thread
+// streams float4 rows to HBM -- with the epilogue maths and coalesced float4 auxiliary loads -- while the MFMAs of
+// the following tile run.  Only the very first prologue and the very last flush of a workgroup are exposed.
+// LDS: 2 x 32 KiB slice buffers + 64 KiB staging = 128 KiB.
+// =======================================================================================
+#define DN_PT_THREADS 512
+#define DN_PT_NP (DN_TM * 128 / 4 / DN_PT_THREADS)   // float4 pieces per thread per tile (8)
+
+struct PtPiece {
+    float4 v, a0;
+    float m[4];
+    float rs;
+    long long off;
+    bool ok;
+};
+
+// phase 1 of a deferred piece: LDS read of the parked accumulators + global loads of the auxiliary operands
+template <int MODE>
+__device__ __forceinline__ void pt_piece_load(const RgArgs& g, const float* sE, int piece, int tid, int row0, int nrows,
+                                              int n0, PtPiece& P) {
+    const int idx = tid + piece * DN_PT_THREADS;
+    const int row = idx >> 5, c4 = idx & 31;
+    const int col = n0 + 4 * c4;
+    P.ok = row < nrows && col < g.N;
+    const long long grow = row0 + (P.ok ? row : 0);
+    const int ccol = P.ok ? col : 0;
+    P.off = grow * g.ldo + ccol;
+    const long long roff = grow * g.ldr + ccol;
+    P.v = *reinterpret_cast<const float4*>(&sE[row * 128 + 4 * c4]);
+    constexpr bool need_r0 = MODE == DN_EPI_BIAS_RESID || MODE == DN_EPI_MUL_DFAC || MODE == DN_EPI_ADD ||
+                             MODE == DN_EPI_DTANH || MODE == DN_EPI_MASS_ADD;
+    if (need_r0 && g.r0) P.a0 = *reinterpret_cast<const float4*>(g.r0 + roff);
+    else P.a0 = dn_f4_zero();
+    if (MODE == DN_EPI_BIAS_RELU) {
+        if (g.mask) {
+            const uint32_t mk = *reinterpret_cast<const uint32_t*>(g.mask + roff);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) P.m[e] = ((mk >> (8 * e)) & 0xffu) ? g.scale : 0.f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) P.m[e] = 1.f;
+        }
+    }
+    if (MODE == DN_EPI_STORE || MODE == DN_EPI_BIAS_RELU || MODE == DN_EPI_BIAS_RESID) {
+        if (g.bias) {
+            const float4 b = *reinterpret_cast<const float4*>(g.bias + ccol);
+            P.v.x += b.x; P.v.y += b.y; P.v.z += b.z; P.v.w += b.w;
+        }
+    }
+    P.rs = (MODE == DN_EPI_MASS_ADD) ? g.rowv[grow] : 0.f;
+}
+
+// phase 2: epilogue maths + one coalesced float4 store
+template <int MODE>
+__device__ __forceinline__ void pt_piece_store(const RgArgs& g, const PtPiece& P) {
+    float x[4] = {P.v.x, P.v.y, P.v.z, P.v.w};
+    const float r[4] = {P.a0.x, P.a0.y, P.a0.z, P.a0.w};
+    float y[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (MODE == DN_EPI_STORE) y[e] = x[e];
+        else if (MODE == DN_EPI_BIAS_RELU) y[e] = (x[e] > 0.f ? x[e] : 0.f) * P.m[e];
+        else if (MODE == DN_EPI_BIAS_RESID) y[e] = x[e] + r[e];
+        else if (MODE == DN_EPI_MUL_DFAC) y[e] = r[e] > 0.f ? x[e] * g.scale : 0.f;
+        else if (MODE == DN_EPI_ADD) y[e] = x[e] + r[e];
+        else if (MODE == DN_EPI_DTANH) y[e] = x[e] * (1.f - r[e] * r[e]);
+        else if (MODE == DN_EPI_MASS_ADD) y[e] = r[e] + P.rs * x[e];
+        else y[e] = x[e];
+    }
+    if (P.ok) *reinterpret_cast<float4*>(g.o0 + P.off) = make_float4(y[0], y[1], y[2], y[3]);
+}
+
+template <int MODE, bool BCOLK>
+__global__ __launch_bounds__(DN_PT_THREADS) void rowgemm_persist_kernel(RgArgs g, int ntiles) {
+    constexpr int TN = 128, WR = 2, WC = 4, NOUT = 1, NTHR = DN_PT_THREADS;
+    constexpr int MT = DN_TM / (32 * WR);            // 2
+    constexpr int NT = TN / (32 * WC);               // 1
+    constexpr int A_IT = DN_TM * 8 / NTHR;           // 2
+    constexpr int B_IT = DN_KB * TN / 4 / NTHR;      // 2
+    constexpr int SA = DN_TM * DN_KB;
+    constexpr int SBUF = SA + DN_KB * TN;
+    constexpr bool HASQ = false;
+    constexpr int MAXP = 4;                          // deferred pieces handled per slice iteration (<= DN_PT_NP)
+
+    DN_DYN_SMEM(smem_raw);
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    float* sE = smem + 2 * SBUF;                     // [128][128] parked accumulators
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WC, wc = wave % WC;
+    const int li = lane & 31, ls = lane >> 5;
+    const int G = gridDim.x;
+    const int n0 = blockIdx.y * TN;
+
+    int nsl = 0;
+    for (int s = 0; s < g.nseg; ++s) nsl += (g.a[s].w + DN_KB - 1) / DN_KB;
+    const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - (int)blockIdx.x + G - 1) / G : 0;
+    const int T = my_tiles * nsl;                    // slices this workgroup processes
+    if (T == 0) return;
+    // pieces per iteration: a parked tile must be fully streamed out within the nsl-1 iterations that follow it
+    const int ppi = (DN_PT_NP + (nsl - 1) - 1) / (nsl - 1);   // host guarantees nsl >= 3 -> ppi <= MAXP
+
+    f32x16 acc[NOUT][MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][mt][0][r] = 0.f;
+
+    RgRegs<NOUT, A_IT, B_IT> R;
+    // load cursor (runs two slices ahead of the compute cursor, across tile boundaries)
+    int lt = blockIdx.x, lseg = 0, lkoff = 0;
+    DnTile ltile = g.tiles[lt];
+    // compute cursor
+    int ct = blockIdx.x, cs = 0;
+    DnTile ctile = g.tiles[ct];
+    // parked tile being streamed out
+    int p_row0 = 0, p_nrows = 0, p_next = DN_PT_NP;   // p_next == NP: nothing pending
+
+    rg_load<TN, NTHR, NOUT, true, BCOLK, HASQ, A_IT, B_IT>(g, ltile, n0, lseg, lkoff, tid, R);
+    rg_store<TN, NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>(smem, smem + SA, tid, R);
+    if (T > 1) {
+        lkoff += DN_KB;
+        if (lkoff >= g.a[lseg].w) { lkoff = 0; ++lseg; if (lseg >= g.nseg) { lseg = 0; lt += G; if (lt < ntiles) ltile = g.tiles[lt]; } }
+        rg_load<TN, NTHR, NOUT, true, BCOLK, HASQ, A_IT, B_IT>(g, ltile, n0, lseg, lkoff, tid, R);
+    }
+    __syncthreads();
+
+    for (int j = 0; j < T; ++j) {
+        float* cur = smem + (j & 1) * SBUF;
+        float* nxt = smem + ((j & 1) ^ 1) * SBUF;
+        if (j + 1 < T) rg_store<TN, NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>(nxt, nxt + SA, tid, R);
+        if (j + 2 < T) {
+            lkoff += DN_KB;
+            if (lkoff >= g.a[lseg].w) { lkoff = 0; ++lseg; if (lseg >= g.nseg) { lseg = 0; lt += G; if (lt < ntiles) ltile = g.tiles[lt]; } }
+            rg_load<TN, NTHR, NOUT, true, BCOLK, HASQ, A_IT, B_IT>(g, ltile, n0, lseg, lkoff, tid, R);
+        }
+        // deferred output of the previously finished tile: loads now, maths + stores after the MFMAs
+        PtPiece P[MAXP];
+        int np = DN_PT_NP - p_next;
+        if (np > ppi) np = ppi;
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k)
+            if (k < np) pt_piece_load<MODE>(g, sE, p_next + k, tid, p_row0, p_nrows, n0, P[k]);
+
+        rg_compute<TN, MT, NT, NOUT, BCOLK>(cur, cur + SA, wr * MT * 32, wc * NT * 32, li, ls, acc);
+
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k)
+            if (k < np) pt_piece_store<MODE>(g, P[k]);
+        p_next += np;
+
+        if (++cs == nsl) {   // tile complete: park the accumulators (fragment layout -> row-major, conflict-free)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sE[((wr * MT + mt) * 32 + dn_acc_row(r, lane)) * 128 + wc * 32 + li] = acc[0][mt][0][r];
+                    acc[0][mt][0][r] = 0.f;
+                }
+            p_row0 = ctile.row0; p_nrows = ctile.nrows; p_next = 0;
+            cs = 0;
+            ct += G;
+            if (ct < ntiles) ctile = g.tiles[ct];
+        }
+        __syncthreads();   // slice buffer hand-off + visibility of the parked tile
+    }
+    // flush what is still parked (the last tile)
+    for (; p_next < DN_PT_NP; ++p_next) {
+        PtPiece P1;
+        pt_piece_load<MODE>(g, sE, p_next, tid, p_row0, p_nrows, n0, P1);
+        pt_piece_store<MODE>(g, P1);
+    }
+}
+
+static int dn_num_cus() {
+#ifdef DN_EMULATE
+    return 3;
+#else
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+#endif
+}
+
+template <int MODE, bool BCOLK>
+static int pt_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
+    const size_t smem = (size_t)(2 * (DN_TM * DN_KB + DN_KB * 128) + DN_TM * 128) * sizeof(float);
+#ifndef DN_EMULATE
+    static bool lds_opt_in = false;
+    if (!lds_opt_in) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_persist_kernel<MODE, BCOLK>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        lds_opt_in = true;
+    }
+#endif
+    int gx = dn_num_cus();
+    if (gx > ntiles) gx = ntiles;
+    DN_LAUNCH((rowgemm_persist_kernel<MODE, BCOLK>), dim3(gx, (g.N + 127) / 128, 1), dim3(DN_PT_THREADS, 1, 1), smem, stream, g, ntiles);
+    return (int)hipGetLastError();
+}
+
+// eligibility of the persistent path: aligned operands, wide output, >= 3 slices, float4-able epilogue operands
+static bool pt_eligible(const RgArgs& g, int nout) {
+    if (nout != 1 || !g.aligned || g.N < 128 || g.N % 4 != 0 || g.ldo % 4 != 0 || g.ldr % 4 != 0) return false;
+    int nsl = 0;
+    for (int s = 0; s < g.nseg; ++s) { nsl += g.a[s].w / DN_KB; if (g.a[s].q) return false; }
+    if (nsl < 3) return false;
+    auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    if (!al(g.o0) || !al(g.r0) || !al(g.bias) || ((uintptr_t)g.mask & 3) != 0) return false;
+    return g.mode == DN_EPI_STORE || g.mode == DN_EPI_BIAS_RELU || g.mode == DN_EPI_BIAS_RESID || g.mode == DN_EPI_MUL_DFAC ||
+           g.mode == DN_EPI_ADD || g.mode == DN_EPI_DTANH || g.mode == DN_EPI_MASS_ADD;
+}
+
+static int pt_dispatch(const RgArgs& g, int ntiles, hipStream_t stream) {
+    const bool ck = g.b_colk != 0;
+    switch (g.mode) {
+        case DN_EPI_STORE: return ck ? pt_launch<DN_EPI_STORE, true>(g, ntiles, stream) : pt_launch<DN_EPI_STORE, false>(g, ntiles, stream);
+        case DN_EPI_BIAS_RELU: return ck ? pt_launch<DN_EPI_BIAS_RELU, true>(g, ntiles, stream) : DN_ERR_BAD_MODE;
+        case DN_EPI_BIAS_RESID: return ck ? pt_launch<DN_EPI_BIAS_RESID, true>(g, ntiles, stream) : DN_ERR_BAD_MODE;
+        case DN_EPI_MUL_DFAC: return ck ? DN_ERR_BAD_MODE : pt_launch<DN_EPI_MUL_DFAC, false>(g, ntiles, stream);
+        case DN_EPI_ADD: return ck ? DN_ERR_BAD_MODE : pt_launch<DN_EPI_ADD, false>(g, ntiles, stream);
+        case DN_EPI_DTANH: return ck ? DN_ERR_BAD_MODE : pt_launch<DN_EPI_DTANH, false>(g, ntiles, stream);
+        case DN_EPI_MASS_ADD: return ck ? DN_ERR_BAD_MODE : pt_launch<DN_EPI_MASS_ADD, false>(g, ntiles, stream);
+        default: return DN_ERR_BAD_MODE;
+    }
+}
+
 int dn_launch_rowgemm(const RgArgs& g, int ntiles, int nout, hipStream_t stream) {
     if (ntiles <= 0 || g.N <= 0 || g.nseg <= 0) return 0;
     int ktot = 0;
@@ -415,6 +664,13 @@ int dn_launch_rowgemm(const RgArgs& g, int ntiles, int nout, hipStream_t stream)
     dn_prof_begin(kind, stream);
     int err = DN_ERR_BAD_MODE;
     const bool ck = g.b_colk != 0;
+#ifndef DN_NO_PERSIST
+    if (pt_eligible(g, nout)) {
+        err = pt_dispatch(g, ntiles, stream);
+        dn_prof_end(kind, stream, flops, bytes);
+        return err;
+    }
+#endif
     if (nout == 1) {
         switch (g.mode) {
             case DN_EPI_STORE:

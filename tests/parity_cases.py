@@ -82,14 +82,20 @@ def pack(meshes, device, with_grad=True, chunk_rows=None):
 
 
 def run_ragged_net(device, sizes=(130, 257, 64), K=24, C=32, C_in=3, C_out=5, N_block=2, outputs_at="vertices",
-                   chunk_rows=None, seed=3):
+                   chunk_rows=None, seed=3, dropout=False):
     torch.manual_seed(seed)
-    model = diffusion_net.layers.DiffusionNet(C_in, C_out, C_width=C, N_block=N_block, outputs_at=outputs_at, dropout=False)
+    model = diffusion_net.layers.DiffusionNet(C_in, C_out, C_width=C, N_block=N_block, outputs_at=outputs_at, dropout=dropout)
     sd = synthetic.randomize_times(model.state_dict(), seed=seed)
     model.load_state_dict(sd)
     params = {k: v.clone() for k, v in model.state_dict().items()}
-    model.to(device).eval()
+    model.to(device).train(dropout)
     meshes, feats = make_ragged(sizes, K, C_in, seed)
+    masks = None
+    if dropout:   # train mode with injected keep-masks: [block][layer-1] -> [Vtot, C] uint8
+        gm = torch.Generator().manual_seed(seed + 7)
+        masks = [[(torch.rand(sum(sizes), C, generator=gm) < 0.5).to(torch.uint8) for _ in range(2)] for _ in range(N_block)]
+        for bi, blk in enumerate(model.blocks):
+            blk.mask_provider = (lambda b: (lambda i, shape, dev: masks[b][i - 1]))(bi)
     mb = pack(meshes, device, chunk_rows=chunk_rows)
     x = torch.cat(feats, 0).to(device).requires_grad_(True)
     gather = None
@@ -112,9 +118,13 @@ def run_ragged_net(device, sizes=(130, 257, 64), K=24, C=32, C_in=3, C_out=5, N_
         if outputs_at == "global_mean":
             wi = wi[0]
         off_out += n_out
+        km = None
+        if masks is not None:
+            r0 = sum(sizes[:len(ref_out)])
+            km = [[mk[r0:r0 + f.shape[0]].float() for mk in blk] for blk in masks]
         o, g = orc.net_forward_backward(
             params, dict(x_in=f, mass=m["mass"], evals=m["evals"], evecs=m["evecs"], gradX=m["gradX"], gradY=m["gradY"],
-                         faces=m["faces"]), outputs_at=outputs_at, loss_weights=wi)
+                         faces=m["faces"]), outputs_at=outputs_at, loss_weights=wi, keep_masks=km)
         ref_out.append(o.reshape(n_out, -1))
         if ref_grads is None:
             ref_grads = {k: v.clone() for k, v in g.items() if k != "x_in"}

@@ -47,6 +47,13 @@ def test_ragged_batch_on_emulator(emu, outputs_at):
     parity_cases.run_ragged_net(emu, outputs_at=outputs_at, chunk_rows=64)
 
 
+def test_persistent_rowgemm_with_dropout_on_emulator(emu):
+    """C = K = 128: the persistent, deferred-store row GEMM (several tiles per workgroup, partial last tiles,
+    dropout-mask epilogue) through forward and backward."""
+    import parity_cases
+    parity_cases.run_ragged_net(emu, sizes=(300, 140), K=128, C=128, N_block=1, dropout=True, chunk_rows=64)
+
+
 def test_mismatched_patterns_on_emulator(emu):
     import parity_cases
     parity_cases.run_mismatched_patterns(emu)

@@ -46,6 +46,12 @@ def test_ragged_batches(dev, outputs_at):
     parity_cases.run_ragged_net(dev, sizes=(2100, 1900, 2500, 1601), K=128, C=64, C_out=30, outputs_at=outputs_at)
 
 
+def test_train_mode_dropout_masks_headline_width(dev):
+    import parity_cases
+    parity_cases.run_ragged_net(dev, sizes=(3000, 1400, 129), K=128, C=128, N_block=2, dropout=True)
+    parity_cases.run_ragged_net(dev, sizes=(700,), K=64, C=256, N_block=1, dropout=True, outputs_at="faces")
+
+
 def test_mismatched_patterns(dev):
     import parity_cases
     parity_cases.run_mismatched_patterns(dev)

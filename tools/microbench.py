@@ -60,6 +60,10 @@ def main():
         print(f"{name:34s} {ms*1e3:9.1f} us  {flops/ms/1e9:7.1f} TFLOP/s ({flops/ms/1e9/157.3*100:5.1f}%)  {byts/ms/1e6:8.0f} GB/s", flush=True)
 
     with torch.no_grad():
+        z = torch.empty_like(x)
+        rec("[calib] torch fill 81MB", timeit(lambda: z.fill_(1.0)), 0.0, 4.0 * V * C)
+        rec("[calib] torch copy 81MB->81MB", timeit(lambda: z.copy_(x)), 0.0, 8.0 * V * C)
+        rec("[calib] torch add 2x81MB->81MB", timeit(lambda: torch.add(x, y, out=z)), 0.0, 12.0 * V * C)
         rec("to_basis (tngemm+reduce)", timeit(lambda: ops._to_basis_raw(mb, x, True)), 2.0 * V * K * C, 4.0 * V * (K + C + 1))
         rec("from_basis (rowgemm NN)", timeit(lambda: ops._from_basis_raw(mb, spec)), 2.0 * V * K * C, 4.0 * V * (K + C))
         rec("diffusion fwd (3 launches)", timeit(lambda: ops.DiffusionFn.apply(x, t, mb)), 4.0 * V * K * C, 4.0 * V * (2 * C + 2 * K + 1))
