@@ -114,7 +114,7 @@ struct RgRegs {
 
 template <int TN, int NTHR, int NOUT, bool ALIGNED, bool BCOLK, bool HASQ, int A_IT, int B_IT>
 __device__ __forceinline__ void rg_load(const RgArgs& g, const DnTile& tile, int n0, int seg, int koff, int tid,
-                                        RgRegs<NOUT, A_IT, B_IT>& R) {
+                                        RgRegs<NOUT, A_IT, B_IT>& R) {   // tile.row0/nrows may describe a sub-tile
     const RgSeg sg = g.a[seg];
     if (ALIGNED) {
         long long off[A_IT];
@@ -426,25 +426,38 @@ static int rg_dispatch_width(const RgArgs& g, int ntiles, hipStream_t stream) {
 // the following tile run.  Only the very first prologue and the very last flush of a workgroup are exposed.
 // LDS: 2 x 32 KiB slice buffers + 64 KiB staging = 128 KiB.
 // =======================================================================================
-#define DN_PT_THREADS 512
-#define DN_PT_NP (DN_TM * 128 / 4 / DN_PT_THREADS)   // float4 pieces per thread per tile (8)
+#ifndef DN_PT_MAX_SLICES
+#define DN_PT_MAX_SLICES 8   // longer contractions amortise the epilogue anyway and prefer 2 independent WGs per CU
+#endif
+#if defined(DN_PT_ABLATE_LOADS)
+#define DN_PT_SKIP_LOADS 1
+#else
+#define DN_PT_SKIP_LOADS 0
+#endif
+#define DN_PT_ROWS 64        // rows per work unit (half a 128-row tile)
+#define DN_PT_THREADS 256     // 4 waves; two such workgroups share a CU (2 x 80 KiB of LDS)
+#define DN_PT_NP (DN_PT_ROWS * 128 / 4 / DN_PT_THREADS)   // float4 pieces per thread per unit (8)
 
 struct PtPiece {
-    float4 v, a0;
-    float m[4];
+    float4 v, a0, bias;
+    uint32_t mk;
     float rs;
     long long off;
     bool ok;
 };
 
-// phase 1 of a deferred piece: LDS read of the parked accumulators + global loads of the auxiliary operands
-template <int MODE>
+// FLAG: STORE -> a bias vector is added; BIAS_RELU -> a dropout keep-mask is applied; unused otherwise.
+// phase 1 of a deferred piece: ISSUE the LDS read of the parked accumulators and the global loads of the auxiliary
+// operands.  Branch-free, and nothing loaded here is used before the MFMA block (a use would put a vmcnt wait --
+// which also waits for the slice prefetch issued just before -- in front of the MFMAs).
+template <int MODE, bool FLAG>
 __device__ __forceinline__ void pt_piece_load(const RgArgs& g, const float* sE, int piece, int tid, int row0, int nrows,
                                               int n0, PtPiece& P) {
-    const int idx = tid + piece * DN_PT_THREADS;
+    const bool live = piece < DN_PT_NP;
+    const int idx = tid + (live ? piece : 0) * DN_PT_THREADS;
     const int row = idx >> 5, c4 = idx & 31;
     const int col = n0 + 4 * c4;
-    P.ok = row < nrows && col < g.N;
+    P.ok = live && row < nrows && col < g.N;
     const long long grow = row0 + (P.ok ? row : 0);
     const int ccol = P.ok ? col : 0;
     P.off = grow * g.ldo + ccol;
@@ -452,37 +465,28 @@ __device__ __forceinline__ void pt_piece_load(const RgArgs& g, const float* sE, 
     P.v = *reinterpret_cast<const float4*>(&sE[row * 128 + 4 * c4]);
     constexpr bool need_r0 = MODE == DN_EPI_BIAS_RESID || MODE == DN_EPI_MUL_DFAC || MODE == DN_EPI_ADD ||
                              MODE == DN_EPI_DTANH || MODE == DN_EPI_MASS_ADD;
-    if (need_r0 && g.r0) P.a0 = *reinterpret_cast<const float4*>(g.r0 + roff);
-    else P.a0 = dn_f4_zero();
-    if (MODE == DN_EPI_BIAS_RELU) {
-        if (g.mask) {
-            const uint32_t mk = *reinterpret_cast<const uint32_t*>(g.mask + roff);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) P.m[e] = ((mk >> (8 * e)) & 0xffu) ? g.scale : 0.f;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) P.m[e] = 1.f;
-        }
-    }
-    if (MODE == DN_EPI_STORE || MODE == DN_EPI_BIAS_RELU || MODE == DN_EPI_BIAS_RESID) {
-        if (g.bias) {
-            const float4 b = *reinterpret_cast<const float4*>(g.bias + ccol);
-            P.v.x += b.x; P.v.y += b.y; P.v.z += b.z; P.v.w += b.w;
-        }
-    }
-    P.rs = (MODE == DN_EPI_MASS_ADD) ? g.rowv[grow] : 0.f;
+    constexpr bool need_bias = (MODE == DN_EPI_STORE && FLAG) || MODE == DN_EPI_BIAS_RELU || MODE == DN_EPI_BIAS_RESID;
+    if (need_r0) P.a0 = *reinterpret_cast<const float4*>(g.r0 + roff);
+    if (need_bias) P.bias = *reinterpret_cast<const float4*>(g.bias + ccol);
+    if (MODE == DN_EPI_BIAS_RELU && FLAG) P.mk = *reinterpret_cast<const uint32_t*>(g.mask + roff);
+    if (MODE == DN_EPI_MASS_ADD) P.rs = g.rowv[grow];
 }
 
-// phase 2: epilogue maths + one coalesced float4 store
-template <int MODE>
+// phase 2 (after the MFMAs): epilogue maths + one coalesced float4 store
+template <int MODE, bool FLAG>
 __device__ __forceinline__ void pt_piece_store(const RgArgs& g, const PtPiece& P) {
+    constexpr bool need_bias = (MODE == DN_EPI_STORE && FLAG) || MODE == DN_EPI_BIAS_RELU || MODE == DN_EPI_BIAS_RESID;
     float x[4] = {P.v.x, P.v.y, P.v.z, P.v.w};
+    if (need_bias) { x[0] += P.bias.x; x[1] += P.bias.y; x[2] += P.bias.z; x[3] += P.bias.w; }
     const float r[4] = {P.a0.x, P.a0.y, P.a0.z, P.a0.w};
     float y[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         if (MODE == DN_EPI_STORE) y[e] = x[e];
-        else if (MODE == DN_EPI_BIAS_RELU) y[e] = (x[e] > 0.f ? x[e] : 0.f) * P.m[e];
+        else if (MODE == DN_EPI_BIAS_RELU) {
+            const float h = x[e] > 0.f ? x[e] : 0.f;
+            y[e] = FLAG ? (((P.mk >> (8 * e)) & 0xffu) ? h * g.scale : 0.f) : h;
+        }
         else if (MODE == DN_EPI_BIAS_RESID) y[e] = x[e] + r[e];
         else if (MODE == DN_EPI_MUL_DFAC) y[e] = r[e] > 0.f ? x[e] * g.scale : 0.f;
         else if (MODE == DN_EPI_ADD) y[e] = x[e] + r[e];
@@ -493,35 +497,35 @@ __device__ __forceinline__ void pt_piece_store(const RgArgs& g, const PtPiece& P
     if (P.ok) *reinterpret_cast<float4*>(g.o0 + P.off) = make_float4(y[0], y[1], y[2], y[3]);
 }
 
-template <int MODE, bool BCOLK>
+template <int MODE, bool BCOLK, bool FLAG>
 __global__ __launch_bounds__(DN_PT_THREADS) void rowgemm_persist_kernel(RgArgs g, int ntiles) {
-    constexpr int TN = 128, WR = 2, WC = 4, NOUT = 1, NTHR = DN_PT_THREADS;
-    constexpr int MT = DN_TM / (32 * WR);            // 2
+    constexpr int TN = 128, WR = 1, WC = 4, NOUT = 1, NTHR = DN_PT_THREADS, TMU = DN_PT_ROWS;
+    constexpr int MT = TMU / (32 * WR);              // 2
     constexpr int NT = TN / (32 * WC);               // 1
-    constexpr int A_IT = DN_TM * 8 / NTHR;           // 2
-    constexpr int B_IT = DN_KB * TN / 4 / NTHR;      // 2
-    constexpr int SA = DN_TM * DN_KB;
+    constexpr int A_IT = TMU * 8 / NTHR;             // 2
+    constexpr int B_IT = DN_KB * TN / 4 / NTHR;      // 4
+    constexpr int SA = TMU * DN_KB;
     constexpr int SBUF = SA + DN_KB * TN;
     constexpr bool HASQ = false;
-    constexpr int MAXP = 4;                          // deferred pieces handled per slice iteration (<= DN_PT_NP)
+    constexpr int PPI = 4;                           // deferred pieces per slice iteration: 8 pieces over 2 iterations
+    static_assert(DN_TM == 2 * TMU, "a work unit is half a row tile");
 
     DN_DYN_SMEM(smem_raw);
     float* smem = reinterpret_cast<float*>(smem_raw);
-    float* sE = smem + 2 * SBUF;                     // [128][128] parked accumulators
+    float* sE = smem + 2 * SBUF;                     // [64][128] parked accumulators
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave / WC, wc = wave % WC;
+    const int wc = wave;
     const int li = lane & 31, ls = lane >> 5;
     const int G = gridDim.x;
     const int n0 = blockIdx.y * TN;
+    const int nunits = 2 * ntiles;                   // unit u = rows [64*(u&1), +64) of tile u>>1
 
     int nsl = 0;
-    for (int s = 0; s < g.nseg; ++s) nsl += (g.a[s].w + DN_KB - 1) / DN_KB;
-    const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - (int)blockIdx.x + G - 1) / G : 0;
-    const int T = my_tiles * nsl;                    // slices this workgroup processes
+    for (int s = 0; s < g.nseg; ++s) nsl += (g.a[s].w + DN_KB - 1) / DN_KB;   // host guarantees nsl >= 3
+    const int my_units = ((int)blockIdx.x < nunits) ? (nunits - (int)blockIdx.x + G - 1) / G : 0;
+    const int T = my_units * nsl;                    // slices this workgroup processes
     if (T == 0) return;
-    // pieces per iteration: a parked tile must be fully streamed out within the nsl-1 iterations that follow it
-    const int ppi = (DN_PT_NP + (nsl - 1) - 1) / (nsl - 1);   // host guarantees nsl >= 3 -> ppi <= MAXP
 
     f32x16 acc[NOUT][MT][NT];
 #pragma unroll
@@ -529,21 +533,32 @@ __global__ __launch_bounds__(DN_PT_THREADS) void rowgemm_persist_kernel(RgArgs g
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][mt][0][r] = 0.f;
 
+    // unit -> (sub-)tile descriptor; an empty second half (tile shorter than 64 rows) yields nrows = 0 (fully masked)
+    auto unit_tile = [&](int u) {
+        DnTile t = g.tiles[u >> 1];
+        const int h = (u & 1) * TMU;
+        int n = t.nrows - h;
+        n = n < 0 ? 0 : (n > TMU ? TMU : n);
+        t.row0 += (n > 0 ? h : 0);
+        t.nrows = n;
+        return t;
+    };
+
     RgRegs<NOUT, A_IT, B_IT> R;
-    // load cursor (runs two slices ahead of the compute cursor, across tile boundaries)
-    int lt = blockIdx.x, lseg = 0, lkoff = 0;
-    DnTile ltile = g.tiles[lt];
+    // load cursor (runs two slices ahead of the compute cursor, across unit boundaries)
+    int lu = blockIdx.x, lseg = 0, lkoff = 0;
+    DnTile ltile = unit_tile(lu);
     // compute cursor
-    int ct = blockIdx.x, cs = 0;
-    DnTile ctile = g.tiles[ct];
-    // parked tile being streamed out
-    int p_row0 = 0, p_nrows = 0, p_next = DN_PT_NP;   // p_next == NP: nothing pending
+    int cu = blockIdx.x, cs = 0;
+    DnTile ctile = ltile;
+    // parked unit being streamed out
+    int p_row0 = ctile.row0, p_nrows = 0, p_next = DN_PT_NP;   // p_next >= NP: nothing pending
 
     rg_load<TN, NTHR, NOUT, true, BCOLK, HASQ, A_IT, B_IT>(g, ltile, n0, lseg, lkoff, tid, R);
     rg_store<TN, NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>(smem, smem + SA, tid, R);
     if (T > 1) {
         lkoff += DN_KB;
-        if (lkoff >= g.a[lseg].w) { lkoff = 0; ++lseg; if (lseg >= g.nseg) { lseg = 0; lt += G; if (lt < ntiles) ltile = g.tiles[lt]; } }
+        if (lkoff >= g.a[lseg].w) { lkoff = 0; ++lseg; if (lseg >= g.nseg) { lseg = 0; lu += G; if (lu < nunits) ltile = unit_tile(lu); } }
         rg_load<TN, NTHR, NOUT, true, BCOLK, HASQ, A_IT, B_IT>(g, ltile, n0, lseg, lkoff, tid, R);
     }
     __syncthreads();
@@ -551,47 +566,56 @@ __global__ __launch_bounds__(DN_PT_THREADS) void rowgemm_persist_kernel(RgArgs g
     for (int j = 0; j < T; ++j) {
         float* cur = smem + (j & 1) * SBUF;
         float* nxt = smem + ((j & 1) ^ 1) * SBUF;
+#if !defined(DN_PT_ABLATE_LOADS)
         if (j + 1 < T) rg_store<TN, NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>(nxt, nxt + SA, tid, R);
-        if (j + 2 < T) {
+#endif
+        if (j + 2 < T && !DN_PT_SKIP_LOADS) {
             lkoff += DN_KB;
-            if (lkoff >= g.a[lseg].w) { lkoff = 0; ++lseg; if (lseg >= g.nseg) { lseg = 0; lt += G; if (lt < ntiles) ltile = g.tiles[lt]; } }
+            if (lkoff >= g.a[lseg].w) { lkoff = 0; ++lseg; if (lseg >= g.nseg) { lseg = 0; lu += G; if (lu < nunits) ltile = unit_tile(lu); } }
             rg_load<TN, NTHR, NOUT, true, BCOLK, HASQ, A_IT, B_IT>(g, ltile, n0, lseg, lkoff, tid, R);
         }
-        // deferred output of the previously finished tile: loads now, maths + stores after the MFMAs
-        PtPiece P[MAXP];
-        int np = DN_PT_NP - p_next;
-        if (np > ppi) np = ppi;
+        // deferred output of the previously finished unit: loads now, maths + stores after the MFMAs
+        PtPiece P[PPI];
+        bool pending = p_next < DN_PT_NP;
+#if defined(DN_PT_ABLATE_OUT)
+        pending = false;
+#endif
+        if (pending) {   // uniform; the block itself is branch-free
 #pragma unroll
-        for (int k = 0; k < MAXP; ++k)
-            if (k < np) pt_piece_load<MODE>(g, sE, p_next + k, tid, p_row0, p_nrows, n0, P[k]);
+            for (int k = 0; k < PPI; ++k) pt_piece_load<MODE, FLAG>(g, sE, p_next + k, tid, p_row0, p_nrows, n0, P[k]);
+        }
 
-        rg_compute<TN, MT, NT, NOUT, BCOLK>(cur, cur + SA, wr * MT * 32, wc * NT * 32, li, ls, acc);
+        rg_compute<TN, MT, NT, NOUT, BCOLK>(cur, cur + SA, 0, wc * NT * 32, li, ls, acc);
 
+        if (pending) {
 #pragma unroll
-        for (int k = 0; k < MAXP; ++k)
-            if (k < np) pt_piece_store<MODE>(g, P[k]);
-        p_next += np;
+            for (int k = 0; k < PPI; ++k) pt_piece_store<MODE, FLAG>(g, P[k]);
+            p_next += PPI;
+        }
 
-        if (++cs == nsl) {   // tile complete: park the accumulators (fragment layout -> row-major, conflict-free)
+        if (++cs == nsl) {   // unit complete: park the accumulators (fragment layout -> row-major, conflict-free)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    sE[((wr * MT + mt) * 32 + dn_acc_row(r, lane)) * 128 + wc * 32 + li] = acc[0][mt][0][r];
+                    sE[(mt * 32 + dn_acc_row(r, lane)) * 128 + wc * 32 + li] = acc[0][mt][0][r];
                     acc[0][mt][0][r] = 0.f;
                 }
             p_row0 = ctile.row0; p_nrows = ctile.nrows; p_next = 0;
             cs = 0;
-            ct += G;
-            if (ct < ntiles) ctile = g.tiles[ct];
+            cu += G;
+            if (cu < nunits) ctile = unit_tile(cu);
         }
-        __syncthreads();   // slice buffer hand-off + visibility of the parked tile
+        __syncthreads();   // slice buffer hand-off + visibility of the parked unit
     }
-    // flush what is still parked (the last tile)
+    // flush what is still parked (the last unit)
+#if defined(DN_PT_ABLATE_OUT)
+    p_next = DN_PT_NP - 1;
+#endif
     for (; p_next < DN_PT_NP; ++p_next) {
         PtPiece P1;
-        pt_piece_load<MODE>(g, sE, p_next, tid, p_row0, p_nrows, n0, P1);
-        pt_piece_store<MODE>(g, P1);
+        pt_piece_load<MODE, FLAG>(g, sE, p_next, tid, p_row0, p_nrows, n0, P1);
+        pt_piece_store<MODE, FLAG>(g, P1);
     }
 }
 
@@ -610,45 +634,54 @@ static int dn_num_cus() {
 #endif
 }
 
-template <int MODE, bool BCOLK>
+template <int MODE, bool BCOLK, bool FLAG>
 static int pt_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
-    const size_t smem = (size_t)(2 * (DN_TM * DN_KB + DN_KB * 128) + DN_TM * 128) * sizeof(float);
+    const size_t smem = (size_t)(2 * (DN_PT_ROWS * DN_KB + DN_KB * 128) + DN_PT_ROWS * 128) * sizeof(float);   // 80 KiB
 #ifndef DN_EMULATE
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_persist_kernel<MODE, BCOLK>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_persist_kernel<MODE, BCOLK, FLAG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         lds_opt_in = true;
     }
 #endif
-    int gx = dn_num_cus();
-    if (gx > ntiles) gx = ntiles;
-    DN_LAUNCH((rowgemm_persist_kernel<MODE, BCOLK>), dim3(gx, (g.N + 127) / 128, 1), dim3(DN_PT_THREADS, 1, 1), smem, stream, g, ntiles);
+    int gx = 2 * dn_num_cus();   // two workgroups per CU
+    if (gx > 2 * ntiles) gx = 2 * ntiles;
+    DN_LAUNCH((rowgemm_persist_kernel<MODE, BCOLK, FLAG>), dim3(gx, (g.N + 127) / 128, 1), dim3(DN_PT_THREADS, 1, 1), smem,
+              stream, g, ntiles);
     return (int)hipGetLastError();
 }
 
-// eligibility of the persistent path: aligned operands, wide output, >= 3 slices, float4-able epilogue operands
+// eligibility of the persistent path: aligned operands, wide output, 3..8 slices, float4-able epilogue operands
 static bool pt_eligible(const RgArgs& g, int nout) {
     if (nout != 1 || !g.aligned || g.N < 128 || g.N % 4 != 0 || g.ldo % 4 != 0 || g.ldr % 4 != 0) return false;
     int nsl = 0;
     for (int s = 0; s < g.nseg; ++s) { nsl += g.a[s].w / DN_KB; if (g.a[s].q) return false; }
-    if (nsl < 3) return false;
+    if (nsl < 3 || nsl > DN_PT_MAX_SLICES) return false;
     auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     if (!al(g.o0) || !al(g.r0) || !al(g.bias) || ((uintptr_t)g.mask & 3) != 0) return false;
-    return g.mode == DN_EPI_STORE || g.mode == DN_EPI_BIAS_RELU || g.mode == DN_EPI_BIAS_RESID || g.mode == DN_EPI_MUL_DFAC ||
-           g.mode == DN_EPI_ADD || g.mode == DN_EPI_DTANH || g.mode == DN_EPI_MASS_ADD;
+    switch (g.mode) {
+        case DN_EPI_STORE: return true;
+        case DN_EPI_BIAS_RELU: return g.bias != nullptr && g.b_colk;
+        case DN_EPI_BIAS_RESID: return g.bias != nullptr && g.r0 != nullptr && g.b_colk;
+        case DN_EPI_MUL_DFAC: case DN_EPI_ADD: case DN_EPI_DTANH: case DN_EPI_MASS_ADD: return g.r0 != nullptr && !g.b_colk;
+        default: return false;
+    }
 }
 
 static int pt_dispatch(const RgArgs& g, int ntiles, hipStream_t stream) {
     const bool ck = g.b_colk != 0;
     switch (g.mode) {
-        case DN_EPI_STORE: return ck ? pt_launch<DN_EPI_STORE, true>(g, ntiles, stream) : pt_launch<DN_EPI_STORE, false>(g, ntiles, stream);
-        case DN_EPI_BIAS_RELU: return ck ? pt_launch<DN_EPI_BIAS_RELU, true>(g, ntiles, stream) : DN_ERR_BAD_MODE;
-        case DN_EPI_BIAS_RESID: return ck ? pt_launch<DN_EPI_BIAS_RESID, true>(g, ntiles, stream) : DN_ERR_BAD_MODE;
-        case DN_EPI_MUL_DFAC: return ck ? DN_ERR_BAD_MODE : pt_launch<DN_EPI_MUL_DFAC, false>(g, ntiles, stream);
-        case DN_EPI_ADD: return ck ? DN_ERR_BAD_MODE : pt_launch<DN_EPI_ADD, false>(g, ntiles, stream);
-        case DN_EPI_DTANH: return ck ? DN_ERR_BAD_MODE : pt_launch<DN_EPI_DTANH, false>(g, ntiles, stream);
-        case DN_EPI_MASS_ADD: return ck ? DN_ERR_BAD_MODE : pt_launch<DN_EPI_MASS_ADD, false>(g, ntiles, stream);
+        case DN_EPI_STORE:
+            if (g.bias) return ck ? pt_launch<DN_EPI_STORE, true, true>(g, ntiles, stream) : pt_launch<DN_EPI_STORE, false, true>(g, ntiles, stream);
+            return ck ? pt_launch<DN_EPI_STORE, true, false>(g, ntiles, stream) : pt_launch<DN_EPI_STORE, false, false>(g, ntiles, stream);
+        case DN_EPI_BIAS_RELU:
+            return g.mask ? pt_launch<DN_EPI_BIAS_RELU, true, true>(g, ntiles, stream) : pt_launch<DN_EPI_BIAS_RELU, true, false>(g, ntiles, stream);
+        case DN_EPI_BIAS_RESID: return pt_launch<DN_EPI_BIAS_RESID, true, false>(g, ntiles, stream);
+        case DN_EPI_MUL_DFAC: return pt_launch<DN_EPI_MUL_DFAC, false, false>(g, ntiles, stream);
+        case DN_EPI_ADD: return pt_launch<DN_EPI_ADD, false, false>(g, ntiles, stream);
+        case DN_EPI_DTANH: return pt_launch<DN_EPI_DTANH, false, false>(g, ntiles, stream);
+        case DN_EPI_MASS_ADD: return pt_launch<DN_EPI_MASS_ADD, false, false>(g, ntiles, stream);
         default: return DN_ERR_BAD_MODE;
     }
 }
