@@ -434,8 +434,13 @@ static int rg_dispatch_width(const RgArgs& g, int ntiles, hipStream_t stream) {
 #else
 #define DN_PT_SKIP_LOADS 0
 #endif
-#define DN_PT_ROWS 64        // rows per work unit (half a 128-row tile)
-#define DN_PT_THREADS 256     // 4 waves; two such workgroups share a CU (2 x 80 KiB of LDS)
+// Work-unit geometry.  Measured on MI355X (K = N = 128 product, 158k rows): 128-row units with 8 waves and one
+// workgroup per CU: 68 us; 64-row units with 4 waves and two workgroups per CU (2 x 80 KiB LDS): 71-75 us (twice the
+// B-operand staging per MFMA); non-persistent kernel: 75-80 us.
+#ifndef DN_PT_ROWS
+#define DN_PT_ROWS 128
+#endif
+#define DN_PT_THREADS (4 * DN_PT_ROWS)   // 64x32 outputs per wave
 #define DN_PT_NP (DN_PT_ROWS * 128 / 4 / DN_PT_THREADS)   // float4 pieces per thread per unit (8)
 
 struct PtPiece {
@@ -499,27 +504,28 @@ __device__ __forceinline__ void pt_piece_store(const RgArgs& g, const PtPiece& P
 
 template <int MODE, bool BCOLK, bool FLAG>
 __global__ __launch_bounds__(DN_PT_THREADS) void rowgemm_persist_kernel(RgArgs g, int ntiles) {
-    constexpr int TN = 128, WR = 1, WC = 4, NOUT = 1, NTHR = DN_PT_THREADS, TMU = DN_PT_ROWS;
+    constexpr int TN = 128, WR = DN_PT_ROWS / 64, WC = 4, NOUT = 1, NTHR = DN_PT_THREADS, TMU = DN_PT_ROWS;
+    constexpr int UPT = DN_TM / TMU;                 // work units per 128-row tile (1 or 2)
     constexpr int MT = TMU / (32 * WR);              // 2
     constexpr int NT = TN / (32 * WC);               // 1
     constexpr int A_IT = TMU * 8 / NTHR;             // 2
-    constexpr int B_IT = DN_KB * TN / 4 / NTHR;      // 4
+    constexpr int B_IT = DN_KB * TN / 4 / NTHR;      // 2 (128-row units) or 4
     constexpr int SA = TMU * DN_KB;
     constexpr int SBUF = SA + DN_KB * TN;
     constexpr bool HASQ = false;
     constexpr int PPI = 4;                           // deferred pieces per slice iteration: 8 pieces over 2 iterations
-    static_assert(DN_TM == 2 * TMU, "a work unit is half a row tile");
+    static_assert(UPT * TMU == DN_TM && (UPT == 1 || UPT == 2), "a work unit is a whole or half a row tile");
 
     DN_DYN_SMEM(smem_raw);
     float* smem = reinterpret_cast<float*>(smem_raw);
-    float* sE = smem + 2 * SBUF;                     // [64][128] parked accumulators
+    float* sE = smem + 2 * SBUF;                     // [TMU][128] parked accumulators
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wc = wave;
+    const int wr = wave / WC, wc = wave % WC;
     const int li = lane & 31, ls = lane >> 5;
     const int G = gridDim.x;
     const int n0 = blockIdx.y * TN;
-    const int nunits = 2 * ntiles;                   // unit u = rows [64*(u&1), +64) of tile u>>1
+    const int nunits = UPT * ntiles;                 // unit u = rows [TMU*(u%UPT), +TMU) of tile u/UPT
 
     int nsl = 0;
     for (int s = 0; s < g.nseg; ++s) nsl += (g.a[s].w + DN_KB - 1) / DN_KB;   // host guarantees nsl >= 3
@@ -535,8 +541,8 @@ __global__ __launch_bounds__(DN_PT_THREADS) void rowgemm_persist_kernel(RgArgs g
 
     // unit -> (sub-)tile descriptor; an empty second half (tile shorter than 64 rows) yields nrows = 0 (fully masked)
     auto unit_tile = [&](int u) {
-        DnTile t = g.tiles[u >> 1];
-        const int h = (u & 1) * TMU;
+        DnTile t = g.tiles[u / UPT];
+        const int h = (u % UPT) * TMU;
         int n = t.nrows - h;
         n = n < 0 ? 0 : (n > TMU ? TMU : n);
         t.row0 += (n > 0 ? h : 0);
@@ -585,7 +591,7 @@ __global__ __launch_bounds__(DN_PT_THREADS) void rowgemm_persist_kernel(RgArgs g
             for (int k = 0; k < PPI; ++k) pt_piece_load<MODE, FLAG>(g, sE, p_next + k, tid, p_row0, p_nrows, n0, P[k]);
         }
 
-        rg_compute<TN, MT, NT, NOUT, BCOLK>(cur, cur + SA, 0, wc * NT * 32, li, ls, acc);
+        rg_compute<TN, MT, NT, NOUT, BCOLK>(cur, cur + SA, wr * MT * 32, wc * NT * 32, li, ls, acc);
 
         if (pending) {
 #pragma unroll
@@ -598,7 +604,7 @@ __global__ __launch_bounds__(DN_PT_THREADS) void rowgemm_persist_kernel(RgArgs g
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    sE[(mt * 32 + dn_acc_row(r, lane)) * 128 + wc * 32 + li] = acc[0][mt][0][r];
+                    sE[((wr * MT + mt) * 32 + dn_acc_row(r, lane)) * 128 + wc * 32 + li] = acc[0][mt][0][r];
                     acc[0][mt][0][r] = 0.f;
                 }
             p_row0 = ctile.row0; p_nrows = ctile.nrows; p_next = 0;
@@ -636,7 +642,7 @@ static int dn_num_cus() {
 
 template <int MODE, bool BCOLK, bool FLAG>
 static int pt_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
-    const size_t smem = (size_t)(2 * (DN_PT_ROWS * DN_KB + DN_KB * 128) + DN_PT_ROWS * 128) * sizeof(float);   // 80 KiB
+    const size_t smem = (size_t)(2 * (DN_PT_ROWS * DN_KB + DN_KB * 128) + DN_PT_ROWS * 128) * sizeof(float);   // 128 KiB (80 KiB for 64-row units)
 #ifndef DN_EMULATE
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
@@ -645,8 +651,9 @@ static int pt_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
         lds_opt_in = true;
     }
 #endif
-    int gx = 2 * dn_num_cus();   // two workgroups per CU
-    if (gx > 2 * ntiles) gx = 2 * ntiles;
+    const int upt = DN_TM / DN_PT_ROWS;
+    int gx = upt * dn_num_cus();   // one 128-row workgroup per CU (two 64-row ones)
+    if (gx > upt * ntiles) gx = upt * ntiles;
     DN_LAUNCH((rowgemm_persist_kernel<MODE, BCOLK, FLAG>), dim3(gx, (g.N + 127) / 128, 1), dim3(DN_PT_THREADS, 1, 1), smem,
               stream, g, ntiles);
     return (int)hipGetLastError();
