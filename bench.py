@@ -146,7 +146,7 @@ def main():
         if nsub == 1:
             mb_j, gather_j, x_j, labels_j, _ = subs[0]
             out = model.forward_packed(x_j, mb_j, gather_j)
-            loss = F.nll_loss(F.log_softmax(out, dim=-1), labels_j)
+            loss = diffusion_net.utils.nll_loss(F.log_softmax(out, dim=-1), labels_j)
             loss.backward()
         else:
             # sub-batches on separate streams: the store phase of one overlaps the MFMA phase of the other;
@@ -157,7 +157,7 @@ def main():
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):
                     out = model.forward_packed(x_j, mb_j, gather_j)
-                    losses.append(F.nll_loss(F.log_softmax(out, dim=-1), labels_j) * (1.0 / nsub))
+                    losses.append(diffusion_net.utils.nll_loss(F.log_softmax(out, dim=-1), labels_j) * (1.0 / nsub))
             for st, l in zip(streams, losses):
                 with torch.cuda.stream(st):
                     l.backward()

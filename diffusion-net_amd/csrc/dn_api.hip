@@ -550,6 +550,20 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     return from_basis(mb, dxs, C, gr->d_x, d_xacc, true, st);
 }
 
+// ------------------------------------------------------------------ loss next to the path
+#define DN_NLL_BLOCKS 1024
+size_t dn_nll_workspace_bytes(void) { return pad256(DN_NLL_BLOCKS) + 512; }
+int dn_nll_loss_fwd_f32(const float* logp, const int64_t* labels, int64_t n, int C, float* loss, void* ws, size_t ws_bytes,
+                        void* stream) {
+    Bump b(ws, ws_bytes);
+    float* partial = b.f(DN_NLL_BLOCKS);
+    if (!b.ok) return DN_ERR_INVALID;
+    return dn_launch_nll_fwd(logp, (const long long*)labels, n, C, partial, DN_NLL_BLOCKS, loss, S(stream));
+}
+int dn_nll_loss_bwd_f32(const int64_t* labels, int64_t n, int C, const float* d_loss, float* d_logp, void* stream) {
+    return dn_launch_nll_bwd((const long long*)labels, n, C, d_loss, d_logp, S(stream));
+}
+
 // ------------------------------------------------------------------ output remaps
 int dn_csr_mean_f32(const int32_t* rowptr, const int32_t* col, int n_rows, const float* x, int C, float div, float* out,
                     void* stream) {

@@ -183,6 +183,9 @@ int dn_launch_smallk_rows(const float* x, int K, const float* W, int w_kn, const
 // partial-free small-N vertex contraction: out[m, n] = sum_r A[r,m] * B[r,n], N <= 16, via per-block partials in ws
 int dn_launch_smalln_tn(const float* A, int M, const float* B, int N, long long rows, float* out, float* ws, int nblk,
                         hipStream_t stream);
+int dn_launch_nll_fwd(const float* logp, const long long* labels, long long n, int C, float* partial, int nb, float* out,
+                      hipStream_t stream);
+int dn_launch_nll_bwd(const long long* labels, long long n, int C, const float* gout, float* dlogp, hipStream_t stream);
 int dn_launch_dtanh(const float* dg, const float* g, float* out, long long n, hipStream_t stream);
 // launchers (host), defined in the .hip files; all return hipError_t as int
 int dn_launch_rowgemm(const RgArgs& g, int ntiles, int nout, hipStream_t stream);

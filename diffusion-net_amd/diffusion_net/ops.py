@@ -354,3 +354,35 @@ class MassMeanFn(torch.autograd.Function):
         _hip.check(_hip.lib().dn_mass_mean_bwd_f32(ctx.mb.ref(), msum.data_ptr(), d_out.data_ptr(), d_out.shape[1],
                                                    d_x.data_ptr(), _hip.stream_of(d_out)), "dn_mass_mean_bwd_f32")
         return d_x, None
+
+
+# ----------------------------------------------------------------------------------------------
+# loss on the far side of the path: F.nll_loss(log_probs, labels) (mean), human_segmentation_original.py:136
+# ----------------------------------------------------------------------------------------------
+class NllLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logp, labels):
+        _hip.require_device(logp)
+        L = _hip.lib()
+        logp = _f32c(logp)
+        if labels.dtype != torch.int64:
+            raise TypeError("labels must be int64")
+        labels = labels.contiguous()
+        n, Cc = logp.shape
+        loss = torch.empty((), dtype=torch.float32, device=logp.device)
+        ws = _hip.workspace(logp.device, L.dn_nll_workspace_bytes())
+        _hip.check(L.dn_nll_loss_fwd_f32(logp.data_ptr(), labels.data_ptr(), n, Cc, loss.data_ptr(), ws.data_ptr(), ws.numel(),
+                                         _hip.stream_of(logp)), "dn_nll_loss_fwd_f32")
+        ctx.save_for_backward(labels)
+        ctx.shape = (n, Cc)
+        return loss
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        (labels,) = ctx.saved_tensors
+        n, Cc = ctx.shape
+        d_loss = _f32c(d_loss)
+        d_logp = torch.empty(n, Cc, dtype=torch.float32, device=d_loss.device)
+        _hip.check(_hip.lib().dn_nll_loss_bwd_f32(labels.data_ptr(), n, Cc, d_loss.data_ptr(), d_logp.data_ptr(),
+                                                  _hip.stream_of(d_loss)), "dn_nll_loss_bwd_f32")
+        return d_logp, None

@@ -150,6 +150,14 @@ int dn_mass_mean_fwd_f32(const dn_mesh_batch_t* mb, const float* x, int C, float
 int dn_mass_mean_bwd_f32(const dn_mesh_batch_t* mb, const float* mass_sum, const float* d_out, int C, float* d_x,
                          void* stream);
 
+/* ---- F.nll_loss(log_probs, labels) with mean reduction -- the loss the experiment scripts apply to the path's output
+ *      (human_segmentation_original.py:136, rna_mesh_segmentation.py:135).  labels int64 (as torch holds them);
+ *      loss: 1 float.  bwd: d_logp[i,c] = -(d_loss / n) * [c == labels[i]]. */
+size_t dn_nll_workspace_bytes(void);
+int dn_nll_loss_fwd_f32(const float* logp, const int64_t* labels, int64_t n, int C, float* loss, void* ws, size_t ws_bytes,
+                        void* stream);
+int dn_nll_loss_bwd_f32(const int64_t* labels, int64_t n, int C, const float* d_loss, float* d_logp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

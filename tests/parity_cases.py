@@ -269,3 +269,17 @@ def run_determinism(device, V=300, K=16, C=32, seed=2):
         outs.append([out.detach().cpu(), x.grad.cpu()] + [p.grad.cpu() for p in model.parameters()])
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def run_nll(device, n=1234, C=8, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    logits = torch.randn(n, C, generator=g)
+    labels = torch.randint(0, C, (n,), generator=g)
+    a = logits.clone().to(device).requires_grad_(True)
+    loss = diffusion_net.utils.nll_loss(torch.log_softmax(a, -1), labels.to(device))
+    (loss * 1.7).backward()
+    b = logits.clone().requires_grad_(True)
+    ref = torch.nn.functional.nll_loss(torch.log_softmax(b, -1), labels)
+    (ref * 1.7).backward()
+    assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    assert helpers.rel_l2(a.grad.cpu(), b.grad) < 1e-5

@@ -59,6 +59,12 @@ def test_mismatched_patterns_on_emulator(emu):
     parity_cases.run_mismatched_patterns(emu)
 
 
+def test_nll_loss_on_emulator(emu):
+    import parity_cases
+    parity_cases.run_nll(emu)
+    parity_cases.run_nll(emu, n=70000, C=3, seed=1)
+
+
 def test_determinism_on_emulator(emu):
     import parity_cases
     parity_cases.run_determinism(emu)

@@ -52,6 +52,13 @@ def test_train_mode_dropout_masks_headline_width(dev):
     parity_cases.run_ragged_net(dev, sizes=(700,), K=64, C=256, N_block=1, dropout=True, outputs_at="faces")
 
 
+def test_nll_loss(dev):
+    import parity_cases
+    parity_cases.run_nll(dev)
+    parity_cases.run_nll(dev, n=317000, C=8, seed=1)
+    parity_cases.run_nll(dev, n=5000, C=260, seed=2)
+
+
 def test_mismatched_patterns(dev):
     import parity_cases
     parity_cases.run_mismatched_patterns(dev)

@@ -24,6 +24,12 @@ for k, d in sorted(agg.items(), key=lambda kv: -sum(kv[1].values())):
 PY
   else echo "no counter file for $name"; tail -5 /tmp/pmc_$name.log; fi
 }
+if [ -n "$ONLY_TRAFFIC" ]; then
+run_pass fetch FETCH_SIZE
+run_pass write WRITE_SIZE
+head -16 "$R/gpurun_out/pmc_fetch.txt" | cut -c1-140; head -16 "$R/gpurun_out/pmc_write.txt" | cut -c1-140
+exit 0
+fi
 run_pass sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 run_pass sq2 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
 head -40 "$R/gpurun_out/pmc_sq.txt"; head -40 "$R/gpurun_out/pmc_sq2.txt"
