@@ -213,6 +213,14 @@ def main():
     else:
         roof = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                 "frac": dom["tflops"] / PEAK_MFMA_F32_TFLOPS, "traffic": None}
+    # HBM bytes per launch of that family from the committed FETCH_SIZE / WRITE_SIZE PMC passes (separate rocprofv3
+    # --pmc runs of the same workload, gfx950 x2 read correction applied; tools/traffic_summary.py)
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        roof["traffic"] = tr[dom["kernel"]]["hbm_bytes_per_launch"]
+        roof["traffic_note"] = "PMC (2*FETCH_SIZE+WRITE_SIZE)*1024 B per launch; algorithmic bytes per launch = %.4g" % dom["bytes_per_launch"]
+    except Exception:
+        pass
     roof.update({"kernel": dom["kernel"], "avg_launch_us": dom["avg_us"], "launches": dom["launches"],
                  "share_of_kernel_time": dom["ms_total"] / sum(f["ms_total"] for f in fam)})
 
