@@ -2,13 +2,16 @@
 
 Signatures follow the reference (geometry.py:572-598): batched tensors, basis [B,V,K],
 values [B,V,C] / [B,K,C], massvec [B,V] (an unbatched leading dimension is accepted too).
-The host-side operator precompute (get_operators & co.) stays outside this module's scope this
-round; ``diffusion_net.synthetic`` provides seeded operators for tests/benchmarks.
+The host-side operator precompute keeps the reference's names here (``compute_operators``, ``get_operators``,
+``get_all_operators``, ``normalize_positions``, ``compute_hks[_autoscale]``) and lives in ``precompute.py``
+(numpy/scipy restatement, triangle meshes).
 """
 import torch
 
 from . import ops
 from .batch import MeshBatch
+from .precompute import (compute_hks, compute_hks_autoscale, compute_operators, get_all_operators,  # noqa: F401
+                         get_operators, normalize_positions)
 
 
 def _spectral_batch(basis, massvec):

@@ -93,3 +93,20 @@ def randomize_times(state_dict, seed: int = 0, lo: float = 1e-3, hi: float = 0.3
         if k.endswith("diffusion_time"):
             v.copy_(lo + (hi - lo) * torch.rand(v.shape, generator=g, dtype=v.dtype))
     return state_dict
+
+
+def sphere_mesh(V: int, seed: int = 0, bump: float = 0.1):
+    """A real closed triangle mesh: V-point Fibonacci lattice on the unit sphere triangulated by its convex hull
+    (valence ~6), then radially perturbed r = 1 + bump*N(0,1).  Returns (verts [V,3] f64, faces [F,3] i64)."""
+    from scipy.spatial import ConvexHull
+    i = np.arange(V) + 0.5
+    phi = np.arccos(1.0 - 2.0 * i / V)
+    theta = math.pi * (1.0 + 5.0 ** 0.5) * i
+    pts = np.stack([np.cos(theta) * np.sin(phi), np.sin(theta) * np.sin(phi), np.cos(phi)], 1)
+    faces = ConvexHull(pts).simplices.astype(np.int64)
+    # consistent outward orientation
+    c = pts[faces]
+    flip = np.einsum("ij,ij->i", np.cross(c[:, 1] - c[:, 0], c[:, 2] - c[:, 0]), c.mean(1)) < 0
+    faces[flip] = faces[flip][:, ::-1]
+    r = 1.0 + bump * np.random.RandomState(seed).randn(V, 1)
+    return pts * r, faces

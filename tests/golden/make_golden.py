@@ -27,6 +27,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "diffusion-net_amd"))
 from diffusion_net import synthetic  # noqa: E402  (product-side generator, no HIP needed)
+from diffusion_net import precompute as my_precompute  # noqa: E402  (ours; bound before the reference takes the package name)
 
 
 def import_reference():
@@ -150,11 +151,31 @@ def run_case(ref, name, case, seed=7):
           f"masks={len(masks)} -> {os.path.getsize(path)/1e3:.0f} kB")
 
 
+def run_geometry_case(ref, V=300, seed=5):
+    """Golden for the host precompute: tangent frames and the complex gradient operator from the reference's
+    own pure-numpy/torch functions (geometry.py:114-273).  The Laplacian itself comes from potpourri3d in the reference
+    (absent here), so the edge set is taken from our cotan Laplacian's pattern and only frames / gradients are pinned."""
+    precompute = my_precompute
+    verts, faces = synthetic.sphere_mesh(V, seed=seed)
+    vt, ft = torch.from_numpy(verts).float(), torch.from_numpy(faces)
+    frames = ref.geometry.build_tangent_frames(vt, ft)
+    Lc = precompute.cotan_laplacian(verts, faces).tocoo()
+    edges = torch.tensor(np.stack((Lc.row, Lc.col), axis=0), dtype=ft.dtype)
+    grad = ref.geometry.build_grad(vt, edges, ref.geometry.edge_tangent_vectors(vt, frames, edges)).tocoo()
+    path = os.path.join(HERE, "geom_sphere%d.npz" % V)
+    np.savez_compressed(path, verts=verts, faces=faces.astype(np.int32), frames=frames.numpy(),
+                        grad_row=grad.row.astype(np.int32), grad_col=grad.col.astype(np.int32),
+                        grad_re=grad.data.real.astype(np.float64), grad_im=grad.data.imag.astype(np.float64))
+    print("geom_sphere%d: frames %s, grad nnz %d -> %.0f kB" % (V, tuple(frames.shape), grad.nnz, os.path.getsize(path) / 1e3))
+
+
 def main():
     ref = import_reference()
     print("reference imported from", ref.__file__, "torch", torch.__version__)
-    for name, case in CASES.items():
-        run_case(ref, name, case)
+    if "--geometry-only" not in sys.argv:
+        for name, case in CASES.items():
+            run_case(ref, name, case)
+    run_geometry_case(ref)
 
 
 if __name__ == "__main__":

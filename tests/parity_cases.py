@@ -283,3 +283,29 @@ def run_nll(device, n=1234, C=8, seed=0):
     (ref * 1.7).backward()
     assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
     assert helpers.rel_l2(a.grad.cpu(), b.grad) < 1e-5
+
+
+def run_real_mesh_pipeline(device, V=400, K=16, C=32, seed=0):
+    """End to end on a real triangle mesh: host precompute (diffusion_net.geometry.get_operators) -> reference-signature
+    forward/backward on the HIP path vs the oracle on the same operators."""
+    from diffusion_net import geometry
+    verts, faces = synthetic.sphere_mesh(V, seed=seed)
+    vt = geometry.normalize_positions(torch.from_numpy(verts).float())
+    ft = torch.from_numpy(faces)
+    frames, mass, L, evals, evecs, gX, gY = geometry.get_operators(vt, ft, k_eig=K)
+    torch.manual_seed(seed)
+    model = diffusion_net.layers.DiffusionNet(3, 6, C_width=C, N_block=2, outputs_at="faces", dropout=False)
+    model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=seed))
+    params = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(device).eval()
+    d = lambda t: t.to(device)
+    x = d(vt).requires_grad_(True)
+    out = model(x, d(mass), L=d(L), evals=d(evals), evecs=d(evecs), gradX=d(gX), gradY=d(gY), faces=d(ft))
+    w = torch.randn(out.shape, generator=torch.Generator().manual_seed(1))
+    (out * w.to(device)).sum().backward()
+    ref, g = orc.net_forward_backward(params, dict(x_in=vt, mass=mass, evals=evals, evecs=evecs, gradX=gX, gradY=gY, faces=ft),
+                                      outputs_at="faces", loss_weights=w)
+    assert helpers.rel_max(out.detach().cpu(), ref) < FWD_TOL
+    assert helpers.rel_l2(x.grad.cpu(), g["x_in"]) < GRAD_TOL
+    for k, p in model.named_parameters():
+        assert helpers.rel_l2(p.grad.cpu(), g[k]) < GRAD_TOL, k

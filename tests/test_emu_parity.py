@@ -65,6 +65,11 @@ def test_nll_loss_on_emulator(emu):
     parity_cases.run_nll(emu, n=70000, C=3, seed=1)
 
 
+def test_real_mesh_pipeline_on_emulator(emu):
+    import parity_cases
+    parity_cases.run_real_mesh_pipeline(emu)
+
+
 def test_determinism_on_emulator(emu):
     import parity_cases
     parity_cases.run_determinism(emu)

@@ -59,6 +59,11 @@ def test_nll_loss(dev):
     parity_cases.run_nll(dev, n=5000, C=260, seed=2)
 
 
+def test_real_mesh_pipeline(dev):
+    import parity_cases
+    parity_cases.run_real_mesh_pipeline(dev, V=3000, K=64, C=128)
+
+
 def test_mismatched_patterns(dev):
     import parity_cases
     parity_cases.run_mismatched_patterns(dev)
