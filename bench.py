@@ -118,6 +118,12 @@ def main():
     import diffusion_net
     from diffusion_net import _hip, synthetic
     from diffusion_net.dist import FlatParams
+    if not os.path.exists(_hip.LIB_PATH):      # fresh checkout: compile the HIP sources once (rank 0), never a fallback
+        if rank == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        if world > 1:
+            dist.barrier()
     lib = _hip.lib()
 
     C_in, C_out = 3, 8

@@ -15,6 +15,9 @@ def dev():
     assert torch.cuda.is_available(), "GPU tier needs a ROCm device"
     from diffusion_net import _hip
     _hip._use_library_for_tests(None, False)
+    if not os.path.exists(_hip.LIB_PATH):  # fresh checkout on the GPU box: compile the HIP sources (hipcc is in the image)
+        import __graft_entry__
+        __graft_entry__.build()
     lib = _hip.lib()                      # raises if libdiffnet_hip.so is missing: no fallback
     assert lib.dn_version() >= 100
     return torch.device("cuda:0")
