@@ -32,16 +32,6 @@ __device__ __forceinline__ f32x16 dn_mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 #endif
 }
-__device__ __forceinline__ void dn_setprio_hi() {
-#if !defined(DN_EMULATE) && defined(DN_USE_SETPRIO)
-    __builtin_amdgcn_s_setprio(1);
-#endif
-}
-__device__ __forceinline__ void dn_setprio_lo() {
-#if !defined(DN_EMULATE) && defined(DN_USE_SETPRIO)
-    __builtin_amdgcn_s_setprio(0);
-#endif
-}
 __device__ __forceinline__ int dn_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // A unit of row work: rows [row0,row0+nrows) of the concatenated vertex axis, all belonging to

@@ -255,7 +255,6 @@ __device__ __forceinline__ void rg_compute(const float* sA, const float* sB, int
                     for (int t = 0; t < 4; ++t)
                         bv[o][nt][t] = sB[o * SB + (8 * kg + 4 * ls + t) * TN + bcol0 + nt * 32 + li];
         }
-        dn_setprio_hi();
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -270,7 +269,6 @@ __device__ __forceinline__ void rg_compute(const float* sA, const float* sB, int
                         acc[o][mt][nt] = dn_mfma(dn_f4_get(af[mt], t), bv[o][nt][t], acc[o][mt][nt]);
 #endif
                     }
-        dn_setprio_lo();
     }
 }
 
@@ -307,12 +305,6 @@ __global__ __launch_bounds__(WR* WC * 64) void rowgemm_kernel(RgArgs g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[o][mt][nt][r] = 0.f;
 
-#if defined(DN_STAGGER) && !defined(DN_EMULATE)
-    // development probe: de-phase the second workgroup of each CU (first dispatch wave only) by DN_STAGGER x 3.4 us
-    if (blockIdx.x >= 256 && blockIdx.x < 512) {
-        for (int i = 0; i < DN_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     RgRegs<NOUT, A_IT, B_IT> R;
     int nslices = 0;
     for (int s = 0; s < g.nseg; ++s) nslices += (g.a[s].w + DN_KB - 1) / DN_KB;

@@ -55,6 +55,12 @@ def test_train_mode_dropout_masks_headline_width(dev):
     parity_cases.run_ragged_net(dev, sizes=(700,), K=64, C=256, N_block=1, dropout=True, outputs_at="faces")
 
 
+def test_rna_like_wide_head(dev):
+    """BASELINE configs[4] shape: C_out = 260 per-vertex classes, C_width = 128 (last_lin N = 260, its backward K = 260)."""
+    import parity_cases
+    parity_cases.run_ragged_net(dev, sizes=(1500, 1100), K=128, C=128, C_out=260, N_block=1)
+
+
 def test_nll_loss(dev):
     import parity_cases
     parity_cases.run_nll(dev)
