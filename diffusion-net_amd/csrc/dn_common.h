@@ -32,6 +32,38 @@ __device__ __forceinline__ f32x16 dn_mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 #endif
 }
+// One 32x32x16 bf16 MFMA step (fp32 accumulate): lane l supplies eight consecutive-k bf16 of row i=l&31 (A) / column j=l&31
+// (B), k = 8*(l>>5) .. +7, packed in a uint4.
+__device__ __forceinline__ f32x16 dn_mfma_bf16(uint4 a, uint4 b, f32x16 c) {
+#ifdef DN_EMULATE
+    return dnemu_mfma_f32_32x32x16_bf16(a, b, c);
+#else
+    typedef __bf16 dn_bf16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dn_bf16x8, a), __builtin_bit_cast(dn_bf16x8, b), c, 0, 0, 0);
+#endif
+}
+// 3-term bf16 split of an fp32 value, x = hi + mid + lo up to 2^-24 relative (round-to-nearest-even at every step; the
+// residuals are exact in fp32).  With the six largest cross products of two split operands accumulated in fp32 the result
+// is as accurate as an fp32 FMA chain (measured rel-L2 1.6e-7 vs 2.0e-7 against fp64, profiles/r01_exp_bf16x3.txt) at
+// 16/6 = 2.7x the f32-MFMA rate.
+__device__ __forceinline__ unsigned dn_bf16_bits(float x, float& back) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u >>= 16;
+    back = __uint_as_float(u << 16);
+    return u;
+}
+__device__ __forceinline__ void dn_split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
+    float b0, b1, b2;
+    hi = dn_bf16_bits(x, b0);
+    const float r1 = x - b0;
+    mid = dn_bf16_bits(r1, b1);
+    lo = dn_bf16_bits(r1 - b1, b2);
+}
+// LDS bf16 plane: R rows x 32 k, 64 bytes per row = four 16-byte slots, slot' = slot ^ ((row>>2)&3): a wave's ds_read_b128 of
+// one slot for 32 consecutive rows hits all sixteen 16-byte positions of the 256-byte bank row once per 16-lane group.
+__device__ __forceinline__ int dn_plane_off(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
+
 __device__ __forceinline__ int dn_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // A unit of row work: rows [row0,row0+nrows) of the concatenated vertex axis, all belonging to

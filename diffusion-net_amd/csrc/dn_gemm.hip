@@ -112,7 +112,9 @@ struct RgRegs {
     float bm[NOUT][B_IT];    // column guard * sign
 };
 
-template <int TN, int NTHR, int NOUT, bool ALIGNED, bool BCOLK, bool HASQ, int A_IT, int B_IT>
+// PAIRK (bf16x3 path, row-contraction B, 512 threads, TN = 128): a thread fetches rows 2p and 2p+1 (p = tid & 15) of its
+// 4-column group q4 = tid >> 4, so that it can write packed (k, k+1) bf16 pairs of the transposed B planes.
+template <int TN, int NTHR, int NOUT, bool ALIGNED, bool BCOLK, bool HASQ, int A_IT, int B_IT, bool PAIRK = false>
 __device__ __forceinline__ void rg_load(const RgArgs& g, const DnTile& tile, int n0, int seg, int koff, int tid,
                                         RgRegs<NOUT, A_IT, B_IT>& R) {   // tile.row0/nrows may describe a sub-tile
     const RgSeg sg = g.a[seg];
@@ -145,7 +147,8 @@ __device__ __forceinline__ void rg_load(const RgArgs& g, const DnTile& tile, int
                     nok = n0 + nrow < g.N;
                     boff = (long long)(nok ? n0 + nrow : 0) * g.ldb + koff + 4 * q;
                 } else {
-                    const int krow = idx / (TN / 4), q4 = idx % (TN / 4);
+                    const int krow = PAIRK ? 2 * (tid & 15) + i : idx / (TN / 4);
+                    const int q4 = PAIRK ? (tid >> 4) : idx % (TN / 4);
                     nok = n0 + 4 * q4 < g.N;
                     boff = (long long)(koff + krow) * g.ldb + (nok ? n0 + 4 * q4 : 0);
                 }
@@ -408,6 +411,91 @@ static int rg_dispatch_width(const RgArgs& g, int ntiles, hipStream_t stream) {
     return rg_launch<128, 2, WC128, NOUT, MODE, true, BCOLK>(g, ntiles, stream);
 }
 
+// ---- split-bf16 ("x3") staging and MFMA for the persistent kernel: both operands live in LDS as three bf16 planes
+//      (hi, mid, lo) of [rows][32 k]; six cross products per k16 step replace sixteen f32 MFMA k2 steps.
+template <int NTHR, bool BCOLK, bool HASQ, int A_IT, int B_IT>
+__device__ __forceinline__ void rg_store_x3(unsigned char* sA, unsigned char* sB, int tid, const RgRegs<1, A_IT, B_IT>& R) {
+    constexpr int PL = DN_TM * 64;    // bytes per A plane (128 rows x 32 bf16)
+    constexpr int PLB = 128 * 64;     // bytes per B plane (128 output columns)
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int idx = tid + i * NTHR;
+        const int row = idx >> 3, q = idx & 7;
+        float4 v = dn_f4_scale(R.a[i], R.am[i]);
+        if (HASQ) v = dn_f4_mul(v, R.q[i]);
+        unsigned h[4], m[4], l[4];
+        dn_split3(v.x, h[0], m[0], l[0]); dn_split3(v.y, h[1], m[1], l[1]);
+        dn_split3(v.z, h[2], m[2], l[2]); dn_split3(v.w, h[3], m[3], l[3]);
+        const int off = dn_plane_off(row, q >> 1) + (q & 1) * 8;
+        *reinterpret_cast<uint2*>(sA + off) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+        *reinterpret_cast<uint2*>(sA + PL + off) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+        *reinterpret_cast<uint2*>(sA + 2 * PL + off) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+    }
+    if (BCOLK) {
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int idx = tid + i * NTHR;
+            const int nrow = idx >> 3, q = idx & 7;
+            const float4 v = dn_f4_scale(R.b[0][i], R.bm[0][i]);
+            unsigned h[4], m[4], l[4];
+            dn_split3(v.x, h[0], m[0], l[0]); dn_split3(v.y, h[1], m[1], l[1]);
+            dn_split3(v.z, h[2], m[2], l[2]); dn_split3(v.w, h[3], m[3], l[3]);
+            const int off = dn_plane_off(nrow, q >> 1) + (q & 1) * 8;
+            *reinterpret_cast<uint2*>(sB + off) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            *reinterpret_cast<uint2*>(sB + PLB + off) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+            *reinterpret_cast<uint2*>(sB + 2 * PLB + off) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+        }
+    } else {   // PAIRK: R.b[0][0] = row 2p, R.b[0][1] = row 2p+1 of column group q4 -> transposed planes, packed (k,k+1) dwords
+        static_assert(BCOLK || B_IT == 2, "pair mapping needs two rows per thread");
+        const int pr = tid & 15, q4 = tid >> 4;
+        const float4 v0 = dn_f4_scale(R.b[0][0], R.bm[0][0]);
+        const float4 v1 = dn_f4_scale(R.b[0][B_IT - 1], R.bm[0][B_IT - 1]);
+        const float e0[4] = {v0.x, v0.y, v0.z, v0.w}, e1[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            dn_split3(e0[e], h0, m0, l0);
+            dn_split3(e1[e], h1, m1, l1);
+            const int off = dn_plane_off(4 * q4 + e, pr >> 2) + (pr & 3) * 4;
+            *reinterpret_cast<unsigned*>(sB + off) = h0 | (h1 << 16);
+            *reinterpret_cast<unsigned*>(sB + PLB + off) = m0 | (m1 << 16);
+            *reinterpret_cast<unsigned*>(sB + 2 * PLB + off) = l0 | (l1 << 16);
+        }
+    }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void rg_compute_x3(const unsigned char* sA, const unsigned char* sB, int arow0, int bcol0, int li,
+                                              int lg, f32x16 (&acc)[1][MT][NT]) {
+    constexpr int PL = DN_TM * 64, PLB = 128 * 64;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {   // two k16 steps per 32-wide slice; lane group lg owns k = 16 s + 8 lg .. +7
+        uint4 a[3][MT], b[3][NT];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                a[p][mt] = *reinterpret_cast<const uint4*>(sA + p * PL + dn_plane_off(arow0 + mt * 32 + li, 2 * s + lg));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                b[p][nt] = *reinterpret_cast<const uint4*>(sB + p * PLB + dn_plane_off(bcol0 + nt * 32 + li, 2 * s + lg));
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x16 c = acc[0][mt][nt];
+                c = dn_mfma_bf16(a[1][mt], b[1][nt], c);   // mid*mid   (smallest terms first)
+                c = dn_mfma_bf16(a[0][mt], b[2][nt], c);   // hi*lo
+                c = dn_mfma_bf16(a[2][mt], b[0][nt], c);   // lo*hi
+                c = dn_mfma_bf16(a[0][mt], b[1][nt], c);   // hi*mid
+                c = dn_mfma_bf16(a[1][mt], b[0][nt], c);   // mid*hi
+                c = dn_mfma_bf16(a[0][mt], b[0][nt], c);   // hi*hi
+                acc[0][mt][nt] = c;
+            }
+    }
+}
+
 // =======================================================================================
 // persistent single-output rowgemm (the heavy N >= 128 products)
 //
@@ -494,7 +582,7 @@ __device__ __forceinline__ void pt_piece_store(const RgArgs& g, const PtPiece& P
     if (P.ok) *reinterpret_cast<float4*>(g.o0 + P.off) = make_float4(y[0], y[1], y[2], y[3]);
 }
 
-template <int MODE, bool BCOLK, bool FLAG>
+template <int MODE, bool BCOLK, bool FLAG, bool X3>
 __global__ __launch_bounds__(DN_PT_THREADS) void rowgemm_persist_kernel(RgArgs g, int ntiles) {
     constexpr int TN = 128, WR = DN_PT_ROWS / 64, WC = 4, NOUT = 1, NTHR = DN_PT_THREADS, TMU = DN_PT_ROWS;
     constexpr int UPT = DN_TM / TMU;                 // work units per 128-row tile (1 or 2)
@@ -502,10 +590,13 @@ __global__ __launch_bounds__(DN_PT_THREADS) void rowgemm_persist_kernel(RgArgs g
     constexpr int NT = TN / (32 * WC);               // 1
     constexpr int A_IT = TMU * 8 / NTHR;             // 2
     constexpr int B_IT = DN_KB * TN / 4 / NTHR;      // 2 (128-row units) or 4
-    constexpr int SA = TMU * DN_KB;
-    constexpr int SBUF = SA + DN_KB * TN;
+    // one (A,B) slice buffer, in floats: f32 tiles (A 4 B/elem + B 4 B/elem) or three bf16 planes each (6 B/elem)
+    constexpr int SA = X3 ? (TMU * 64 * 3) / 4 : TMU * DN_KB;
+    constexpr int SBUF = SA + (X3 ? (128 * 64 * 3) / 4 : DN_KB * TN);
     constexpr bool HASQ = false;
+    constexpr bool PAIRK = X3 && !BCOLK;
     constexpr int PPI = 4;                           // deferred pieces per slice iteration: 8 pieces over 2 iterations
+    static_assert(!X3 || (TMU == 128 && NTHR == 512), "the bf16x3 staging is written for 128-row units and 512 threads");
     static_assert(UPT * TMU == DN_TM && (UPT == 1 || UPT == 2), "a work unit is a whole or half a row tile");
 
     DN_DYN_SMEM(smem_raw);
@@ -552,12 +643,13 @@ __global__ __launch_bounds__(DN_PT_THREADS) void rowgemm_persist_kernel(RgArgs g
     // parked unit being streamed out
     int p_row0 = ctile.row0, p_nrows = 0, p_next = DN_PT_NP;   // p_next >= NP: nothing pending
 
-    rg_load<TN, NTHR, NOUT, true, BCOLK, HASQ, A_IT, B_IT>(g, ltile, n0, lseg, lkoff, tid, R);
-    rg_store<TN, NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>(smem, smem + SA, tid, R);
+    rg_load<TN, NTHR, NOUT, true, BCOLK, HASQ, A_IT, B_IT, PAIRK>(g, ltile, n0, lseg, lkoff, tid, R);
+    if constexpr (X3) rg_store_x3<NTHR, BCOLK, HASQ, A_IT, B_IT>(reinterpret_cast<unsigned char*>(smem), reinterpret_cast<unsigned char*>(smem + SA), tid, R);
+    else rg_store<TN, NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>(smem, smem + SA, tid, R);
     if (T > 1) {
         lkoff += DN_KB;
         if (lkoff >= g.a[lseg].w) { lkoff = 0; ++lseg; if (lseg >= g.nseg) { lseg = 0; lu += G; if (lu < nunits) ltile = unit_tile(lu); } }
-        rg_load<TN, NTHR, NOUT, true, BCOLK, HASQ, A_IT, B_IT>(g, ltile, n0, lseg, lkoff, tid, R);
+        rg_load<TN, NTHR, NOUT, true, BCOLK, HASQ, A_IT, B_IT, PAIRK>(g, ltile, n0, lseg, lkoff, tid, R);
     }
     __syncthreads();
 
@@ -565,12 +657,15 @@ __global__ __launch_bounds__(DN_PT_THREADS) void rowgemm_persist_kernel(RgArgs g
         float* cur = smem + (j & 1) * SBUF;
         float* nxt = smem + ((j & 1) ^ 1) * SBUF;
 #if !defined(DN_PT_ABLATE_LOADS)
-        if (j + 1 < T) rg_store<TN, NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>(nxt, nxt + SA, tid, R);
+        if (j + 1 < T) {
+            if constexpr (X3) rg_store_x3<NTHR, BCOLK, HASQ, A_IT, B_IT>(reinterpret_cast<unsigned char*>(nxt), reinterpret_cast<unsigned char*>(nxt + SA), tid, R);
+            else rg_store<TN, NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>(nxt, nxt + SA, tid, R);
+        }
 #endif
         if (j + 2 < T && !DN_PT_SKIP_LOADS) {
             lkoff += DN_KB;
             if (lkoff >= g.a[lseg].w) { lkoff = 0; ++lseg; if (lseg >= g.nseg) { lseg = 0; lu += G; if (lu < nunits) ltile = unit_tile(lu); } }
-            rg_load<TN, NTHR, NOUT, true, BCOLK, HASQ, A_IT, B_IT>(g, ltile, n0, lseg, lkoff, tid, R);
+            rg_load<TN, NTHR, NOUT, true, BCOLK, HASQ, A_IT, B_IT, PAIRK>(g, ltile, n0, lseg, lkoff, tid, R);
         }
         // deferred output of the previously finished unit: loads now, maths + stores after the MFMAs
         PtPiece P[PPI];
@@ -583,7 +678,8 @@ __global__ __launch_bounds__(DN_PT_THREADS) void rowgemm_persist_kernel(RgArgs g
             for (int k = 0; k < PPI; ++k) pt_piece_load<MODE, FLAG>(g, sE, p_next + k, tid, p_row0, p_nrows, n0, P[k]);
         }
 
-        rg_compute<TN, MT, NT, NOUT, BCOLK>(cur, cur + SA, wr * MT * 32, wc * NT * 32, li, ls, acc);
+        if constexpr (X3) rg_compute_x3<MT, NT>(reinterpret_cast<const unsigned char*>(cur), reinterpret_cast<const unsigned char*>(cur + SA), wr * MT * 32, wc * NT * 32, li, ls, acc);
+        else rg_compute<TN, MT, NT, NOUT, BCOLK>(cur, cur + SA, wr * MT * 32, wc * NT * 32, li, ls, acc);
 
         if (pending) {
 #pragma unroll
@@ -632,13 +728,19 @@ static int dn_num_cus() {
 #endif
 }
 
+#ifndef DN_PT_X3
+#define DN_PT_X3 (DN_PT_ROWS == 128)   // split-bf16 MFMA in the persistent kernel (build with -DDN_PT_X3=0 for exact-f32 MFMA)
+#endif
 template <int MODE, bool BCOLK, bool FLAG>
 static int pt_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
-    const size_t smem = (size_t)(2 * (DN_PT_ROWS * DN_KB + DN_KB * 128) + DN_PT_ROWS * 128) * sizeof(float);   // 128 KiB (80 KiB for 64-row units)
+    constexpr bool X3 = DN_PT_X3 != 0;
+    // slice buffers (2x) + parked accumulators: 128 KiB with f32 tiles, exactly 160 KiB with bf16x3 planes
+    const size_t smem = X3 ? (size_t)(2 * (DN_PT_ROWS * 64 * 3 + 128 * 64 * 3) + DN_PT_ROWS * 128 * 4)
+                           : (size_t)(2 * (DN_PT_ROWS * DN_KB + DN_KB * 128) + DN_PT_ROWS * 128) * sizeof(float);
 #ifndef DN_EMULATE
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_persist_kernel<MODE, BCOLK, FLAG>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_persist_kernel<MODE, BCOLK, FLAG, X3>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         lds_opt_in = true;
     }
@@ -646,7 +748,7 @@ static int pt_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
     const int upt = DN_TM / DN_PT_ROWS;
     int gx = upt * dn_num_cus();   // one 128-row workgroup per CU (two 64-row ones)
     if (gx > upt * ntiles) gx = upt * ntiles;
-    DN_LAUNCH((rowgemm_persist_kernel<MODE, BCOLK, FLAG>), dim3(gx, (g.N + 127) / 128, 1), dim3(DN_PT_THREADS, 1, 1), smem,
+    DN_LAUNCH((rowgemm_persist_kernel<MODE, BCOLK, FLAG, X3>), dim3(gx, (g.N + 127) / 128, 1), dim3(DN_PT_THREADS, 1, 1), smem,
               stream, g, ntiles);
     return (int)hipGetLastError();
 }

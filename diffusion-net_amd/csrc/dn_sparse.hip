@@ -14,11 +14,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpArgs s, int tpr) {
     const int tid = threadIdx.x;
     const int rl = tid / tpr, cg = tid % tpr;
     const int rows_per_block = 256 / tpr;
-    // XCD-aware placement: block b runs on XCD b % 8 (observed dispatch order; affects speed only), so give every XCD a
-    // contiguous range of row blocks -- the ~7 neighbour rows a row gathers then mostly live in the same XCD's L2.
-    const int per_xcd = gridDim.x >> 3;                       // the launcher rounds the grid up to a multiple of 8
-    const int rb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int row = rb * rows_per_block + rl;
+    const int row = blockIdx.x * rows_per_block + rl;
     if (row >= s.nrows) return;
     const int beg = s.rowptr[row], end = s.rowptr[row + 1];
     for (int c = cg * VEC; c < s.C; c += tpr * VEC) {
@@ -91,7 +87,7 @@ int dn_launch_spmm(const SpArgs& s, hipStream_t stream) {
     int tpr = pow2_at_least(vec ? (s.C + 3) / 4 : s.C);
     if (tpr > 256) tpr = 256;
     const int rpb = 256 / tpr;
-    dim3 grid((((s.nrows + rpb - 1) / rpb) + 7) / 8 * 8, 1, 1);
+    dim3 grid((s.nrows + rpb - 1) / rpb, 1, 1);
     dn_prof_begin(DN_K_SPMM, stream);
     if (vec) {
         DN_LAUNCH(spmm_kernel<4>, grid, dim3(256, 1, 1), 0, stream, s, tpr);

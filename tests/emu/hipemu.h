@@ -31,6 +31,12 @@ struct dim3 {
 struct alignas(16) float4 { float x, y, z, w; };
 struct alignas(8) float2 { float x, y; };
 struct alignas(16) int4 { int x, y, z, w; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+struct alignas(8) uint2 { unsigned x, y; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 
@@ -55,6 +61,7 @@ struct WaveState {
     int count = 0;
     unsigned gen = 0;
     float a[2][64], b[2][64];
+    unsigned short ha[2][64][8], hb[2][64][8];   // bf16 MFMA operands
 };
 struct BlockState {
     std::vector<ucontext_t> ctx;
@@ -172,6 +179,31 @@ static inline dnemu_f32x16 dnemu_mfma_f32_32x32x2f32(float a, float b, dnemu_f32
         float v = c[r];
         v = fmaf(w.a[slot][row], w.b[slot][col], v);
         v = fmaf(w.a[slot][row + 32], w.b[slot][col + 32], v);
+        d[r] = v;
+    }
+    return d;
+}
+// v_mfma_f32_32x32x16_bf16: lane l supplies A[i=l&31][k=8*(l>>5)+j] and B[k=8*(l>>5)+j][col=l&31], j = 0..7 (8 bf16 = 16 bytes);
+// C/D layout as the f32 form.  fp32 accumulation (order inside the instruction is not architecturally specified).
+static inline dnemu_f32x16 dnemu_mfma_f32_32x32x16_bf16(uint4 a, uint4 b, dnemu_f32x16 c) {
+    dnemu::WaveState& w = dnemu::cur_wave();
+    int l = dnemu::cur_lane();
+    unsigned slot = w.gen & 1;
+    const unsigned aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+    for (int j = 0; j < 8; ++j) {
+        w.ha[slot][l][j] = (unsigned short)((aw[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+        w.hb[slot][l][j] = (unsigned short)((bw[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+    }
+    dnemu::wave_barrier();
+    dnemu_f32x16 d;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        int col = l & 31;
+        float v = c[r];
+        for (int g = 0; g < 2; ++g)
+            for (int j = 0; j < 8; ++j)
+                v = fmaf(__uint_as_float((unsigned)w.ha[slot][row + 32 * g][j] << 16),
+                         __uint_as_float((unsigned)w.hb[slot][col + 32 * g][j] << 16), v);
         d[r] = v;
     }
     return d;
