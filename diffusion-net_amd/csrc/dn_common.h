@@ -42,6 +42,17 @@ __device__ __forceinline__ f32x16 dn_mfma_bf16(uint4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dn_bf16x8, a), __builtin_bit_cast(dn_bf16x8, b), c, 0, 0, 0);
 #endif
 }
+// gfx950 LDS transpose read: lane l of a 16-lane group gets column l&15 of the 4x16 16-bit matrix whose row j is named by
+// the addresses of lanes 4j..4j+3 of the group (each an 8-byte chunk).  Turns k-major LDS tiles into MFMA operands.
+__device__ __forceinline__ uint2 dn_lds_tr16(const unsigned char* p) {
+#ifdef DN_EMULATE
+    return dnemu_ds_read_tr16_b64(p);
+#else
+    typedef short dn_v4s __attribute__((ext_vector_type(4)));
+    const dn_v4s v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) dn_v4s*)p);
+    return __builtin_bit_cast(uint2, v);
+#endif
+}
 // 3-term bf16 split of an fp32 value, x = hi + mid + lo up to 2^-24 relative (round-to-nearest-even at every step; the
 // residuals are exact in fp32).  With the six largest cross products of two split operands accumulated in fp32 the result
 // is as accurate as an fp32 FMA chain (measured rel-L2 1.6e-7 vs 2.0e-7 against fp64, profiles/r01_exp_bf16x3.txt) at

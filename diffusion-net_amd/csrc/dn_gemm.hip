@@ -1076,6 +1076,210 @@ static int tn_launch(const TnArgs& g, dim3 grid, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
+// =======================================================================================
+// tngemm on split-bf16 MFMA (aligned operands).  The operands are k-major (the contraction runs over the rows r of
+// A[r, m] and B[r, n]), so their bf16 planes are stored as loaded -- [32 r][128 cols], 320-byte rows: four consecutive
+// rows start 16 banks apart -- and turned into MFMA operands by the LDS transpose read.  8 waves (64 x 32 outputs each),
+// two 60 KiB step buffers.
+// =======================================================================================
+#define DN_TX_THREADS 512
+#define DN_TX_ROWB 320                      // bytes per LDS plane row (128 bf16 + 32 B pad)
+#define DN_TX_PLANE (DN_KB * DN_TX_ROWB)    // bytes per plane (10 KiB)
+
+struct TxRegs {
+    float4 a[2], b[2], qa[2];
+    float ma[2], mb[2];
+};
+
+template <int FLAVOR>
+__device__ __forceinline__ void tx_load(const TnArgs& g, const DnTile& ch, int step, int kr0, bool a_ok, bool b_ok,
+                                        const float* ap, const float* aq, int ald, const float* bp, int bld, TxRegs& R) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int kr = step * DN_KB + kr0 + 16 * i;
+        const bool kok = kr < ch.nrows;
+        const long long row = (long long)ch.row0 + (kok ? kr : 0);
+        R.ma[i] = (kok && a_ok) ? 1.f : 0.f;
+        R.mb[i] = (kok && b_ok) ? 1.f : 0.f;
+        R.a[i] = *reinterpret_cast<const float4*>(ap + row * ald);
+        R.b[i] = *reinterpret_cast<const float4*>(bp + row * bld);
+        if (FLAVOR == DN_TN_QA) R.qa[i] = *reinterpret_cast<const float4*>(aq + row * ald);
+        if (FLAVOR == DN_TN_ROWSCALE) R.qa[i].x = g.b_rowscale[row];
+    }
+}
+
+__device__ __forceinline__ void tx_put(unsigned char* planes, int off, float4 v) {
+    unsigned h[4], m[4], l[4];
+    dn_split3(v.x, h[0], m[0], l[0]); dn_split3(v.y, h[1], m[1], l[1]);
+    dn_split3(v.z, h[2], m[2], l[2]); dn_split3(v.w, h[3], m[3], l[3]);
+    *reinterpret_cast<uint2*>(planes + off) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    *reinterpret_cast<uint2*>(planes + DN_TX_PLANE + off) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+    *reinterpret_cast<uint2*>(planes + 2 * DN_TX_PLANE + off) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+}
+
+template <int FLAVOR>
+__device__ __forceinline__ void tx_store(unsigned char* sA, unsigned char* sB, int kr0, int q, const TxRegs& R, float4& csum) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float4 va = dn_f4_scale(R.a[i], R.ma[i]);
+        const float4 vb = dn_f4_scale(R.b[i], FLAVOR == DN_TN_ROWSCALE ? R.mb[i] * R.qa[i].x : R.mb[i]);
+        if (FLAVOR == DN_TN_QA) va = dn_f4_mul(va, R.qa[i]);
+        if (FLAVOR == DN_TN_COLSUM) { csum.x += va.x; csum.y += va.y; csum.z += va.z; csum.w += va.w; }
+        const int off = (kr0 + 16 * i) * DN_TX_ROWB + q * 8;
+        tx_put(sA, off, va);
+        tx_put(sB, off, vb);
+    }
+}
+
+// one MFMA operand (8 consecutive k of a column) from a k-major plane: two transpose reads of 4 rows each
+__device__ __forceinline__ uint4 tx_frag(const unsigned char* p) {
+    const uint2 lo = dn_lds_tr16(p), hi = dn_lds_tr16(p + 4 * DN_TX_ROWB);
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
+__device__ __forceinline__ void tx_compute(const unsigned char* sA, const unsigned char* sB, int wr, int wc, int lane,
+                                           f32x16 (&acc)[2]) {
+    // lane -> chunk it names inside its 16-lane group: row (c/4) of the 4-row block, columns 4*(c%4)..+3 of the 16-column half
+    const int g = lane >> 4, c = lane & 15;
+    const int lane_off = (8 * (g >> 1) + (c >> 2)) * DN_TX_ROWB + (16 * (g & 1) + 4 * (c & 3)) * 2;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {   // two k16 steps per 32-row step
+        uint4 a[3][2], b[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int base = p * DN_TX_PLANE + s * 16 * DN_TX_ROWB + lane_off;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) a[p][mt] = tx_frag(sA + base + (wr * 64 + mt * 32) * 2);
+            b[p] = tx_frag(sB + base + (wc * 32) * 2);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x16 cacc = acc[mt];
+            cacc = dn_mfma_bf16(a[1][mt], b[1], cacc);
+            cacc = dn_mfma_bf16(a[0][mt], b[2], cacc);
+            cacc = dn_mfma_bf16(a[2][mt], b[0], cacc);
+            cacc = dn_mfma_bf16(a[0][mt], b[1], cacc);
+            cacc = dn_mfma_bf16(a[1][mt], b[0], cacc);
+            cacc = dn_mfma_bf16(a[0][mt], b[0], cacc);
+            acc[mt] = cacc;
+        }
+    }
+}
+
+template <int FLAVOR>
+__global__ __launch_bounds__(DN_TX_THREADS) void tngemm_x3_kernel(TnArgs g) {
+    constexpr int SBUF = 6 * DN_TX_PLANE;   // bytes of one (A,B) step buffer (3 planes each); two buffers in LDS
+    DN_DYN_SMEM(smem_raw);
+    unsigned char* smem = reinterpret_cast<unsigned char*>(smem_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;           // 2 x 4 waves, 64 x 32 outputs each
+    const int li = lane & 31;
+    const int n0 = blockIdx.y * DN_TO, m0 = blockIdx.z * DN_TO;
+    const bool do_colsum = FLAVOR == DN_TN_COLSUM && blockIdx.y == 0;
+    const bool wave_active = (m0 + wr * 64 < g.M) && (n0 + wc * 32 < g.N);
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const int q = tid & 31, kr0 = tid >> 5;            // this thread stages column group q of rows kr0, kr0 + 16
+    const int acol = m0 + 4 * q, bcol = n0 + 4 * q;
+    const float* ap = g.a[0].p; const float* aq = g.a[0].q ? g.a[0].q : g.a[0].p; int ald = g.a[0].ld;
+    const float* bp = g.b[0].p; int bld = g.b[0].ld;
+    const bool a_ok = acol < g.M, b_ok = bcol < g.N;
+    {
+        int c = acol;
+        for (int i = 0; i < g.na; ++i) {
+            if (a_ok && c >= 0 && c < g.a[i].w) { ap = g.a[i].p + c; aq = (g.a[i].q ? g.a[i].q : g.a[i].p) + c; ald = g.a[i].ld; }
+            c -= g.a[i].w;
+        }
+        c = bcol;
+        for (int i = 0; i < g.nb; ++i) {
+            if (b_ok && c >= 0 && c < g.b[i].w) { bp = g.b[i].p + c; bld = g.b[i].ld; }
+            c -= g.b[i].w;
+        }
+    }
+    float4 csum = dn_f4_zero();
+    TxRegs R;
+
+    const int c_beg = blockIdx.x * g.group;
+    const int c_end = (c_beg + g.group < g.nchunks) ? c_beg + g.group : g.nchunks;
+    for (int ci = c_beg; ci < c_end; ++ci) {
+        const DnTile ch = g.chunks[ci];
+        const int nsteps = (ch.nrows + DN_KB - 1) / DN_KB;
+        tx_load<FLAVOR>(g, ch, 0, kr0, a_ok, b_ok, ap, aq, ald, bp, bld, R);
+        tx_store<FLAVOR>(smem, smem + 3 * DN_TX_PLANE, kr0, q, R, csum);
+        if (nsteps > 1) tx_load<FLAVOR>(g, ch, 1, kr0, a_ok, b_ok, ap, aq, ald, bp, bld, R);
+        __syncthreads();
+        int st = 0;
+        for (; st + 2 < nsteps; ++st) {
+            unsigned char* cur = smem + (st & 1) * SBUF;
+            unsigned char* nxt = smem + ((st & 1) ^ 1) * SBUF;
+            tx_store<FLAVOR>(nxt, nxt + 3 * DN_TX_PLANE, kr0, q, R, csum);
+            tx_load<FLAVOR>(g, ch, st + 2, kr0, a_ok, b_ok, ap, aq, ald, bp, bld, R);
+            tx_compute(cur, cur + 3 * DN_TX_PLANE, wr, wc, lane, acc);
+            __syncthreads();
+        }
+        if (st + 1 < nsteps) {
+            unsigned char* cur = smem + (st & 1) * SBUF;
+            unsigned char* nxt = smem + ((st & 1) ^ 1) * SBUF;
+            tx_store<FLAVOR>(nxt, nxt + 3 * DN_TX_PLANE, kr0, q, R, csum);
+            tx_compute(cur, cur + 3 * DN_TX_PLANE, wr, wc, lane, acc);
+            __syncthreads();
+            ++st;
+        }
+        {
+            unsigned char* cur = smem + (st & 1) * SBUF;
+            tx_compute(cur, cur + 3 * DN_TX_PLANE, wr, wc, lane, acc);
+            __syncthreads();   // the next chunk's prologue overwrites buffer 0
+        }
+    }
+    float* out = g.partial + (long long)blockIdx.x * g.M * g.N;
+    if (wave_active) {
+        const int n = n0 + wc * 32 + li;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wr * 2 + i) * 32 + dn_acc_row(r, lane);
+                if (m < g.M && n < g.N) out[(long long)m * g.N + n] = acc[i][r];
+            }
+    }
+    if (do_colsum) {   // uniform per block: 16 row lanes x 32 column groups -> [16][128] floats in LDS
+        float* red = reinterpret_cast<float*>(smem);
+        *reinterpret_cast<float4*>(&red[kr0 * DN_TO + 4 * q]) = csum;
+        __syncthreads();
+        if (tid < DN_TO && m0 + tid < g.M) {
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sum += red[k * DN_TO + tid];
+            g.colsum[(long long)blockIdx.x * g.M + m0 + tid] = sum;
+        }
+    }
+}
+
+template <int FLAVOR>
+static int tx_launch(const TnArgs& g, dim3 grid, hipStream_t stream) {
+    const size_t smem = (size_t)2 * 6 * DN_TX_PLANE;   // 120 KiB
+#ifndef DN_EMULATE
+    static bool lds_opt_in = false;
+    if (!lds_opt_in) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tngemm_x3_kernel<FLAVOR>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem);
+        lds_opt_in = true;
+    }
+#endif
+    DN_LAUNCH((tngemm_x3_kernel<FLAVOR>), grid, dim3(DN_TX_THREADS, 1, 1), smem, stream, g);
+    return (int)hipGetLastError();
+}
+
+#ifndef DN_TN_X3
+#define DN_TN_X3 1   // -DDN_TN_X3=0: exact-f32 MFMA in the split-V kernels
+#endif
+
 // returns the number of partials written (= gridDim.x) through *npartial
 int dn_launch_tngemm(const TnArgs& g_in, int nchunks, hipStream_t stream) {
     if (nchunks <= 0 || g_in.M <= 0 || g_in.N <= 0) return 0;
@@ -1093,7 +1297,14 @@ int dn_launch_tngemm(const TnArgs& g_in, int nchunks, hipStream_t stream) {
     const double rows = g.acct_rows;
     dn_prof_begin(DN_K_TNGEMM, stream);
     int err;
-    if (g.aligned) {
+    if (g.aligned && DN_TN_X3) {
+        switch (flavor) {
+            case DN_TN_QA: err = tx_launch<DN_TN_QA>(g, grid, stream); break;
+            case DN_TN_COLSUM: err = tx_launch<DN_TN_COLSUM>(g, grid, stream); break;
+            case DN_TN_ROWSCALE: err = tx_launch<DN_TN_ROWSCALE>(g, grid, stream); break;
+            default: err = tx_launch<DN_TN_PLAIN>(g, grid, stream); break;
+        }
+    } else if (g.aligned) {
         switch (flavor) {
             case DN_TN_QA: err = tn_launch<true, DN_TN_QA>(g, grid, stream); break;
             case DN_TN_COLSUM: err = tn_launch<true, DN_TN_COLSUM>(g, grid, stream); break;

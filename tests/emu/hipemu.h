@@ -62,6 +62,7 @@ struct WaveState {
     unsigned gen = 0;
     float a[2][64], b[2][64];
     unsigned short ha[2][64][8], hb[2][64][8];   // bf16 MFMA operands
+    const unsigned char* ptr[2][64];             // ds_read_b64_tr_b16 lane addresses
 };
 struct BlockState {
     std::vector<ucontext_t> ctx;
@@ -207,6 +208,20 @@ static inline dnemu_f32x16 dnemu_mfma_f32_32x32x16_bf16(uint4 a, uint4 b, dnemu_
         d[r] = v;
     }
     return d;
+}
+// ds_read_b64_tr_b16 (semantics probed on gfx950, profiles/r01_exp_tr_read.txt): inside every 16-lane group the lanes'
+// addresses name sixteen 8-byte chunks = a 4x16 matrix of 16-bit elements (row j = chunks of lanes 4j..4j+3); lane l
+// receives column l&15, i.e. element j comes from the address of lane 4j + (l&15)/4 of its group, 16-bit slot (l&15)%4.
+static inline uint2 dnemu_ds_read_tr16_b64(const unsigned char* p) {
+    dnemu::WaveState& w = dnemu::cur_wave();
+    int l = dnemu::cur_lane();
+    unsigned slot = w.gen & 1;
+    w.ptr[slot][l] = p;
+    dnemu::wave_barrier();
+    unsigned short e[4];
+    const int g0 = l & ~15, c = l & 15;
+    for (int j = 0; j < 4; ++j) memcpy(&e[j], w.ptr[slot][g0 + 4 * j + c / 4] + 2 * (c % 4), 2);
+    return uint2{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16)};
 }
 static inline float dnemu_shfl(float v, int src_lane, bool relative_xor, int width) {
     dnemu::WaveState& w = dnemu::cur_wave();
