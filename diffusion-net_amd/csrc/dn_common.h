@@ -57,19 +57,48 @@ __device__ __forceinline__ uint2 dn_lds_tr16(const unsigned char* p) {
 // residuals are exact in fp32).  With the six largest cross products of two split operands accumulated in fp32 the result
 // is as accurate as an fp32 FMA chain (measured rel-L2 1.6e-7 vs 2.0e-7 against fp64, profiles/r01_exp_bf16x3.txt) at
 // 16/6 = 2.7x the f32-MFMA rate.
-__device__ __forceinline__ unsigned dn_bf16_bits(float x, float& back) {
+// The split works on PAIRS: gfx950's v_cvt_pk_bf16_f32 rounds and packs two values in one instruction and the residuals
+// are one v_pk_add_f32 each, 9 VALU instructions per pair (the scalar formulation took ~27 and made the staging phase,
+// not the MFMAs, the critical path of the split-bf16 kernels).
+__device__ __forceinline__ unsigned dn_bf16_bits(float x, float& back) {   // software RNE (emulator and odd call sites)
     unsigned u = __float_as_uint(x);
     u += 0x7fffu + ((u >> 16) & 1u);
     u >>= 16;
     back = __uint_as_float(u << 16);
     return u;
 }
-__device__ __forceinline__ void dn_split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
-    float b0, b1, b2;
-    hi = dn_bf16_bits(x, b0);
-    const float r1 = x - b0;
-    mid = dn_bf16_bits(r1, b1);
-    lo = dn_bf16_bits(r1 - b1, b2);
+// packed dwords: low half = bf16 of x, high half = bf16 of y
+__device__ __forceinline__ void dn_split3_pair(float x, float y, unsigned& hi, unsigned& mid, unsigned& lo) {
+#if defined(DN_EMULATE)
+    float bx, by;
+    unsigned hx = dn_bf16_bits(x, bx), hy = dn_bf16_bits(y, by);
+    hi = hx | (hy << 16);
+    const float rx = x - bx, ry = y - by;
+    hx = dn_bf16_bits(rx, bx); hy = dn_bf16_bits(ry, by);
+    mid = hx | (hy << 16);
+    hx = dn_bf16_bits(rx - bx, bx); hy = dn_bf16_bits(ry - by, by);
+    lo = hx | (hy << 16);
+#else
+    typedef float dn_f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 dn_bf2 __attribute__((ext_vector_type(2)));
+    const dn_f2 v = {x, y};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, dn_bf2));
+#if defined(DN_X3_ABLATE_SPLIT)   // development ablation: no residual arithmetic
+    mid = lo = hi;
+    return;
+#endif
+    const dn_f2 hf = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+    const dn_f2 r = v - hf;
+    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r, dn_bf2));
+    const dn_f2 mf = {__uint_as_float(mid << 16), __uint_as_float(mid & 0xffff0000u)};
+    const dn_f2 t = r - mf;
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(t, dn_bf2));
+#endif
+}
+// a float4 (four consecutive k) -> one 8-byte chunk per plane
+__device__ __forceinline__ void dn_split3_f4(float4 v, uint2& hi, uint2& mid, uint2& lo) {
+    dn_split3_pair(v.x, v.y, hi.x, mid.x, lo.x);
+    dn_split3_pair(v.z, v.w, hi.y, mid.y, lo.y);
 }
 // LDS bf16 plane: R rows x 32 k, 64 bytes per row = four 16-byte slots, slot' = slot ^ ((row>>2)&3): a wave's ds_read_b128 of
 // one slot for 32 consecutive rows hits all sixteen 16-byte positions of the 256-byte bank row once per 16-lane group.
@@ -85,11 +114,15 @@ struct DnTile {
 
 __device__ __forceinline__ float4 dn_f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 dn_f4_mul(float4 a, float4 b) {
+#if defined(DN_EMULATE)
     return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+#else   // two v_pk_mul_f32
+    typedef float dn_f2 __attribute__((ext_vector_type(2)));
+    const dn_f2 lo = dn_f2{a.x, a.y} * dn_f2{b.x, b.y}, hi = dn_f2{a.z, a.w} * dn_f2{b.z, b.w};
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+#endif
 }
-__device__ __forceinline__ float4 dn_f4_scale(float4 a, float s) {
-    return make_float4(a.x * s, a.y * s, a.z * s, a.w * s);
-}
+__device__ __forceinline__ float4 dn_f4_scale(float4 a, float s) { return dn_f4_mul(a, make_float4(s, s, s, s)); }
 __device__ __forceinline__ float dn_f4_get(const float4& v, int t) {
     return t == 0 ? v.x : (t == 1 ? v.y : (t == 2 ? v.z : v.w));
 }

@@ -285,15 +285,15 @@ __device__ __forceinline__ void rg_store_x3(unsigned char* sA, unsigned char* sB
     for (int i = 0; i < A_IT; ++i) {
         const int idx = tid + i * NTHR;
         const int row = idx >> 3, q = idx & 7;
-        float4 v = dn_f4_scale(R.a[i], R.am[i]);
+        // no row mask here: a row past the unit's end (its address was clamped) only feeds its own, never stored, output row
+        float4 v = R.a[i];
         if (HASQ) v = dn_f4_mul(v, R.q[i]);
-        unsigned h[4], m[4], l[4];
-        dn_split3(v.x, h[0], m[0], l[0]); dn_split3(v.y, h[1], m[1], l[1]);
-        dn_split3(v.z, h[2], m[2], l[2]); dn_split3(v.w, h[3], m[3], l[3]);
+        uint2 h, m, l;
+        dn_split3_f4(v, h, m, l);
         const int off = dn_plane_off(row, q >> 1) + (q & 1) * 8;
-        *reinterpret_cast<uint2*>(sA + off) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-        *reinterpret_cast<uint2*>(sA + PL + off) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
-        *reinterpret_cast<uint2*>(sA + 2 * PL + off) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+        *reinterpret_cast<uint2*>(sA + off) = h;
+        *reinterpret_cast<uint2*>(sA + PL + off) = m;
+        *reinterpret_cast<uint2*>(sA + 2 * PL + off) = l;
     }
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
@@ -303,30 +303,30 @@ __device__ __forceinline__ void rg_store_x3(unsigned char* sA, unsigned char* sB
             for (int i = 0; i < B_IT; ++i) {
                 const int idx = tid + i * NTHR;
                 const int nrow = idx >> 3, q = idx & 7;
-                const float4 v = dn_f4_scale(R.b[o][i], R.bm[o][i]);
-                unsigned h[4], m[4], l[4];
-                dn_split3(v.x, h[0], m[0], l[0]); dn_split3(v.y, h[1], m[1], l[1]);
-                dn_split3(v.z, h[2], m[2], l[2]); dn_split3(v.w, h[3], m[3], l[3]);
+                // the factor carries the sign of a two-output product; with one output it is the column mask only, and
+                // a column past N (clamped address) only feeds its own, never stored, output column
+                const float4 v = NOUT == 2 ? dn_f4_scale(R.b[o][i], R.bm[o][i]) : R.b[o][i];
+                uint2 h, m, l;
+                dn_split3_f4(v, h, m, l);
                 const int off = dn_plane_off(nrow, q >> 1) + (q & 1) * 8;
-                *reinterpret_cast<uint2*>(sBo + off) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-                *reinterpret_cast<uint2*>(sBo + PLB + off) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
-                *reinterpret_cast<uint2*>(sBo + 2 * PLB + off) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                *reinterpret_cast<uint2*>(sBo + off) = h;
+                *reinterpret_cast<uint2*>(sBo + PLB + off) = m;
+                *reinterpret_cast<uint2*>(sBo + 2 * PLB + off) = l;
             }
         } else {   // PAIRK: R.b[o][0] = row 2p, R.b[o][1] = row 2p+1 of column group q4 -> transposed planes, packed (k,k+1) dwords
             static_assert(BCOLK || B_IT == 2, "pair mapping needs two rows per thread");
             const int pr = tid & 15, q4 = tid >> 4;
-            const float4 v0 = dn_f4_scale(R.b[o][0], R.bm[o][0]);
-            const float4 v1 = dn_f4_scale(R.b[o][B_IT - 1], R.bm[o][B_IT - 1]);
+            const float4 v0 = NOUT == 2 ? dn_f4_scale(R.b[o][0], R.bm[o][0]) : R.b[o][0];
+            const float4 v1 = NOUT == 2 ? dn_f4_scale(R.b[o][B_IT - 1], R.bm[o][B_IT - 1]) : R.b[o][B_IT - 1];
             const float e0[4] = {v0.x, v0.y, v0.z, v0.w}, e1[4] = {v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                unsigned h0, m0, l0, h1, m1, l1;
-                dn_split3(e0[e], h0, m0, l0);
-                dn_split3(e1[e], h1, m1, l1);
+                unsigned h, m, l;
+                dn_split3_pair(e0[e], e1[e], h, m, l);
                 const int off = dn_plane_off(4 * q4 + e, pr >> 2) + (pr & 3) * 4;
-                *reinterpret_cast<unsigned*>(sBo + off) = h0 | (h1 << 16);
-                *reinterpret_cast<unsigned*>(sBo + PLB + off) = m0 | (m1 << 16);
-                *reinterpret_cast<unsigned*>(sBo + 2 * PLB + off) = l0 | (l1 << 16);
+                *reinterpret_cast<unsigned*>(sBo + off) = h;
+                *reinterpret_cast<unsigned*>(sBo + PLB + off) = m;
+                *reinterpret_cast<unsigned*>(sBo + 2 * PLB + off) = l;
             }
         }
     }
@@ -339,6 +339,16 @@ __device__ __forceinline__ void rg_compute_x3(const unsigned char* sA, const uns
 #pragma unroll
     for (int s = 0; s < 2; ++s) {   // two k16 steps per 32-wide slice; lane group lg owns k = 16 s + 8 lg .. +7
         uint4 a[3][MT], b[NOUT][3][NT];
+#if defined(DN_X3_ABLATE_LDSR)   // development ablation: one LDS read feeds every fragment
+        {
+            const uint4 one = *reinterpret_cast<const uint4*>(sA + dn_plane_off(arow0 + li, 2 * s + lg));
+            for (int p = 0; p < 3; ++p) {
+                for (int mt = 0; mt < MT; ++mt) a[p][mt] = one;
+                for (int o = 0; o < NOUT; ++o)
+                    for (int nt = 0; nt < NT; ++nt) b[o][p][nt] = one;
+            }
+        }
+#else
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
@@ -350,6 +360,7 @@ __device__ __forceinline__ void rg_compute_x3(const unsigned char* sA, const uns
                 for (int nt = 0; nt < NT; ++nt)
                     b[o][p][nt] = *reinterpret_cast<const uint4*>(sB + (o * 3 + p) * PLB + dn_plane_off(bcol0 + nt * 32 + li, 2 * s + lg));
         }
+#endif
 #pragma unroll
         for (int o = 0; o < NOUT; ++o)
 #pragma unroll
@@ -357,6 +368,11 @@ __device__ __forceinline__ void rg_compute_x3(const unsigned char* sA, const uns
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     f32x16 c = acc[o][mt][nt];
+#if defined(DN_X3_ABLATE_MFMA)   // development ablation: operands stay live, no matrix work
+                    c[0] += __uint_as_float((a[0][mt].x ^ a[1][mt].y ^ a[2][mt].z) & (b[o][0][nt].x ^ b[o][1][nt].y ^ b[o][2][nt].z) & 0x3f800000u);
+                    acc[o][mt][nt] = c;
+                    continue;
+#endif
                     c = dn_mfma_bf16(a[1][mt], b[o][1][nt], c);   // mid*mid   (smallest terms first)
                     c = dn_mfma_bf16(a[0][mt], b[o][2][nt], c);   // hi*lo
                     c = dn_mfma_bf16(a[2][mt], b[o][0][nt], c);   // lo*hi
@@ -541,6 +557,9 @@ static int rg_dispatch_width(const RgArgs& g, int ntiles, hipStream_t stream) {
 #ifndef DN_PT_MAX_SLICES
 #define DN_PT_MAX_SLICES 12  // up to K = 384 (the 3C -> C MLP layer); measured 177 -> 155 us with the bf16x3 path
 #endif
+#ifndef DN_PT_DEPTH
+#define DN_PT_DEPTH 1   // measured on MI355X: depth 1, 2, 3 within noise (the staging VALU work, not load latency, was the limiter)
+#endif
 #if defined(DN_PT_ABLATE_LOADS)
 #define DN_PT_SKIP_LOADS 1
 #else
@@ -665,8 +684,17 @@ __global__ __launch_bounds__(DN_PT_THREADS) void rowgemm_persist_kernel(RgArgs g
         return t;
     };
 
-    RgRegs<NOUT, A_IT, B_IT> R;
-    // load cursor (runs two slices ahead of the compute cursor, across unit boundaries)
+    // DN_PT_DEPTH register sets form the prefetch ring: slice s travels in set s % DEPTH and is loaded DEPTH iterations
+    // before it is written to LDS, so DEPTH x 16 KiB of reads per CU are in flight (one slice ahead covers only ~1 us of HBM
+    // latency once the split-bf16 MFMAs made an iteration that short).
+#if DN_PT_DEPTH == 3
+    RgRegs<NOUT, A_IT, B_IT> R0, R1, R2;
+#elif DN_PT_DEPTH == 2
+    RgRegs<NOUT, A_IT, B_IT> R0, R1;
+#else
+    RgRegs<NOUT, A_IT, B_IT> R0;
+#endif
+    // load cursor (runs ahead of the compute cursor, across unit boundaries)
     int lu = blockIdx.x, lseg = 0, lkoff = 0;
     DnTile ltile = unit_tile(lu);
     // compute cursor
@@ -675,65 +703,83 @@ __global__ __launch_bounds__(DN_PT_THREADS) void rowgemm_persist_kernel(RgArgs g
     // parked unit being streamed out
     int p_row0 = ctile.row0, p_nrows = 0, p_next = DN_PT_NP;   // p_next >= NP: nothing pending
 
-    rg_load<TN, NTHR, NOUT, true, BCOLK, HASQ, A_IT, B_IT, PAIRK>(g, ltile, n0, lseg, lkoff, tid, R);
-    if constexpr (X3) rg_store_x3<NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>(reinterpret_cast<unsigned char*>(smem), reinterpret_cast<unsigned char*>(smem + SA), tid, R);
-    else rg_store<TN, NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>(smem, smem + SA, tid, R);
-    if (T > 1) {
-        lkoff += DN_KB;
-        if (lkoff >= g.a[lseg].w) { lkoff = 0; ++lseg; if (lseg >= g.nseg) { lseg = 0; lu += G; if (lu < nunits) ltile = unit_tile(lu); } }
-        rg_load<TN, NTHR, NOUT, true, BCOLK, HASQ, A_IT, B_IT, PAIRK>(g, ltile, n0, lseg, lkoff, tid, R);
-    }
+#define PT_ADVANCE()                                                                                                    \
+    do {                                                                                                                \
+        lkoff += DN_KB;                                                                                                 \
+        if (lkoff >= g.a[lseg].w) { lkoff = 0; ++lseg; if (lseg >= g.nseg) { lseg = 0; lu += G; if (lu < nunits) ltile = unit_tile(lu); } } \
+    } while (0)
+#define PT_LOAD(RS) rg_load<TN, NTHR, NOUT, true, BCOLK, HASQ, A_IT, B_IT, PAIRK>(g, ltile, n0, lseg, lkoff, tid, RS)
+#define PT_STORE(buf, RS)                                                                                               \
+    do {                                                                                                                \
+        if constexpr (X3) rg_store_x3<NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>(reinterpret_cast<unsigned char*>(buf),        \
+                                                                          reinterpret_cast<unsigned char*>((buf) + SA), tid, RS); \
+        else rg_store<TN, NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>((buf), (buf) + SA, tid, RS);                             \
+    } while (0)
+// one pipeline iteration on slice j; RS is the ring set of slice j+1 (stored now) and of slice j+4 (loaded now)
+#define PT_ITER(j, RS)                                                                                                  \
+    do {                                                                                                                \
+        float* cur = smem + ((j) & 1) * SBUF;                                                                           \
+        float* nxt = smem + (((j) & 1) ^ 1) * SBUF;                                                                     \
+        if ((j) + 1 < T) PT_STORE(nxt, RS);                                                                             \
+        if ((j) + 1 + DN_PT_DEPTH < T) { PT_ADVANCE(); PT_LOAD(RS); }                                                   \
+        PtPiece P[PPI];                                                                                                 \
+        const bool pending = p_next < DN_PT_NP;                                                                         \
+        if (pending) {                                                                                                  \
+            _Pragma("unroll") for (int k = 0; k < PPI; ++k)                                                             \
+                pt_piece_load<MODE, FLAG>(g, sE, p_next + k, tid, p_row0, p_nrows, n0, P[k]);                           \
+        }                                                                                                               \
+        if constexpr (X3) rg_compute_x3<MT, NT, NOUT>(reinterpret_cast<const unsigned char*>(cur),                      \
+                                                      reinterpret_cast<const unsigned char*>(cur + SA), wr * MT * 32,   \
+                                                      wc * NT * 32, li, ls, acc);                                       \
+        else rg_compute<TN, MT, NT, NOUT, BCOLK>(cur, cur + SA, wr * MT * 32, wc * NT * 32, li, ls, acc);               \
+        if (pending) {                                                                                                  \
+            _Pragma("unroll") for (int k = 0; k < PPI; ++k) pt_piece_store<MODE, FLAG>(g, P[k]);                        \
+            p_next += PPI;                                                                                              \
+        }                                                                                                               \
+        if (++cs == nsl) { /* unit complete: park the accumulators (fragment layout -> row-major, conflict-free) */     \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                           \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
+                    sE[((wr * MT + mt) * 32 + dn_acc_row(r, lane)) * 128 + wc * 32 + li] = acc[0][mt][0][r];            \
+                    acc[0][mt][0][r] = 0.f;                                                                             \
+                }                                                                                                       \
+            p_row0 = ctile.row0; p_nrows = ctile.nrows; p_next = 0;                                                     \
+            cs = 0;                                                                                                     \
+            cu += G;                                                                                                    \
+            if (cu < nunits) ctile = unit_tile(cu);                                                                     \
+        }                                                                                                               \
+        __syncthreads(); /* slice buffer hand-off + visibility of the parked unit */                                    \
+    } while (0)
+
+    // prologue: slice 0 -> LDS, slices 1..DEPTH -> ring sets (slice % DEPTH)
+    PT_LOAD(R0);
+    PT_STORE(smem, R0);
+#if DN_PT_DEPTH == 3
+    if (T > 1) { PT_ADVANCE(); PT_LOAD(R1); }
+    if (T > 2) { PT_ADVANCE(); PT_LOAD(R2); }
+    if (T > 3) { PT_ADVANCE(); PT_LOAD(R0); }
     __syncthreads();
-
-    for (int j = 0; j < T; ++j) {
-        float* cur = smem + (j & 1) * SBUF;
-        float* nxt = smem + ((j & 1) ^ 1) * SBUF;
-#if !defined(DN_PT_ABLATE_LOADS)
-        if (j + 1 < T) {
-            if constexpr (X3) rg_store_x3<NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>(reinterpret_cast<unsigned char*>(nxt), reinterpret_cast<unsigned char*>(nxt + SA), tid, R);
-            else rg_store<TN, NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>(nxt, nxt + SA, tid, R);
-        }
-#endif
-        if (j + 2 < T && !DN_PT_SKIP_LOADS) {
-            lkoff += DN_KB;
-            if (lkoff >= g.a[lseg].w) { lkoff = 0; ++lseg; if (lseg >= g.nseg) { lseg = 0; lu += G; if (lu < nunits) ltile = unit_tile(lu); } }
-            rg_load<TN, NTHR, NOUT, true, BCOLK, HASQ, A_IT, B_IT, PAIRK>(g, ltile, n0, lseg, lkoff, tid, R);
-        }
-        // deferred output of the previously finished unit: loads now, maths + stores after the MFMAs
-        PtPiece P[PPI];
-        bool pending = p_next < DN_PT_NP;
-#if defined(DN_PT_ABLATE_OUT)
-        pending = false;
-#endif
-        if (pending) {   // uniform; the block itself is branch-free
-#pragma unroll
-            for (int k = 0; k < PPI; ++k) pt_piece_load<MODE, FLAG>(g, sE, p_next + k, tid, p_row0, p_nrows, n0, P[k]);
-        }
-
-        if constexpr (X3) rg_compute_x3<MT, NT, NOUT>(reinterpret_cast<const unsigned char*>(cur), reinterpret_cast<const unsigned char*>(cur + SA), wr * MT * 32, wc * NT * 32, li, ls, acc);
-        else rg_compute<TN, MT, NT, NOUT, BCOLK>(cur, cur + SA, wr * MT * 32, wc * NT * 32, li, ls, acc);
-
-        if (pending) {
-#pragma unroll
-            for (int k = 0; k < PPI; ++k) pt_piece_store<MODE, FLAG>(g, P[k]);
-            p_next += PPI;
-        }
-
-        if (++cs == nsl) {   // unit complete: park the accumulators (fragment layout -> row-major, conflict-free)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    sE[((wr * MT + mt) * 32 + dn_acc_row(r, lane)) * 128 + wc * 32 + li] = acc[0][mt][0][r];
-                    acc[0][mt][0][r] = 0.f;
-                }
-            p_row0 = ctile.row0; p_nrows = ctile.nrows; p_next = 0;
-            cs = 0;
-            cu += G;
-            if (cu < nunits) ctile = unit_tile(cu);
-        }
-        __syncthreads();   // slice buffer hand-off + visibility of the parked unit
+    for (int j = 0; j < T; j += 3) {
+        PT_ITER(j, R1);
+        if (j + 1 < T) PT_ITER(j + 1, R2);
+        if (j + 2 < T) PT_ITER(j + 2, R0);
     }
+#elif DN_PT_DEPTH == 2
+    if (T > 1) { PT_ADVANCE(); PT_LOAD(R1); }
+    if (T > 2) { PT_ADVANCE(); PT_LOAD(R0); }
+    __syncthreads();
+    for (int j = 0; j < T; j += 2) {
+        PT_ITER(j, R1);
+        if (j + 1 < T) PT_ITER(j + 1, R0);
+    }
+#else
+    if (T > 1) { PT_ADVANCE(); PT_LOAD(R0); }
+    __syncthreads();
+    for (int j = 0; j < T; ++j) PT_ITER(j, R0);
+#endif
+#undef PT_ITER
+#undef PT_STORE
+#undef PT_LOAD
+#undef PT_ADVANCE
     // flush what is still parked (the last unit)
 #if defined(DN_PT_ABLATE_OUT)
     p_next = DN_PT_NP - 1;
@@ -1109,12 +1155,11 @@ __device__ __forceinline__ void tx_load(const TnArgs& g, const DnTile& ch, int s
 }
 
 __device__ __forceinline__ void tx_put(unsigned char* planes, int off, float4 v) {
-    unsigned h[4], m[4], l[4];
-    dn_split3(v.x, h[0], m[0], l[0]); dn_split3(v.y, h[1], m[1], l[1]);
-    dn_split3(v.z, h[2], m[2], l[2]); dn_split3(v.w, h[3], m[3], l[3]);
-    *reinterpret_cast<uint2*>(planes + off) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-    *reinterpret_cast<uint2*>(planes + DN_TX_PLANE + off) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
-    *reinterpret_cast<uint2*>(planes + 2 * DN_TX_PLANE + off) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+    uint2 h, m, l;
+    dn_split3_f4(v, h, m, l);
+    *reinterpret_cast<uint2*>(planes + off) = h;
+    *reinterpret_cast<uint2*>(planes + DN_TX_PLANE + off) = m;
+    *reinterpret_cast<uint2*>(planes + 2 * DN_TX_PLANE + off) = l;
 }
 
 template <int FLAVOR>
