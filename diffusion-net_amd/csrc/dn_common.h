@@ -13,12 +13,15 @@
     dnemu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
 #define DN_DYN_SMEM(name) char* name = dnemu::dyn_smem()
 #define DN_RESTRICT
+#define DN_WAVES_PER_EU(n)
 #else
 #include <hip/hip_runtime.h>
 #define DN_LAUNCH(kernel, grid, block, smem, stream, ...) \
     hipLaunchKernelGGL(kernel, (grid), (block), (smem), (stream), __VA_ARGS__)
 #define DN_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define DN_RESTRICT __restrict__
+// occupancy the kernel is designed for: stops the scheduler from trading instruction order for registers it cannot use
+#define DN_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -112,8 +112,8 @@ struct RgRegs {
     float bm[NOUT][B_IT];    // column guard * sign
 };
 
-// PAIRK (bf16x3 path, row-contraction B, 512 threads, TN = 128): a thread fetches rows 2p and 2p+1 (p = tid & 15) of its
-// 4-column group q4 = tid >> 4, so that it can write packed (k, k+1) bf16 pairs of the transposed B planes.
+// PAIRK (bf16x3 path, row-contraction B, TN = 128): a thread fetches rows 2p and 2p+1 (p = tid & 15) of a 4-column group
+// q4 = (tid >> 4) + (NTHR / 16) * h, h < B_IT / 2, so that it can write packed (k, k+1) bf16 pairs of the transposed B planes.
 template <int TN, int NTHR, int NOUT, bool ALIGNED, bool BCOLK, bool HASQ, int A_IT, int B_IT, bool PAIRK = false>
 __device__ __forceinline__ void rg_load(const RgArgs& g, const DnTile& tile, int n0, int seg, int koff, int tid,
                                         RgRegs<NOUT, A_IT, B_IT>& R) {   // tile.row0/nrows may describe a sub-tile
@@ -133,6 +133,9 @@ __device__ __forceinline__ void rg_load(const RgArgs& g, const DnTile& tile, int
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) R.q[i] = *reinterpret_cast<const float4*>(sg.q + off[i]);
         }
+#if defined(DN_X3_ABLATE_BSTAGE)
+        if (NTHR == 512) return;
+#endif
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) {
             const float* bp = g.b[o][seg] + (long long)tile.mesh * g.b_mesh_stride;
@@ -147,8 +150,8 @@ __device__ __forceinline__ void rg_load(const RgArgs& g, const DnTile& tile, int
                     nok = n0 + nrow < g.N;
                     boff = (long long)(nok ? n0 + nrow : 0) * g.ldb + koff + 4 * q;
                 } else {
-                    const int krow = PAIRK ? 2 * (tid & 15) + i : idx / (TN / 4);
-                    const int q4 = PAIRK ? (tid >> 4) : idx % (TN / 4);
+                    const int krow = PAIRK ? 2 * (tid & 15) + (i & 1) : idx / (TN / 4);
+                    const int q4 = PAIRK ? (tid >> 4) + (NTHR / 16) * (i >> 1) : idx % (TN / 4);
                     nok = n0 + 4 * q4 < g.N;
                     boff = (long long)(koff + krow) * g.ldb + (nok ? n0 + 4 * q4 : 0);
                 }
@@ -277,24 +280,67 @@ __device__ __forceinline__ void rg_compute(const float* sA, const float* sB, int
 
 // ---- split-bf16 ("x3") staging and MFMA for the persistent and the two-output kernels: both operands live in LDS as three bf16 planes
 //      (hi, mid, lo) of [rows][32 k]; six cross products per k16 step replace sixteen f32 MFMA k2 steps.
-template <int NTHR, int NOUT, bool BCOLK, bool HASQ, int A_IT, int B_IT>
-__device__ __forceinline__ void rg_store_x3(unsigned char* sA, unsigned char* sB, int tid, const RgRegs<NOUT, A_IT, B_IT>& R) {
+// The staging is written as two halves so that a kernel can put the MFMAs of the current slice between them: rg_split_x3
+// is pure VALU on the prefetched registers, rg_put_x3 only writes LDS (the compiler must keep LDS writes behind earlier LDS
+// reads of the other buffer -- it cannot prove they do not alias -- so the reads are issued first, see rg_frag_x3).
+template <int NOUT, int A_IT, int B_IT>
+struct X3Planes {
+    uint2 a[A_IT][3];
+    uint2 b[NOUT][B_IT][3];   // BCOLK: one 8-byte chunk per float4; PAIRK: dword e of column group h is (i = 2h + (e >> 1), .x/.y = e & 1)
+};
+
+template <int NOUT, bool BCOLK, bool HASQ, int A_IT, int B_IT>
+__device__ __forceinline__ void rg_split_x3(const RgRegs<NOUT, A_IT, B_IT>& R, X3Planes<NOUT, A_IT, B_IT>& P) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        // no row mask here: a row past the unit's end (its address was clamped) only feeds its own, never stored, output row
+        float4 v = R.a[i];
+        if (HASQ) v = dn_f4_mul(v, R.q[i]);
+        dn_split3_f4(v, P.a[i][0], P.a[i][1], P.a[i][2]);
+    }
+#if defined(DN_X3_ABLATE_BSTAGE)   // development ablation: B operand neither loaded, split nor written
+    return;
+#endif
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        if (BCOLK) {
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                // the factor carries the sign of a two-output product; with one output it is the column mask only, and
+                // a column past N (clamped address) only feeds its own, never stored, output column
+                const float4 v = NOUT == 2 ? dn_f4_scale(R.b[o][i], R.bm[o][i]) : R.b[o][i];
+                dn_split3_f4(v, P.b[o][i][0], P.b[o][i][1], P.b[o][i][2]);
+            }
+        } else {   // PAIRK: R.b[o][2h] = row 2p, R.b[o][2h+1] = row 2p+1 of column group q4(h) -> packed (k, k+1) dwords per column
+            static_assert(BCOLK || B_IT % 2 == 0, "pair mapping needs two rows per thread and column group");
+#pragma unroll
+            for (int h = 0; h < B_IT / 2; ++h) {
+                const float4 v0 = NOUT == 2 ? dn_f4_scale(R.b[o][2 * h], R.bm[o][2 * h]) : R.b[o][2 * h];
+                const float4 v1 = NOUT == 2 ? dn_f4_scale(R.b[o][2 * h + 1], R.bm[o][2 * h + 1]) : R.b[o][2 * h + 1];
+                dn_split3_pair(v0.x, v1.x, P.b[o][2 * h][0].x, P.b[o][2 * h][1].x, P.b[o][2 * h][2].x);
+                dn_split3_pair(v0.y, v1.y, P.b[o][2 * h][0].y, P.b[o][2 * h][1].y, P.b[o][2 * h][2].y);
+                dn_split3_pair(v0.z, v1.z, P.b[o][2 * h + 1][0].x, P.b[o][2 * h + 1][1].x, P.b[o][2 * h + 1][2].x);
+                dn_split3_pair(v0.w, v1.w, P.b[o][2 * h + 1][0].y, P.b[o][2 * h + 1][1].y, P.b[o][2 * h + 1][2].y);
+            }
+        }
+    }
+}
+
+template <int NTHR, int NOUT, bool BCOLK, int A_IT, int B_IT>
+__device__ __forceinline__ void rg_put_x3(unsigned char* sA, unsigned char* sB, int tid, const X3Planes<NOUT, A_IT, B_IT>& P) {
     constexpr int PL = DN_TM * 64;    // bytes per A plane (128 rows x 32 bf16)
     constexpr int PLB = 128 * 64;     // bytes per B plane (128 output columns); output o uses planes [3o, 3o+3)
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int idx = tid + i * NTHR;
         const int row = idx >> 3, q = idx & 7;
-        // no row mask here: a row past the unit's end (its address was clamped) only feeds its own, never stored, output row
-        float4 v = R.a[i];
-        if (HASQ) v = dn_f4_mul(v, R.q[i]);
-        uint2 h, m, l;
-        dn_split3_f4(v, h, m, l);
         const int off = dn_plane_off(row, q >> 1) + (q & 1) * 8;
-        *reinterpret_cast<uint2*>(sA + off) = h;
-        *reinterpret_cast<uint2*>(sA + PL + off) = m;
-        *reinterpret_cast<uint2*>(sA + 2 * PL + off) = l;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(sA + p * PL + off) = P.a[i][p];
     }
+#if defined(DN_X3_ABLATE_BSTAGE)
+    return;
+#endif
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
         unsigned char* sBo = sB + o * 3 * PLB;
@@ -303,84 +349,101 @@ __device__ __forceinline__ void rg_store_x3(unsigned char* sA, unsigned char* sB
             for (int i = 0; i < B_IT; ++i) {
                 const int idx = tid + i * NTHR;
                 const int nrow = idx >> 3, q = idx & 7;
-                // the factor carries the sign of a two-output product; with one output it is the column mask only, and
-                // a column past N (clamped address) only feeds its own, never stored, output column
-                const float4 v = NOUT == 2 ? dn_f4_scale(R.b[o][i], R.bm[o][i]) : R.b[o][i];
-                uint2 h, m, l;
-                dn_split3_f4(v, h, m, l);
                 const int off = dn_plane_off(nrow, q >> 1) + (q & 1) * 8;
-                *reinterpret_cast<uint2*>(sBo + off) = h;
-                *reinterpret_cast<uint2*>(sBo + PLB + off) = m;
-                *reinterpret_cast<uint2*>(sBo + 2 * PLB + off) = l;
-            }
-        } else {   // PAIRK: R.b[o][0] = row 2p, R.b[o][1] = row 2p+1 of column group q4 -> transposed planes, packed (k,k+1) dwords
-            static_assert(BCOLK || B_IT == 2, "pair mapping needs two rows per thread");
-            const int pr = tid & 15, q4 = tid >> 4;
-            const float4 v0 = NOUT == 2 ? dn_f4_scale(R.b[o][0], R.bm[o][0]) : R.b[o][0];
-            const float4 v1 = NOUT == 2 ? dn_f4_scale(R.b[o][B_IT - 1], R.bm[o][B_IT - 1]) : R.b[o][B_IT - 1];
-            const float e0[4] = {v0.x, v0.y, v0.z, v0.w}, e1[4] = {v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                unsigned h, m, l;
-                dn_split3_pair(e0[e], e1[e], h, m, l);
-                const int off = dn_plane_off(4 * q4 + e, pr >> 2) + (pr & 3) * 4;
-                *reinterpret_cast<unsigned*>(sBo + off) = h;
-                *reinterpret_cast<unsigned*>(sBo + PLB + off) = m;
-                *reinterpret_cast<unsigned*>(sBo + 2 * PLB + off) = l;
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(sBo + p * PLB + off) = P.b[o][i][p];
+            }
+        } else {
+            const int pr = tid & 15;
+#pragma unroll
+            for (int h = 0; h < B_IT / 2; ++h) {
+                const int q4 = (tid >> 4) + (NTHR / 16) * h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int off = dn_plane_off(4 * q4 + e, pr >> 2) + (pr & 3) * 4;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const uint2 w = P.b[o][2 * h + (e >> 1)][p];
+                        *reinterpret_cast<unsigned*>(sBo + p * PLB + off) = (e & 1) ? w.y : w.x;
+                    }
+                }
             }
         }
     }
 }
 
+template <int NTHR, int NOUT, bool BCOLK, bool HASQ, int A_IT, int B_IT>
+__device__ __forceinline__ void rg_store_x3(unsigned char* sA, unsigned char* sB, int tid, const RgRegs<NOUT, A_IT, B_IT>& R) {
+    X3Planes<NOUT, A_IT, B_IT> P;
+    rg_split_x3<NOUT, BCOLK, HASQ, A_IT, B_IT>(R, P);
+    rg_put_x3<NTHR, NOUT, BCOLK, A_IT, B_IT>(sA, sB, tid, P);
+}
+
+// MFMA operands of one 32-wide slice (two k16 steps; lane group lg owns k = 16 s + 8 lg .. +7), read in one burst
 template <int MT, int NT, int NOUT>
-__device__ __forceinline__ void rg_compute_x3(const unsigned char* sA, const unsigned char* sB, int arow0, int bcol0, int li,
-                                              int lg, f32x16 (&acc)[NOUT][MT][NT]) {
+struct X3Frags {
+    uint4 a[2][3][MT];
+    uint4 b[2][NOUT][3][NT];
+};
+
+template <int MT, int NT, int NOUT>
+__device__ __forceinline__ void rg_frag_x3(const unsigned char* sA, const unsigned char* sB, int arow0, int bcol0, int li, int lg,
+                                           int s, X3Frags<MT, NT, NOUT>& F) {
     constexpr int PL = DN_TM * 64, PLB = 128 * 64;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {   // two k16 steps per 32-wide slice; lane group lg owns k = 16 s + 8 lg .. +7
-        uint4 a[3][MT], b[NOUT][3][NT];
 #if defined(DN_X3_ABLATE_LDSR)   // development ablation: one LDS read feeds every fragment
-        {
-            const uint4 one = *reinterpret_cast<const uint4*>(sA + dn_plane_off(arow0 + li, 2 * s + lg));
-            for (int p = 0; p < 3; ++p) {
-                for (int mt = 0; mt < MT; ++mt) a[p][mt] = one;
-                for (int o = 0; o < NOUT; ++o)
-                    for (int nt = 0; nt < NT; ++nt) b[o][p][nt] = one;
-            }
-        }
+    const uint4 one = *reinterpret_cast<const uint4*>(sA + dn_plane_off(arow0 + li, 2 * s + lg));
+    for (int p = 0; p < 3; ++p) {
+        for (int mt = 0; mt < MT; ++mt) F.a[s][p][mt] = one;
+        for (int o = 0; o < NOUT; ++o)
+            for (int nt = 0; nt < NT; ++nt) F.b[s][o][p][nt] = one;
+    }
 #else
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < 3; ++p) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                a[p][mt] = *reinterpret_cast<const uint4*>(sA + p * PL + dn_plane_off(arow0 + mt * 32 + li, 2 * s + lg));
-#pragma unroll
-            for (int o = 0; o < NOUT; ++o)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    b[o][p][nt] = *reinterpret_cast<const uint4*>(sB + (o * 3 + p) * PLB + dn_plane_off(bcol0 + nt * 32 + li, 2 * s + lg));
-        }
-#endif
+        for (int mt = 0; mt < MT; ++mt)
+            F.a[s][p][mt] = *reinterpret_cast<const uint4*>(sA + p * PL + dn_plane_off(arow0 + mt * 32 + li, 2 * s + lg));
 #pragma unroll
         for (int o = 0; o < NOUT; ++o)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    f32x16 c = acc[o][mt][nt];
-#if defined(DN_X3_ABLATE_MFMA)   // development ablation: operands stay live, no matrix work
-                    c[0] += __uint_as_float((a[0][mt].x ^ a[1][mt].y ^ a[2][mt].z) & (b[o][0][nt].x ^ b[o][1][nt].y ^ b[o][2][nt].z) & 0x3f800000u);
-                    acc[o][mt][nt] = c;
-                    continue;
+            for (int nt = 0; nt < NT; ++nt)
+                F.b[s][o][p][nt] = *reinterpret_cast<const uint4*>(sB + (o * 3 + p) * PLB + dn_plane_off(bcol0 + nt * 32 + li, 2 * s + lg));
+    }
 #endif
-                    c = dn_mfma_bf16(a[1][mt], b[o][1][nt], c);   // mid*mid   (smallest terms first)
-                    c = dn_mfma_bf16(a[0][mt], b[o][2][nt], c);   // hi*lo
-                    c = dn_mfma_bf16(a[2][mt], b[o][0][nt], c);   // lo*hi
-                    c = dn_mfma_bf16(a[0][mt], b[o][1][nt], c);   // hi*mid
-                    c = dn_mfma_bf16(a[1][mt], b[o][0][nt], c);   // mid*hi
-                    c = dn_mfma_bf16(a[0][mt], b[o][0][nt], c);   // hi*hi
-                    acc[o][mt][nt] = c;
-                }
+}
+
+template <int MT, int NT, int NOUT>
+__device__ __forceinline__ void rg_mma_x3(const X3Frags<MT, NT, NOUT>& F, int s, f32x16 (&acc)[NOUT][MT][NT]) {
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x16 c = acc[o][mt][nt];
+#if defined(DN_X3_ABLATE_MFMA)   // development ablation: operands stay live, no matrix work
+                c[0] += __uint_as_float((F.a[s][0][mt].x ^ F.a[s][1][mt].y ^ F.a[s][2][mt].z) &
+                                        (F.b[s][o][0][nt].x ^ F.b[s][o][1][nt].y ^ F.b[s][o][2][nt].z) & 0x3f800000u);
+#else
+                c = dn_mfma_bf16(F.a[s][1][mt], F.b[s][o][1][nt], c);   // mid*mid   (smallest terms first)
+                c = dn_mfma_bf16(F.a[s][0][mt], F.b[s][o][2][nt], c);   // hi*lo
+                c = dn_mfma_bf16(F.a[s][2][mt], F.b[s][o][0][nt], c);   // lo*hi
+                c = dn_mfma_bf16(F.a[s][0][mt], F.b[s][o][1][nt], c);   // hi*mid
+                c = dn_mfma_bf16(F.a[s][1][mt], F.b[s][o][0][nt], c);   // mid*hi
+                c = dn_mfma_bf16(F.a[s][0][mt], F.b[s][o][0][nt], c);   // hi*hi
+#endif
+                acc[o][mt][nt] = c;
+            }
+}
+
+template <int MT, int NT, int NOUT>
+__device__ __forceinline__ void rg_compute_x3(const unsigned char* sA, const unsigned char* sB, int arow0, int bcol0, int li,
+                                              int lg, f32x16 (&acc)[NOUT][MT][NT]) {
+    X3Frags<MT, NT, NOUT> F;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        rg_frag_x3<MT, NT, NOUT>(sA, sB, arow0, bcol0, li, lg, s, F);
+        rg_mma_x3<MT, NT, NOUT>(F, s, acc);
     }
 }
 
@@ -558,7 +621,12 @@ static int rg_dispatch_width(const RgArgs& g, int ntiles, hipStream_t stream) {
 #define DN_PT_MAX_SLICES 12  // up to K = 384 (the 3C -> C MLP layer); measured 177 -> 155 us with the bf16x3 path
 #endif
 #ifndef DN_PT_DEPTH
-#define DN_PT_DEPTH 1   // measured on MI355X: depth 1, 2, 3 within noise (the staging VALU work, not load latency, was the limiter)
+#define DN_PT_DEPTH 1   // register sets in the prefetch ring (slice s+DEPTH is loaded once slice s has been split)
+#endif
+#if defined(DN_PT_ABLATE_OUT)   // development ablation: parked units are never streamed out
+#define DN_PT_OUT_START DN_PT_NP
+#else
+#define DN_PT_OUT_START 0
 #endif
 #if defined(DN_PT_ABLATE_LOADS)
 #define DN_PT_SKIP_LOADS 1
@@ -633,8 +701,25 @@ __device__ __forceinline__ void pt_piece_store(const RgArgs& g, const PtPiece& P
     if (P.ok) *reinterpret_cast<float4*>(g.o0 + P.off) = make_float4(y[0], y[1], y[2], y[3]);
 }
 
+#if defined(DN_PT_TRACE)   // development build only: per-phase timestamps of workgroup 0 (waves 0 and 7), tools/trace_pt.py
+__device__ unsigned long long dn_pt_trace_buf[2 * 4096];
+#define PT_T()                                                                                                          \
+    do {                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                     \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && (tid == 0 || tid == 448) && trn < 4096)                              \
+            dn_pt_trace_buf[(tid ? 4096 : 0) + trn] = t_;                                                              \
+        ++trn;                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    } while (0)
+extern "C" int dn_debug_trace_read(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dn_pt_trace_buf), sizeof(unsigned long long) * n);
+}
+#else
+#define PT_T() do {} while (0)
+#endif
 template <int MODE, bool BCOLK, bool FLAG, bool X3>
-__global__ __launch_bounds__(DN_PT_THREADS) void rowgemm_persist_kernel(RgArgs g, int ntiles) {
+__global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_persist_kernel(RgArgs g, int ntiles) {
     constexpr int TN = 128, WR = DN_PT_ROWS / 64, WC = 4, NOUT = 1, NTHR = DN_PT_THREADS, TMU = DN_PT_ROWS;
     constexpr int UPT = DN_TM / TMU;                 // work units per 128-row tile (1 or 2)
     constexpr int MT = TMU / (32 * WR);              // 2
@@ -702,39 +787,95 @@ __global__ __launch_bounds__(DN_PT_THREADS) void rowgemm_persist_kernel(RgArgs g
     DnTile ctile = ltile;
     // parked unit being streamed out
     int p_row0 = ctile.row0, p_nrows = 0, p_next = DN_PT_NP;   // p_next >= NP: nothing pending
+#if DN_PT_SKIP_LOADS
+    bool pt_first_load = true;
+#endif
+#if defined(DN_PT_TRACE)
+    int trn = 0;
+#endif
 
 #define PT_ADVANCE()                                                                                                    \
     do {                                                                                                                \
         lkoff += DN_KB;                                                                                                 \
         if (lkoff >= g.a[lseg].w) { lkoff = 0; ++lseg; if (lseg >= g.nseg) { lseg = 0; lu += G; if (lu < nunits) ltile = unit_tile(lu); } } \
     } while (0)
+// the same step without control flow (the split-bf16 iteration must stay ONE basic block: at a join the compiler
+// falls back to s_waitcnt vmcnt(0), which would wait for the prefetch it has just issued); past the last slice the
+// cursor stays put and the final slice is simply fetched again
+#define PT_ADVANCE_SEL(commit)                                                                                          \
+    do {                                                                                                                \
+        int nk_ = lkoff + DN_KB, ns_ = lseg, nu_ = lu;                                                                  \
+        const bool se_ = nk_ >= g.a[lseg].w;                                                                            \
+        nk_ = se_ ? 0 : nk_;                                                                                            \
+        ns_ = se_ ? ns_ + 1 : ns_;                                                                                      \
+        const bool ue_ = ns_ >= g.nseg;                                                                                 \
+        ns_ = ue_ ? 0 : ns_;                                                                                            \
+        nu_ = ue_ ? nu_ + G : nu_;                                                                                      \
+        const bool ok_ = (commit) && nu_ < nunits;                                                                      \
+        lkoff = ok_ ? nk_ : lkoff; lseg = ok_ ? ns_ : lseg; lu = ok_ ? nu_ : lu;                                        \
+        ltile = unit_tile(lu);                                                                                          \
+    } while (0)
+#if DN_PT_SKIP_LOADS   // development ablation: only the prologue fetches
+#define PT_LOAD(RS) do { if (pt_first_load) rg_load<TN, NTHR, NOUT, true, BCOLK, HASQ, A_IT, B_IT, PAIRK>(g, ltile, n0, lseg, lkoff, tid, RS); pt_first_load = false; } while (0)
+#else
 #define PT_LOAD(RS) rg_load<TN, NTHR, NOUT, true, BCOLK, HASQ, A_IT, B_IT, PAIRK>(g, ltile, n0, lseg, lkoff, tid, RS)
+#endif
 #define PT_STORE(buf, RS)                                                                                               \
     do {                                                                                                                \
         if constexpr (X3) rg_store_x3<NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>(reinterpret_cast<unsigned char*>(buf),        \
                                                                           reinterpret_cast<unsigned char*>((buf) + SA), tid, RS); \
         else rg_store<TN, NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>((buf), (buf) + SA, tid, RS);                             \
     } while (0)
-// one pipeline iteration on slice j; RS is the ring set of slice j+1 (stored now) and of slice j+4 (loaded now)
+// One pipeline iteration on slice j; RS is the ring set of slice j+1 (staged now) and of slice j+1+DEPTH (loaded now).
+// Split-bf16 order: every LDS read of slice j is issued first, then the pure-VALU split of slice j+1 and the MFMAs of slice j
+// (independent instruction streams the scheduler can interleave), then the LDS writes of slice j+1.  With the writes first
+// the MFMAs had to wait behind them (may-alias LDS), and a slice took ~5.8k cycles of which the matrix pipe was busy 1.5k.
 #define PT_ITER(j, RS)                                                                                                  \
     do {                                                                                                                \
         float* cur = smem + ((j) & 1) * SBUF;                                                                           \
         float* nxt = smem + (((j) & 1) ^ 1) * SBUF;                                                                     \
-        if ((j) + 1 < T) PT_STORE(nxt, RS);                                                                             \
-        if ((j) + 1 + DN_PT_DEPTH < T) { PT_ADVANCE(); PT_LOAD(RS); }                                                   \
         PtPiece P[PPI];                                                                                                 \
         const bool pending = p_next < DN_PT_NP;                                                                         \
-        if (pending) {                                                                                                  \
+        PT_T();                                                                                                         \
+        if constexpr (X3) {                                                                                             \
+            const unsigned char* cA = reinterpret_cast<const unsigned char*>(cur);                                      \
+            const unsigned char* cB = reinterpret_cast<const unsigned char*>(cur + SA);                                 \
+            X3Frags<MT, NT, NOUT> F;                                                                                    \
+            X3Planes<NOUT, A_IT, B_IT> PLN;                                                                             \
+            /* no branches in here except around the prefetch: pieces past the end are dead (ok = false), and the   */ \
+            /* last iteration stages stale registers into a buffer nobody reads                                      */ \
+            rg_frag_x3<MT, NT, NOUT>(cA, cB, wr * MT * 32, wc * NT * 32, li, ls, 0, F);                                 \
+            /* every auxiliary load of this iteration's pieces goes out BEFORE the prefetch: loads retire in order,   */ \
+            /* so a piece that waited on a younger load would wait for the prefetch too                              */ \
             _Pragma("unroll") for (int k = 0; k < PPI; ++k)                                                             \
                 pt_piece_load<MODE, FLAG>(g, sE, p_next + k, tid, p_row0, p_nrows, n0, P[k]);                           \
-        }                                                                                                               \
-        if constexpr (X3) rg_compute_x3<MT, NT, NOUT>(reinterpret_cast<const unsigned char*>(cur),                      \
-                                                      reinterpret_cast<const unsigned char*>(cur + SA), wr * MT * 32,   \
-                                                      wc * NT * 32, li, ls, acc);                                       \
-        else rg_compute<TN, MT, NT, NOUT, BCOLK>(cur, cur + SA, wr * MT * 32, wc * NT * 32, li, ls, acc);               \
-        if (pending) {                                                                                                  \
+            PT_T();                                                                                                     \
+            rg_split_x3<NOUT, BCOLK, HASQ, A_IT, B_IT>(RS, PLN);                                                        \
+            rg_mma_x3<MT, NT, NOUT>(F, 0, acc);                                                                         \
+            PT_T();                                                                                                     \
+            PT_ADVANCE_SEL((j) + 1 + DN_PT_DEPTH < T);                                                                  \
+            PT_LOAD(RS);                                                                                                \
+            rg_frag_x3<MT, NT, NOUT>(cA, cB, wr * MT * 32, wc * NT * 32, li, ls, 1, F);                                 \
+            PT_T();                                                                                                     \
+            rg_mma_x3<MT, NT, NOUT>(F, 1, acc);                                                                         \
+            PT_T();                                                                                                     \
+            rg_put_x3<NTHR, NOUT, BCOLK, A_IT, B_IT>(reinterpret_cast<unsigned char*>(nxt),                             \
+                                                     reinterpret_cast<unsigned char*>(nxt + SA), tid, PLN);             \
             _Pragma("unroll") for (int k = 0; k < PPI; ++k) pt_piece_store<MODE, FLAG>(g, P[k]);                        \
-            p_next += PPI;                                                                                              \
+            p_next = (p_next + PPI < DN_PT_NP) ? p_next + PPI : DN_PT_NP;                                               \
+            PT_T();                                                                                                     \
+        } else {                                                                                                        \
+            if ((j) + 1 < T) PT_STORE(nxt, RS);                                                                         \
+            if ((j) + 1 + DN_PT_DEPTH < T) { PT_ADVANCE(); PT_LOAD(RS); }                                               \
+            if (pending) {                                                                                              \
+                _Pragma("unroll") for (int k = 0; k < PPI; ++k)                                                         \
+                    pt_piece_load<MODE, FLAG>(g, sE, p_next + k, tid, p_row0, p_nrows, n0, P[k]);                       \
+            }                                                                                                           \
+            rg_compute<TN, MT, NT, NOUT, BCOLK>(cur, cur + SA, wr * MT * 32, wc * NT * 32, li, ls, acc);                \
+            if (pending) {                                                                                              \
+                _Pragma("unroll") for (int k = 0; k < PPI; ++k) pt_piece_store<MODE, FLAG>(g, P[k]);                    \
+                p_next += PPI;                                                                                          \
+            }                                                                                                           \
         }                                                                                                               \
         if (++cs == nsl) { /* unit complete: park the accumulators (fragment layout -> row-major, conflict-free) */     \
             _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                           \
@@ -742,11 +883,12 @@ __global__ __launch_bounds__(DN_PT_THREADS) void rowgemm_persist_kernel(RgArgs g
                     sE[((wr * MT + mt) * 32 + dn_acc_row(r, lane)) * 128 + wc * 32 + li] = acc[0][mt][0][r];            \
                     acc[0][mt][0][r] = 0.f;                                                                             \
                 }                                                                                                       \
-            p_row0 = ctile.row0; p_nrows = ctile.nrows; p_next = 0;                                                     \
+            p_row0 = ctile.row0; p_nrows = ctile.nrows; p_next = DN_PT_OUT_START;                                       \
             cs = 0;                                                                                                     \
             cu += G;                                                                                                    \
             if (cu < nunits) ctile = unit_tile(cu);                                                                     \
         }                                                                                                               \
+        PT_T();                                                                                                         \
         __syncthreads(); /* slice buffer hand-off + visibility of the parked unit */                                    \
     } while (0)
 
@@ -809,9 +951,297 @@ static int dn_num_cus() {
 #ifndef DN_PT_X3
 #define DN_PT_X3 (DN_PT_ROWS == 128)   // split-bf16 MFMA in the persistent kernel (build with -DDN_PT_X3=0 for exact-f32 MFMA)
 #endif
+// ---- wave-specialised persistent row GEMM (split-bf16, one output, >= 4 slices) --------------------------------------------
+// Measured on the lock-step kernel above (linear C->C, 158k rows): the compute side alone (no global traffic) takes 36 us,
+// the memory side alone (no MFMA / split / LDS reads) 35 us, the two together 52-56 us -- every wave ran the same phase at
+// the same time and sat in the memory instructions it issued.  Here the eight waves of a workgroup have fixed roles:
+//   waves 0-3 (one per SIMD): LDS fragment reads + MFMAs of a 64x64 sub-tile each, and parking the finished unit in LDS;
+//   waves 4-11              : global prefetch of the next slice, split into bf16 planes, LDS writes, and the deferred
+//                             epilogue of the parked unit (LDS read, auxiliary operands, float4 stores).
+// One barrier per slice hands the slice buffer over.  A parked unit must be streamed out before the next one is parked at
+// the end of the following unit's last slice, hence PPI = ceil(NP / (nsl - 1)) pieces per loader thread and slice.
+#ifndef DN_PT_WS
+#define DN_PT_WS 1
+#endif
+#ifndef DN_WS_LW
+#define DN_WS_LW 8                            // loader waves per workgroup (4 or 8); measured: 4 loader waves made the loaders the pole
+#endif
+#define DN_WS_LTHR (64 * DN_WS_LW)             // loader threads
+#define DN_WS_NP (128 * 128 / 4 / DN_WS_LTHR)   // float4 pieces per loader thread and unit (16 or 8)
+
+struct WsAux {
+    float4 a0;
+    uint32_t mk;
+    float rs;
+    long long off;
+    int lds;      // float index of the piece in the parked unit
+    bool ok;
+};
+
+// issue the auxiliary loads of one deferred piece (nothing here is used before the next slice iteration)
+template <int MODE, bool FLAG>
+__device__ __forceinline__ void ws_aux_load(const RgArgs& g, int piece, int lt, int row0, int nrows, int n0, WsAux& A) {
+    const bool live = piece < DN_WS_NP;
+    const int idx = lt + (live ? piece : 0) * DN_WS_LTHR;
+    const int row = idx >> 5, c4 = idx & 31;
+    const int col = n0 + 4 * c4;
+    A.ok = live && row < nrows && col < g.N;
+    A.lds = row * 128 + 4 * c4;
+    const long long grow = row0 + (A.ok ? row : 0);
+    const int ccol = A.ok ? col : 0;
+    A.off = grow * g.ldo + ccol;
+    const long long roff = grow * g.ldr + ccol;
+    constexpr bool need_r0 = MODE == DN_EPI_BIAS_RESID || MODE == DN_EPI_MUL_DFAC || MODE == DN_EPI_ADD ||
+                             MODE == DN_EPI_DTANH || MODE == DN_EPI_MASS_ADD;
+    if (need_r0) A.a0 = *reinterpret_cast<const float4*>(g.r0 + roff);
+    if (MODE == DN_EPI_BIAS_RELU && FLAG) A.mk = *reinterpret_cast<const uint32_t*>(g.mask + roff);
+    if (MODE == DN_EPI_MASS_ADD) A.rs = g.rowv[grow];
+}
+
+template <int MODE, bool FLAG>
+__device__ __forceinline__ void ws_piece_out(const RgArgs& g, const float* sE, const float4& bias, const WsAux& A) {
+    PtPiece P;
+    P.v = *reinterpret_cast<const float4*>(&sE[A.lds]);
+    P.a0 = A.a0; P.bias = bias; P.mk = A.mk; P.rs = A.rs; P.off = A.off; P.ok = A.ok;
+    pt_piece_store<MODE, FLAG>(g, P);
+}
+
+// six cross products of one k16 step, product-major: consecutive MFMAs go to different accumulators
+__device__ __forceinline__ void ws_mma(const X3Frags<2, 2, 1>& F, int s, f32x16 (&acc)[1][2][2]) {
+    constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};   // mid*mid, hi*lo, lo*hi, hi*mid, mid*hi, hi*hi
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+#if defined(DN_X3_ABLATE_MFMA)
+                acc[0][mt][nt][0] += __uint_as_float((F.a[s][PA[p]][mt].x & F.b[s][0][PB[p]][nt].x) & 0x3f800000u);
+#else
+                acc[0][mt][nt] = dn_mfma_bf16(F.a[s][PA[p]][mt], F.b[s][0][PB[p]][nt], acc[0][mt][nt]);
+#endif
+            }
+}
+
+// loader-side fetch of one slice with every descriptor already in registers (no kernel-argument or tile-table loads on the
+// path to the global loads: a dependent scalar load costs a few hundred cycles, and the lock-step kernel paid four per slice)
+template <bool BCOLK, int A_IT, int B_IT>
+__device__ __forceinline__ void ws_load(const float* ap, int ald, const float* bp, int ldb, int N, int row0, int nrows, int n0,
+                                        int koff, int lt, RgRegs<1, A_IT, B_IT>& R) {
+    constexpr int LTHR = DN_WS_LTHR;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int idx = lt + i * LTHR;
+        const int row = idx >> 3, q = idx & 7;
+        const long long off = (long long)(row0 + (row < nrows ? row : 0)) * ald + koff + 4 * q;
+        R.a[i] = *reinterpret_cast<const float4*>(ap + off);
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int idx = lt + i * LTHR;
+        long long boff;
+        if (BCOLK) {
+            const int nrow = idx >> 3, q = idx & 7;
+            boff = (long long)(n0 + nrow < N ? n0 + nrow : 0) * ldb + koff + 4 * q;
+        } else {
+            const int krow = 2 * (lt & 15) + (i & 1);
+            const int q4 = (lt >> 4) + (LTHR / 16) * (i >> 1);
+            boff = (long long)(koff + krow) * ldb + (n0 + 4 * q4 < N ? n0 + 4 * q4 : 0);
+        }
+        R.b[0][i] = *reinterpret_cast<const float4*>(bp + boff);
+    }
+}
+
+template <int MODE, bool BCOLK, bool FLAG, int PPI>
+__global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2 : 3) void rowgemm_ws_kernel(RgArgs g, int ntiles) {
+    constexpr int TN = 128, NOUT = 1, LTHR = DN_WS_LTHR;
+    constexpr int A_IT = DN_TM * 8 / LTHR;            // 4 float4 of the A slice per loader thread
+    constexpr int B_IT = DN_KB * TN / 4 / LTHR;       // 4 float4 of the B slice
+    constexpr int SA = (DN_TM * 64 * 3) / 4;          // floats of the A planes of one slice (24 KiB)
+    constexpr int SBUF = SA + (128 * 64 * 3) / 4;     // one (A,B) slice buffer (48 KiB); two in LDS + the parked unit (64 KiB)
+    constexpr bool PAIRK = !BCOLK;
+    constexpr bool HASQ = false;
+    constexpr bool need_bias = (MODE == DN_EPI_STORE && FLAG) || MODE == DN_EPI_BIAS_RELU || MODE == DN_EPI_BIAS_RESID;
+
+    DN_DYN_SMEM(smem_raw);
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    float* sE = smem + 2 * SBUF;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = gridDim.x;
+    const int n0 = blockIdx.y * TN;
+    int nsl = 0;
+    for (int s = 0; s < g.nseg; ++s) nsl += g.a[s].w / DN_KB;   // host guarantees nsl >= 4 and whole slices
+    const int my_units = ((int)blockIdx.x < ntiles) ? (ntiles - (int)blockIdx.x + G - 1) / G : 0;
+    const int T = my_units * nsl;
+    if (T == 0) return;
+
+    if (wave < 4) {
+        // ------------------------------------------------ MFMA waves ------------------------------------------------
+        const int wr = wave >> 1, wc = wave & 1;
+        const int li = lane & 31, lg = lane >> 5;
+        f32x16 acc[1][2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][mt][nt][r] = 0.f;
+        int cs = 0;
+        __syncthreads();   // slice 0 staged
+        for (int j = 0; j < T; ++j) {
+            const unsigned char* cA = reinterpret_cast<const unsigned char*>(smem + (j & 1) * SBUF);
+            const unsigned char* cB = cA + SA * 4;
+            X3Frags<2, 2, 1> F;
+            rg_frag_x3<2, 2, 1>(cA, cB, wr * 64, wc * 64, li, lg, 0, F);
+            rg_frag_x3<2, 2, 1>(cA, cB, wr * 64, wc * 64, li, lg, 1, F);
+            ws_mma(F, 0, acc);
+            ws_mma(F, 1, acc);
+            if (++cs == nsl) {   // unit complete: park it (fragment layout -> row-major) for the loader waves to stream out
+                cs = 0;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            sE[(wr * 64 + mt * 32 + dn_acc_row(r, lane)) * 128 + wc * 64 + nt * 32 + li] = acc[0][mt][nt][r];
+                            acc[0][mt][nt][r] = 0.f;
+                        }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------------------------------------------- loader waves ----------------------------------------------------
+    const int lt = tid - 256;
+    float4 bias = dn_f4_zero();
+    {
+        const int col = n0 + 4 * (lt & 31);
+        if (need_bias) bias = *reinterpret_cast<const float4*>(g.bias + (col < g.N ? col : 0));
+    }
+    RgRegs<NOUT, A_IT, B_IT> R0;
+    // segment descriptors in registers (nseg <= 3); the B operand of segment s starts koff = 0 again
+    const float* sp0 = g.a[0].p; const float* sp1 = g.a[1].p; const float* sp2 = g.a[2].p;
+    const int sl0 = g.a[0].ld, sl1 = g.a[1].ld, sl2 = g.a[2].ld;
+    const int sw0 = g.a[0].w, sw1 = g.a[1].w, sw2 = g.a[2].w;
+    const float* sb0 = g.b[0][0]; const float* sb1 = g.b[0][1]; const float* sb2 = g.b[0][2];
+    const int nseg = g.nseg, ldb = g.ldb, Ncols = g.N;
+    const long long bms = g.b_mesh_stride;
+    // load cursor; the next unit's tile descriptor is fetched one unit ahead
+    int lu = blockIdx.x, lseg = 0, lkoff = 0;
+    DnTile ltile = g.tiles[lu];
+    DnTile ltile_next = g.tiles[lu + G < ntiles ? lu + G : lu];
+    // mirror of the compute cursor (which unit is parked when) and the parked unit being streamed out
+    int cu = blockIdx.x, cs = 0;
+    DnTile ctile = ltile, ctile_next = ltile_next;
+    int p_row0 = ctile.row0, p_nrows = 0, p_next = DN_WS_NP;   // p_next >= NP: nothing pending
+    WsAux AX[PPI];
+#pragma unroll
+    for (int k = 0; k < PPI; ++k) ws_aux_load<MODE, FLAG>(g, DN_WS_NP, lt, p_row0, p_nrows, n0, AX[k]);   // dead pieces
+
+// one step of the load cursor without control flow or memory access on the path; past the last slice it stays put
+#define WS_ADVANCE(commit)                                                                                              \
+    do {                                                                                                                \
+        const int cw_ = lseg == 0 ? sw0 : (lseg == 1 ? sw1 : sw2);                                                      \
+        int nk_ = lkoff + DN_KB, ns_ = lseg, nu_ = lu;                                                                  \
+        const bool se_ = nk_ >= cw_;                                                                                    \
+        nk_ = se_ ? 0 : nk_;                                                                                            \
+        ns_ = se_ ? ns_ + 1 : ns_;                                                                                      \
+        const bool ue_ = ns_ >= nseg;                                                                                   \
+        ns_ = ue_ ? 0 : ns_;                                                                                            \
+        nu_ = ue_ ? nu_ + G : nu_;                                                                                      \
+        const bool ok_ = (commit) && nu_ < ntiles;                                                                      \
+        const bool sw_ = ok_ && ue_;                                                                                    \
+        lkoff = ok_ ? nk_ : lkoff; lseg = ok_ ? ns_ : lseg; lu = ok_ ? nu_ : lu;                                        \
+        ltile.row0 = sw_ ? ltile_next.row0 : ltile.row0; ltile.nrows = sw_ ? ltile_next.nrows : ltile.nrows;            \
+        ltile.mesh = sw_ ? ltile_next.mesh : ltile.mesh;                                                                \
+        ltile_next = g.tiles[lu + G < ntiles ? lu + G : lu];   /* consumed at the next unit switch at the earliest */    \
+    } while (0)
+#define WS_LOAD(RS)                                                                                                     \
+    ws_load<BCOLK, A_IT, B_IT>(lseg == 0 ? sp0 : (lseg == 1 ? sp1 : sp2), lseg == 0 ? sl0 : (lseg == 1 ? sl1 : sl2),     \
+                               (lseg == 0 ? sb0 : (lseg == 1 ? sb1 : sb2)) + (long long)ltile.mesh * bms, ldb, Ncols,    \
+                               ltile.row0, ltile.nrows, n0, lkoff, lt, RS)
+#define WS_STAGE(buf, RS)                                                                                               \
+    do {                                                                                                                \
+        X3Planes<NOUT, A_IT, B_IT> PLN;                                                                                 \
+        rg_split_x3<NOUT, BCOLK, HASQ, A_IT, B_IT>(RS, PLN);                                                            \
+        rg_put_x3<LTHR, NOUT, BCOLK, A_IT, B_IT>(reinterpret_cast<unsigned char*>(buf),                                 \
+                                                 reinterpret_cast<unsigned char*>((buf) + SA), lt, PLN);                \
+    } while (0)
+
+// Order inside an iteration: stage -> slice prefetch -> deferred pieces (their operands were requested an iteration ago) ->
+// operands of the next iteration's pieces.  (Measured: a second register set / fetching two slices ahead, and requesting
+// the piece operands before the prefetch, were both slower -- 60/48/135 us vs 53/51/127 us for the NN, C->C, 3C->C products.)
+    WS_LOAD(R0);
+    WS_STAGE(smem, R0);
+    WS_ADVANCE(T > 1);
+    WS_LOAD(R0);                       // slice 1
+    __syncthreads();                   // slice 0 staged
+    for (int j = 0; j < T; ++j) {
+        float* nxt = smem + ((j & 1) ^ 1) * SBUF;
+        WS_STAGE(nxt, R0);             // slice j+1 (the last iteration stages a stale copy nobody reads)
+        WS_ADVANCE(j + 2 < T);
+        WS_LOAD(R0);                   // slice j+2
+#pragma unroll
+        for (int k = 0; k < PPI; ++k) ws_piece_out<MODE, FLAG>(g, sE, bias, AX[k]);
+        p_next = (p_next + PPI < DN_WS_NP) ? p_next + PPI : DN_WS_NP;
+        {   // the MFMA waves park unit cu at the end of the iteration that multiplies its last slice (selects only)
+            const bool park = ++cs == nsl;
+            p_row0 = park ? ctile.row0 : p_row0; p_nrows = park ? ctile.nrows : p_nrows;
+            p_next = park ? (DN_PT_OUT_START ? DN_WS_NP : 0) : p_next;
+            cs = park ? 0 : cs;
+            cu = park ? cu + G : cu;
+            ctile.row0 = park ? ctile_next.row0 : ctile.row0; ctile.nrows = park ? ctile_next.nrows : ctile.nrows;
+            const int cn = cu + G < ntiles ? cu + G : ntiles - 1;
+            ctile_next = g.tiles[cn];   // consumed at the next park at the earliest
+        }
+#pragma unroll
+        for (int k = 0; k < PPI; ++k) ws_aux_load<MODE, FLAG>(g, p_next + k, lt, p_row0, p_nrows, n0, AX[k]);
+        __syncthreads();
+    }
+#undef WS_STAGE
+#undef WS_LOAD
+#undef WS_ADVANCE
+    // flush the last parked unit
+#if defined(DN_PT_ABLATE_OUT)
+    p_next = DN_WS_NP;
+#endif
+    for (; p_next < DN_WS_NP; ++p_next) {
+        WsAux A1;
+        ws_aux_load<MODE, FLAG>(g, p_next, lt, p_row0, p_nrows, n0, A1);
+        ws_piece_out<MODE, FLAG>(g, sE, bias, A1);
+    }
+}
+
+template <int MODE, bool BCOLK, bool FLAG, int PPI>
+static int ws_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
+    const size_t smem = (size_t)(2 * (DN_TM * 64 * 3 + 128 * 64 * 3) + 128 * 128 * 4);   // 160 KiB
+#ifndef DN_EMULATE
+    static bool lds_opt_in = false;
+    if (!lds_opt_in) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_ws_kernel<MODE, BCOLK, FLAG, PPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        lds_opt_in = true;
+    }
+#endif
+    int gx = dn_num_cus();
+    if (gx > ntiles) gx = ntiles;
+    DN_LAUNCH((rowgemm_ws_kernel<MODE, BCOLK, FLAG, PPI>), dim3(gx, (g.N + 127) / 128, 1), dim3(256 + DN_WS_LTHR, 1, 1), smem, stream, g, ntiles);
+    return (int)hipGetLastError();
+}
+
 template <int MODE, bool BCOLK, bool FLAG>
 static int pt_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
     constexpr bool X3 = DN_PT_X3 != 0;
+    if (X3 && DN_PT_WS && DN_PT_ROWS == 128) {
+        int nsl = 0;
+        for (int s = 0; s < g.nseg; ++s) nsl += g.a[s].w / DN_KB;
+        // PPI = ceil(NP / (nsl - 1)) for the two slice counts that matter (K = 128: 4 slices, K = 384: 12)
+        if (nsl >= 9) return ws_launch<MODE, BCOLK, FLAG, (DN_WS_NP + 7) / 8>(g, ntiles, stream);
+        if (nsl >= 4) return ws_launch<MODE, BCOLK, FLAG, (DN_WS_NP + 2) / 3>(g, ntiles, stream);
+    }
     // slice buffers (2x) + parked accumulators: 128 KiB with f32 tiles, exactly 160 KiB with bf16x3 planes
     const size_t smem = X3 ? (size_t)(2 * (DN_PT_ROWS * 64 * 3 + 128 * 64 * 3) + DN_PT_ROWS * 128 * 4)
                            : (size_t)(2 * (DN_PT_ROWS * DN_KB + DN_KB * 128) + DN_PT_ROWS * 128) * sizeof(float);
