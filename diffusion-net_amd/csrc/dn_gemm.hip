@@ -715,8 +715,20 @@ __device__ unsigned long long dn_pt_trace_buf[2 * 4096];
 extern "C" int dn_debug_trace_read(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dn_pt_trace_buf), sizeof(unsigned long long) * n);
 }
+#ifndef DN_WS_TRACE_TID
+#define DN_WS_TRACE_TID 256   // first lane of the traced loader wave
+#endif
+#define WS_T(who)                                                                                                       \
+    do {                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                     \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == (who) && trn < 4096) dn_pt_trace_buf[((who) ? 4096 : 0) + trn] = t_; \
+        ++trn;                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    } while (0)
 #else
 #define PT_T() do {} while (0)
+#define WS_T(who) do {} while (0)
 #endif
 template <int MODE, bool BCOLK, bool FLAG, bool X3>
 __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_persist_kernel(RgArgs g, int ntiles) {
@@ -966,6 +978,12 @@ static int dn_num_cus() {
 #ifndef DN_WS_LW
 #define DN_WS_LW 8                            // loader waves per workgroup (4 or 8); measured: 4 loader waves made the loaders the pole
 #endif
+#ifndef DN_WS_DEPTH
+#define DN_WS_DEPTH 1                         // register sets of the loader's prefetch ring
+#endif
+#ifndef DN_WS_SPLIT_SIMD
+#define DN_WS_SPLIT_SIMD 0   // 1: MFMA waves on two SIMDs, loaders on the other two -- measured slower (58 vs 51 us, C->C product)
+#endif
 #define DN_WS_LTHR (64 * DN_WS_LW)             // loader threads
 #define DN_WS_NP (128 * 128 / 4 / DN_WS_LTHR)   // float4 pieces per loader thread and unit (16 or 8)
 
@@ -1075,10 +1093,23 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     const int my_units = ((int)blockIdx.x < ntiles) ? (ntiles - (int)blockIdx.x + G - 1) / G : 0;
     const int T = my_units * nsl;
     if (T == 0) return;
+#if defined(DN_PT_TRACE)
+    int trn = 0;
+#endif
 
-    if (wave < 4) {
+    // Roles.  Default: waves 0-3 (one per SIMD) multiply, waves 4-11 load.  DN_WS_SPLIT_SIMD=1 instead puts the four MFMA
+    // waves on two SIMDs (a workgroup's waves are dealt to the SIMDs cyclically) and leaves the other two to the loaders.
+#if DN_WS_SPLIT_SIMD
+    const bool is_mfma = wave < 8 && (wave & 3) < 2;
+    const int mw = wave < 4 ? wave : wave - 2;          // 0, 1, 4, 5 -> 0..3
+    const int lw = wave < 4 ? wave - 2 : wave - 4;      // 2, 3, 6, 7, 8..11 -> 0..7
+#else
+    const bool is_mfma = wave < 4;
+    const int mw = wave, lw = wave - 4;
+#endif
+    if (is_mfma) {
         // ------------------------------------------------ MFMA waves ------------------------------------------------
-        const int wr = wave >> 1, wc = wave & 1;
+        const int wr = mw >> 1, wc = mw & 1;
         const int li = lane & 31, lg = lane >> 5;
         f32x16 acc[1][2][2];
 #pragma unroll
@@ -1093,10 +1124,13 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
             const unsigned char* cA = reinterpret_cast<const unsigned char*>(smem + (j & 1) * SBUF);
             const unsigned char* cB = cA + SA * 4;
             X3Frags<2, 2, 1> F;
+            WS_T(0);
             rg_frag_x3<2, 2, 1>(cA, cB, wr * 64, wc * 64, li, lg, 0, F);
             rg_frag_x3<2, 2, 1>(cA, cB, wr * 64, wc * 64, li, lg, 1, F);
             ws_mma(F, 0, acc);
+            WS_T(0);
             ws_mma(F, 1, acc);
+            WS_T(0);
             if (++cs == nsl) {   // unit complete: park it (fragment layout -> row-major) for the loader waves to stream out
                 cs = 0;
 #pragma unroll
@@ -1109,19 +1143,23 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
                             acc[0][mt][nt][r] = 0.f;
                         }
             }
+            WS_T(0);
             __syncthreads();
         }
         return;
     }
 
     // ---------------------------------------------------- loader waves ----------------------------------------------------
-    const int lt = tid - 256;
+    const int lt = lw * 64 + lane;
     float4 bias = dn_f4_zero();
     {
         const int col = n0 + 4 * (lt & 31);
         if (need_bias) bias = *reinterpret_cast<const float4*>(g.bias + (col < g.N ? col : 0));
     }
     RgRegs<NOUT, A_IT, B_IT> R0;
+#if DN_WS_DEPTH == 2
+    RgRegs<NOUT, A_IT, B_IT> R1;
+#endif
     // segment descriptors in registers (nseg <= 3); the B operand of segment s starts koff = 0 again
     const float* sp0 = g.a[0].p; const float* sp1 = g.a[1].p; const float* sp2 = g.a[2].p;
     const int sl0 = g.a[0].ld, sl1 = g.a[1].ld, sl2 = g.a[2].ld;
@@ -1174,33 +1212,52 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
 // Order inside an iteration: stage -> slice prefetch -> deferred pieces (their operands were requested an iteration ago) ->
 // operands of the next iteration's pieces.  (Measured: a second register set / fetching two slices ahead, and requesting
 // the piece operands before the prefetch, were both slower -- 60/48/135 us vs 53/51/127 us for the NN, C->C, 3C->C products.)
+#define WS_ITER(j, RS)                                                                                                  \
+    do {                                                                                                                \
+        float* nxt = smem + (((j) & 1) ^ 1) * SBUF;                                                                     \
+        WS_T(DN_WS_TRACE_TID);                                                                                                      \
+        WS_STAGE(nxt, RS);             /* slice j+1 (the last iteration stages a stale copy nobody reads) */            \
+        WS_T(DN_WS_TRACE_TID);                                                                                                      \
+        WS_ADVANCE((j) + 1 + DN_WS_DEPTH < T);                                                                          \
+        WS_LOAD(RS);                   /* slice j+1+DEPTH */                                                            \
+        WS_T(DN_WS_TRACE_TID);                                                                                                      \
+        _Pragma("unroll") for (int k = 0; k < PPI; ++k) ws_piece_out<MODE, FLAG>(g, sE, bias, AX[k]);                   \
+        WS_T(DN_WS_TRACE_TID);                                                                                                      \
+        p_next = (p_next + PPI < DN_WS_NP) ? p_next + PPI : DN_WS_NP;                                                   \
+        {   /* the MFMA waves park unit cu at the end of the iteration that multiplies its last slice (selects only) */  \
+            const bool park = ++cs == nsl;                                                                              \
+            p_row0 = park ? ctile.row0 : p_row0; p_nrows = park ? ctile.nrows : p_nrows;                                \
+            p_next = park ? (DN_PT_OUT_START ? DN_WS_NP : 0) : p_next;                                                  \
+            cs = park ? 0 : cs;                                                                                         \
+            cu = park ? cu + G : cu;                                                                                    \
+            ctile.row0 = park ? ctile_next.row0 : ctile.row0; ctile.nrows = park ? ctile_next.nrows : ctile.nrows;      \
+            const int cn = cu + G < ntiles ? cu + G : ntiles - 1;                                                       \
+            ctile_next = g.tiles[cn];   /* consumed at the next park at the earliest */                                 \
+        }                                                                                                               \
+        _Pragma("unroll") for (int k = 0; k < PPI; ++k)                                                                 \
+            ws_aux_load<MODE, FLAG>(g, p_next + k, lt, p_row0, p_nrows, n0, AX[k]);                                     \
+        __syncthreads();                                                                                                \
+    } while (0)
+
     WS_LOAD(R0);
     WS_STAGE(smem, R0);
+#if DN_WS_DEPTH == 2
+    WS_ADVANCE(T > 1);
+    WS_LOAD(R1);                       // slice 1
+    WS_ADVANCE(T > 2);
+    WS_LOAD(R0);                       // slice 2
+    __syncthreads();                   // slice 0 staged
+    for (int j = 0; j < T; j += 2) {
+        WS_ITER(j, R1);
+        if (j + 1 < T) WS_ITER(j + 1, R0);
+    }
+#else
     WS_ADVANCE(T > 1);
     WS_LOAD(R0);                       // slice 1
     __syncthreads();                   // slice 0 staged
-    for (int j = 0; j < T; ++j) {
-        float* nxt = smem + ((j & 1) ^ 1) * SBUF;
-        WS_STAGE(nxt, R0);             // slice j+1 (the last iteration stages a stale copy nobody reads)
-        WS_ADVANCE(j + 2 < T);
-        WS_LOAD(R0);                   // slice j+2
-#pragma unroll
-        for (int k = 0; k < PPI; ++k) ws_piece_out<MODE, FLAG>(g, sE, bias, AX[k]);
-        p_next = (p_next + PPI < DN_WS_NP) ? p_next + PPI : DN_WS_NP;
-        {   // the MFMA waves park unit cu at the end of the iteration that multiplies its last slice (selects only)
-            const bool park = ++cs == nsl;
-            p_row0 = park ? ctile.row0 : p_row0; p_nrows = park ? ctile.nrows : p_nrows;
-            p_next = park ? (DN_PT_OUT_START ? DN_WS_NP : 0) : p_next;
-            cs = park ? 0 : cs;
-            cu = park ? cu + G : cu;
-            ctile.row0 = park ? ctile_next.row0 : ctile.row0; ctile.nrows = park ? ctile_next.nrows : ctile.nrows;
-            const int cn = cu + G < ntiles ? cu + G : ntiles - 1;
-            ctile_next = g.tiles[cn];   // consumed at the next park at the earliest
-        }
-#pragma unroll
-        for (int k = 0; k < PPI; ++k) ws_aux_load<MODE, FLAG>(g, p_next + k, lt, p_row0, p_nrows, n0, AX[k]);
-        __syncthreads();
-    }
+    for (int j = 0; j < T; ++j) WS_ITER(j, R0);
+#endif
+#undef WS_ITER
 #undef WS_STAGE
 #undef WS_LOAD
 #undef WS_ADVANCE

@@ -17,7 +17,8 @@ import torch
 import bench
 from diffusion_net import _hip, ops
 
-PHASES = ["LDS reads+piece loads", "split + MFMA", "LDS writes", "issue loads", "piece stores+park", "barrier"]
+PHASES_MFMA = ["reads+MFMA k16 #0", "MFMA k16 #1", "park", "barrier wait"]
+PHASES_LOAD = ["wait+split+LDS writes", "cursor+prefetch issue", "pieces out", "piece operands+barrier"]
 
 
 def dump(name):
@@ -29,17 +30,18 @@ def dump(name):
     assert rc == 0, rc
     t = np.frombuffer(buf, dtype=np.uint64).astype(np.int64).reshape(2, 4096)
     print("== %s" % name)
-    for w, lab in ((0, "wave0"), (1, "wave7")):
+    for w, lab, ph in ((0, "MFMA wave 0", PHASES_MFMA), (1, "loader wave 4", PHASES_LOAD)):
         tt = t[w]
-        n = int(np.argmax(tt[1:] < tt[:-1])) + 1 if np.any(tt[1:] < tt[:-1]) else 4096
-        n = (n // 7) * 7
-        it = tt[:n].reshape(-1, 7)
-        d = np.diff(it, axis=1)
+        good = tt > 0
+        n = int(np.argmin(good)) if not good.all() else 4096
+        n = (n // 4) * 4
+        it = tt[:n].reshape(-1, 4)
+        d = np.concatenate([np.diff(it, axis=1), (it[1:, 0] - it[:-1, 3])[:, None].tolist() + [[0]]], axis=1)
         whole = np.diff(it[:, 0])
-        print(" %s: %d iterations, %.0f cycles/iteration (ticks of s_memtime)" % (lab, it.shape[0], whole.mean() if len(whole) else 0))
-        for k, ph in enumerate(PHASES):
-            print("   %-20s mean %7.0f  min %6d  max %6d" % (ph, d[:, k].mean(), d[:, k].min(), d[:, k].max()))
-        print("   first 12 iterations (per-phase):")
+        print(" %s: %d iterations, %.0f cycles/iteration" % (lab, it.shape[0], whole.mean() if len(whole) else 0))
+        for k, name in enumerate(ph):
+            print("   %-26s mean %7.0f  min %6d  max %6d" % (name, d[:-1, k].mean(), d[:-1, k].min(), d[:-1, k].max()))
+        print("   first 12 iterations:")
         for r in d[:12]:
             print("    ", " ".join("%6d" % v for v in r))
 
