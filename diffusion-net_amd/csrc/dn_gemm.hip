@@ -981,6 +981,9 @@ static int dn_num_cus() {
 #ifndef DN_WS_DEPTH
 #define DN_WS_DEPTH 1                         // register sets of the loader's prefetch ring
 #endif
+#ifndef DN_WS_LOADER_PRIO
+#define DN_WS_LOADER_PRIO 0   // s_setprio of the loader waves (the MFMA waves are the older ones and win arbitration at equal priority)
+#endif
 #ifndef DN_WS_SPLIT_SIMD
 #define DN_WS_SPLIT_SIMD 0   // 1: MFMA waves on two SIMDs, loaders on the other two -- measured slower (58 vs 51 us, C->C product)
 #endif
@@ -1150,6 +1153,7 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     }
 
     // ---------------------------------------------------- loader waves ----------------------------------------------------
+    DN_SETPRIO(DN_WS_LOADER_PRIO);
     const int lt = lw * 64 + lane;
     float4 bias = dn_f4_zero();
     {
@@ -1289,6 +1293,325 @@ static int ws_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
+// ---- wave-specialised TWO-output row GEMM (the gradient-feature products, split-bf16) --------------------------------------
+// Same roles as rowgemm_ws_kernel.  A work unit is 128 rows x 64 output columns of BOTH outputs, so that two slice buffers
+// (A planes 24 KiB + 2 x 12 KiB B planes each) and the two parked 128 x 64 accumulator tiles (2 x 32 KiB) fill the 160 KiB of
+// LDS exactly; the column halves of a row tile are consecutive units of the same workgroup (the second pass over the A rows is
+// an L2 / MALL hit).  The epilogue runs on parked float4 pieces: the lock-step kernel it replaces did it with per-element
+// dword loads and stores after its main loop, with one workgroup per CU and nothing to overlap them with.
+#ifndef DN_RG_WS2
+#define DN_RG_WS2 0   // measured on MI355X: 228 us vs 187 us for the lock-step two-output kernel (gradient features, 158k rows) -> off
+#endif
+#define DN_WS2_NP (128 * 64 / 4 / 512)   // float4 pieces (of each output) per loader thread and unit (4)
+
+struct Ws2Aux {
+    float4 r0, r1, r2;
+    long long off;
+    int lds;
+    bool ok;
+};
+
+template <int MODE>
+__device__ __forceinline__ void ws2_aux_load(const RgArgs& g, int piece, int lt, int row0, int nrows, int n0, Ws2Aux& A) {
+    const bool live = piece < DN_WS2_NP;
+    const int idx = lt + (live ? piece : 0) * 512;
+    const int row = idx >> 4, c4 = idx & 15;
+    const int col = n0 + 4 * c4;
+    A.ok = live && row < nrows && col < g.N;
+    A.lds = row * 64 + 4 * c4;
+    const long long grow = row0 + (A.ok ? row : 0);
+    const int ccol = A.ok ? col : 0;
+    A.off = grow * g.ldo + ccol;
+    const long long roff = grow * g.ldr + ccol;
+    A.r0 = *reinterpret_cast<const float4*>(g.r0 + roff);
+    A.r1 = *reinterpret_cast<const float4*>(g.r1 + roff);
+    if (MODE == DN_EPI_GRADFEAT_BWD) A.r2 = *reinterpret_cast<const float4*>(g.r2 + roff);
+}
+
+template <int MODE>
+__device__ __forceinline__ void ws2_piece_out(const RgArgs& g, const float* sE0, const float* sE1, const Ws2Aux& A) {
+    const float4 a0 = *reinterpret_cast<const float4*>(&sE0[A.lds]);
+    const float4 a1 = *reinterpret_cast<const float4*>(&sE1[A.lds]);
+    if (MODE == DN_EPI_GRADFEAT) {   // o0 = tanh(r0*acc0 + r1*acc1); o1 = acc0; o2 = acc1 (if wanted)
+        const float4 y = make_float4(tanhf(A.r0.x * a0.x + A.r1.x * a1.x), tanhf(A.r0.y * a0.y + A.r1.y * a1.y),
+                                     tanhf(A.r0.z * a0.z + A.r1.z * a1.z), tanhf(A.r0.w * a0.w + A.r1.w * a1.w));
+        if (A.ok) {
+            *reinterpret_cast<float4*>(g.o0 + A.off) = y;
+            if (g.o1) {
+                *reinterpret_cast<float4*>(g.o1 + A.off) = a0;
+                *reinterpret_cast<float4*>(g.o2 + A.off) = a1;
+            }
+        }
+    } else {                         // o0 = acc0 + r0*r1 ; o1 = acc1 + r0*r2
+        const float4 y0 = make_float4(a0.x + A.r0.x * A.r1.x, a0.y + A.r0.y * A.r1.y, a0.z + A.r0.z * A.r1.z, a0.w + A.r0.w * A.r1.w);
+        const float4 y1 = make_float4(a1.x + A.r0.x * A.r2.x, a1.y + A.r0.y * A.r2.y, a1.z + A.r0.z * A.r2.z, a1.w + A.r0.w * A.r2.w);
+        if (A.ok) {
+            *reinterpret_cast<float4*>(g.o0 + A.off) = y0;
+            *reinterpret_cast<float4*>(g.o1 + A.off) = y1;
+        }
+    }
+}
+
+template <int MODE, bool BCOLK>
+__global__ __launch_bounds__(768) DN_WAVES_PER_EU(3) void rowgemm_ws2_kernel(RgArgs g, int ntiles) {
+    constexpr bool HASQ = MODE == DN_EPI_GRADFEAT_BWD;   // its A operand is an elementwise product
+    constexpr int PLA = 128 * 64, PLB = 64 * 64;         // bytes of one A / B plane of a slice
+    constexpr int SA_B = 3 * PLA, SBUF_B = SA_B + 2 * 3 * PLB;   // 24 KiB + 24 KiB per slice buffer
+
+    DN_DYN_SMEM(smem_raw);
+    unsigned char* smem = reinterpret_cast<unsigned char*>(smem_raw);
+    float* sE0 = reinterpret_cast<float*>(smem + 2 * SBUF_B);   // parked accumulators [128][64] of output 0 ...
+    float* sE1 = sE0 + 128 * 64;                                 // ... and of output 1
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = gridDim.x;
+    const int NH = (g.N + 63) / 64;
+    int nsl = 0;
+    for (int s = 0; s < g.nseg; ++s) nsl += g.a[s].w / DN_KB;   // host guarantees nsl >= 5 and whole slices
+    const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - (int)blockIdx.x + G - 1) / G : 0;
+    const int T = my_tiles * NH * nsl;
+    if (T == 0) return;
+
+    if (wave < 4) {
+        // ------------------------------------------------ MFMA waves ------------------------------------------------
+        const int wr = wave >> 1, wc = wave & 1;   // 64 rows x 32 columns of both outputs
+        const int li = lane & 31, lg = lane >> 5;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[o][mt][r] = 0.f;
+        int cs = 0;
+        __syncthreads();   // slice 0 staged
+        for (int j = 0; j < T; ++j) {
+            const unsigned char* cA = smem + (j & 1) * SBUF_B;
+            const unsigned char* cB = cA + SA_B;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                uint4 a[3][2], b[2][3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        a[p][mt] = *reinterpret_cast<const uint4*>(cA + p * PLA + dn_plane_off(wr * 64 + mt * 32 + li, 2 * s + lg));
+#pragma unroll
+                    for (int o = 0; o < 2; ++o)
+                        b[o][p] = *reinterpret_cast<const uint4*>(cB + (o * 3 + p) * PLB + dn_plane_off(wc * 32 + li, 2 * s + lg));
+                }
+                constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};   // smallest terms first
+#pragma unroll
+                for (int p = 0; p < 6; ++p)
+#pragma unroll
+                    for (int o = 0; o < 2; ++o)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) acc[o][mt] = dn_mfma_bf16(a[PA[p]][mt], b[o][PB[p]], acc[o][mt]);
+            }
+            if (++cs == nsl) {   // unit complete: park both accumulator tiles
+                cs = 0;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int e = (wr * 64 + mt * 32 + dn_acc_row(r, lane)) * 64 + wc * 32 + li;
+                        sE0[e] = acc[0][mt][r]; sE1[e] = acc[1][mt][r];
+                        acc[0][mt][r] = 0.f; acc[1][mt][r] = 0.f;
+                    }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------------------------------------------- loader waves ----------------------------------------------------
+    DN_SETPRIO(DN_WS_LOADER_PRIO);
+    const int lt = tid - 256;
+    const int ob = lt >> 8, l8 = lt & 255;   // each loader thread stages the B operand of ONE output
+    // segment descriptors in registers (two segments in both users; a third is carried for generality)
+    const float* sp0 = g.a[0].p; const float* sp1 = g.a[1].p; const float* sp2 = g.a[2].p;
+    const float* sq0 = g.a[0].q; const float* sq1 = g.a[1].q; const float* sq2 = g.a[2].q;
+    const int sl0 = g.a[0].ld, sl1 = g.a[1].ld, sl2 = g.a[2].ld;
+    const int sw0 = g.a[0].w, sw1 = g.a[1].w, sw2 = g.a[2].w;
+    const float* sb0 = g.b[ob][0]; const float* sb1 = g.b[ob][1]; const float* sb2 = g.b[ob][2];
+    const float sg0 = g.bsign[ob][0], sg1 = g.bsign[ob][1], sg2 = g.bsign[ob][2];
+    const int nseg = g.nseg, ldb = g.ldb, Ncols = g.N;
+    const long long bms = g.b_mesh_stride;
+    // load cursor: tile, column half, segment, k offset; the next tile's descriptor is fetched one tile ahead
+    int lti = blockIdx.x, lh = 0, lseg = 0, lkoff = 0;
+    DnTile ltile = g.tiles[lti];
+    DnTile ltile_next = g.tiles[lti + G < ntiles ? lti + G : lti];
+    // mirror of the compute cursor and the parked unit being streamed out
+    int cti = blockIdx.x, ch = 0, cs = 0;
+    DnTile ctile = ltile, ctile_next = ltile_next;
+    int p_row0 = ctile.row0, p_nrows = 0, p_n0 = 0, p_next = DN_WS2_NP;
+    Ws2Aux AX;
+    ws2_aux_load<MODE>(g, DN_WS2_NP, lt, p_row0, p_nrows, p_n0, AX);   // dead piece
+
+    float4 Ra[2], Rq[2], Rb[2];
+    float Rsg = 0.f;
+
+#define WS2_ADVANCE(commit)                                                                                             \
+    do {                                                                                                                \
+        const int cw_ = lseg == 0 ? sw0 : (lseg == 1 ? sw1 : sw2);                                                      \
+        int nk_ = lkoff + DN_KB, ns_ = lseg, nh_ = lh, nt_ = lti;                                                       \
+        const bool se_ = nk_ >= cw_;                                                                                    \
+        nk_ = se_ ? 0 : nk_;                                                                                            \
+        ns_ = se_ ? ns_ + 1 : ns_;                                                                                      \
+        const bool ue_ = ns_ >= nseg;                                                                                   \
+        ns_ = ue_ ? 0 : ns_;                                                                                            \
+        nh_ = ue_ ? nh_ + 1 : nh_;                                                                                      \
+        const bool te_ = nh_ >= NH;                                                                                     \
+        nh_ = te_ ? 0 : nh_;                                                                                            \
+        nt_ = te_ ? nt_ + G : nt_;                                                                                      \
+        const bool ok_ = (commit) && nt_ < ntiles;                                                                      \
+        const bool sw_ = ok_ && te_;                                                                                    \
+        lkoff = ok_ ? nk_ : lkoff; lseg = ok_ ? ns_ : lseg; lh = ok_ ? nh_ : lh; lti = ok_ ? nt_ : lti;                 \
+        ltile.row0 = sw_ ? ltile_next.row0 : ltile.row0; ltile.nrows = sw_ ? ltile_next.nrows : ltile.nrows;            \
+        ltile.mesh = sw_ ? ltile_next.mesh : ltile.mesh;                                                                \
+        ltile_next = g.tiles[lti + G < ntiles ? lti + G : lti];                                                         \
+    } while (0)
+#define WS2_LOAD()                                                                                                      \
+    do {                                                                                                                \
+        const float* ap_ = lseg == 0 ? sp0 : (lseg == 1 ? sp1 : sp2);                                                   \
+        const float* aq_ = lseg == 0 ? sq0 : (lseg == 1 ? sq1 : sq2);                                                   \
+        const int ald_ = lseg == 0 ? sl0 : (lseg == 1 ? sl1 : sl2);                                                     \
+        const float* bp_ = (lseg == 0 ? sb0 : (lseg == 1 ? sb1 : sb2)) + (long long)ltile.mesh * bms;                   \
+        Rsg = lseg == 0 ? sg0 : (lseg == 1 ? sg1 : sg2);                                                                \
+        const int n0_ = lh * 64;                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                 \
+            const int idx = lt + i * 512;                                                                               \
+            const int row = idx >> 3, q = idx & 7;                                                                      \
+            const long long off = (long long)(ltile.row0 + (row < ltile.nrows ? row : 0)) * ald_ + lkoff + 4 * q;       \
+            Ra[i] = *reinterpret_cast<const float4*>(ap_ + off);                                                        \
+            if (HASQ) Rq[i] = *reinterpret_cast<const float4*>(aq_ + off);                                              \
+        }                                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                 \
+            long long boff;                                                                                             \
+            if (BCOLK) {                                                                                                \
+                const int idx = l8 + i * 256;                                                                           \
+                const int nrow = idx >> 3, q = idx & 7;                                                                 \
+                boff = (long long)(n0_ + nrow < Ncols ? n0_ + nrow : 0) * ldb + lkoff + 4 * q;                          \
+            } else {                                                                                                    \
+                const int pr = l8 & 15, q4 = l8 >> 4;                                                                   \
+                boff = (long long)(lkoff + 2 * pr + i) * ldb + (n0_ + 4 * q4 < Ncols ? n0_ + 4 * q4 : 0);               \
+            }                                                                                                           \
+            Rb[i] = *reinterpret_cast<const float4*>(bp_ + boff);                                                       \
+        }                                                                                                               \
+    } while (0)
+#define WS2_STAGE(buf)                                                                                                  \
+    do {                                                                                                                \
+        unsigned char* sA_ = (buf);                                                                                     \
+        unsigned char* sB_ = (buf) + SA_B + ob * 3 * PLB;                                                               \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                 \
+            const int idx = lt + i * 512;                                                                               \
+            const int row = idx >> 3, q = idx & 7;                                                                      \
+            float4 v = Ra[i];                                                                                           \
+            if (HASQ) v = dn_f4_mul(v, Rq[i]);                                                                          \
+            uint2 h_, m_, l_;                                                                                           \
+            dn_split3_f4(v, h_, m_, l_);                                                                                \
+            const int off = dn_plane_off(row, q >> 1) + (q & 1) * 8;                                                    \
+            *reinterpret_cast<uint2*>(sA_ + off) = h_;                                                                  \
+            *reinterpret_cast<uint2*>(sA_ + PLA + off) = m_;                                                            \
+            *reinterpret_cast<uint2*>(sA_ + 2 * PLA + off) = l_;                                                        \
+        }                                                                                                               \
+        if (BCOLK) {                                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                             \
+                const int idx = l8 + i * 256;                                                                           \
+                const int nrow = idx >> 3, q = idx & 7;                                                                 \
+                uint2 h_, m_, l_;                                                                                       \
+                dn_split3_f4(dn_f4_scale(Rb[i], Rsg), h_, m_, l_);                                                      \
+                const int off = dn_plane_off(nrow, q >> 1) + (q & 1) * 8;                                               \
+                *reinterpret_cast<uint2*>(sB_ + off) = h_;                                                              \
+                *reinterpret_cast<uint2*>(sB_ + PLB + off) = m_;                                                        \
+                *reinterpret_cast<uint2*>(sB_ + 2 * PLB + off) = l_;                                                    \
+            }                                                                                                           \
+        } else {   /* rows 2p and 2p+1 of column group q4 -> packed (k, k+1) dwords of the transposed planes */          \
+            const int pr = l8 & 15, q4 = l8 >> 4;                                                                       \
+            const float4 v0 = dn_f4_scale(Rb[0], Rsg), v1 = dn_f4_scale(Rb[1], Rsg);                                    \
+            const float e0[4] = {v0.x, v0.y, v0.z, v0.w}, e1[4] = {v1.x, v1.y, v1.z, v1.w};                             \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                             \
+                unsigned h_, m_, l_;                                                                                    \
+                dn_split3_pair(e0[e], e1[e], h_, m_, l_);                                                               \
+                const int off = dn_plane_off(4 * q4 + e, pr >> 2) + (pr & 3) * 4;                                       \
+                *reinterpret_cast<unsigned*>(sB_ + off) = h_;                                                           \
+                *reinterpret_cast<unsigned*>(sB_ + PLB + off) = m_;                                                     \
+                *reinterpret_cast<unsigned*>(sB_ + 2 * PLB + off) = l_;                                                 \
+            }                                                                                                           \
+        }                                                                                                               \
+    } while (0)
+
+    WS2_LOAD();
+    WS2_STAGE(smem);
+    WS2_ADVANCE(T > 1);
+    WS2_LOAD();                        // slice 1
+    __syncthreads();                   // slice 0 staged
+    for (int j = 0; j < T; ++j) {
+        WS2_STAGE(smem + ((j & 1) ^ 1) * SBUF_B);   // slice j+1 (the last iteration stages a stale copy nobody reads)
+        WS2_ADVANCE(j + 2 < T);
+        WS2_LOAD();                    // slice j+2
+        ws2_piece_out<MODE>(g, sE0, sE1, AX);   // its operands were requested an iteration ago
+        p_next = (p_next + 1 < DN_WS2_NP) ? p_next + 1 : DN_WS2_NP;
+        {   // the MFMA waves park the unit whose last slice they multiply in this iteration (selects only)
+            const bool park = ++cs == nsl;
+            p_row0 = park ? ctile.row0 : p_row0; p_nrows = park ? ctile.nrows : p_nrows; p_n0 = park ? ch * 64 : p_n0;
+            p_next = park ? 0 : p_next;
+            cs = park ? 0 : cs;
+            const int nh = park ? ch + 1 : ch;
+            const bool te = nh >= NH;
+            ch = te ? 0 : nh;
+            cti = te ? cti + G : cti;
+            ctile.row0 = te ? ctile_next.row0 : ctile.row0; ctile.nrows = te ? ctile_next.nrows : ctile.nrows;
+            const int cn = cti + G < ntiles ? cti + G : ntiles - 1;
+            ctile_next = g.tiles[cn];
+        }
+        ws2_aux_load<MODE>(g, p_next, lt, p_row0, p_nrows, p_n0, AX);
+        __syncthreads();
+    }
+#undef WS2_STAGE
+#undef WS2_LOAD
+#undef WS2_ADVANCE
+    for (; p_next < DN_WS2_NP; ++p_next) {   // flush the last parked unit
+        Ws2Aux A1;
+        ws2_aux_load<MODE>(g, p_next, lt, p_row0, p_nrows, p_n0, A1);
+        ws2_piece_out<MODE>(g, sE0, sE1, A1);
+    }
+}
+
+template <int MODE, bool BCOLK>
+static int ws2_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
+    const size_t smem = (size_t)(2 * (3 * 128 * 64 + 6 * 64 * 64) + 2 * 128 * 64 * 4);   // 160 KiB
+#ifndef DN_EMULATE
+    static bool lds_opt_in = false;
+    if (!lds_opt_in) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_ws2_kernel<MODE, BCOLK>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        lds_opt_in = true;
+    }
+#endif
+    int gx = dn_num_cus();
+    if (gx > ntiles) gx = ntiles;
+    DN_LAUNCH((rowgemm_ws2_kernel<MODE, BCOLK>), dim3(gx, 1, 1), dim3(768, 1, 1), smem, stream, g, ntiles);
+    return (int)hipGetLastError();
+}
+
+// eligibility of the two-output wave-specialised path
+static bool ws2_eligible(const RgArgs& g, int nout) {
+    if (!DN_RG_WS2 || !DN_RG_X3 || nout != 2 || !g.aligned || g.N < 64 || g.N % 4 != 0 || g.ldo % 4 != 0 || g.ldr % 4 != 0) return false;
+    if (g.mode != DN_EPI_GRADFEAT && g.mode != DN_EPI_GRADFEAT_BWD) return false;
+    int nsl = 0;
+    for (int s = 0; s < g.nseg; ++s) {
+        nsl += g.a[s].w / DN_KB;
+        if ((g.a[s].q != nullptr) != (g.mode == DN_EPI_GRADFEAT_BWD)) return false;
+    }
+    if (nsl < 5) return false;   // one deferred piece per slice must drain a parked unit: (nsl - 1) >= DN_WS2_NP
+    auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    if (!g.r0 || !g.r1 || !al(g.o0) || !al(g.o1) || !al(g.o2) || !al(g.r0) || !al(g.r1) || !al(g.r2)) return false;
+    if (g.mode == DN_EPI_GRADFEAT_BWD && (!g.r2 || !g.o1)) return false;
+    if ((g.o1 == nullptr) != (g.o2 == nullptr) && g.mode == DN_EPI_GRADFEAT) return false;
+    return true;
+}
+
 template <int MODE, bool BCOLK, bool FLAG>
 static int pt_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
     constexpr bool X3 = DN_PT_X3 != 0;
@@ -1366,6 +1689,12 @@ int dn_launch_rowgemm(const RgArgs& g, int ntiles, int nout, hipStream_t stream)
 #ifndef DN_NO_PERSIST
     if (pt_eligible(g, nout)) {
         err = pt_dispatch(g, ntiles, stream);
+        dn_prof_end(kind, stream, flops, bytes);
+        return err;
+    }
+    if (ws2_eligible(g, nout)) {
+        if (g.mode == DN_EPI_GRADFEAT) err = ck ? ws2_launch<DN_EPI_GRADFEAT, true>(g, ntiles, stream) : ws2_launch<DN_EPI_GRADFEAT, false>(g, ntiles, stream);
+        else err = ck ? ws2_launch<DN_EPI_GRADFEAT_BWD, true>(g, ntiles, stream) : ws2_launch<DN_EPI_GRADFEAT_BWD, false>(g, ntiles, stream);
         dn_prof_end(kind, stream, flops, bytes);
         return err;
     }

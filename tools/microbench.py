@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--cwidth", type=int, default=128)
     ap.add_argument("--keig", type=int, default=128)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--zeros", action="store_true", help="all-zero operands (DVFS probe: same instruction stream, least switching power)")
     a = ap.parse_args()
     REPS[0] = a.reps
     dev = torch.device("cuda:0")
@@ -45,7 +46,7 @@ def main():
     meshes, mb, gather, x3 = bench.build_batch(sizes, a.keig, dev, 0)
     V, C, K = sum(sizes), a.cwidth, a.keig
     g = torch.Generator(device="cpu").manual_seed(0)
-    R = lambda *s: torch.randn(*s, generator=g).to(dev)
+    R = (lambda *s: torch.zeros(*s, device=dev)) if a.zeros else (lambda *s: torch.randn(*s, generator=g).to(dev))
     x, y = R(V, C), R(V, C)
     W = R(C, C) / C ** 0.5
     W3 = R(C, 3 * C) / C ** 0.5
