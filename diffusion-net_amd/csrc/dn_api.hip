@@ -147,7 +147,7 @@ int gradfeat_bwd_weights(const dn_mesh_batch_t* mb, const float* ddots, const fl
     tn_b(g, gx, nullptr, C, C);
     tn_b(g, gy, nullptr, C, C);
     g.partial = partial;
-    g.group = dn_tn_global_group(mb->n_chunks);
+    g.group = dn_tn_global_group_mn(mb->n_chunks, g.M, g.N);
     tn_finish(g);
     DN_CHECK(dn_launch_tngemm(g, mb->n_chunks, st));
     DN_CHECK(dn_launch_reduce(partial, psum, dn_tn_npartial(mb->n_chunks, g.group), 4LL * C * C, 4LL * C * C, st));
@@ -155,7 +155,8 @@ int gradfeat_bwd_weights(const dn_mesh_batch_t* mb, const float* ddots, const fl
 }
 // y = act(sum_s x_s W[:, off_s:off_s+w_s]^T + b)
 int linear_fwd(const dn_mesh_batch_t* mb, const float* const* xs, const int* ws_, int nseg, const float* W, int ldw,
-               const float* b, int C_out, int mode, const uint8_t* mask, const float* resid, float* out, hipStream_t st) {
+               const float* b, int C_out, int mode, const uint8_t* mask, const float* resid, float* out, hipStream_t st,
+               unsigned long long rng_seed = 0) {
     RgArgs g = rg_new(mb);
     int off = 0;
     for (int s = 0; s < nseg; ++s) {
@@ -164,7 +165,7 @@ int linear_fwd(const dn_mesh_batch_t* mb, const float* const* xs, const int* ws_
         off += ws_[s];
     }
     g.ldb = ldw; g.b_colk = 1; g.N = C_out;
-    g.mode = mode; g.bias = b; g.mask = mask; g.scale = mask ? 2.f : 1.f; g.r0 = resid; g.ldr = C_out;
+    g.mode = mode; g.bias = b; g.mask = mask; g.rng_seed = mask ? 0ull : rng_seed; g.scale = (mask || rng_seed) ? 2.f : 1.f; g.r0 = resid; g.ldr = C_out;
     g.o0 = out; g.ldo = C_out;
     rg_finish(g, 1);
     return dn_launch_rowgemm(g, mb->n_tiles, 1, st);
@@ -187,13 +188,19 @@ int linear_bwd_weights(const dn_mesh_batch_t* mb, const float* d_a, int C_out, c
     tn_a(g, d_a, nullptr, C_out, C_out);
     for (int s = 0; s < nseg; ++s) tn_b(g, ins[s], nullptr, ws_[s], ws_[s]);
     g.partial = partial; g.colsum = db ? colsum : nullptr;
-    g.group = dn_tn_global_group(mb->n_chunks);
+    g.group = dn_tn_global_group_mn(mb->n_chunks, g.M, g.N);
     tn_finish(g);
     const int npart = dn_tn_npartial(mb->n_chunks, g.group);
     DN_CHECK(dn_launch_tngemm(g, mb->n_chunks, st));
     DN_CHECK(dn_launch_reduce(partial, dW, npart, (long long)g.M * g.N, (long long)g.M * g.N, st));
     if (db) DN_CHECK(dn_launch_reduce(colsum, db, npart, g.M, g.M, st));
     return 0;
+}
+// per-layer key of the in-kernel dropout (0 stays 0 = off; never maps a live seed to 0)
+unsigned long long layer_seed(unsigned long long seed, int layer) {
+    if (!seed) return 0ull;
+    unsigned long long s = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(layer + 1);
+    return s ? s : 0x9E3779B97F4A7C15ull;
 }
 int max_width(const dn_block_params_t* p) {
     int m = p->C;
@@ -474,7 +481,7 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
         float* dst = last ? out : (sv ? sv->h[j] : hbuf[j & 1]);
         DN_CHECK(linear_fwd(mb, in_ptr, in_w, nseg, p->W[j], p->widths[j], p->b[j], p->widths[j + 1],
                             last ? DN_EPI_BIAS_RESID : DN_EPI_BIAS_RELU, last ? nullptr : p->mask[j + 1],
-                            last ? x : nullptr, dst, st));
+                            last ? x : nullptr, dst, st, last ? 0ull : layer_seed(p->drop_seed, j + 1)));
         in_ptr[0] = dst; in_w[0] = p->widths[j + 1]; nseg = 1;
     }
     return 0;
@@ -522,7 +529,7 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
             float* nxt = da[j & 1];
             // d(pre-act of layer j-1) = (d_a W_j) * relu'(.) * dropout scale; h>0 <=> kept and active
             DN_CHECK(linear_bwd_input(mb, d_a, wo, p->W[j], wi, 0, wi, DN_EPI_MUL_DFAC, sv->h[j - 1],
-                                      p->mask[j] ? 2.f : 1.f, nxt, st));
+                                      (p->mask[j] || p->drop_seed) ? 2.f : 1.f, nxt, st));
             d_a = nxt;
         } else {
             const float* ins[3] = {x, sv->xd, sv->g};

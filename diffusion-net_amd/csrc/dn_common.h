@@ -109,6 +109,22 @@ __device__ __forceinline__ void dn_split3_f4(float4 v, uint2& hi, uint2& mid, ui
 // one slot for 32 consecutive rows hits all sixteen 16-byte positions of the 256-byte bank row once per 16-lane group.
 __device__ __forceinline__ int dn_plane_off(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
 
+// Dropout keep bits of the four consecutive columns 4*c4 .. 4*c4+3 of row `grow` (p = 1/2): bits 28..31 of a 32-bit
+// integer hash (two multiply-xorshift rounds, "lowbias32") of the group index keyed by the 64-bit seed.  One hash per float4;
+// every kernel path derives the same bit for the same (seed, row, column), so the mask does not depend on tiling.
+__device__ __forceinline__ unsigned dn_keep_bits(unsigned long long seed, long long grow, int c4, int groups_per_row) {
+    unsigned x = (unsigned)(grow * groups_per_row + c4) ^ (unsigned)seed;
+    x += (unsigned)(seed >> 32) * 0x9E3779B9u;
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x >> 28;
+}
+// the same bits as a 4-byte keep mask (byte e != 0 <=> column 4*c4+e kept), the format of an explicit uint8 mask load
+__device__ __forceinline__ unsigned dn_keep_bytes(unsigned bits) {
+    return (bits & 1u) | ((bits & 2u) << 7) | ((bits & 4u) << 14) | ((bits & 8u) << 21);
+}
+
 __device__ __forceinline__ int dn_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // A unit of row work: rows [row0,row0+nrows) of the concatenated vertex axis, all belonging to
@@ -169,6 +185,7 @@ struct RgArgs {
     const float* r0; const float* r1; const float* r2; int ldr;
     const float* rowv;
     const uint8_t* mask;
+    unsigned long long rng_seed;   // != 0 with mask == null: Bernoulli(1/2) keep bits drawn in the epilogue (dn_keep_bits)
     float scale;
     int acct_rows;         // host-side accounting only (rows covered by the launch)
 };
@@ -212,6 +229,17 @@ static inline int dn_tn_npartial(int nchunks, int group) { return (nchunks + (gr
 #define DN_TN_TARGET_PARTIALS 512
 #endif
 static inline int dn_tn_global_group(int nchunks) { int g = (nchunks + DN_TN_TARGET_PARTIALS - 1) / DN_TN_TARGET_PARTIALS; return g < 1 ? 1 : g; }
+// the same for an M x N result of several 128 x 128 output tiles: every (partial, tile) pair is a workgroup, so the partial count --
+// and with it the partial-result traffic, 2 x 4 M N bytes each -- shrinks with the tile count (never below 128 partials; never
+// more partials than dn_tn_global_group(nchunks) gives, which is what the workspace is sized for)
+static inline int dn_tn_global_group_mn(int nchunks, int M, int N) {
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    int target = DN_TN_TARGET_PARTIALS / (tiles < 1 ? 1 : tiles);
+    if (target < 128) target = 128;
+    int g = (nchunks + target - 1) / target;
+    const int g0 = dn_tn_global_group(nchunks);
+    return g < g0 ? g0 : g;
+}
 
 // ---------------------------------------------------------------------------------------
 // CSR gather (dn_sparse.hip)

@@ -57,6 +57,12 @@ __device__ __forceinline__ void rg_epilogue_tile(const RgArgs& g, int row_base, 
         if (g.mask) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) v1[r] = g.mask[ir[r]] ? g.scale : 0.f;
+        } else if (g.rng_seed) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long rr = row_base + (ok[r] ? dn_acc_row(r, lane) : 0);
+                v1[r] = ((dn_keep_bits(g.rng_seed, rr, cc >> 2, (g.N + 3) >> 2) >> (cc & 3)) & 1u) ? g.scale : 0.f;
+            }
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) v1[r] = 1.f;
@@ -672,7 +678,10 @@ __device__ __forceinline__ void pt_piece_load(const RgArgs& g, const float* sE, 
     constexpr bool need_bias = (MODE == DN_EPI_STORE && FLAG) || MODE == DN_EPI_BIAS_RELU || MODE == DN_EPI_BIAS_RESID;
     if (need_r0) P.a0 = *reinterpret_cast<const float4*>(g.r0 + roff);
     if (need_bias) P.bias = *reinterpret_cast<const float4*>(g.bias + ccol);
-    if (MODE == DN_EPI_BIAS_RELU && FLAG) P.mk = *reinterpret_cast<const uint32_t*>(g.mask + roff);
+    if (MODE == DN_EPI_BIAS_RELU && FLAG) {   // explicit mask or drawn bits, without a branch: the load goes to a valid address either way
+        const uint32_t ld = *reinterpret_cast<const uint32_t*>(g.mask ? g.mask + roff : reinterpret_cast<const uint8_t*>(g.bias));
+        P.mk = g.mask ? ld : dn_keep_bytes(dn_keep_bits(g.rng_seed, grow, ccol >> 2, (g.N + 3) >> 2));
+    }
     if (MODE == DN_EPI_MASS_ADD) P.rs = g.rowv[grow];
 }
 
@@ -1015,7 +1024,10 @@ __device__ __forceinline__ void ws_aux_load(const RgArgs& g, int piece, int lt, 
     constexpr bool need_r0 = MODE == DN_EPI_BIAS_RESID || MODE == DN_EPI_MUL_DFAC || MODE == DN_EPI_ADD ||
                              MODE == DN_EPI_DTANH || MODE == DN_EPI_MASS_ADD;
     if (need_r0) A.a0 = *reinterpret_cast<const float4*>(g.r0 + roff);
-    if (MODE == DN_EPI_BIAS_RELU && FLAG) A.mk = *reinterpret_cast<const uint32_t*>(g.mask + roff);
+    if (MODE == DN_EPI_BIAS_RELU && FLAG) {   // explicit mask or drawn bits (see pt_piece_load)
+        const uint32_t ld = *reinterpret_cast<const uint32_t*>(g.mask ? g.mask + roff : reinterpret_cast<const uint8_t*>(g.bias));
+        A.mk = g.mask ? ld : dn_keep_bytes(dn_keep_bits(g.rng_seed, grow, ccol >> 2, (g.N + 3) >> 2));
+    }
     if (MODE == DN_EPI_MASS_ADD) A.rs = g.rowv[grow];
 }
 
@@ -1665,7 +1677,7 @@ static int pt_dispatch(const RgArgs& g, int ntiles, hipStream_t stream) {
             if (g.bias) return ck ? pt_launch<DN_EPI_STORE, true, true>(g, ntiles, stream) : pt_launch<DN_EPI_STORE, false, true>(g, ntiles, stream);
             return ck ? pt_launch<DN_EPI_STORE, true, false>(g, ntiles, stream) : pt_launch<DN_EPI_STORE, false, false>(g, ntiles, stream);
         case DN_EPI_BIAS_RELU:
-            return g.mask ? pt_launch<DN_EPI_BIAS_RELU, true, true>(g, ntiles, stream) : pt_launch<DN_EPI_BIAS_RELU, true, false>(g, ntiles, stream);
+            return (g.mask || g.rng_seed) ? pt_launch<DN_EPI_BIAS_RELU, true, true>(g, ntiles, stream) : pt_launch<DN_EPI_BIAS_RELU, true, false>(g, ntiles, stream);
         case DN_EPI_BIAS_RESID: return pt_launch<DN_EPI_BIAS_RESID, true, false>(g, ntiles, stream);
         case DN_EPI_MUL_DFAC: return pt_launch<DN_EPI_MUL_DFAC, false, false>(g, ntiles, stream);
         case DN_EPI_ADD: return pt_launch<DN_EPI_ADD, false, false>(g, ntiles, stream);

@@ -33,6 +33,7 @@ class FlatParams:
                 self.flat[o:o + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat[o:o + n].view(p.shape)
                 p.grad = self.grad[o:o + n].view(p.shape)
+                p._dn_grad_sink = p.grad   # the HIP ops accumulate here directly (ops._deliver), one launch per op
         self.params, self.offsets, self.sizes = params, offs, sizes
         self.master = torch.nn.Parameter(self.flat, requires_grad=True)   # what the optimizer updates
         self.master.grad = self.grad
@@ -47,6 +48,7 @@ class FlatParams:
                     p.data = self.flat[o:o + n].view(p.shape)
                 if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + o * self.grad.element_size():
                     p.grad = self.grad[o:o + n].view(p.shape)
+                p._dn_grad_sink = p.grad
 
     def zero_grad(self):
         self.grad.zero_()

@@ -169,18 +169,22 @@ class DiffusionNetBlock(nn.Module):
         self.mlp = MiniMLP([self.MLP_C] + list(mlp_hidden_dims) + [C_width], dropout=dropout)
         self._cfg = ops.BlockConfig(C_width, self.mlp.layer_sizes, with_gradient_features, with_gradient_rotations)
         self.mask_provider = None   # test hook: callable(layer_index, shape, device) -> uint8 keep mask
+        self.drop_seed_provider = None   # test hook: callable() -> int seed of the in-kernel dropout
 
     def _dropout_masks(self, n_rows, device):
+        """nn.Dropout(p=.5) on the inputs of MLP layers 1.. (layers.py:143-147) in train mode.  Default: a 64-bit seed drawn
+        from torch's CPU generator (reproducible under torch.manual_seed); the HIP epilogues derive the keep bits from it, no
+        mask tensor exists.  With a ``mask_provider`` (tests): explicit uint8 keep masks."""
         if not (self.training and self.dropout):
             return None
+        if self.mask_provider is None:
+            if self.drop_seed_provider is not None:
+                return int(self.drop_seed_provider())
+            return int(torch.randint(1, 2 ** 62, (1,), dtype=torch.int64).item())
         masks = [None]
         for i in range(1, self._cfg.n_mlp):
             shape = (n_rows, self._cfg.widths[i])
-            if self.mask_provider is not None:
-                m = self.mask_provider(i, shape, device).to(device=device, dtype=torch.uint8).contiguous()
-            else:
-                m = torch.empty(shape, dtype=torch.uint8, device=device).bernoulli_(0.5)
-            masks.append(m)
+            masks.append(self.mask_provider(i, shape, device).to(device=device, dtype=torch.uint8).contiguous())
         return masks
 
     def forward_packed(self, x2d: torch.Tensor, mb: MeshBatch) -> torch.Tensor:

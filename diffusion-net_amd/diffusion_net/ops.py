@@ -169,10 +169,28 @@ class GradFeatFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------
 # nn.Linear on the row axis (first_lin / last_lin / stand-alone MiniMLP layers)
 # ----------------------------------------------------------------------------------------------
+# ----------------------------------------------------------------------------------------------
+# gradient sinks: a parameter may carry ``_dn_grad_sink`` (set by dist.FlatParams: its slice of the flat
+# gradient bucket).  Backward then ACCUMULATES the parameter gradients of a whole op into their sinks with
+# one multi-tensor add and returns None for them, instead of handing ~10 small tensors per block to
+# autograd's AccumulateGrad (one 5 us add kernel each: 40 launches per step of the 4-block network).
+# ----------------------------------------------------------------------------------------------
+def _sinks(params):
+    return [getattr(p, "_dn_grad_sink", None) if p is not None else None for p in params]
+
+
+def _deliver(sinks, grads):
+    dst = [s for s, g in zip(sinks, grads) if s is not None and g is not None]
+    if dst:
+        torch._foreach_add_(dst, [g for s, g in zip(sinks, grads) if s is not None and g is not None])
+    return [g if s is None else None for s, g in zip(sinks, grads)]
+
+
 class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b, mb):
         _hip.require_device(x)
+        ctx.sinks = _sinks([W, b])
         x, W, b = _f32c(x), _f32c(W), _f32c(b)
         out = torch.empty(x.shape[0], W.shape[0], dtype=torch.float32, device=x.device)
         _hip.check(_hip.lib().dn_linear_fwd_f32(mb.ref(), x.data_ptr(), W.shape[1], W.data_ptr(), b.data_ptr(), W.shape[0],
@@ -194,6 +212,7 @@ class LinearFn(torch.autograd.Function):
         _hip.check(L.dn_linear_bwd_f32(mb.ref(), d_out.data_ptr(), x.data_ptr(), W.data_ptr(), C_in, C_out, _hip.ptr(d_x),
                                        dW.data_ptr(), db.data_ptr(), ws.data_ptr(), n, _hip.stream_of(d_out)),
                    "dn_linear_bwd_f32")
+        dW, db = _deliver(ctx.sinks, [dW, db])
         return d_x, dW, db, None
 
 
@@ -216,10 +235,32 @@ def _params_struct(cfg: BlockConfig, time, A_re, A_im, Ws, bs, masks):
     for i, w in enumerate(cfg.widths):
         p.widths[i] = w
     p.time, p.A_re, p.A_im = time.data_ptr(), _hip.ptr(A_re), _hip.ptr(A_im)
+    seeded = isinstance(masks, int)   # in-kernel dropout: `masks` is the 64-bit seed
+    p.drop_seed = masks if seeded else 0
     for i in range(cfg.n_mlp):
         p.W[i], p.b[i] = Ws[i].data_ptr(), bs[i].data_ptr()
-        p.mask[i] = _hip.ptr(masks[i]) if masks is not None else None
+        p.mask[i] = _hip.ptr(masks[i]) if (masks is not None and not seeded) else None
     return p
+
+
+def keep_mask_reference(seed: int, layer: int, n_rows: int, width: int):
+    """numpy restatement of the in-kernel dropout bits (dn_common.h: dn_keep_bits, dn_api.hip: layer_seed) -- what
+    ``mask[layer]`` would have to be for the explicit-mask path to reproduce the seeded one.  Test infrastructure."""
+    import numpy as np
+    M64, M32 = (1 << 64) - 1, np.uint64(0xFFFFFFFF)
+    s = (seed + 0x9E3779B97F4A7C15 * (layer + 1)) & M64
+    s = s or 0x9E3779B97F4A7C15
+    groups = (width + 3) // 4
+    rows = np.arange(n_rows, dtype=np.uint64)[:, None]
+    c4 = np.arange(groups, dtype=np.uint64)[None, :]
+    x = ((rows * np.uint64(groups) + c4) & M32) ^ np.uint64(s & 0xFFFFFFFF)
+    x = (x + np.uint64(((s >> 32) * 0x9E3779B9) & 0xFFFFFFFF)) & M32
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & M32
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & M32
+    x ^= x >> np.uint64(16)
+    bits = (x >> np.uint64(28)).astype(np.uint8)
+    keep = np.stack([(bits >> e) & 1 for e in range(4)], axis=-1).reshape(n_rows, groups * 4)[:, :width]
+    return torch.from_numpy(np.ascontiguousarray(keep))
 
 
 class BlockFn(torch.autograd.Function):
@@ -228,6 +269,7 @@ class BlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mb, cfg, masks, x, time, A_re, A_im, *wb):
         _hip.require_device(x)
+        ctx.sinks = _sinks([time, A_re, A_im, *wb])
         L = _hip.lib()
         x, time = _f32c(x), _f32c(time)
         A_re = _f32c(A_re) if A_re is not None else None
@@ -301,6 +343,7 @@ class BlockFn(torch.autograd.Function):
         wb = []
         for dw, db in zip(dWs, dbs):
             wb += [dw, db]
+        d_time, dA_re, dA_im, *wb = _deliver(ctx.sinks, [d_time, dA_re, dA_im, *wb])
         return (None, None, None, d_x, d_time, dA_re, dA_im, *wb)
 
 

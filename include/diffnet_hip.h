@@ -58,7 +58,11 @@ typedef struct dn_block_params {
     const float* W[DN_MAX_MLP_LAYERS];     /* [widths[i+1], widths[i]] */
     const float* b[DN_MAX_MLP_LAYERS];     /* [widths[i+1]] */
     const uint8_t* mask[DN_MAX_MLP_LAYERS];/* mask[i], i>=1: dropout keep-mask of layer i's INPUT [v_total, widths[i]]
-                                              (layers.py:143-147), NULL = no dropout; kept values are scaled by 2 */
+                                              (layers.py:143-147), NULL = no mask given; kept values are scaled by 2 */
+    uint64_t drop_seed;                    /* != 0 and mask[i] == NULL: nn.Dropout(p=.5) of layer i's input is drawn IN the
+                                              producing kernel's epilogue, keep = bit of hash(drop_seed, i, row, column): no mask
+                                              tensor is written or read (the backward needs none: a saved activation is > 0
+                                              exactly where it was kept and active).  0 = no dropout where mask[i] == NULL. */
 } dn_block_params_t;
 
 /* Activations the forward saves for the backward (caller-allocated). */

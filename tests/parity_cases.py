@@ -271,6 +271,63 @@ def run_determinism(device, V=300, K=16, C=32, seed=2):
         assert torch.equal(a, b)
 
 
+def run_grad_sinks(device, V=300, K=16, C=32, seed=4):
+    """FlatParams registers gradient sinks: the ops accumulate parameter gradients straight into the flat bucket.
+    Two backward passes must leave exactly grad1 + grad2 of the plain autograd path there (accumulate, not assign)."""
+    from diffusion_net.dist import FlatParams
+    grads = []
+    for use_flat in (False, True):
+        torch.manual_seed(seed)
+        model = diffusion_net.layers.DiffusionNet(3, 4, C_width=C, N_block=2, dropout=False).to(device)
+        synthetic.randomize_times(model.state_dict(), seed=seed)
+        flat = FlatParams(model) if use_flat else None
+        m = synthetic.make_mesh_operators(V, K, seed=seed)
+        kw = dict(evals=m["evals"].to(device), evecs=m["evecs"].to(device), gradX=m["gradX"].to(device), gradY=m["gradY"].to(device))
+        for scale in (1.0, 0.5):   # two accumulating backward passes
+            out = model(m["verts"].to(device), m["mass"].to(device), **kw)
+            (out.square().sum() * scale).backward()
+        if use_flat:
+            assert all(p.grad.data_ptr() == flat.grad.data_ptr() + o * 4 for p, o in zip(flat.params, flat.offsets))
+        grads.append([p.grad.detach().cpu().clone() for p in model.parameters()])
+    for a, b in zip(*grads):
+        assert helpers.rel_l2(b, a) < 1e-6, helpers.rel_l2(b, a)
+
+
+def run_inkernel_dropout(device, sizes=(300, 140), K=32, C=128, seed=6):
+    """Seeded in-kernel dropout == explicit-mask path fed the restated keep bits, bit for bit (forward and gradients),
+    on every kernel path the shape selects; the bits are a fair coin and different seeds give different masks."""
+    from diffusion_net import ops
+    drop_seed = 0x1234567887654321
+    res = []
+    for explicit in (False, True):
+        torch.manual_seed(seed)
+        model = diffusion_net.layers.DiffusionNet(3, 5, C_width=C, N_block=2, dropout=True)
+        synthetic.randomize_times(model.state_dict(), seed=seed)
+        model.to(device).train(True)
+        for bi, blk in enumerate(model.blocks):
+            s_b = drop_seed + bi
+            if explicit:
+                blk.mask_provider = (lambda sb: (lambda i, shape, dev: ops.keep_mask_reference(sb, i, shape[0], shape[1])))(s_b)
+            else:
+                blk.drop_seed_provider = (lambda sb: (lambda: sb))(s_b)
+        meshes, feats = make_ragged(sizes, K, 3, seed)
+        mb = pack(meshes, device)
+        x = torch.cat(feats, 0).to(device).requires_grad_(True)
+        out = model.forward_packed(x, mb, None)
+        out.square().sum().backward()
+        res.append([out.detach().cpu(), x.grad.cpu()] + [p.grad.cpu() for p in model.parameters()])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    m = ops.keep_mask_reference(drop_seed, 1, 4096, C).float()
+    sig = lambda n: 0.5 / n ** 0.5   # standard deviation of the mean of n fair coin flips
+    assert abs(float(m.mean()) - 0.5) < 5 * sig(m.numel())
+    assert float((m.mean(0) - 0.5).abs().max()) < 5 * sig(m.shape[0]) and float((m.mean(1) - 0.5).abs().max()) < 5 * sig(m.shape[1])
+    lag = lambda a, b: abs(float(((2 * a - 1) * (2 * b - 1)).mean()))   # correlation of neighbouring bits
+    assert lag(m[:, 1:], m[:, :-1]) < 5 / m.numel() ** 0.5 and lag(m[1:], m[:-1]) < 5 / m.numel() ** 0.5
+    assert not torch.equal(ops.keep_mask_reference(drop_seed, 1, 64, C), ops.keep_mask_reference(drop_seed, 2, 64, C))
+    assert not torch.equal(ops.keep_mask_reference(drop_seed, 1, 64, C), ops.keep_mask_reference(drop_seed + 1, 1, 64, C))
+
+
 def run_nll(device, n=1234, C=8, seed=0):
     g = torch.Generator().manual_seed(seed)
     logits = torch.randn(n, C, generator=g)

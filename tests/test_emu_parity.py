@@ -73,3 +73,14 @@ def test_real_mesh_pipeline_on_emulator(emu):
 def test_determinism_on_emulator(emu):
     import parity_cases
     parity_cases.run_determinism(emu)
+
+
+def test_gradient_sinks_on_emulator(emu):
+    import parity_cases
+    parity_cases.run_grad_sinks(emu)
+
+
+@pytest.mark.parametrize("C", [128, 40])
+def test_inkernel_dropout_on_emulator(emu, C):
+    import parity_cases
+    parity_cases.run_inkernel_dropout(emu, C=C)

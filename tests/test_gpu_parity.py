@@ -83,6 +83,17 @@ def test_bitwise_determinism(dev):
     parity_cases.run_determinism(dev, V=5000, K=64, C=128)
 
 
+@pytest.mark.parametrize("C", [128, 40])
+def test_inkernel_dropout_matches_explicit_masks(dev, C):
+    import parity_cases
+    parity_cases.run_inkernel_dropout(dev, sizes=(3000, 1400), K=64, C=C)
+
+
+def test_gradient_sinks_accumulate_into_flat_bucket(dev):
+    import parity_cases
+    parity_cases.run_grad_sinks(dev, V=3000, K=64, C=128)
+
+
 def test_headline_shape_against_fp32_and_fp64_oracle(dev):
     """BASELINE north-star shape: >=10k-vertex meshes, C_width=128, K=128, 4 blocks, ragged batch."""
     import diffusion_net
