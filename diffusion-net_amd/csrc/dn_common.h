@@ -14,6 +14,7 @@
 #define DN_DYN_SMEM(name) char* name = dnemu::dyn_smem()
 #define DN_RESTRICT
 #define DN_WAVES_PER_EU(n)
+#define DN_MIN_WAVES_PER_EU(n)
 #define DN_SETPRIO(n) do {} while (0)
 #else
 #include <hip/hip_runtime.h>
@@ -23,6 +24,7 @@
 #define DN_RESTRICT __restrict__
 // occupancy the kernel is designed for: stops the scheduler from trading instruction order for registers it cannot use
 #define DN_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#define DN_MIN_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
 #define DN_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 #endif
 

@@ -469,8 +469,16 @@ __device__ __forceinline__ void rg_compute_x3(const unsigned char* sA, const uns
                                                       wc * NT * 32, li, ls, acc);                                              \
         else rg_compute<TN, MT, NT, NOUT, BCOLK>((buf), (buf) + SA, wr * MT * 32, wc * NT * 32, li, ls, acc);                  \
     } while (0)
+// DN_RG2_SINGLE=1: the split-bf16 two-output configuration keeps ONE 72 KiB slice buffer, so that two workgroups share a CU
+// (<= 128 VGPRs) and one's MFMAs run under the other's loads and epilogue; two barriers per slice.  Measured 267 us vs 180 us
+// for the double-buffered form (45-71 spilled registers at the 128 cap) -> off.
+#ifndef DN_RG2_SINGLE
+#define DN_RG2_SINGLE 0
+#endif
+constexpr bool rg_is_x3(int TN, int NTHR, int NOUT, bool ALIGNED) { return DN_RG_X3 && ALIGNED && NOUT == 2 && TN == 128 && NTHR == 512; }
 template <int TN, int WR, int WC, int NOUT, int MODE, bool ALIGNED, bool BCOLK>
-__global__ __launch_bounds__(WR* WC * 64) void rowgemm_kernel(RgArgs g) {
+__global__ __launch_bounds__(WR* WC * 64) DN_MIN_WAVES_PER_EU((rg_is_x3(TN, WR * WC * 64, NOUT, ALIGNED) && DN_RG2_SINGLE) ? 4 : 1)
+void rowgemm_kernel(RgArgs g) {
     constexpr int NTHR = WR * WC * 64;
     constexpr int MT = DN_TM / (32 * WR);
     constexpr int NT = TN / (32 * WC);
@@ -514,6 +522,19 @@ __global__ __launch_bounds__(WR* WC * 64) void rowgemm_kernel(RgArgs g) {
     // The steady-state body has no branch, so the LDS writes and the global loads can be scheduled under the MFMAs.
     int seg = 0, koff = 0;
     rg_load<TN, NTHR, NOUT, ALIGNED, BCOLK, HASQ, A_IT, B_IT, PAIRK>(g, tile, n0, seg, koff, tid, R);
+    if constexpr (X3 && DN_RG2_SINGLE) {
+        for (int s1 = 0; s1 < nslices; ++s1) {
+            RG_STORE(smem);                       // slice s1
+            if (s1 + 1 < nslices) {               // slice s1+1 into the registers just freed; in flight under the MFMAs
+                koff += DN_KB;
+                if (koff >= g.a[seg].w) { koff = 0; ++seg; }
+                rg_load<TN, NTHR, NOUT, ALIGNED, BCOLK, HASQ, A_IT, B_IT, PAIRK>(g, tile, n0, seg, koff, tid, R);
+            }
+            __syncthreads();
+            RG_COMPUTE(smem);
+            __syncthreads();
+        }
+    } else {
     RG_STORE(smem);
     if (nslices > 1) {
         koff += DN_KB;
@@ -549,6 +570,7 @@ __global__ __launch_bounds__(WR* WC * 64) void rowgemm_kernel(RgArgs g) {
     {
         float* cur = smem + (sl & 1) * SBUF;
         RG_COMPUTE(cur);
+    }
     }
 
     // ---------------- epilogue ----------------
@@ -588,7 +610,7 @@ template <int TN, int WR, int WC, int NOUT, int MODE, bool ALIGNED, bool BCOLK>
 static int rg_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
     const int ncol = (g.N + TN - 1) / TN;
     constexpr bool X3 = DN_RG_X3 && ALIGNED && NOUT == 2 && TN == 128 && WR * WC == 8;
-    const size_t smem = X3 ? (size_t)2 * (DN_TM * 64 * 3 + NOUT * 128 * 64 * 3)
+    const size_t smem = X3 ? (size_t)(DN_RG2_SINGLE ? 1 : 2) * (DN_TM * 64 * 3 + NOUT * 128 * 64 * 3)
                            : (size_t)2 * (DN_TM * DN_KB + NOUT * DN_KB * TN) * sizeof(float);
 #ifndef DN_EMULATE
     static bool lds_opt_in = false;   // idempotent: allow > 64 KiB of dynamic LDS for this instantiation
