@@ -475,6 +475,9 @@ __device__ __forceinline__ void rg_compute_x3(const unsigned char* sA, const uns
 #ifndef DN_RG2_SINGLE
 #define DN_RG2_SINGLE 0
 #endif
+#ifndef DN_RG2_VEC_EPI
+#define DN_RG2_VEC_EPI 1   // parked float4 epilogue of the two-output split-bf16 kernel (0: per-element dword epilogue)
+#endif
 constexpr bool rg_is_x3(int TN, int NTHR, int NOUT, bool ALIGNED) { return DN_RG_X3 && ALIGNED && NOUT == 2 && TN == 128 && NTHR == 512; }
 template <int TN, int WR, int WC, int NOUT, int MODE, bool ALIGNED, bool BCOLK>
 __global__ __launch_bounds__(WR* WC * 64) DN_MIN_WAVES_PER_EU((rg_is_x3(TN, WR * WC * 64, NOUT, ALIGNED) && DN_RG2_SINGLE) ? 4 : 1)
@@ -589,6 +592,71 @@ void rowgemm_kernel(RgArgs g) {
         return;
     }
 #endif
+    if constexpr (X3 && DN_RG2_VEC_EPI) {
+        // Two-output split-bf16 configuration: the slice buffers are dead now, so both 128 x 128 accumulator tiles are parked in
+        // them (2 x 64 KiB of the 144 KiB) and the epilogue runs on float4 pieces with coalesced 16-byte loads and stores --
+        // 8 pieces x (2-3 loads + 2-3 stores) per thread instead of 32 elements x (2-3 dword loads + 2-3 dword stores).
+        const bool vec_ok = (((uintptr_t)g.o0 | (uintptr_t)g.o1 | (uintptr_t)g.o2 | (uintptr_t)g.r0 | (uintptr_t)g.r1 | (uintptr_t)g.r2) & 15) == 0 &&
+                            g.ldo % 4 == 0 && g.ldr % 4 == 0 && g.N % 4 == 0;
+        if (vec_ok) {
+            float* sE0 = smem;
+            float* sE1 = smem + 128 * 128;
+            __syncthreads();   // every wave is done with the slice buffers
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int e = ((wr * MT + mt) * 32 + dn_acc_row(r, lane)) * 128 + wc * 32 + li;
+                    sE0[e] = acc[0][mt][0][r];
+                    sE1[e] = acc[NOUT - 1][mt][0][r];
+                }
+            __syncthreads();
+            constexpr int NPC = 128 * 128 / 4 / NTHR;   // 8 pieces per thread
+            float4 r0[NPC], r1[NPC], r2[NPC];
+            long long off[NPC];
+            bool ok[NPC];
+#pragma unroll
+            for (int k = 0; k < NPC; ++k) {
+                const int idx = tid + k * NTHR;
+                const int row = idx >> 5, c4 = idx & 31;
+                const int col = n0 + 4 * c4;
+                ok[k] = row < tile.nrows && col < g.N;
+                const long long grow = tile.row0 + (ok[k] ? row : 0);
+                const int ccol = ok[k] ? col : 0;
+                off[k] = grow * g.ldo + ccol;
+                const long long roff = grow * g.ldr + ccol;
+                r0[k] = *reinterpret_cast<const float4*>(g.r0 + roff);
+                r1[k] = *reinterpret_cast<const float4*>(g.r1 + roff);
+                if (MODE == DN_EPI_GRADFEAT_BWD) r2[k] = *reinterpret_cast<const float4*>(g.r2 + roff);
+            }
+#pragma unroll
+            for (int k = 0; k < NPC; ++k) {
+                const int idx = tid + k * NTHR;
+                const int row = idx >> 5, c4 = idx & 31;
+                const float4 a0 = *reinterpret_cast<const float4*>(&sE0[row * 128 + 4 * c4]);
+                const float4 a1 = *reinterpret_cast<const float4*>(&sE1[row * 128 + 4 * c4]);
+                if (MODE == DN_EPI_GRADFEAT) {
+                    const float4 y = make_float4(tanhf(r0[k].x * a0.x + r1[k].x * a1.x), tanhf(r0[k].y * a0.y + r1[k].y * a1.y),
+                                                 tanhf(r0[k].z * a0.z + r1[k].z * a1.z), tanhf(r0[k].w * a0.w + r1[k].w * a1.w));
+                    if (ok[k]) {
+                        *reinterpret_cast<float4*>(g.o0 + off[k]) = y;
+                        if (g.o1) {
+                            *reinterpret_cast<float4*>(g.o1 + off[k]) = a0;
+                            *reinterpret_cast<float4*>(g.o2 + off[k]) = a1;
+                        }
+                    }
+                } else {
+                    const float4 y0 = make_float4(a0.x + r0[k].x * r1[k].x, a0.y + r0[k].y * r1[k].y, a0.z + r0[k].z * r1[k].z, a0.w + r0[k].w * r1[k].w);
+                    const float4 y1 = make_float4(a1.x + r0[k].x * r2[k].x, a1.y + r0[k].y * r2[k].y, a1.z + r0[k].z * r2[k].z, a1.w + r0[k].w * r2[k].w);
+                    if (ok[k]) {
+                        *reinterpret_cast<float4*>(g.o0 + off[k]) = y0;
+                        *reinterpret_cast<float4*>(g.o1 + off[k]) = y1;
+                    }
+                }
+            }
+            return;
+        }
+    }
     if (wave_active) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
