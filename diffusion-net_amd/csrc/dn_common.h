@@ -136,16 +136,27 @@ struct DnTile {
 };
 
 __device__ __forceinline__ float4 dn_f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// Plain multiplies on purpose.  An explicit two-element vector multiply here (v_pk_mul_f32 with a broadcast operand in src1,
+// `op_sel_hi:[1,0]`) produced INTERMITTENTLY wrong low halves on gfx950 / ROCm 7.2: one stale bf16 pair in a few launches per
+// thousand at small sizes, in every launch at the benchmark size -- a whole output column of a tile off by ~1e-1 relative, found
+// by tools/determinism_stress.py, invisible to the 2e-4 gradient tolerance.  -DDN_F4_PACKED restores that form for re-testing;
+// the packed forms the compiler's SLP pass emits from the code below were bitwise stable in the same stress runs.
 __device__ __forceinline__ float4 dn_f4_mul(float4 a, float4 b) {
-#if defined(DN_EMULATE)
-    return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
-#else   // two v_pk_mul_f32
+#if defined(DN_F4_PACKED) && !defined(DN_EMULATE)   // experiment switch: explicit two-element vector multiplies
     typedef float dn_f2 __attribute__((ext_vector_type(2)));
     const dn_f2 lo = dn_f2{a.x, a.y} * dn_f2{b.x, b.y}, hi = dn_f2{a.z, a.w} * dn_f2{b.z, b.w};
     return make_float4(lo.x, lo.y, hi.x, hi.y);
+#else
+    return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
 #endif
 }
-__device__ __forceinline__ float4 dn_f4_scale(float4 a, float s) { return dn_f4_mul(a, make_float4(s, s, s, s)); }
+__device__ __forceinline__ float4 dn_f4_scale(float4 a, float s) {
+#if defined(DN_F4_PACKED) && !defined(DN_EMULATE)
+    return dn_f4_mul(a, make_float4(s, s, s, s));
+#else
+    return make_float4(a.x * s, a.y * s, a.z * s, a.w * s);
+#endif
+}
 __device__ __forceinline__ float dn_f4_get(const float4& v, int t) {
     return t == 0 ? v.x : (t == 1 ? v.y : (t == 2 ? v.z : v.w));
 }

@@ -82,7 +82,7 @@ def pack(meshes, device, with_grad=True, chunk_rows=None):
 
 
 def run_ragged_net(device, sizes=(130, 257, 64), K=24, C=32, C_in=3, C_out=5, N_block=2, outputs_at="vertices",
-                   chunk_rows=None, seed=3, dropout=False):
+                   chunk_rows=None, seed=3, dropout=False, fp64_bracket=False):
     torch.manual_seed(seed)
     model = diffusion_net.layers.DiffusionNet(C_in, C_out, C_width=C, N_block=N_block, outputs_at=outputs_at, dropout=dropout)
     sd = synthetic.randomize_times(model.state_dict(), seed=seed)
@@ -111,36 +111,53 @@ def run_ragged_net(device, sizes=(130, 257, 64), K=24, C=32, C_in=3, C_out=5, N_
     (out * w.to(device)).sum().backward()
 
     # oracle: one mesh at a time, gradients summed
-    ref_out, ref_grads, off_out = [], None, 0
-    for m, f in zip(meshes, feats):
-        n_out = {"vertices": f.shape[0], "faces": m["faces"].shape[0], "global_mean": 1}[outputs_at]
-        wi = w[off_out:off_out + n_out]
-        if outputs_at == "global_mean":
-            wi = wi[0]
-        off_out += n_out
-        km = None
-        if masks is not None:
-            r0 = sum(sizes[:len(ref_out)])
-            km = [[mk[r0:r0 + f.shape[0]].float() for mk in blk] for blk in masks]
-        o, g = orc.net_forward_backward(
-            params, dict(x_in=f, mass=m["mass"], evals=m["evals"], evecs=m["evecs"], gradX=m["gradX"], gradY=m["gradY"],
-                         faces=m["faces"]), outputs_at=outputs_at, loss_weights=wi, keep_masks=km)
-        ref_out.append(o.reshape(n_out, -1))
-        if ref_grads is None:
-            ref_grads = {k: v.clone() for k, v in g.items() if k != "x_in"}
-            ref_grads["x_in"] = [g["x_in"]]
-        else:
-            for k, v in g.items():
-                if k == "x_in":
-                    ref_grads["x_in"].append(v)
-                else:
-                    ref_grads[k] += v
-    ref_out = torch.cat(ref_out, 0)
-    assert helpers.rel_max(out.detach().cpu(), ref_out) < FWD_TOL
-    assert helpers.rel_l2(x.grad.cpu(), torch.cat(ref_grads["x_in"], 0)) < GRAD_TOL
-    for k, p in model.named_parameters():
-        e = helpers.rel_l2(p.grad.cpu(), ref_grads[k])
-        assert e < GRAD_TOL, (k, e)
+    def oracle_pass(dt):
+        cast = lambda t: t.to(dt) if t.is_floating_point() else t
+        prm = {k: cast(v) for k, v in params.items()}
+        ref_out, ref_grads, off_out = [], None, 0
+        for m, f in zip(meshes, feats):
+            n_out = {"vertices": f.shape[0], "faces": m["faces"].shape[0], "global_mean": 1}[outputs_at]
+            wi = w[off_out:off_out + n_out]
+            if outputs_at == "global_mean":
+                wi = wi[0]
+            off_out += n_out
+            km = None
+            if masks is not None:
+                r0 = sum(sizes[:len(ref_out)])
+                km = [[mk[r0:r0 + f.shape[0]].to(dt) for mk in blk] for blk in masks]
+            o, g = orc.net_forward_backward(
+                prm, dict(x_in=cast(f), mass=cast(m["mass"]), evals=cast(m["evals"]), evecs=cast(m["evecs"]), gradX=cast(m["gradX"]),
+                          gradY=cast(m["gradY"]), faces=m["faces"]), outputs_at=outputs_at, loss_weights=cast(wi), keep_masks=km)
+            ref_out.append(o.reshape(n_out, -1))
+            if ref_grads is None:
+                ref_grads = {k: v.clone() for k, v in g.items() if k != "x_in"}
+                ref_grads["x_in"] = [g["x_in"]]
+            else:
+                for k, v in g.items():
+                    if k == "x_in":
+                        ref_grads["x_in"].append(v)
+                    else:
+                        ref_grads[k] += v
+        ref_grads["x_in"] = torch.cat(ref_grads["x_in"], 0)
+        return torch.cat(ref_out, 0), ref_grads
+
+    ref_out, ref_grads = oracle_pass(torch.float32)
+    got = {k: p.grad.cpu() for k, p in model.named_parameters()}
+    got["x_in"] = x.grad.cpu()
+    e_out = helpers.rel_max(out.detach().cpu(), ref_out)
+    assert e_out < FWD_TOL, ("out", e_out)
+    if not fp64_bracket:
+        for k, gk in got.items():
+            e = helpers.rel_l2(gk, ref_grads[k])
+            assert e < GRAD_TOL, (k, e)
+        return
+    # Deep train-mode nets sit at the fp32 oracle's own noise floor (its multi-threaded CPU reductions are not even
+    # run-to-run identical: 1 run in 10 moved first_lin.weight's gradient across 2e-4), so gradients are judged against the
+    # fp64 oracle and allowed twice the distance the fp32 oracle itself keeps from it.
+    _, ref64 = oracle_pass(torch.float64)
+    for k, gk in got.items():
+        e_new, e_ref = helpers.rel_l2(gk.double(), ref64[k]), helpers.rel_l2(ref_grads[k].double(), ref64[k])
+        assert e_new < max(GRAD_TOL, 2 * e_ref), (k, e_new, e_ref)
 
 
 # ------------------------------------------------------------------------------------------

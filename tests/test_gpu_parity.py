@@ -51,7 +51,7 @@ def test_ragged_batches(dev, outputs_at):
 
 def test_train_mode_dropout_masks_headline_width(dev):
     import parity_cases
-    parity_cases.run_ragged_net(dev, sizes=(3000, 1400, 129), K=128, C=128, N_block=2, dropout=True)
+    parity_cases.run_ragged_net(dev, sizes=(3000, 1400, 129), K=128, C=128, N_block=2, dropout=True, fp64_bracket=True)
     parity_cases.run_ragged_net(dev, sizes=(700,), K=64, C=256, N_block=1, dropout=True, outputs_at="faces")
 
 
@@ -92,6 +92,18 @@ def test_inkernel_dropout_matches_explicit_masks(dev, C):
 def test_gradient_sinks_accumulate_into_flat_bucket(dev):
     import parity_cases
     parity_cases.run_grad_sinks(dev, V=3000, K=64, C=128)
+
+
+def test_run_to_run_determinism_stress(dev):
+    """Every op of the block, repeated on identical inputs at a multi-mesh 128-wide shape, must be bitwise identical every
+    time (tools/determinism_stress.py; this is the test that exposes stale-register / packed-op hazards that stay far
+    below the parity tolerances: one wrong bf16 pair per few thousand tiles)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "determinism_stress.py"), "--reps", "40", "--meshes", "8",
+                        "--verts", "6000"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_headline_shape_against_fp32_and_fp64_oracle(dev):

@@ -18,8 +18,10 @@ def read_pmc(path):
 
 
 def family(name):
-    if name.startswith("void rowgemm_persist_kernel"):
+    if name.startswith("void rowgemm_persist_kernel") or name.startswith("void rowgemm_ws_kernel"):
         return "rowgemm_kernel<*,1>"
+    if name.startswith("void rowgemm_ws2_kernel"):
+        return "rowgemm_kernel<*,2>"
     m = re.match(r"void rowgemm_kernel<\d+, \d+, \d+, (\d)", name)
     if m:
         return "rowgemm_kernel<*,%s>" % m.group(1)
