@@ -64,9 +64,8 @@ __device__ __forceinline__ uint2 dn_lds_tr16(const unsigned char* p) {
 // residuals are exact in fp32).  With the six largest cross products of two split operands accumulated in fp32 the result
 // is as accurate as an fp32 FMA chain (measured rel-L2 1.6e-7 vs 2.0e-7 against fp64, profiles/r01_exp_bf16x3.txt) at
 // 16/6 = 2.7x the f32-MFMA rate.
-// The split works on PAIRS: gfx950's v_cvt_pk_bf16_f32 rounds and packs two values in one instruction and the residuals
-// are one v_pk_add_f32 each, 9 VALU instructions per pair (the scalar formulation took ~27 and made the staging phase,
-// not the MFMAs, the critical path of the split-bf16 kernels).
+// The split works on PAIRS: gfx950's v_cvt_pk_bf16_f32 rounds and packs two values in one instruction; 11 VALU instructions
+// per pair (the software-rounding formulation took ~27 and made the staging phase, not the MFMAs, the critical path).
 __device__ __forceinline__ unsigned dn_bf16_bits(float x, float& back) {   // software RNE (emulator and odd call sites)
     unsigned u = __float_as_uint(x);
     u += 0x7fffu + ((u >> 16) & 1u);
@@ -86,20 +85,19 @@ __device__ __forceinline__ void dn_split3_pair(float x, float y, unsigned& hi, u
     hx = dn_bf16_bits(rx - bx, bx); hy = dn_bf16_bits(ry - by, by);
     lo = hx | (hy << 16);
 #else
+    // v_cvt_pk_bf16_f32 rounds (RNE) and packs two values; the residuals are plain v_sub_f32 -- no packed-f32 VALU ops
+    // anywhere in this library (see dn_f4_mul for why)
     typedef float dn_f2 __attribute__((ext_vector_type(2)));
     typedef __bf16 dn_bf2 __attribute__((ext_vector_type(2)));
-    const dn_f2 v = {x, y};
-    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, dn_bf2));
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(dn_f2{x, y}, dn_bf2));
 #if defined(DN_X3_ABLATE_SPLIT)   // development ablation: no residual arithmetic
     mid = lo = hi;
     return;
 #endif
-    const dn_f2 hf = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
-    const dn_f2 r = v - hf;
-    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r, dn_bf2));
-    const dn_f2 mf = {__uint_as_float(mid << 16), __uint_as_float(mid & 0xffff0000u)};
-    const dn_f2 t = r - mf;
-    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(t, dn_bf2));
+    const float rx = x - __uint_as_float(hi << 16), ry = y - __uint_as_float(hi & 0xffff0000u);
+    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(dn_f2{rx, ry}, dn_bf2));
+    const float tx = rx - __uint_as_float(mid << 16), ty = ry - __uint_as_float(mid & 0xffff0000u);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(dn_f2{tx, ty}, dn_bf2));
 #endif
 }
 // a float4 (four consecutive k) -> one 8-byte chunk per plane
