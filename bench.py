@@ -133,11 +133,11 @@ def main():
                                               outputs_at="faces", dropout=True)
     model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=0))
     model.to(device).train()
-    flat = FlatParams(model)
+    nsub = max(1, min(args.streams, args.meshes))
+    flat = FlatParams(model, direct_sinks=(nsub == 1))   # concurrent backward streams need autograd's ordered accumulation
     opt = torch.optim.Adam([flat.master], lr=1e-3)
 
     sizes = mesh_sizes(args.meshes, args.verts, rank)
-    nsub = max(1, min(args.streams, args.meshes))
     subs = []
     for j in range(nsub):
         sub_sizes = sizes[j::nsub]

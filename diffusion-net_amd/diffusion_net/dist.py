@@ -15,7 +15,11 @@ import torch.distributed as dist
 
 
 class FlatParams:
-    def __init__(self, module: torch.nn.Module):
+    def __init__(self, module: torch.nn.Module, direct_sinks: bool = True):
+        """direct_sinks: let the HIP ops accumulate parameter gradients straight into the bucket (ops._deliver).  Turn it off
+        when backward passes run concurrently on several streams: the direct adds are not ordered across streams, autograd's
+        AccumulateGrad is."""
+        self.direct_sinks = bool(direct_sinks)
         params = [p for p in module.parameters()]
         if not params:
             raise ValueError("module has no parameters")
@@ -33,7 +37,7 @@ class FlatParams:
                 self.flat[o:o + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat[o:o + n].view(p.shape)
                 p.grad = self.grad[o:o + n].view(p.shape)
-                p._dn_grad_sink = p.grad   # the HIP ops accumulate here directly (ops._deliver), one launch per op
+                p._dn_grad_sink = p.grad if self.direct_sinks else None   # ops._deliver: one multi-tensor add per op
         self.params, self.offsets, self.sizes = params, offs, sizes
         self.master = torch.nn.Parameter(self.flat, requires_grad=True)   # what the optimizer updates
         self.master.grad = self.grad
@@ -48,7 +52,7 @@ class FlatParams:
                     p.data = self.flat[o:o + n].view(p.shape)
                 if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + o * self.grad.element_size():
                     p.grad = self.grad[o:o + n].view(p.shape)
-                p._dn_grad_sink = p.grad
+                p._dn_grad_sink = p.grad if self.direct_sinks else None
 
     def zero_grad(self):
         self.grad.zero_()
