@@ -167,7 +167,7 @@ __device__ __forceinline__ float dn_f4_get(const float4& v, int t) {
 __device__ __forceinline__ int dn_colk_off(int row, int slot) { return row * 32 + ((slot ^ ((row >> 1) & 7)) << 2); }
 
 // ---------------------------------------------------------------------------------------
-// row-tile GEMM   out[r, n] = epilogue( sum_s sum_k A_s[r, k] * B_s(k, n) )    (dn_gemm.hip)
+// row-tile GEMM   out[r, n] = epilogue( sum_s sum_k A_s[r, k] * B_s(k, n) )    (dn_rowgemm.hip, dn_rowgemm_persist.hip)
 // ---------------------------------------------------------------------------------------
 #define DN_TM 128      // rows per workgroup tile
 #define DN_KB 32       // contraction slice staged per step
@@ -214,7 +214,7 @@ enum {
 #define DN_ERR_BAD_MODE 1
 
 // ---------------------------------------------------------------------------------------
-// split-V "TN" GEMM   partial[chunk][m, n] = sum_{r in chunk} A[r, m] * B[r, n]   (dn_gemm.hip)
+// split-V "TN" GEMM   partial[chunk][m, n] = sum_{r in chunk} A[r, m] * B[r, n]   (dn_tngemm.hip)
 // ---------------------------------------------------------------------------------------
 struct TnSeg {
     const float* p;

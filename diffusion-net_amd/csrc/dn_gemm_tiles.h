@@ -1,0 +1,442 @@
+// dn_gemm_tiles.h -- device-side building blocks shared by the row-GEMM kernels (dn_rowgemm.hip, dn_rowgemm_persist.hip):
+// the compile-time epilogue of one accumulator tile, the branch-free slice loaders, the exact-f32 LDS staging / MFMA step, and
+// the split-bf16 ("x3") staging halves (split -> planes, planes -> LDS) and operand fetch / MFMA halves.
+#pragma once
+#include "dn_common.h"
+
+
+// =======================================================================================
+// rowgemm
+// =======================================================================================
+// Epilogue of one 32x32 accumulator tile.  MODE is a compile-time constant, all auxiliary operands of the 16
+// elements a lane owns are fetched first (from clamped, always-valid addresses -> no branches between the
+// loads), then combined and stored under the validity predicate.
+template <int MODE, int NOUT>
+__device__ __forceinline__ void rg_epilogue_tile(const RgArgs& g, int row_base, int rows_valid, int col, bool col_ok,
+                                                 int lane, const f32x16& a0, const f32x16& a1) {
+    bool ok[16];
+    long long io[16], ir[16];
+    const int cc = col_ok ? col : 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rl = dn_acc_row(r, lane);
+        ok[r] = col_ok && rl < rows_valid;
+        const long long rr = row_base + (ok[r] ? rl : 0);
+        io[r] = rr * g.ldo + cc;
+        ir[r] = rr * g.ldr + cc;
+    }
+    float v0[16], v1[16], v2[16], res0[16], res1[16];
+    constexpr bool need_r0 = MODE == DN_EPI_BIAS_RESID || MODE == DN_EPI_GRADFEAT || MODE == DN_EPI_MUL_DFAC ||
+                             MODE == DN_EPI_ADD || MODE == DN_EPI_DTANH || MODE == DN_EPI_GRADFEAT_BWD ||
+                             MODE == DN_EPI_MASS_ADD;
+    constexpr bool need_r1 = MODE == DN_EPI_GRADFEAT || MODE == DN_EPI_GRADFEAT_BWD;
+    constexpr bool need_r2 = MODE == DN_EPI_GRADFEAT_BWD;
+    const bool has_r0 = g.r0 != nullptr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        v0[r] = (need_r0 && has_r0) ? g.r0[ir[r]] : 0.f;
+        v1[r] = need_r1 ? g.r1[ir[r]] : 0.f;
+        v2[r] = need_r2 ? g.r2[ir[r]] : 0.f;
+    }
+    float bias = 0.f;
+    if (MODE == DN_EPI_STORE || MODE == DN_EPI_BIAS_RELU || MODE == DN_EPI_BIAS_RESID) bias = g.bias ? g.bias[cc] : 0.f;
+    if (MODE == DN_EPI_BIAS_RELU) {
+        if (g.mask) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v1[r] = g.mask[ir[r]] ? g.scale : 0.f;
+        } else if (g.rng_seed) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long rr = row_base + (ok[r] ? dn_acc_row(r, lane) : 0);
+                v1[r] = ((dn_keep_bits(g.rng_seed, rr, cc >> 2, (g.N + 3) >> 2) >> (cc & 3)) & 1u) ? g.scale : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v1[r] = 1.f;
+        }
+    }
+    if (MODE == DN_EPI_MASS_ADD) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v1[r] = g.rowv[row_base + (ok[r] ? dn_acc_row(r, lane) : 0)];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float x0 = a0[r], x1 = NOUT == 2 ? a1[r] : 0.f;
+        float y0 = 0.f, y1 = 0.f;
+        if (MODE == DN_EPI_STORE) y0 = x0 + bias;
+        else if (MODE == DN_EPI_BIAS_RELU) { float h = x0 + bias; y0 = (h > 0.f ? h : 0.f) * v1[r]; }
+        else if (MODE == DN_EPI_BIAS_RESID) y0 = (x0 + bias) + v0[r];
+        else if (MODE == DN_EPI_GRADFEAT) y0 = tanhf(v0[r] * x0 + v1[r] * x1);
+        else if (MODE == DN_EPI_MUL_DFAC) y0 = v0[r] > 0.f ? x0 * g.scale : 0.f;
+        else if (MODE == DN_EPI_ADD) y0 = x0 + v0[r];
+        else if (MODE == DN_EPI_DTANH) y0 = x0 * (1.f - v0[r] * v0[r]);
+        else if (MODE == DN_EPI_GRADFEAT_BWD) { y0 = x0 + v0[r] * v1[r]; y1 = x1 + v0[r] * v2[r]; }
+        else if (MODE == DN_EPI_MASS_ADD) y0 = v0[r] + v1[r] * x0;
+        res0[r] = y0;
+        res1[r] = y1;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (ok[r]) g.o0[io[r]] = res0[r];
+    if (MODE == DN_EPI_GRADFEAT_BWD) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (ok[r]) g.o1[io[r]] = res1[r];
+    }
+    if (MODE == DN_EPI_GRADFEAT && g.o1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (ok[r]) { g.o1[io[r]] = a0[r]; g.o2[io[r]] = a1[r]; }
+    }
+}
+
+// ---- staging helpers -------------------------------------------------------------------------------------
+// ALIGNED fast path: no branch sits between the loads (row / column guards are applied by clamping the address to
+// a valid one and zeroing the value afterwards), so every global_load of a slice is in flight at once and the
+// wait lands at the LDS store after the MFMAs of the previous slice.
+// A staged slice in registers: raw loaded values plus the factors applied when it is written to LDS.  Nothing
+// here is *used* before the MFMAs of the previous slice have been issued, so the loads stay in flight under them.
+template <int NOUT, int A_IT, int B_IT>
+struct RgRegs {
+    float4 a[A_IT];
+    float4 q[A_IT];          // optional elementwise factor of A (valid when has_q)
+    float am[A_IT];          // row guard as 0/1 factor
+    float4 b[NOUT][B_IT];
+    float bm[NOUT][B_IT];    // column guard * sign
+};
+
+// PAIRK (bf16x3 path, row-contraction B, TN = 128): a thread fetches rows 2p and 2p+1 (p = tid & 15) of a 4-column group
+// q4 = (tid >> 4) + (NTHR / 16) * h, h < B_IT / 2, so that it can write packed (k, k+1) bf16 pairs of the transposed B planes.
+template <int TN, int NTHR, int NOUT, bool ALIGNED, bool BCOLK, bool HASQ, int A_IT, int B_IT, bool PAIRK = false>
+__device__ __forceinline__ void rg_load(const RgArgs& g, const DnTile& tile, int n0, int seg, int koff, int tid,
+                                        RgRegs<NOUT, A_IT, B_IT>& R) {   // tile.row0/nrows may describe a sub-tile
+    const RgSeg sg = g.a[seg];
+    if (ALIGNED) {
+        long long off[A_IT];
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int idx = tid + i * NTHR;
+            const int row = idx >> 3, q = idx & 7;
+            const bool rok = row < tile.nrows;
+            R.am[i] = rok ? 1.f : 0.f;
+            off[i] = (long long)(tile.row0 + (rok ? row : 0)) * sg.ld + koff + 4 * q;
+            R.a[i] = *reinterpret_cast<const float4*>(sg.p + off[i]);
+        }
+        if (HASQ) {   // compile-time; loads only, no use
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) R.q[i] = *reinterpret_cast<const float4*>(sg.q + off[i]);
+        }
+#if defined(DN_X3_ABLATE_BSTAGE)
+        if (NTHR == 512) return;
+#endif
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            const float* bp = g.b[o][seg] + (long long)tile.mesh * g.b_mesh_stride;
+            const float sgn = g.bsign[o][seg];
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                const int idx = tid + i * NTHR;
+                long long boff;
+                bool nok;
+                if (BCOLK) {
+                    const int nrow = idx >> 3, q = idx & 7;
+                    nok = n0 + nrow < g.N;
+                    boff = (long long)(nok ? n0 + nrow : 0) * g.ldb + koff + 4 * q;
+                } else {
+                    const int krow = PAIRK ? 2 * (tid & 15) + (i & 1) : idx / (TN / 4);
+                    const int q4 = PAIRK ? (tid >> 4) + (NTHR / 16) * (i >> 1) : idx % (TN / 4);
+                    nok = n0 + 4 * q4 < g.N;
+                    boff = (long long)(koff + krow) * g.ldb + (nok ? n0 + 4 * q4 : 0);
+                }
+                R.b[o][i] = *reinterpret_cast<const float4*>(bp + boff);
+                R.bm[o][i] = nok ? sgn : 0.f;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int idx = tid + i * NTHR;
+            const int row = idx >> 3, q = idx & 7;
+            const long long base = (long long)(tile.row0 + row) * sg.ld + koff + 4 * q;
+            float e[4] = {0.f, 0.f, 0.f, 0.f};
+            if (row < tile.nrows) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (koff + 4 * q + c < sg.w) {
+                        e[c] = sg.p[base + c];
+                        if (sg.q) e[c] *= sg.q[base + c];
+                    }
+                }
+            }
+            R.a[i] = make_float4(e[0], e[1], e[2], e[3]);
+            R.am[i] = 1.f;
+            if (HASQ) R.q[i] = make_float4(1.f, 1.f, 1.f, 1.f);   // already folded in above
+        }
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            const float* bp = g.b[o][seg] + (long long)tile.mesh * g.b_mesh_stride;
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                const int idx = tid + i * NTHR;
+                float e[4] = {0.f, 0.f, 0.f, 0.f};
+                if (BCOLK) {
+                    const int nrow = idx >> 3, q = idx & 7;
+                    const long long base = (long long)(n0 + nrow) * g.ldb + koff + 4 * q;
+                    if (n0 + nrow < g.N) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (koff + 4 * q + c < sg.w) e[c] = bp[base + c];
+                    }
+                } else {
+                    const int krow = idx / (TN / 4), q4 = idx % (TN / 4);
+                    const long long base = (long long)(koff + krow) * g.ldb + n0 + 4 * q4;
+                    if (koff + krow < sg.w) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (n0 + 4 * q4 + c < g.N) e[c] = bp[base + c];
+                    }
+                }
+                R.b[o][i] = make_float4(e[0], e[1], e[2], e[3]);
+                R.bm[o][i] = g.bsign[o][seg];
+            }
+        }
+    }
+}
+
+template <int TN, int NTHR, int NOUT, bool BCOLK, bool HASQ, int A_IT, int B_IT>
+__device__ __forceinline__ void rg_store(float* sA, float* sB, int tid, const RgRegs<NOUT, A_IT, B_IT>& R) {
+    constexpr int SB = DN_KB * TN;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int idx = tid + i * NTHR;
+        float4 v = dn_f4_scale(R.a[i], R.am[i]);
+        if (HASQ) v = dn_f4_mul(v, R.q[i]);
+        *reinterpret_cast<float4*>(&sA[dn_colk_off(idx >> 3, idx & 7)]) = v;
+    }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int idx = tid + i * NTHR;
+            const float4 v = dn_f4_scale(R.b[o][i], R.bm[o][i]);
+            if (BCOLK)
+                *reinterpret_cast<float4*>(&sB[o * SB + dn_colk_off(idx >> 3, idx & 7)]) = v;
+            else
+                *reinterpret_cast<float4*>(&sB[o * SB + 4 * idx]) = v;
+        }
+}
+
+template <int TN, int MT, int NT, int NOUT, bool BCOLK>
+__device__ __forceinline__ void rg_compute(const float* sA, const float* sB, int arow0, int bcol0, int li, int ls,
+                                           f32x16 (&acc)[NOUT][MT][NT]) {
+    constexpr int SB = DN_KB * TN;
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+        float4 af[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            af[mt] = *reinterpret_cast<const float4*>(&sA[dn_colk_off(arow0 + mt * 32 + li, 2 * kg + ls)]);
+        float bv[NOUT][NT][4];
+        if (BCOLK) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(&sB[o * SB + dn_colk_off(bcol0 + nt * 32 + li, 2 * kg + ls)]);
+                    bv[o][nt][0] = t4.x; bv[o][nt][1] = t4.y; bv[o][nt][2] = t4.z; bv[o][nt][3] = t4.w;
+                }
+        } else {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        bv[o][nt][t] = sB[o * SB + (8 * kg + 4 * ls + t) * TN + bcol0 + nt * 32 + li];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int o = 0; o < NOUT; ++o) {
+#if defined(DN_ABLATE_MFMA)   // development ablation: operands stay live, no matrix work
+                        acc[o][mt][nt][0] += dn_f4_get(af[mt], t) * bv[o][nt][t];
+#else
+                        acc[o][mt][nt] = dn_mfma(dn_f4_get(af[mt], t), bv[o][nt][t], acc[o][mt][nt]);
+#endif
+                    }
+    }
+}
+
+// ---- split-bf16 ("x3") staging and MFMA for the persistent and the two-output kernels: both operands live in LDS as three bf16 planes
+//      (hi, mid, lo) of [rows][32 k]; six cross products per k16 step replace sixteen f32 MFMA k2 steps.
+// The staging is written as two halves so that a kernel can put the MFMAs of the current slice between them: rg_split_x3
+// is pure VALU on the prefetched registers, rg_put_x3 only writes LDS (the compiler must keep LDS writes behind earlier LDS
+// reads of the other buffer -- it cannot prove they do not alias -- so the reads are issued first, see rg_frag_x3).
+template <int NOUT, int A_IT, int B_IT>
+struct X3Planes {
+    uint2 a[A_IT][3];
+    uint2 b[NOUT][B_IT][3];   // BCOLK: one 8-byte chunk per float4; PAIRK: dword e of column group h is (i = 2h + (e >> 1), .x/.y = e & 1)
+};
+
+template <int NOUT, bool BCOLK, bool HASQ, int A_IT, int B_IT>
+__device__ __forceinline__ void rg_split_x3(const RgRegs<NOUT, A_IT, B_IT>& R, X3Planes<NOUT, A_IT, B_IT>& P) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        // no row mask here: a row past the unit's end (its address was clamped) only feeds its own, never stored, output row
+        float4 v = R.a[i];
+        if (HASQ) v = dn_f4_mul(v, R.q[i]);
+        dn_split3_f4(v, P.a[i][0], P.a[i][1], P.a[i][2]);
+    }
+#if defined(DN_X3_ABLATE_BSTAGE)   // development ablation: B operand neither loaded, split nor written
+    return;
+#endif
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        if (BCOLK) {
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                // the factor carries the sign of a two-output product; with one output it is the column mask only, and
+                // a column past N (clamped address) only feeds its own, never stored, output column
+                const float4 v = NOUT == 2 ? dn_f4_scale(R.b[o][i], R.bm[o][i]) : R.b[o][i];
+                dn_split3_f4(v, P.b[o][i][0], P.b[o][i][1], P.b[o][i][2]);
+            }
+        } else {   // PAIRK: R.b[o][2h] = row 2p, R.b[o][2h+1] = row 2p+1 of column group q4(h) -> packed (k, k+1) dwords per column
+            static_assert(BCOLK || B_IT % 2 == 0, "pair mapping needs two rows per thread and column group");
+#pragma unroll
+            for (int h = 0; h < B_IT / 2; ++h) {
+                const float4 v0 = NOUT == 2 ? dn_f4_scale(R.b[o][2 * h], R.bm[o][2 * h]) : R.b[o][2 * h];
+                const float4 v1 = NOUT == 2 ? dn_f4_scale(R.b[o][2 * h + 1], R.bm[o][2 * h + 1]) : R.b[o][2 * h + 1];
+                dn_split3_pair(v0.x, v1.x, P.b[o][2 * h][0].x, P.b[o][2 * h][1].x, P.b[o][2 * h][2].x);
+                dn_split3_pair(v0.y, v1.y, P.b[o][2 * h][0].y, P.b[o][2 * h][1].y, P.b[o][2 * h][2].y);
+                dn_split3_pair(v0.z, v1.z, P.b[o][2 * h + 1][0].x, P.b[o][2 * h + 1][1].x, P.b[o][2 * h + 1][2].x);
+                dn_split3_pair(v0.w, v1.w, P.b[o][2 * h + 1][0].y, P.b[o][2 * h + 1][1].y, P.b[o][2 * h + 1][2].y);
+            }
+        }
+    }
+}
+
+template <int NTHR, int NOUT, bool BCOLK, int A_IT, int B_IT>
+__device__ __forceinline__ void rg_put_x3(unsigned char* sA, unsigned char* sB, int tid, const X3Planes<NOUT, A_IT, B_IT>& P) {
+    constexpr int PL = DN_TM * 64;    // bytes per A plane (128 rows x 32 bf16)
+    constexpr int PLB = 128 * 64;     // bytes per B plane (128 output columns); output o uses planes [3o, 3o+3)
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int idx = tid + i * NTHR;
+        const int row = idx >> 3, q = idx & 7;
+        const int off = dn_plane_off(row, q >> 1) + (q & 1) * 8;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(sA + p * PL + off) = P.a[i][p];
+    }
+#if defined(DN_X3_ABLATE_BSTAGE)
+    return;
+#endif
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        unsigned char* sBo = sB + o * 3 * PLB;
+        if (BCOLK) {
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                const int idx = tid + i * NTHR;
+                const int nrow = idx >> 3, q = idx & 7;
+                const int off = dn_plane_off(nrow, q >> 1) + (q & 1) * 8;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(sBo + p * PLB + off) = P.b[o][i][p];
+            }
+        } else {
+            const int pr = tid & 15;
+#pragma unroll
+            for (int h = 0; h < B_IT / 2; ++h) {
+                const int q4 = (tid >> 4) + (NTHR / 16) * h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int off = dn_plane_off(4 * q4 + e, pr >> 2) + (pr & 3) * 4;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const uint2 w = P.b[o][2 * h + (e >> 1)][p];
+                        *reinterpret_cast<unsigned*>(sBo + p * PLB + off) = (e & 1) ? w.y : w.x;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int NTHR, int NOUT, bool BCOLK, bool HASQ, int A_IT, int B_IT>
+__device__ __forceinline__ void rg_store_x3(unsigned char* sA, unsigned char* sB, int tid, const RgRegs<NOUT, A_IT, B_IT>& R) {
+    X3Planes<NOUT, A_IT, B_IT> P;
+    rg_split_x3<NOUT, BCOLK, HASQ, A_IT, B_IT>(R, P);
+    rg_put_x3<NTHR, NOUT, BCOLK, A_IT, B_IT>(sA, sB, tid, P);
+}
+
+// MFMA operands of one 32-wide slice (two k16 steps; lane group lg owns k = 16 s + 8 lg .. +7), read in one burst
+template <int MT, int NT, int NOUT>
+struct X3Frags {
+    uint4 a[2][3][MT];
+    uint4 b[2][NOUT][3][NT];
+};
+
+template <int MT, int NT, int NOUT>
+__device__ __forceinline__ void rg_frag_x3(const unsigned char* sA, const unsigned char* sB, int arow0, int bcol0, int li, int lg,
+                                           int s, X3Frags<MT, NT, NOUT>& F) {
+    constexpr int PL = DN_TM * 64, PLB = 128 * 64;
+#if defined(DN_X3_ABLATE_LDSR)   // development ablation: one LDS read feeds every fragment
+    const uint4 one = *reinterpret_cast<const uint4*>(sA + dn_plane_off(arow0 + li, 2 * s + lg));
+    for (int p = 0; p < 3; ++p) {
+        for (int mt = 0; mt < MT; ++mt) F.a[s][p][mt] = one;
+        for (int o = 0; o < NOUT; ++o)
+            for (int nt = 0; nt < NT; ++nt) F.b[s][o][p][nt] = one;
+    }
+#else
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            F.a[s][p][mt] = *reinterpret_cast<const uint4*>(sA + p * PL + dn_plane_off(arow0 + mt * 32 + li, 2 * s + lg));
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                F.b[s][o][p][nt] = *reinterpret_cast<const uint4*>(sB + (o * 3 + p) * PLB + dn_plane_off(bcol0 + nt * 32 + li, 2 * s + lg));
+    }
+#endif
+}
+
+template <int MT, int NT, int NOUT>
+__device__ __forceinline__ void rg_mma_x3(const X3Frags<MT, NT, NOUT>& F, int s, f32x16 (&acc)[NOUT][MT][NT]) {
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x16 c = acc[o][mt][nt];
+#if defined(DN_X3_ABLATE_MFMA)   // development ablation: operands stay live, no matrix work
+                c[0] += __uint_as_float((F.a[s][0][mt].x ^ F.a[s][1][mt].y ^ F.a[s][2][mt].z) &
+                                        (F.b[s][o][0][nt].x ^ F.b[s][o][1][nt].y ^ F.b[s][o][2][nt].z) & 0x3f800000u);
+#else
+                c = dn_mfma_bf16(F.a[s][1][mt], F.b[s][o][1][nt], c);   // mid*mid   (smallest terms first)
+                c = dn_mfma_bf16(F.a[s][0][mt], F.b[s][o][2][nt], c);   // hi*lo
+                c = dn_mfma_bf16(F.a[s][2][mt], F.b[s][o][0][nt], c);   // lo*hi
+                c = dn_mfma_bf16(F.a[s][0][mt], F.b[s][o][1][nt], c);   // hi*mid
+                c = dn_mfma_bf16(F.a[s][1][mt], F.b[s][o][0][nt], c);   // mid*hi
+                c = dn_mfma_bf16(F.a[s][0][mt], F.b[s][o][0][nt], c);   // hi*hi
+#endif
+                acc[o][mt][nt] = c;
+            }
+}
+
+template <int MT, int NT, int NOUT>
+__device__ __forceinline__ void rg_compute_x3(const unsigned char* sA, const unsigned char* sB, int arow0, int bcol0, int li,
+                                              int lg, f32x16 (&acc)[NOUT][MT][NT]) {
+    X3Frags<MT, NT, NOUT> F;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        rg_frag_x3<MT, NT, NOUT>(sA, sB, arow0, bcol0, li, lg, s, F);
+        rg_mma_x3<MT, NT, NOUT>(F, s, acc);
+    }
+}
+

@@ -1,707 +1,12 @@
-// dn_gemm.hip -- the two exact-f32 MFMA contraction engines every dense op of the
-// DiffusionNet block is built from (gfx950, wave64, v_mfma_f32_32x32x2_f32).
-//
-//  rowgemm : out[r, n] = epi( sum_k A[r, k] * B(k, n) )  over a 128-row vertex tile.  A is the
-//            long operand ([V, .] activations or the eigenbasis), B a small matrix (weights or a
-//            per-mesh spectrum).  Replaces: geometry.from_basis (geometry.py:598), every nn.Linear
-//            of the block (layers.py:122-126, :236), and their input-gradients in backward.
-//  tngemm  : partial[chunk][m, n] = sum_{r in chunk} A[r, m] * B[r, n]  -- the contraction runs over
-//            the vertex axis, split into chunks, partials reduced afterwards in fixed order
-//            (deterministic, no float atomics).  Replaces: geometry.to_basis (geometry.py:582-583)
-//            and every weight gradient dW = dY^T X of backward.
-//
-// Both engines stage 32-wide slices of the contraction axis through LDS with a register
-// prefetch of the next slice (global loads stay in flight under the MFMAs of the current one).
-// One 32x32x2 MFMA consumes lane-slot s = lane>>5; four consecutive MFMAs (t = 0..3) of a
-// k-group cover k = 8*kg + 4*s + t, which lets a "column-contraction" operand be fetched with
-// one ds_read_b128 per k-group from the swizzled COLK tile (dn_common.h) and a
-// "row-contraction" operand with four conflict-free ds_read_b32.
-#include "dn_common.h"
-
-// =======================================================================================
-// rowgemm
-// =======================================================================================
-// Epilogue of one 32x32 accumulator tile.  MODE is a compile-time constant, all auxiliary operands of the 16
-// elements a lane owns are fetched first (from clamped, always-valid addresses -> no branches between the
-// loads), then combined and stored under the validity predicate.
-template <int MODE, int NOUT>
-__device__ __forceinline__ void rg_epilogue_tile(const RgArgs& g, int row_base, int rows_valid, int col, bool col_ok,
-                                                 int lane, const f32x16& a0, const f32x16& a1) {
-    bool ok[16];
-    long long io[16], ir[16];
-    const int cc = col_ok ? col : 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int rl = dn_acc_row(r, lane);
-        ok[r] = col_ok && rl < rows_valid;
-        const long long rr = row_base + (ok[r] ? rl : 0);
-        io[r] = rr * g.ldo + cc;
-        ir[r] = rr * g.ldr + cc;
-    }
-    float v0[16], v1[16], v2[16], res0[16], res1[16];
-    constexpr bool need_r0 = MODE == DN_EPI_BIAS_RESID || MODE == DN_EPI_GRADFEAT || MODE == DN_EPI_MUL_DFAC ||
-                             MODE == DN_EPI_ADD || MODE == DN_EPI_DTANH || MODE == DN_EPI_GRADFEAT_BWD ||
-                             MODE == DN_EPI_MASS_ADD;
-    constexpr bool need_r1 = MODE == DN_EPI_GRADFEAT || MODE == DN_EPI_GRADFEAT_BWD;
-    constexpr bool need_r2 = MODE == DN_EPI_GRADFEAT_BWD;
-    const bool has_r0 = g.r0 != nullptr;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        v0[r] = (need_r0 && has_r0) ? g.r0[ir[r]] : 0.f;
-        v1[r] = need_r1 ? g.r1[ir[r]] : 0.f;
-        v2[r] = need_r2 ? g.r2[ir[r]] : 0.f;
-    }
-    float bias = 0.f;
-    if (MODE == DN_EPI_STORE || MODE == DN_EPI_BIAS_RELU || MODE == DN_EPI_BIAS_RESID) bias = g.bias ? g.bias[cc] : 0.f;
-    if (MODE == DN_EPI_BIAS_RELU) {
-        if (g.mask) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v1[r] = g.mask[ir[r]] ? g.scale : 0.f;
-        } else if (g.rng_seed) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long rr = row_base + (ok[r] ? dn_acc_row(r, lane) : 0);
-                v1[r] = ((dn_keep_bits(g.rng_seed, rr, cc >> 2, (g.N + 3) >> 2) >> (cc & 3)) & 1u) ? g.scale : 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v1[r] = 1.f;
-        }
-    }
-    if (MODE == DN_EPI_MASS_ADD) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v1[r] = g.rowv[row_base + (ok[r] ? dn_acc_row(r, lane) : 0)];
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float x0 = a0[r], x1 = NOUT == 2 ? a1[r] : 0.f;
-        float y0 = 0.f, y1 = 0.f;
-        if (MODE == DN_EPI_STORE) y0 = x0 + bias;
-        else if (MODE == DN_EPI_BIAS_RELU) { float h = x0 + bias; y0 = (h > 0.f ? h : 0.f) * v1[r]; }
-        else if (MODE == DN_EPI_BIAS_RESID) y0 = (x0 + bias) + v0[r];
-        else if (MODE == DN_EPI_GRADFEAT) y0 = tanhf(v0[r] * x0 + v1[r] * x1);
-        else if (MODE == DN_EPI_MUL_DFAC) y0 = v0[r] > 0.f ? x0 * g.scale : 0.f;
-        else if (MODE == DN_EPI_ADD) y0 = x0 + v0[r];
-        else if (MODE == DN_EPI_DTANH) y0 = x0 * (1.f - v0[r] * v0[r]);
-        else if (MODE == DN_EPI_GRADFEAT_BWD) { y0 = x0 + v0[r] * v1[r]; y1 = x1 + v0[r] * v2[r]; }
-        else if (MODE == DN_EPI_MASS_ADD) y0 = v0[r] + v1[r] * x0;
-        res0[r] = y0;
-        res1[r] = y1;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-        if (ok[r]) g.o0[io[r]] = res0[r];
-    if (MODE == DN_EPI_GRADFEAT_BWD) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (ok[r]) g.o1[io[r]] = res1[r];
-    }
-    if (MODE == DN_EPI_GRADFEAT && g.o1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (ok[r]) { g.o1[io[r]] = a0[r]; g.o2[io[r]] = a1[r]; }
-    }
-}
-
-// ---- staging helpers -------------------------------------------------------------------------------------
-// ALIGNED fast path: no branch sits between the loads (row / column guards are applied by clamping the address to
-// a valid one and zeroing the value afterwards), so every global_load of a slice is in flight at once and the
-// wait lands at the LDS store after the MFMAs of the previous slice.
-// A staged slice in registers: raw loaded values plus the factors applied when it is written to LDS.  Nothing
-// here is *used* before the MFMAs of the previous slice have been issued, so the loads stay in flight under them.
-template <int NOUT, int A_IT, int B_IT>
-struct RgRegs {
-    float4 a[A_IT];
-    float4 q[A_IT];          // optional elementwise factor of A (valid when has_q)
-    float am[A_IT];          // row guard as 0/1 factor
-    float4 b[NOUT][B_IT];
-    float bm[NOUT][B_IT];    // column guard * sign
-};
-
-// PAIRK (bf16x3 path, row-contraction B, TN = 128): a thread fetches rows 2p and 2p+1 (p = tid & 15) of a 4-column group
-// q4 = (tid >> 4) + (NTHR / 16) * h, h < B_IT / 2, so that it can write packed (k, k+1) bf16 pairs of the transposed B planes.
-template <int TN, int NTHR, int NOUT, bool ALIGNED, bool BCOLK, bool HASQ, int A_IT, int B_IT, bool PAIRK = false>
-__device__ __forceinline__ void rg_load(const RgArgs& g, const DnTile& tile, int n0, int seg, int koff, int tid,
-                                        RgRegs<NOUT, A_IT, B_IT>& R) {   // tile.row0/nrows may describe a sub-tile
-    const RgSeg sg = g.a[seg];
-    if (ALIGNED) {
-        long long off[A_IT];
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int idx = tid + i * NTHR;
-            const int row = idx >> 3, q = idx & 7;
-            const bool rok = row < tile.nrows;
-            R.am[i] = rok ? 1.f : 0.f;
-            off[i] = (long long)(tile.row0 + (rok ? row : 0)) * sg.ld + koff + 4 * q;
-            R.a[i] = *reinterpret_cast<const float4*>(sg.p + off[i]);
-        }
-        if (HASQ) {   // compile-time; loads only, no use
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i) R.q[i] = *reinterpret_cast<const float4*>(sg.q + off[i]);
-        }
-#if defined(DN_X3_ABLATE_BSTAGE)
-        if (NTHR == 512) return;
-#endif
-#pragma unroll
-        for (int o = 0; o < NOUT; ++o) {
-            const float* bp = g.b[o][seg] + (long long)tile.mesh * g.b_mesh_stride;
-            const float sgn = g.bsign[o][seg];
-#pragma unroll
-            for (int i = 0; i < B_IT; ++i) {
-                const int idx = tid + i * NTHR;
-                long long boff;
-                bool nok;
-                if (BCOLK) {
-                    const int nrow = idx >> 3, q = idx & 7;
-                    nok = n0 + nrow < g.N;
-                    boff = (long long)(nok ? n0 + nrow : 0) * g.ldb + koff + 4 * q;
-                } else {
-                    const int krow = PAIRK ? 2 * (tid & 15) + (i & 1) : idx / (TN / 4);
-                    const int q4 = PAIRK ? (tid >> 4) + (NTHR / 16) * (i >> 1) : idx % (TN / 4);
-                    nok = n0 + 4 * q4 < g.N;
-                    boff = (long long)(koff + krow) * g.ldb + (nok ? n0 + 4 * q4 : 0);
-                }
-                R.b[o][i] = *reinterpret_cast<const float4*>(bp + boff);
-                R.bm[o][i] = nok ? sgn : 0.f;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int idx = tid + i * NTHR;
-            const int row = idx >> 3, q = idx & 7;
-            const long long base = (long long)(tile.row0 + row) * sg.ld + koff + 4 * q;
-            float e[4] = {0.f, 0.f, 0.f, 0.f};
-            if (row < tile.nrows) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (koff + 4 * q + c < sg.w) {
-                        e[c] = sg.p[base + c];
-                        if (sg.q) e[c] *= sg.q[base + c];
-                    }
-                }
-            }
-            R.a[i] = make_float4(e[0], e[1], e[2], e[3]);
-            R.am[i] = 1.f;
-            if (HASQ) R.q[i] = make_float4(1.f, 1.f, 1.f, 1.f);   // already folded in above
-        }
-#pragma unroll
-        for (int o = 0; o < NOUT; ++o) {
-            const float* bp = g.b[o][seg] + (long long)tile.mesh * g.b_mesh_stride;
-#pragma unroll
-            for (int i = 0; i < B_IT; ++i) {
-                const int idx = tid + i * NTHR;
-                float e[4] = {0.f, 0.f, 0.f, 0.f};
-                if (BCOLK) {
-                    const int nrow = idx >> 3, q = idx & 7;
-                    const long long base = (long long)(n0 + nrow) * g.ldb + koff + 4 * q;
-                    if (n0 + nrow < g.N) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (koff + 4 * q + c < sg.w) e[c] = bp[base + c];
-                    }
-                } else {
-                    const int krow = idx / (TN / 4), q4 = idx % (TN / 4);
-                    const long long base = (long long)(koff + krow) * g.ldb + n0 + 4 * q4;
-                    if (koff + krow < sg.w) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (n0 + 4 * q4 + c < g.N) e[c] = bp[base + c];
-                    }
-                }
-                R.b[o][i] = make_float4(e[0], e[1], e[2], e[3]);
-                R.bm[o][i] = g.bsign[o][seg];
-            }
-        }
-    }
-}
-
-template <int TN, int NTHR, int NOUT, bool BCOLK, bool HASQ, int A_IT, int B_IT>
-__device__ __forceinline__ void rg_store(float* sA, float* sB, int tid, const RgRegs<NOUT, A_IT, B_IT>& R) {
-    constexpr int SB = DN_KB * TN;
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-        const int idx = tid + i * NTHR;
-        float4 v = dn_f4_scale(R.a[i], R.am[i]);
-        if (HASQ) v = dn_f4_mul(v, R.q[i]);
-        *reinterpret_cast<float4*>(&sA[dn_colk_off(idx >> 3, idx & 7)]) = v;
-    }
-#pragma unroll
-    for (int o = 0; o < NOUT; ++o)
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            const int idx = tid + i * NTHR;
-            const float4 v = dn_f4_scale(R.b[o][i], R.bm[o][i]);
-            if (BCOLK)
-                *reinterpret_cast<float4*>(&sB[o * SB + dn_colk_off(idx >> 3, idx & 7)]) = v;
-            else
-                *reinterpret_cast<float4*>(&sB[o * SB + 4 * idx]) = v;
-        }
-}
-
-template <int TN, int MT, int NT, int NOUT, bool BCOLK>
-__device__ __forceinline__ void rg_compute(const float* sA, const float* sB, int arow0, int bcol0, int li, int ls,
-                                           f32x16 (&acc)[NOUT][MT][NT]) {
-    constexpr int SB = DN_KB * TN;
-#pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
-        float4 af[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            af[mt] = *reinterpret_cast<const float4*>(&sA[dn_colk_off(arow0 + mt * 32 + li, 2 * kg + ls)]);
-        float bv[NOUT][NT][4];
-        if (BCOLK) {
-#pragma unroll
-            for (int o = 0; o < NOUT; ++o)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(&sB[o * SB + dn_colk_off(bcol0 + nt * 32 + li, 2 * kg + ls)]);
-                    bv[o][nt][0] = t4.x; bv[o][nt][1] = t4.y; bv[o][nt][2] = t4.z; bv[o][nt][3] = t4.w;
-                }
-        } else {
-#pragma unroll
-            for (int o = 0; o < NOUT; ++o)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        bv[o][nt][t] = sB[o * SB + (8 * kg + 4 * ls + t) * TN + bcol0 + nt * 32 + li];
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int o = 0; o < NOUT; ++o) {
-#if defined(DN_ABLATE_MFMA)   // development ablation: operands stay live, no matrix work
-                        acc[o][mt][nt][0] += dn_f4_get(af[mt], t) * bv[o][nt][t];
-#else
-                        acc[o][mt][nt] = dn_mfma(dn_f4_get(af[mt], t), bv[o][nt][t], acc[o][mt][nt]);
-#endif
-                    }
-    }
-}
-
-// ---- split-bf16 ("x3") staging and MFMA for the persistent and the two-output kernels: both operands live in LDS as three bf16 planes
-//      (hi, mid, lo) of [rows][32 k]; six cross products per k16 step replace sixteen f32 MFMA k2 steps.
-// The staging is written as two halves so that a kernel can put the MFMAs of the current slice between them: rg_split_x3
-// is pure VALU on the prefetched registers, rg_put_x3 only writes LDS (the compiler must keep LDS writes behind earlier LDS
-// reads of the other buffer -- it cannot prove they do not alias -- so the reads are issued first, see rg_frag_x3).
-template <int NOUT, int A_IT, int B_IT>
-struct X3Planes {
-    uint2 a[A_IT][3];
-    uint2 b[NOUT][B_IT][3];   // BCOLK: one 8-byte chunk per float4; PAIRK: dword e of column group h is (i = 2h + (e >> 1), .x/.y = e & 1)
-};
-
-template <int NOUT, bool BCOLK, bool HASQ, int A_IT, int B_IT>
-__device__ __forceinline__ void rg_split_x3(const RgRegs<NOUT, A_IT, B_IT>& R, X3Planes<NOUT, A_IT, B_IT>& P) {
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-        // no row mask here: a row past the unit's end (its address was clamped) only feeds its own, never stored, output row
-        float4 v = R.a[i];
-        if (HASQ) v = dn_f4_mul(v, R.q[i]);
-        dn_split3_f4(v, P.a[i][0], P.a[i][1], P.a[i][2]);
-    }
-#if defined(DN_X3_ABLATE_BSTAGE)   // development ablation: B operand neither loaded, split nor written
-    return;
-#endif
-#pragma unroll
-    for (int o = 0; o < NOUT; ++o) {
-        if (BCOLK) {
-#pragma unroll
-            for (int i = 0; i < B_IT; ++i) {
-                // the factor carries the sign of a two-output product; with one output it is the column mask only, and
-                // a column past N (clamped address) only feeds its own, never stored, output column
-                const float4 v = NOUT == 2 ? dn_f4_scale(R.b[o][i], R.bm[o][i]) : R.b[o][i];
-                dn_split3_f4(v, P.b[o][i][0], P.b[o][i][1], P.b[o][i][2]);
-            }
-        } else {   // PAIRK: R.b[o][2h] = row 2p, R.b[o][2h+1] = row 2p+1 of column group q4(h) -> packed (k, k+1) dwords per column
-            static_assert(BCOLK || B_IT % 2 == 0, "pair mapping needs two rows per thread and column group");
-#pragma unroll
-            for (int h = 0; h < B_IT / 2; ++h) {
-                const float4 v0 = NOUT == 2 ? dn_f4_scale(R.b[o][2 * h], R.bm[o][2 * h]) : R.b[o][2 * h];
-                const float4 v1 = NOUT == 2 ? dn_f4_scale(R.b[o][2 * h + 1], R.bm[o][2 * h + 1]) : R.b[o][2 * h + 1];
-                dn_split3_pair(v0.x, v1.x, P.b[o][2 * h][0].x, P.b[o][2 * h][1].x, P.b[o][2 * h][2].x);
-                dn_split3_pair(v0.y, v1.y, P.b[o][2 * h][0].y, P.b[o][2 * h][1].y, P.b[o][2 * h][2].y);
-                dn_split3_pair(v0.z, v1.z, P.b[o][2 * h + 1][0].x, P.b[o][2 * h + 1][1].x, P.b[o][2 * h + 1][2].x);
-                dn_split3_pair(v0.w, v1.w, P.b[o][2 * h + 1][0].y, P.b[o][2 * h + 1][1].y, P.b[o][2 * h + 1][2].y);
-            }
-        }
-    }
-}
-
-template <int NTHR, int NOUT, bool BCOLK, int A_IT, int B_IT>
-__device__ __forceinline__ void rg_put_x3(unsigned char* sA, unsigned char* sB, int tid, const X3Planes<NOUT, A_IT, B_IT>& P) {
-    constexpr int PL = DN_TM * 64;    // bytes per A plane (128 rows x 32 bf16)
-    constexpr int PLB = 128 * 64;     // bytes per B plane (128 output columns); output o uses planes [3o, 3o+3)
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-        const int idx = tid + i * NTHR;
-        const int row = idx >> 3, q = idx & 7;
-        const int off = dn_plane_off(row, q >> 1) + (q & 1) * 8;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(sA + p * PL + off) = P.a[i][p];
-    }
-#if defined(DN_X3_ABLATE_BSTAGE)
-    return;
-#endif
-#pragma unroll
-    for (int o = 0; o < NOUT; ++o) {
-        unsigned char* sBo = sB + o * 3 * PLB;
-        if (BCOLK) {
-#pragma unroll
-            for (int i = 0; i < B_IT; ++i) {
-                const int idx = tid + i * NTHR;
-                const int nrow = idx >> 3, q = idx & 7;
-                const int off = dn_plane_off(nrow, q >> 1) + (q & 1) * 8;
-#pragma unroll
-                for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(sBo + p * PLB + off) = P.b[o][i][p];
-            }
-        } else {
-            const int pr = tid & 15;
-#pragma unroll
-            for (int h = 0; h < B_IT / 2; ++h) {
-                const int q4 = (tid >> 4) + (NTHR / 16) * h;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int off = dn_plane_off(4 * q4 + e, pr >> 2) + (pr & 3) * 4;
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        const uint2 w = P.b[o][2 * h + (e >> 1)][p];
-                        *reinterpret_cast<unsigned*>(sBo + p * PLB + off) = (e & 1) ? w.y : w.x;
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <int NTHR, int NOUT, bool BCOLK, bool HASQ, int A_IT, int B_IT>
-__device__ __forceinline__ void rg_store_x3(unsigned char* sA, unsigned char* sB, int tid, const RgRegs<NOUT, A_IT, B_IT>& R) {
-    X3Planes<NOUT, A_IT, B_IT> P;
-    rg_split_x3<NOUT, BCOLK, HASQ, A_IT, B_IT>(R, P);
-    rg_put_x3<NTHR, NOUT, BCOLK, A_IT, B_IT>(sA, sB, tid, P);
-}
-
-// MFMA operands of one 32-wide slice (two k16 steps; lane group lg owns k = 16 s + 8 lg .. +7), read in one burst
-template <int MT, int NT, int NOUT>
-struct X3Frags {
-    uint4 a[2][3][MT];
-    uint4 b[2][NOUT][3][NT];
-};
-
-template <int MT, int NT, int NOUT>
-__device__ __forceinline__ void rg_frag_x3(const unsigned char* sA, const unsigned char* sB, int arow0, int bcol0, int li, int lg,
-                                           int s, X3Frags<MT, NT, NOUT>& F) {
-    constexpr int PL = DN_TM * 64, PLB = 128 * 64;
-#if defined(DN_X3_ABLATE_LDSR)   // development ablation: one LDS read feeds every fragment
-    const uint4 one = *reinterpret_cast<const uint4*>(sA + dn_plane_off(arow0 + li, 2 * s + lg));
-    for (int p = 0; p < 3; ++p) {
-        for (int mt = 0; mt < MT; ++mt) F.a[s][p][mt] = one;
-        for (int o = 0; o < NOUT; ++o)
-            for (int nt = 0; nt < NT; ++nt) F.b[s][o][p][nt] = one;
-    }
-#else
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            F.a[s][p][mt] = *reinterpret_cast<const uint4*>(sA + p * PL + dn_plane_off(arow0 + mt * 32 + li, 2 * s + lg));
-#pragma unroll
-        for (int o = 0; o < NOUT; ++o)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                F.b[s][o][p][nt] = *reinterpret_cast<const uint4*>(sB + (o * 3 + p) * PLB + dn_plane_off(bcol0 + nt * 32 + li, 2 * s + lg));
-    }
-#endif
-}
-
-template <int MT, int NT, int NOUT>
-__device__ __forceinline__ void rg_mma_x3(const X3Frags<MT, NT, NOUT>& F, int s, f32x16 (&acc)[NOUT][MT][NT]) {
-#pragma unroll
-    for (int o = 0; o < NOUT; ++o)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                f32x16 c = acc[o][mt][nt];
-#if defined(DN_X3_ABLATE_MFMA)   // development ablation: operands stay live, no matrix work
-                c[0] += __uint_as_float((F.a[s][0][mt].x ^ F.a[s][1][mt].y ^ F.a[s][2][mt].z) &
-                                        (F.b[s][o][0][nt].x ^ F.b[s][o][1][nt].y ^ F.b[s][o][2][nt].z) & 0x3f800000u);
-#else
-                c = dn_mfma_bf16(F.a[s][1][mt], F.b[s][o][1][nt], c);   // mid*mid   (smallest terms first)
-                c = dn_mfma_bf16(F.a[s][0][mt], F.b[s][o][2][nt], c);   // hi*lo
-                c = dn_mfma_bf16(F.a[s][2][mt], F.b[s][o][0][nt], c);   // lo*hi
-                c = dn_mfma_bf16(F.a[s][0][mt], F.b[s][o][1][nt], c);   // hi*mid
-                c = dn_mfma_bf16(F.a[s][1][mt], F.b[s][o][0][nt], c);   // mid*hi
-                c = dn_mfma_bf16(F.a[s][0][mt], F.b[s][o][0][nt], c);   // hi*hi
-#endif
-                acc[o][mt][nt] = c;
-            }
-}
-
-template <int MT, int NT, int NOUT>
-__device__ __forceinline__ void rg_compute_x3(const unsigned char* sA, const unsigned char* sB, int arow0, int bcol0, int li,
-                                              int lg, f32x16 (&acc)[NOUT][MT][NT]) {
-    X3Frags<MT, NT, NOUT> F;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        rg_frag_x3<MT, NT, NOUT>(sA, sB, arow0, bcol0, li, lg, s, F);
-        rg_mma_x3<MT, NT, NOUT>(F, s, acc);
-    }
-}
+// dn_rowgemm_persist.hip -- persistent forms of the row GEMM (see dn_rowgemm.hip for the product): the lock-step persistent
+// kernel, the wave-specialised kernel (4 MFMA waves + 8 loader/epilogue waves; the default for one-output products with
+// >= 4 slices) and the wave-specialised two-output kernel (parity-green, measured slower, off).
+#include "dn_gemm_tiles.h"
 
 #ifndef DN_RG_X3
-#define DN_RG_X3 1   // -DDN_RG_X3=0: exact-f32 MFMA in the two-output kernels
+#define DN_RG_X3 1   // keep in step with dn_rowgemm.hip (two-output split-bf16 path)
 #endif
-#define RG_STORE(buf)                                                                                                          \
-    do {                                                                                                                       \
-        if constexpr (X3) rg_store_x3<NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>(reinterpret_cast<unsigned char*>(buf),               \
-                                                                          reinterpret_cast<unsigned char*>((buf) + SA), tid, R); \
-        else rg_store<TN, NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>((buf), (buf) + SA, tid, R);                                      \
-    } while (0)
-#define RG_COMPUTE(buf)                                                                                                        \
-    do {                                                                                                                       \
-        if constexpr (X3) rg_compute_x3<MT, NT, NOUT>(reinterpret_cast<const unsigned char*>(buf),                             \
-                                                      reinterpret_cast<const unsigned char*>((buf) + SA), wr * MT * 32,        \
-                                                      wc * NT * 32, li, ls, acc);                                              \
-        else rg_compute<TN, MT, NT, NOUT, BCOLK>((buf), (buf) + SA, wr * MT * 32, wc * NT * 32, li, ls, acc);                  \
-    } while (0)
-// DN_RG2_SINGLE=1: the split-bf16 two-output configuration keeps ONE 72 KiB slice buffer, so that two workgroups share a CU
-// (<= 128 VGPRs) and one's MFMAs run under the other's loads and epilogue; two barriers per slice.  Measured 267 us vs 180 us
-// for the double-buffered form (45-71 spilled registers at the 128 cap) -> off.
-#ifndef DN_RG2_SINGLE
-#define DN_RG2_SINGLE 0
-#endif
-#ifndef DN_RG2_VEC_EPI
-#define DN_RG2_VEC_EPI 1   // parked float4 epilogue of the two-output split-bf16 kernel (0: per-element dword epilogue)
-#endif
-constexpr bool rg_is_x3(int TN, int NTHR, int NOUT, bool ALIGNED) { return DN_RG_X3 && ALIGNED && NOUT == 2 && TN == 128 && NTHR == 512; }
-template <int TN, int WR, int WC, int NOUT, int MODE, bool ALIGNED, bool BCOLK>
-__global__ __launch_bounds__(WR* WC * 64) DN_MIN_WAVES_PER_EU((rg_is_x3(TN, WR * WC * 64, NOUT, ALIGNED) && DN_RG2_SINGLE) ? 4 : 1)
-void rowgemm_kernel(RgArgs g) {
-    constexpr int NTHR = WR * WC * 64;
-    constexpr int MT = DN_TM / (32 * WR);
-    constexpr int NT = TN / (32 * WC);
-    constexpr int A_IT = DN_TM * 8 / NTHR;
-    constexpr int B_IT = DN_KB * TN / 4 / NTHR;
-    // the two-output (gradient feature) products run on split-bf16 MFMA: three bf16 planes per operand tile
-    constexpr bool X3 = DN_RG_X3 && ALIGNED && NOUT == 2 && TN == 128 && NTHR == 512;
-    constexpr int SA = X3 ? (DN_TM * 64 * 3) / 4 : DN_TM * DN_KB;                     // floats of one A slice
-    constexpr int SBUF = SA + NOUT * (X3 ? (128 * 64 * 3) / 4 : DN_KB * TN);          // one (A,B) slice buffer; two in LDS
-    constexpr bool HASQ = (MODE == DN_EPI_GRADFEAT_BWD);   // the only op whose A operand is an elementwise product
-    constexpr bool PAIRK = X3 && !BCOLK;
-    static_assert(MT >= 1 && NT >= 1 && A_IT >= 1 && B_IT >= 1, "bad tile config");
 
-    DN_DYN_SMEM(smem_raw);
-    float* smem = reinterpret_cast<float*>(smem_raw);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave / WC, wc = wave % WC;
-    const int li = lane & 31, ls = lane >> 5;
-    const DnTile tile = g.tiles[blockIdx.x];
-    const int n0 = blockIdx.y * TN;
-    // a wave whose whole sub-tile lies outside the tile's rows / the output's columns has nothing to store
-    const bool wave_active = (wr * MT * 32 < tile.nrows) && (n0 + wc * NT * 32 < g.N);
-
-    f32x16 acc[NOUT][MT][NT];
-#pragma unroll
-    for (int o = 0; o < NOUT; ++o)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[o][mt][nt][r] = 0.f;
-
-    RgRegs<NOUT, A_IT, B_IT> R;
-    int nslices = 0;
-    for (int s = 0; s < g.nseg; ++s) nslices += (g.a[s].w + DN_KB - 1) / DN_KB;
-
-    // Software pipeline over 32-wide slices of the contraction axis, two LDS buffers, ONE barrier per slice:
-    //   iteration sl:  regs(slice sl+1) -> LDS[other] ; global loads of slice sl+2 -> regs ; MFMAs on LDS[cur] ; barrier
-    // The steady-state body has no branch, so the LDS writes and the global loads can be scheduled under the MFMAs.
-    int seg = 0, koff = 0;
-    rg_load<TN, NTHR, NOUT, ALIGNED, BCOLK, HASQ, A_IT, B_IT, PAIRK>(g, tile, n0, seg, koff, tid, R);
-    if constexpr (X3 && DN_RG2_SINGLE) {
-        for (int s1 = 0; s1 < nslices; ++s1) {
-            RG_STORE(smem);                       // slice s1
-            if (s1 + 1 < nslices) {               // slice s1+1 into the registers just freed; in flight under the MFMAs
-                koff += DN_KB;
-                if (koff >= g.a[seg].w) { koff = 0; ++seg; }
-                rg_load<TN, NTHR, NOUT, ALIGNED, BCOLK, HASQ, A_IT, B_IT, PAIRK>(g, tile, n0, seg, koff, tid, R);
-            }
-            __syncthreads();
-            RG_COMPUTE(smem);
-            __syncthreads();
-        }
-    } else {
-    RG_STORE(smem);
-    if (nslices > 1) {
-        koff += DN_KB;
-        if (koff >= g.a[seg].w) { koff = 0; ++seg; }
-        rg_load<TN, NTHR, NOUT, ALIGNED, BCOLK, HASQ, A_IT, B_IT, PAIRK>(g, tile, n0, seg, koff, tid, R);
-    }
-    __syncthreads();
-    int sl = 0;
-    for (; sl + 2 < nslices; ++sl) {
-        float* cur = smem + (sl & 1) * SBUF;
-        float* nxt = smem + ((sl & 1) ^ 1) * SBUF;
-#if !defined(DN_ABLATE_LOADS)
-        RG_STORE(nxt);
-        koff += DN_KB;
-        if (koff >= g.a[seg].w) { koff = 0; ++seg; }
-        rg_load<TN, NTHR, NOUT, ALIGNED, BCOLK, HASQ, A_IT, B_IT, PAIRK>(g, tile, n0, seg, koff, tid, R);
-#else
-        (void)nxt;
-#endif
-        RG_COMPUTE(cur);
-#if !defined(DN_ABLATE_BARRIER)
-        __syncthreads();
-#endif
-    }
-    if (sl + 1 < nslices) {   // second-to-last slice: stage the last one, nothing left to load
-        float* cur = smem + (sl & 1) * SBUF;
-        float* nxt = smem + ((sl & 1) ^ 1) * SBUF;
-        RG_STORE(nxt);
-        RG_COMPUTE(cur);
-        __syncthreads();
-        ++sl;
-    }
-    {
-        float* cur = smem + (sl & 1) * SBUF;
-        RG_COMPUTE(cur);
-    }
-    }
-
-    // ---------------- epilogue ----------------
-#if defined(DN_ABLATE_EPILOGUE)   // development ablation: keep the accumulators live, store one value per wave
-    {
-        float keep = 0.f;
-#pragma unroll
-        for (int o = 0; o < NOUT; ++o)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) keep += acc[o][mt][nt][r];
-        if (lane == 0 && wave_active) g.o0[(long long)tile.row0 * g.ldo + n0 + wave] = keep;
-        return;
-    }
-#endif
-    if constexpr (X3 && DN_RG2_VEC_EPI) {
-        // Two-output split-bf16 configuration: the slice buffers are dead now, so both 128 x 128 accumulator tiles are parked in
-        // them (2 x 64 KiB of the 144 KiB) and the epilogue runs on float4 pieces with coalesced 16-byte loads and stores --
-        // 8 pieces x (2-3 loads + 2-3 stores) per thread instead of 32 elements x (2-3 dword loads + 2-3 dword stores).
-        const bool vec_ok = (((uintptr_t)g.o0 | (uintptr_t)g.o1 | (uintptr_t)g.o2 | (uintptr_t)g.r0 | (uintptr_t)g.r1 | (uintptr_t)g.r2) & 15) == 0 &&
-                            g.ldo % 4 == 0 && g.ldr % 4 == 0 && g.N % 4 == 0;
-        if (vec_ok) {
-            float* sE0 = smem;
-            float* sE1 = smem + 128 * 128;
-            __syncthreads();   // every wave is done with the slice buffers
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int e = ((wr * MT + mt) * 32 + dn_acc_row(r, lane)) * 128 + wc * 32 + li;
-                    sE0[e] = acc[0][mt][0][r];
-                    sE1[e] = acc[NOUT - 1][mt][0][r];
-                }
-            __syncthreads();
-            constexpr int NPC = 128 * 128 / 4 / NTHR;   // 8 pieces per thread
-            float4 r0[NPC], r1[NPC], r2[NPC];
-            long long off[NPC];
-            bool ok[NPC];
-#pragma unroll
-            for (int k = 0; k < NPC; ++k) {
-                const int idx = tid + k * NTHR;
-                const int row = idx >> 5, c4 = idx & 31;
-                const int col = n0 + 4 * c4;
-                ok[k] = row < tile.nrows && col < g.N;
-                const long long grow = tile.row0 + (ok[k] ? row : 0);
-                const int ccol = ok[k] ? col : 0;
-                off[k] = grow * g.ldo + ccol;
-                const long long roff = grow * g.ldr + ccol;
-                r0[k] = *reinterpret_cast<const float4*>(g.r0 + roff);
-                r1[k] = *reinterpret_cast<const float4*>(g.r1 + roff);
-                if (MODE == DN_EPI_GRADFEAT_BWD) r2[k] = *reinterpret_cast<const float4*>(g.r2 + roff);
-            }
-#pragma unroll
-            for (int k = 0; k < NPC; ++k) {
-                const int idx = tid + k * NTHR;
-                const int row = idx >> 5, c4 = idx & 31;
-                const float4 a0 = *reinterpret_cast<const float4*>(&sE0[row * 128 + 4 * c4]);
-                const float4 a1 = *reinterpret_cast<const float4*>(&sE1[row * 128 + 4 * c4]);
-                if (MODE == DN_EPI_GRADFEAT) {
-                    const float4 y = make_float4(tanhf(r0[k].x * a0.x + r1[k].x * a1.x), tanhf(r0[k].y * a0.y + r1[k].y * a1.y),
-                                                 tanhf(r0[k].z * a0.z + r1[k].z * a1.z), tanhf(r0[k].w * a0.w + r1[k].w * a1.w));
-                    if (ok[k]) {
-                        *reinterpret_cast<float4*>(g.o0 + off[k]) = y;
-                        if (g.o1) {
-                            *reinterpret_cast<float4*>(g.o1 + off[k]) = a0;
-                            *reinterpret_cast<float4*>(g.o2 + off[k]) = a1;
-                        }
-                    }
-                } else {
-                    const float4 y0 = make_float4(a0.x + r0[k].x * r1[k].x, a0.y + r0[k].y * r1[k].y, a0.z + r0[k].z * r1[k].z, a0.w + r0[k].w * r1[k].w);
-                    const float4 y1 = make_float4(a1.x + r0[k].x * r2[k].x, a1.y + r0[k].y * r2[k].y, a1.z + r0[k].z * r2[k].z, a1.w + r0[k].w * r2[k].w);
-                    if (ok[k]) {
-                        *reinterpret_cast<float4*>(g.o0 + off[k]) = y0;
-                        *reinterpret_cast<float4*>(g.o1 + off[k]) = y1;
-                    }
-                }
-            }
-            return;
-        }
-    }
-    if (wave_active) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int rbase = (wr * MT + mt) * 32;
-                const int col = n0 + (wc * NT + nt) * 32 + li;
-                if (rbase < tile.nrows)
-                    rg_epilogue_tile<MODE, NOUT>(g, tile.row0 + rbase, tile.nrows - rbase, col, col < g.N, lane,
-                                                 acc[0][mt][nt], acc[NOUT - 1][mt][nt]);
-            }
-    }
-}
-
-#undef RG_STORE
-#undef RG_COMPUTE
-
-template <int TN, int WR, int WC, int NOUT, int MODE, bool ALIGNED, bool BCOLK>
-static int rg_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
-    const int ncol = (g.N + TN - 1) / TN;
-    constexpr bool X3 = DN_RG_X3 && ALIGNED && NOUT == 2 && TN == 128 && WR * WC == 8;
-    const size_t smem = X3 ? (size_t)(DN_RG2_SINGLE ? 1 : 2) * (DN_TM * 64 * 3 + NOUT * 128 * 64 * 3)
-                           : (size_t)2 * (DN_TM * DN_KB + NOUT * DN_KB * TN) * sizeof(float);
-#ifndef DN_EMULATE
-    static bool lds_opt_in = false;   // idempotent: allow > 64 KiB of dynamic LDS for this instantiation
-    if (!lds_opt_in) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_kernel<TN, WR, WC, NOUT, MODE, ALIGNED, BCOLK>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        lds_opt_in = true;
-    }
-#endif
-    DN_LAUNCH((rowgemm_kernel<TN, WR, WC, NOUT, MODE, ALIGNED, BCOLK>), dim3(ntiles, ncol, 1), dim3(WR * WC * 64, 1, 1), smem,
-              stream, g);
-    return (int)hipGetLastError();
-}
-
-// tile width by output width on the aligned path; the general (odd-size) path always uses the 128-wide tile
-template <int NOUT, int MODE, bool BCOLK>
-static int rg_dispatch_width(const RgArgs& g, int ntiles, hipStream_t stream) {
-    constexpr int WC128 = NOUT == 1 ? 2 : 4;
-    if (!g.aligned) return rg_launch<128, 2, WC128, NOUT, MODE, false, BCOLK>(g, ntiles, stream);
-    if (g.N <= 32) return rg_launch<32, 4, 1, NOUT, MODE, true, BCOLK>(g, ntiles, stream);
-    if (g.N <= 64) return rg_launch<64, 2, 2, NOUT, MODE, true, BCOLK>(g, ntiles, stream);
-    return rg_launch<128, 2, WC128, NOUT, MODE, true, BCOLK>(g, ntiles, stream);
-}
 
 // =======================================================================================
 // persistent single-output rowgemm (the heavy N >= 128 products)
@@ -1777,532 +1082,16 @@ static int pt_dispatch(const RgArgs& g, int ntiles, hipStream_t stream) {
     }
 }
 
-int dn_launch_rowgemm(const RgArgs& g, int ntiles, int nout, hipStream_t stream) {
-    if (ntiles <= 0 || g.N <= 0 || g.nseg <= 0) return 0;
-    int ktot = 0;
-    for (int s = 0; s < g.nseg; ++s) ktot += g.a[s].w;
-    const double rows = g.acct_rows;
-    const double flops = 2.0 * rows * ktot * g.N * nout;
-    const double bytes = 4.0 * (rows * ktot + rows * (double)g.N * nout + (double)ktot * g.N * nout);
-    const int kind = nout == 1 ? DN_K_ROWGEMM : DN_K_ROWGEMM_DUAL;
-    dn_prof_begin(kind, stream);
-    int err = DN_ERR_BAD_MODE;
+bool dn_rowgemm_try_persistent(const RgArgs& g, int ntiles, int nout, hipStream_t stream, int* err) {
     const bool ck = g.b_colk != 0;
-#ifndef DN_NO_PERSIST
     if (pt_eligible(g, nout)) {
-        err = pt_dispatch(g, ntiles, stream);
-        dn_prof_end(kind, stream, flops, bytes);
-        return err;
+        *err = pt_dispatch(g, ntiles, stream);
+        return true;
     }
     if (ws2_eligible(g, nout)) {
-        if (g.mode == DN_EPI_GRADFEAT) err = ck ? ws2_launch<DN_EPI_GRADFEAT, true>(g, ntiles, stream) : ws2_launch<DN_EPI_GRADFEAT, false>(g, ntiles, stream);
-        else err = ck ? ws2_launch<DN_EPI_GRADFEAT_BWD, true>(g, ntiles, stream) : ws2_launch<DN_EPI_GRADFEAT_BWD, false>(g, ntiles, stream);
-        dn_prof_end(kind, stream, flops, bytes);
-        return err;
+        if (g.mode == DN_EPI_GRADFEAT) *err = ck ? ws2_launch<DN_EPI_GRADFEAT, true>(g, ntiles, stream) : ws2_launch<DN_EPI_GRADFEAT, false>(g, ntiles, stream);
+        else *err = ck ? ws2_launch<DN_EPI_GRADFEAT_BWD, true>(g, ntiles, stream) : ws2_launch<DN_EPI_GRADFEAT_BWD, false>(g, ntiles, stream);
+        return true;
     }
-#endif
-    if (nout == 1) {
-        switch (g.mode) {
-            case DN_EPI_STORE:
-                err = ck ? rg_dispatch_width<1, DN_EPI_STORE, true>(g, ntiles, stream)
-                         : rg_dispatch_width<1, DN_EPI_STORE, false>(g, ntiles, stream);
-                break;
-            case DN_EPI_BIAS_RELU: if (ck) err = rg_dispatch_width<1, DN_EPI_BIAS_RELU, true>(g, ntiles, stream); break;
-            case DN_EPI_BIAS_RESID: if (ck) err = rg_dispatch_width<1, DN_EPI_BIAS_RESID, true>(g, ntiles, stream); break;
-            case DN_EPI_MUL_DFAC: if (!ck) err = rg_dispatch_width<1, DN_EPI_MUL_DFAC, false>(g, ntiles, stream); break;
-            case DN_EPI_ADD: if (!ck) err = rg_dispatch_width<1, DN_EPI_ADD, false>(g, ntiles, stream); break;
-            case DN_EPI_DTANH: if (!ck) err = rg_dispatch_width<1, DN_EPI_DTANH, false>(g, ntiles, stream); break;
-            case DN_EPI_MASS_ADD: if (!ck) err = rg_dispatch_width<1, DN_EPI_MASS_ADD, false>(g, ntiles, stream); break;
-            default: break;
-        }
-    } else {
-        switch (g.mode) {
-            case DN_EPI_GRADFEAT: if (ck) err = rg_dispatch_width<2, DN_EPI_GRADFEAT, true>(g, ntiles, stream); break;
-            case DN_EPI_GRADFEAT_BWD: if (!ck) err = rg_dispatch_width<2, DN_EPI_GRADFEAT_BWD, false>(g, ntiles, stream); break;
-            default: break;
-        }
-    }
-    dn_prof_end(kind, stream, flops, bytes);
-    return err;
-}
-
-// =======================================================================================
-// tngemm
-// =======================================================================================
-#define DN_TO 128  // output tile edge (both m and n)
-
-// value of the virtually concatenated operand at (row, col); col is resolved to its segment
-__device__ __forceinline__ float tn_elem(const TnSeg* s, int ns, long long row, int col) {
-    int c = col;
-    for (int i = 0; i < ns; ++i) {
-        if (c < s[i].w) {
-            const long long off = row * s[i].ld + c;
-            float v = s[i].p[off];
-            if (s[i].q) v *= s[i].q[off];
-            return v;
-        }
-        c -= s[i].w;
-    }
-    return 0.f;
-}
-
-enum { DN_TN_PLAIN = 0, DN_TN_ROWSCALE = 1, DN_TN_COLSUM = 2, DN_TN_QA = 3 };
-
-struct TnRegs {
-    float4 a[4], b[4], qa[4];
-    float ma[4], mb[4];
-};
-
-// raw loads of one 32-row step (nothing is used here, so the loads stay in flight under the MFMAs)
-template <bool ALIGNED, int FLAVOR>
-__device__ __forceinline__ void tn_load(const TnArgs& g, const DnTile& ch, int step, int kr0, int acol, int bcol, bool a_ok,
-                                        bool b_ok, const float* ap, const float* aq, int ald, const float* bp, int bld,
-                                        TnRegs& R) {
-    if (ALIGNED) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int kr = step * DN_KB + kr0 + 8 * i;
-            const bool kok = kr < ch.nrows;
-            const long long row = (long long)ch.row0 + (kok ? kr : 0);
-            R.ma[i] = (kok && a_ok) ? 1.f : 0.f;
-            R.mb[i] = (kok && b_ok) ? 1.f : 0.f;
-            R.a[i] = *reinterpret_cast<const float4*>(ap + row * ald);
-            R.b[i] = *reinterpret_cast<const float4*>(bp + row * bld);
-            if (FLAVOR == DN_TN_QA) R.qa[i] = *reinterpret_cast<const float4*>(aq + row * ald);
-            if (FLAVOR == DN_TN_ROWSCALE) R.qa[i].x = g.b_rowscale[row];
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int kr = step * DN_KB + kr0 + 8 * i;
-            const long long row = (long long)ch.row0 + kr;
-            float e[4] = {0.f, 0.f, 0.f, 0.f}, f[4] = {0.f, 0.f, 0.f, 0.f};
-            if (kr < ch.nrows) {
-                const float rs = g.b_rowscale ? g.b_rowscale[row] : 1.f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (acol + c < g.M) e[c] = tn_elem(g.a, g.na, row, acol + c);
-                    if (bcol + c < g.N) f[c] = tn_elem(g.b, g.nb, row, bcol + c) * rs;
-                }
-            }
-            R.a[i] = make_float4(e[0], e[1], e[2], e[3]);
-            R.b[i] = make_float4(f[0], f[1], f[2], f[3]);
-            R.ma[i] = 1.f;
-            R.mb[i] = 1.f;
-            if (FLAVOR == DN_TN_QA) R.qa[i] = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (FLAVOR == DN_TN_ROWSCALE) R.qa[i].x = 1.f;
-        }
-    }
-}
-
-template <int FLAVOR>
-__device__ __forceinline__ void tn_store(float* sA, float* sB, int kr0, int q, const TnRegs& R, float4& csum) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float4 va = dn_f4_scale(R.a[i], R.ma[i]);
-        float4 vb = dn_f4_scale(R.b[i], FLAVOR == DN_TN_ROWSCALE ? R.mb[i] * R.qa[i].x : R.mb[i]);
-        if (FLAVOR == DN_TN_QA) va = dn_f4_mul(va, R.qa[i]);
-        if (FLAVOR == DN_TN_COLSUM) { csum.x += va.x; csum.y += va.y; csum.z += va.z; csum.w += va.w; }
-        const int kr = kr0 + 8 * i;
-        *reinterpret_cast<float4*>(&sA[kr * DN_TO + 4 * q]) = va;
-        *reinterpret_cast<float4*>(&sB[kr * DN_TO + 4 * q]) = vb;
-    }
-}
-
-__device__ __forceinline__ void tn_compute(const float* sA, const float* sB, int wr, int wc, int li, int ls, f32x16 (&acc)[2][2]) {
-#pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
-        float af[2][4], bf[2][4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int kr = 8 * kg + 4 * ls + t;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i][t] = sA[kr * DN_TO + (wr * 2 + i) * 32 + li];
-                bf[i][t] = sB[kr * DN_TO + (wc * 2 + i) * 32 + li];
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = dn_mfma(af[i][t], bf[j][t], acc[i][j]);
-    }
-}
-
-template <bool ALIGNED, int FLAVOR>
-__global__ __launch_bounds__(256) void tngemm_kernel(TnArgs g) {
-    constexpr int SBUF = 2 * DN_KB * DN_TO;   // floats of one (A,B) step buffer; two buffers in LDS
-    DN_DYN_SMEM(smem_raw);
-    float* smem = reinterpret_cast<float*>(smem_raw);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int li = lane & 31, ls = lane >> 5;
-    const int n0 = blockIdx.y * DN_TO, m0 = blockIdx.z * DN_TO;
-    const bool do_colsum = FLAVOR == DN_TN_COLSUM && blockIdx.y == 0;
-    const bool wave_active = (m0 + wr * 64 < g.M) && (n0 + wc * 64 < g.N);
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // each thread always stages the same 4-column group (q) of both operands; on the aligned path its segment is
-    // resolved once, out-of-range groups read a valid (clamped) address and are zeroed by the 0/1 factor
-    const int q = tid & 31, kr0 = tid >> 5;
-    const int acol = m0 + 4 * q, bcol = n0 + 4 * q;
-    const float* ap = g.a[0].p; const float* aq = g.a[0].q ? g.a[0].q : g.a[0].p; int ald = g.a[0].ld;
-    const float* bp = g.b[0].p; int bld = g.b[0].ld;
-    const bool a_ok = acol < g.M, b_ok = bcol < g.N;
-    if (ALIGNED) {
-        int c = acol;
-        for (int i = 0; i < g.na; ++i) {
-            if (a_ok && c >= 0 && c < g.a[i].w) { ap = g.a[i].p + c; aq = (g.a[i].q ? g.a[i].q : g.a[i].p) + c; ald = g.a[i].ld; }
-            c -= g.a[i].w;
-        }
-        c = bcol;
-        for (int i = 0; i < g.nb; ++i) {
-            if (b_ok && c >= 0 && c < g.b[i].w) { bp = g.b[i].p + c; bld = g.b[i].ld; }
-            c -= g.b[i].w;
-        }
-    }
-    float4 csum = dn_f4_zero();
-    TnRegs R;
-
-    const int c_beg = blockIdx.x * g.group;
-    const int c_end = (c_beg + g.group < g.nchunks) ? c_beg + g.group : g.nchunks;
-    for (int ci = c_beg; ci < c_end; ++ci) {
-        const DnTile ch = g.chunks[ci];
-        const int nsteps = (ch.nrows + DN_KB - 1) / DN_KB;
-        // pipeline: regs(step+1) -> LDS[other]; loads(step+2) -> regs; MFMAs on LDS[cur]; ONE barrier per step
-        tn_load<ALIGNED, FLAVOR>(g, ch, 0, kr0, acol, bcol, a_ok, b_ok, ap, aq, ald, bp, bld, R);
-        tn_store<FLAVOR>(smem, smem + DN_KB * DN_TO, kr0, q, R, csum);
-        if (nsteps > 1) tn_load<ALIGNED, FLAVOR>(g, ch, 1, kr0, acol, bcol, a_ok, b_ok, ap, aq, ald, bp, bld, R);
-        __syncthreads();
-        int st = 0;
-        for (; st + 2 < nsteps; ++st) {
-            float* cur = smem + (st & 1) * SBUF;
-            float* nxt = smem + ((st & 1) ^ 1) * SBUF;
-            tn_store<FLAVOR>(nxt, nxt + DN_KB * DN_TO, kr0, q, R, csum);
-            tn_load<ALIGNED, FLAVOR>(g, ch, st + 2, kr0, acol, bcol, a_ok, b_ok, ap, aq, ald, bp, bld, R);
-            tn_compute(cur, cur + DN_KB * DN_TO, wr, wc, li, ls, acc);
-            __syncthreads();
-        }
-        if (st + 1 < nsteps) {
-            float* cur = smem + (st & 1) * SBUF;
-            float* nxt = smem + ((st & 1) ^ 1) * SBUF;
-            tn_store<FLAVOR>(nxt, nxt + DN_KB * DN_TO, kr0, q, R, csum);
-            tn_compute(cur, cur + DN_KB * DN_TO, wr, wc, li, ls, acc);
-            __syncthreads();
-            ++st;
-        }
-        {
-            float* cur = smem + (st & 1) * SBUF;
-            tn_compute(cur, cur + DN_KB * DN_TO, wr, wc, li, ls, acc);
-            __syncthreads();   // the next chunk's prologue overwrites buffer 0
-        }
-    }
-    // partial tile out
-    float* out = g.partial + (long long)blockIdx.x * g.M * g.N;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (!wave_active) continue;
-            const int n = n0 + (wc * 2 + j) * 32 + li;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wr * 2 + i) * 32 + dn_acc_row(r, lane);
-                if (m < g.M && n < g.N) out[(long long)m * g.N + n] = acc[i][j][r];
-            }
-        }
-    if (do_colsum) {   // uniform per block
-        *reinterpret_cast<float4*>(&smem[kr0 * DN_TO + 4 * q]) = csum;
-        __syncthreads();
-        if (tid < DN_TO && m0 + tid < g.M) {
-            float sum = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) sum += smem[k * DN_TO + tid];
-            g.colsum[(long long)blockIdx.x * g.M + m0 + tid] = sum;
-        }
-    }
-}
-
-template <bool ALIGNED, int FLAVOR>
-static int tn_launch(const TnArgs& g, dim3 grid, hipStream_t stream) {
-    const size_t smem = (size_t)2 * 2 * DN_KB * DN_TO * sizeof(float);
-    DN_LAUNCH((tngemm_kernel<ALIGNED, FLAVOR>), grid, dim3(256, 1, 1), smem, stream, g);
-    return (int)hipGetLastError();
-}
-
-// =======================================================================================
-// tngemm on split-bf16 MFMA (aligned operands).  The operands are k-major (the contraction runs over the rows r of
-// A[r, m] and B[r, n]), so their bf16 planes are stored as loaded -- [32 r][128 cols], 320-byte rows: four consecutive
-// rows start 16 banks apart -- and turned into MFMA operands by the LDS transpose read.  8 waves (64 x 32 outputs each),
-// two 60 KiB step buffers.
-// =======================================================================================
-#define DN_TX_THREADS 512
-#define DN_TX_ROWB 320                      // bytes per LDS plane row (128 bf16 + 32 B pad)
-#define DN_TX_PLANE (DN_KB * DN_TX_ROWB)    // bytes per plane (10 KiB)
-
-struct TxRegs {
-    float4 a[2], b[2], qa[2];
-    float ma[2], mb[2];
-};
-
-template <int FLAVOR>
-__device__ __forceinline__ void tx_load(const TnArgs& g, const DnTile& ch, int step, int kr0, bool a_ok, bool b_ok,
-                                        const float* ap, const float* aq, int ald, const float* bp, int bld, TxRegs& R) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int kr = step * DN_KB + kr0 + 16 * i;
-        const bool kok = kr < ch.nrows;
-        const long long row = (long long)ch.row0 + (kok ? kr : 0);
-        R.ma[i] = (kok && a_ok) ? 1.f : 0.f;
-        R.mb[i] = (kok && b_ok) ? 1.f : 0.f;
-        R.a[i] = *reinterpret_cast<const float4*>(ap + row * ald);
-        R.b[i] = *reinterpret_cast<const float4*>(bp + row * bld);
-        if (FLAVOR == DN_TN_QA) R.qa[i] = *reinterpret_cast<const float4*>(aq + row * ald);
-        if (FLAVOR == DN_TN_ROWSCALE) R.qa[i].x = g.b_rowscale[row];
-    }
-}
-
-__device__ __forceinline__ void tx_put(unsigned char* planes, int off, float4 v) {
-    uint2 h, m, l;
-    dn_split3_f4(v, h, m, l);
-    *reinterpret_cast<uint2*>(planes + off) = h;
-    *reinterpret_cast<uint2*>(planes + DN_TX_PLANE + off) = m;
-    *reinterpret_cast<uint2*>(planes + 2 * DN_TX_PLANE + off) = l;
-}
-
-template <int FLAVOR>
-__device__ __forceinline__ void tx_store(unsigned char* sA, unsigned char* sB, int kr0, int q, const TxRegs& R, float4& csum) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        float4 va = dn_f4_scale(R.a[i], R.ma[i]);
-        const float4 vb = dn_f4_scale(R.b[i], FLAVOR == DN_TN_ROWSCALE ? R.mb[i] * R.qa[i].x : R.mb[i]);
-        if (FLAVOR == DN_TN_QA) va = dn_f4_mul(va, R.qa[i]);
-        if (FLAVOR == DN_TN_COLSUM) { csum.x += va.x; csum.y += va.y; csum.z += va.z; csum.w += va.w; }
-        const int off = (kr0 + 16 * i) * DN_TX_ROWB + q * 8;
-        tx_put(sA, off, va);
-        tx_put(sB, off, vb);
-    }
-}
-
-// one MFMA operand (8 consecutive k of a column) from a k-major plane: two transpose reads of 4 rows each
-__device__ __forceinline__ uint4 tx_frag(const unsigned char* p) {
-    const uint2 lo = dn_lds_tr16(p), hi = dn_lds_tr16(p + 4 * DN_TX_ROWB);
-    return make_uint4(lo.x, lo.y, hi.x, hi.y);
-}
-
-__device__ __forceinline__ void tx_compute(const unsigned char* sA, const unsigned char* sB, int wr, int wc, int lane,
-                                           f32x16 (&acc)[2]) {
-    // lane -> chunk it names inside its 16-lane group: row (c/4) of the 4-row block, columns 4*(c%4)..+3 of the 16-column half
-    const int g = lane >> 4, c = lane & 15;
-    const int lane_off = (8 * (g >> 1) + (c >> 2)) * DN_TX_ROWB + (16 * (g & 1) + 4 * (c & 3)) * 2;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {   // two k16 steps per 32-row step
-        uint4 a[3][2], b[3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const int base = p * DN_TX_PLANE + s * 16 * DN_TX_ROWB + lane_off;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) a[p][mt] = tx_frag(sA + base + (wr * 64 + mt * 32) * 2);
-            b[p] = tx_frag(sB + base + (wc * 32) * 2);
-        }
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            f32x16 cacc = acc[mt];
-            cacc = dn_mfma_bf16(a[1][mt], b[1], cacc);
-            cacc = dn_mfma_bf16(a[0][mt], b[2], cacc);
-            cacc = dn_mfma_bf16(a[2][mt], b[0], cacc);
-            cacc = dn_mfma_bf16(a[0][mt], b[1], cacc);
-            cacc = dn_mfma_bf16(a[1][mt], b[0], cacc);
-            cacc = dn_mfma_bf16(a[0][mt], b[0], cacc);
-            acc[mt] = cacc;
-        }
-    }
-}
-
-#ifndef DN_TX_SINGLE
-#define DN_TX_SINGLE 1   // measured: 60.1 vs 62.2 us (to_basis, 158k rows) against the double-buffered 1-WG/CU form
-#endif
-template <int FLAVOR>
-__global__ __launch_bounds__(DN_TX_THREADS, DN_TX_SINGLE ? 4 : 2) void tngemm_x3_kernel(TnArgs g) {
-    constexpr int SBUF = 6 * DN_TX_PLANE;   // bytes of one (A,B) step buffer (3 planes each); two buffers in LDS
-    DN_DYN_SMEM(smem_raw);
-    unsigned char* smem = reinterpret_cast<unsigned char*>(smem_raw);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 2, wc = wave & 3;           // 2 x 4 waves, 64 x 32 outputs each
-    const int li = lane & 31;
-    const int n0 = blockIdx.y * DN_TO, m0 = blockIdx.z * DN_TO;
-    const bool do_colsum = FLAVOR == DN_TN_COLSUM && blockIdx.y == 0;
-    const bool wave_active = (m0 + wr * 64 < g.M) && (n0 + wc * 32 < g.N);
-
-    f32x16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
-    const int q = tid & 31, kr0 = tid >> 5;            // this thread stages column group q of rows kr0, kr0 + 16
-    const int acol = m0 + 4 * q, bcol = n0 + 4 * q;
-    const float* ap = g.a[0].p; const float* aq = g.a[0].q ? g.a[0].q : g.a[0].p; int ald = g.a[0].ld;
-    const float* bp = g.b[0].p; int bld = g.b[0].ld;
-    const bool a_ok = acol < g.M, b_ok = bcol < g.N;
-    {
-        int c = acol;
-        for (int i = 0; i < g.na; ++i) {
-            if (a_ok && c >= 0 && c < g.a[i].w) { ap = g.a[i].p + c; aq = (g.a[i].q ? g.a[i].q : g.a[i].p) + c; ald = g.a[i].ld; }
-            c -= g.a[i].w;
-        }
-        c = bcol;
-        for (int i = 0; i < g.nb; ++i) {
-            if (b_ok && c >= 0 && c < g.b[i].w) { bp = g.b[i].p + c; bld = g.b[i].ld; }
-            c -= g.b[i].w;
-        }
-    }
-    float4 csum = dn_f4_zero();
-    TxRegs R;
-
-    const int c_beg = blockIdx.x * g.group;
-    const int c_end = (c_beg + g.group < g.nchunks) ? c_beg + g.group : g.nchunks;
-    for (int ci = c_beg; ci < c_end; ++ci) {
-        const DnTile ch = g.chunks[ci];
-        const int nsteps = (ch.nrows + DN_KB - 1) / DN_KB;
-#if DN_TX_SINGLE
-        // single 60 KiB step buffer, two barriers per step: two workgroups (16 waves) share a CU and cover each other's
-        // staging phases and HBM latency
-        tx_load<FLAVOR>(g, ch, 0, kr0, a_ok, b_ok, ap, aq, ald, bp, bld, R);
-        tx_store<FLAVOR>(smem, smem + 3 * DN_TX_PLANE, kr0, q, R, csum);
-        __syncthreads();
-        for (int st = 0; st < nsteps; ++st) {
-            if (st + 1 < nsteps) tx_load<FLAVOR>(g, ch, st + 1, kr0, a_ok, b_ok, ap, aq, ald, bp, bld, R);
-            tx_compute(smem, smem + 3 * DN_TX_PLANE, wr, wc, lane, acc);
-            __syncthreads();
-            if (st + 1 < nsteps) {
-                tx_store<FLAVOR>(smem, smem + 3 * DN_TX_PLANE, kr0, q, R, csum);
-                __syncthreads();
-            }
-        }
-#else
-        tx_load<FLAVOR>(g, ch, 0, kr0, a_ok, b_ok, ap, aq, ald, bp, bld, R);
-        tx_store<FLAVOR>(smem, smem + 3 * DN_TX_PLANE, kr0, q, R, csum);
-        if (nsteps > 1) tx_load<FLAVOR>(g, ch, 1, kr0, a_ok, b_ok, ap, aq, ald, bp, bld, R);
-        __syncthreads();
-        int st = 0;
-        for (; st + 2 < nsteps; ++st) {
-            unsigned char* cur = smem + (st & 1) * SBUF;
-            unsigned char* nxt = smem + ((st & 1) ^ 1) * SBUF;
-            tx_store<FLAVOR>(nxt, nxt + 3 * DN_TX_PLANE, kr0, q, R, csum);
-            tx_load<FLAVOR>(g, ch, st + 2, kr0, a_ok, b_ok, ap, aq, ald, bp, bld, R);
-            tx_compute(cur, cur + 3 * DN_TX_PLANE, wr, wc, lane, acc);
-            __syncthreads();
-        }
-        if (st + 1 < nsteps) {
-            unsigned char* cur = smem + (st & 1) * SBUF;
-            unsigned char* nxt = smem + ((st & 1) ^ 1) * SBUF;
-            tx_store<FLAVOR>(nxt, nxt + 3 * DN_TX_PLANE, kr0, q, R, csum);
-            tx_compute(cur, cur + 3 * DN_TX_PLANE, wr, wc, lane, acc);
-            __syncthreads();
-            ++st;
-        }
-        {
-            unsigned char* cur = smem + (st & 1) * SBUF;
-            tx_compute(cur, cur + 3 * DN_TX_PLANE, wr, wc, lane, acc);
-            __syncthreads();   // the next chunk's prologue overwrites buffer 0
-        }
-#endif
-    }
-    float* out = g.partial + (long long)blockIdx.x * g.M * g.N;
-    if (wave_active) {
-        const int n = n0 + wc * 32 + li;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wr * 2 + i) * 32 + dn_acc_row(r, lane);
-                if (m < g.M && n < g.N) out[(long long)m * g.N + n] = acc[i][r];
-            }
-    }
-    if (do_colsum) {   // uniform per block: 16 row lanes x 32 column groups -> [16][128] floats in LDS
-        float* red = reinterpret_cast<float*>(smem);
-        *reinterpret_cast<float4*>(&red[kr0 * DN_TO + 4 * q]) = csum;
-        __syncthreads();
-        if (tid < DN_TO && m0 + tid < g.M) {
-            float sum = 0.f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) sum += red[k * DN_TO + tid];
-            g.colsum[(long long)blockIdx.x * g.M + m0 + tid] = sum;
-        }
-    }
-}
-
-template <int FLAVOR>
-static int tx_launch(const TnArgs& g, dim3 grid, hipStream_t stream) {
-    const size_t smem = (size_t)(DN_TX_SINGLE ? 1 : 2) * 6 * DN_TX_PLANE;   // 120 KiB (60 KiB single-buffered)
-#ifndef DN_EMULATE
-    static bool lds_opt_in = false;
-    if (!lds_opt_in) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tngemm_x3_kernel<FLAVOR>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)smem);
-        lds_opt_in = true;
-    }
-#endif
-    DN_LAUNCH((tngemm_x3_kernel<FLAVOR>), grid, dim3(DN_TX_THREADS, 1, 1), smem, stream, g);
-    return (int)hipGetLastError();
-}
-
-#ifndef DN_TN_X3
-#define DN_TN_X3 1   // -DDN_TN_X3=0: exact-f32 MFMA in the split-V kernels
-#endif
-
-// returns the number of partials written (= gridDim.x) through *npartial
-int dn_launch_tngemm(const TnArgs& g_in, int nchunks, hipStream_t stream) {
-    if (nchunks <= 0 || g_in.M <= 0 || g_in.N <= 0) return 0;
-    TnArgs g = g_in;
-    g.nchunks = nchunks;
-    if (g.group < 1) g.group = 1;
-    const int nblk = (nchunks + g.group - 1) / g.group;
-    dim3 grid(nblk, (g.N + DN_TO - 1) / DN_TO, (g.M + DN_TO - 1) / DN_TO);
-    // flavour: which optional operand treatment the launch needs (at most one is ever combined by the callers)
-    bool has_qa = false;
-    for (int i = 0; i < g.na; ++i) has_qa = has_qa || g.a[i].q != nullptr;
-    for (int i = 0; i < g.nb; ++i) if (g.b[i].q) return DN_ERR_BAD_MODE;
-    const int flavor = has_qa ? DN_TN_QA : (g.colsum ? DN_TN_COLSUM : (g.b_rowscale ? DN_TN_ROWSCALE : DN_TN_PLAIN));
-    if ((has_qa && (g.colsum || g.b_rowscale)) || (g.colsum && g.b_rowscale)) return DN_ERR_BAD_MODE;
-    const double rows = g.acct_rows;
-    dn_prof_begin(DN_K_TNGEMM, stream);
-    int err;
-    if (g.aligned && DN_TN_X3) {
-        switch (flavor) {
-            case DN_TN_QA: err = tx_launch<DN_TN_QA>(g, grid, stream); break;
-            case DN_TN_COLSUM: err = tx_launch<DN_TN_COLSUM>(g, grid, stream); break;
-            case DN_TN_ROWSCALE: err = tx_launch<DN_TN_ROWSCALE>(g, grid, stream); break;
-            default: err = tx_launch<DN_TN_PLAIN>(g, grid, stream); break;
-        }
-    } else if (g.aligned) {
-        switch (flavor) {
-            case DN_TN_QA: err = tn_launch<true, DN_TN_QA>(g, grid, stream); break;
-            case DN_TN_COLSUM: err = tn_launch<true, DN_TN_COLSUM>(g, grid, stream); break;
-            case DN_TN_ROWSCALE: err = tn_launch<true, DN_TN_ROWSCALE>(g, grid, stream); break;
-            default: err = tn_launch<true, DN_TN_PLAIN>(g, grid, stream); break;
-        }
-    } else {
-        switch (flavor) {
-            case DN_TN_QA: err = tn_launch<false, DN_TN_QA>(g, grid, stream); break;
-            case DN_TN_COLSUM: err = tn_launch<false, DN_TN_COLSUM>(g, grid, stream); break;
-            case DN_TN_ROWSCALE: err = tn_launch<false, DN_TN_ROWSCALE>(g, grid, stream); break;
-            default: err = tn_launch<false, DN_TN_PLAIN>(g, grid, stream); break;
-        }
-    }
-    dn_prof_end(DN_K_TNGEMM, stream, 2.0 * rows * g.M * g.N,
-                4.0 * (rows * (g.M + g.N) + (double)nblk * g.M * g.N));
-    return err;
+    return false;
 }
