@@ -135,7 +135,10 @@ def main():
     model.to(device).train()
     nsub = max(1, min(args.streams, args.meshes))
     flat = FlatParams(model, direct_sinks=(nsub == 1))   # concurrent backward streams need autograd's ordered accumulation
-    opt = torch.optim.Adam([flat.master], lr=1e-3)
+    try:                                       # one fused update kernel over the flat parameter buffer
+        opt = torch.optim.Adam([flat.master], lr=1e-3, fused=True)
+    except (TypeError, RuntimeError):
+        opt = torch.optim.Adam([flat.master], lr=1e-3)
 
     sizes = mesh_sizes(args.meshes, args.verts, rank)
     subs = []
