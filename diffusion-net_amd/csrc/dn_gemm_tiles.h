@@ -405,28 +405,26 @@ __device__ __forceinline__ void rg_frag_x3(const unsigned char* sA, const unsign
 #endif
 }
 
+// The six cross products of one k16 step, smallest terms first.  Product-major issue order: consecutive MFMAs go to
+// DIFFERENT accumulators (an MFMA on the accumulator of the previous one waits out its full latency), while every
+// accumulator still receives its six products in the same order -- bitwise the same sums as an accumulator-major loop.
 template <int MT, int NT, int NOUT>
 __device__ __forceinline__ void rg_mma_x3(const X3Frags<MT, NT, NOUT>& F, int s, f32x16 (&acc)[NOUT][MT][NT]) {
+    constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};   // mid*mid, hi*lo, lo*hi, hi*mid, mid*hi, hi*hi
 #pragma unroll
-    for (int o = 0; o < NOUT; ++o)
+    for (int p = 0; p < 6; ++p)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int o = 0; o < NOUT; ++o)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                f32x16 c = acc[o][mt][nt];
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
 #if defined(DN_X3_ABLATE_MFMA)   // development ablation: operands stay live, no matrix work
-                c[0] += __uint_as_float((F.a[s][0][mt].x ^ F.a[s][1][mt].y ^ F.a[s][2][mt].z) &
-                                        (F.b[s][o][0][nt].x ^ F.b[s][o][1][nt].y ^ F.b[s][o][2][nt].z) & 0x3f800000u);
+                    acc[o][mt][nt][0] += __uint_as_float((F.a[s][PA[p]][mt].x & F.b[s][o][PB[p]][nt].x) & 0x3f800000u);
 #else
-                c = dn_mfma_bf16(F.a[s][1][mt], F.b[s][o][1][nt], c);   // mid*mid   (smallest terms first)
-                c = dn_mfma_bf16(F.a[s][0][mt], F.b[s][o][2][nt], c);   // hi*lo
-                c = dn_mfma_bf16(F.a[s][2][mt], F.b[s][o][0][nt], c);   // lo*hi
-                c = dn_mfma_bf16(F.a[s][0][mt], F.b[s][o][1][nt], c);   // hi*mid
-                c = dn_mfma_bf16(F.a[s][1][mt], F.b[s][o][0][nt], c);   // mid*hi
-                c = dn_mfma_bf16(F.a[s][0][mt], F.b[s][o][0][nt], c);   // hi*hi
+                    acc[o][mt][nt] = dn_mfma_bf16(F.a[s][PA[p]][mt], F.b[s][o][PB[p]][nt], acc[o][mt][nt]);
 #endif
-                acc[o][mt][nt] = c;
-            }
+                }
 }
 
 template <int MT, int NT, int NOUT>

@@ -293,17 +293,12 @@ __device__ __forceinline__ void tx_compute(const unsigned char* sA, const unsign
             for (int mt = 0; mt < 2; ++mt) a[p][mt] = tx_frag(sA + base + (wr * 64 + mt * 32) * 2);
             b[p] = tx_frag(sB + base + (wc * 32) * 2);
         }
+        // product-major: consecutive MFMAs alternate between the two accumulators (same per-accumulator order, same sums)
+        constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};   // mid*mid, hi*lo, lo*hi, hi*mid, mid*hi, hi*hi
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            f32x16 cacc = acc[mt];
-            cacc = dn_mfma_bf16(a[1][mt], b[1], cacc);
-            cacc = dn_mfma_bf16(a[0][mt], b[2], cacc);
-            cacc = dn_mfma_bf16(a[2][mt], b[0], cacc);
-            cacc = dn_mfma_bf16(a[0][mt], b[1], cacc);
-            cacc = dn_mfma_bf16(a[1][mt], b[0], cacc);
-            cacc = dn_mfma_bf16(a[0][mt], b[0], cacc);
-            acc[mt] = cacc;
-        }
+        for (int p = 0; p < 6; ++p)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) acc[mt] = dn_mfma_bf16(a[PA[p]][mt], b[PB[p]], acc[mt]);
     }
 }
 
