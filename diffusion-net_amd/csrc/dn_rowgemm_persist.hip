@@ -392,7 +392,11 @@ static int dn_num_cus() {
 #define DN_WS_SPLIT_SIMD 0   // 1: MFMA waves on two SIMDs, loaders on the other two -- measured slower (58 vs 51 us, C->C product)
 #endif
 #define DN_WS_LTHR (64 * DN_WS_LW)             // loader threads
-#define DN_WS_NP (128 * 128 / 4 / DN_WS_LTHR)   // float4 pieces per loader thread and unit (16 or 8)
+#ifndef DN_WS_PW
+#define DN_WS_PW DN_WS_LW                     // loader waves that also stream the parked unit out; measured: 4 or 2 (the oldest) instead of all 8 is slower (C->C 47-52 / 59 us vs 46-49)
+#endif
+#define DN_WS_PTHR (64 * DN_WS_PW)
+#define DN_WS_NP (128 * 128 / 4 / DN_WS_PTHR)   // float4 pieces per piece thread and unit
 
 struct WsAux {
     float4 a0;
@@ -407,7 +411,7 @@ struct WsAux {
 template <int MODE, bool FLAG>
 __device__ __forceinline__ void ws_aux_load(const RgArgs& g, int piece, int lt, int row0, int nrows, int n0, WsAux& A) {
     const bool live = piece < DN_WS_NP;
-    const int idx = lt + (live ? piece : 0) * DN_WS_LTHR;
+    const int idx = lt + (live ? piece : 0) * DN_WS_PTHR;
     const int row = idx >> 5, c4 = idx & 31;
     const int col = n0 + 4 * c4;
     A.ok = live && row < nrows && col < g.N;
@@ -586,6 +590,7 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     int cu = blockIdx.x, cs = 0;
     DnTile ctile = ltile, ctile_next = ltile_next;
     int p_row0 = ctile.row0, p_nrows = 0, p_next = DN_WS_NP;   // p_next >= NP: nothing pending
+    const bool piece_wave = lt < DN_WS_PTHR;
     WsAux AX[PPI];
 #pragma unroll
     for (int k = 0; k < PPI; ++k) ws_aux_load<MODE, FLAG>(g, DN_WS_NP, lt, p_row0, p_nrows, n0, AX[k]);   // dead pieces
@@ -620,8 +625,8 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
                                                  reinterpret_cast<unsigned char*>((buf) + SA), lt, PLN);                \
     } while (0)
 
-// Order inside an iteration: stage -> slice prefetch -> deferred pieces (their operands were requested an iteration ago) ->
-// operands of the next iteration's pieces.  (Measured: a second register set / fetching two slices ahead, and requesting
+// Order inside an iteration: stage -> deferred pieces (their operands were requested an iteration ago) -> operands of the
+// next iteration's pieces -> slice prefetch.  (Measured: a second register set / fetching two slices ahead, and requesting
 // the piece operands before the prefetch, were both slower -- 60/48/135 us vs 53/51/127 us for the NN, C->C, 3C->C products.)
 #define WS_ITER(j, RS)                                                                                                  \
     do {                                                                                                                \
@@ -629,24 +634,26 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
         WS_T(DN_WS_TRACE_TID);                                                                                                      \
         WS_STAGE(nxt, RS);             /* slice j+1 (the last iteration stages a stale copy nobody reads) */            \
         WS_T(DN_WS_TRACE_TID);                                                                                                      \
+        if (piece_wave) {              /* wave-uniform: only the first DN_WS_PW loader waves stream the parked unit out */ \
+            _Pragma("unroll") for (int k = 0; k < PPI; ++k) ws_piece_out<MODE, FLAG>(g, sE, bias, AX[k]);               \
+            WS_T(DN_WS_TRACE_TID);                                                                                      \
+            p_next = (p_next + PPI < DN_WS_NP) ? p_next + PPI : DN_WS_NP;                                               \
+            {   /* the MFMA waves park unit cu at the end of the iteration that multiplies its last slice */            \
+                const bool park = ++cs == nsl;                                                                          \
+                p_row0 = park ? ctile.row0 : p_row0; p_nrows = park ? ctile.nrows : p_nrows;                            \
+                p_next = park ? (DN_PT_OUT_START ? DN_WS_NP : 0) : p_next;                                              \
+                cs = park ? 0 : cs;                                                                                     \
+                cu = park ? cu + G : cu;                                                                                \
+                ctile.row0 = park ? ctile_next.row0 : ctile.row0; ctile.nrows = park ? ctile_next.nrows : ctile.nrows;  \
+                const int cn = cu + G < ntiles ? cu + G : ntiles - 1;                                                   \
+                ctile_next = g.tiles[cn];   /* consumed at the next park at the earliest */                             \
+            }                                                                                                           \
+            _Pragma("unroll") for (int k = 0; k < PPI; ++k)                                                             \
+                ws_aux_load<MODE, FLAG>(g, p_next + k, lt, p_row0, p_nrows, n0, AX[k]);                                 \
+        }                                                                                                               \
         WS_ADVANCE((j) + 1 + DN_WS_DEPTH < T);                                                                          \
         WS_LOAD(RS);                   /* slice j+1+DEPTH */                                                            \
-        WS_T(DN_WS_TRACE_TID);                                                                                                      \
-        _Pragma("unroll") for (int k = 0; k < PPI; ++k) ws_piece_out<MODE, FLAG>(g, sE, bias, AX[k]);                   \
-        WS_T(DN_WS_TRACE_TID);                                                                                                      \
-        p_next = (p_next + PPI < DN_WS_NP) ? p_next + PPI : DN_WS_NP;                                                   \
-        {   /* the MFMA waves park unit cu at the end of the iteration that multiplies its last slice (selects only) */  \
-            const bool park = ++cs == nsl;                                                                              \
-            p_row0 = park ? ctile.row0 : p_row0; p_nrows = park ? ctile.nrows : p_nrows;                                \
-            p_next = park ? (DN_PT_OUT_START ? DN_WS_NP : 0) : p_next;                                                  \
-            cs = park ? 0 : cs;                                                                                         \
-            cu = park ? cu + G : cu;                                                                                    \
-            ctile.row0 = park ? ctile_next.row0 : ctile.row0; ctile.nrows = park ? ctile_next.nrows : ctile.nrows;      \
-            const int cn = cu + G < ntiles ? cu + G : ntiles - 1;                                                       \
-            ctile_next = g.tiles[cn];   /* consumed at the next park at the earliest */                                 \
-        }                                                                                                               \
-        _Pragma("unroll") for (int k = 0; k < PPI; ++k)                                                                 \
-            ws_aux_load<MODE, FLAG>(g, p_next + k, lt, p_row0, p_nrows, n0, AX[k]);                                     \
+        WS_T(DN_WS_TRACE_TID);                                                                                          \
         __syncthreads();                                                                                                \
     } while (0)
 
@@ -676,6 +683,7 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
 #if defined(DN_PT_ABLATE_OUT)
     p_next = DN_WS_NP;
 #endif
+    if (!piece_wave) return;
     for (; p_next < DN_WS_NP; ++p_next) {
         WsAux A1;
         ws_aux_load<MODE, FLAG>(g, p_next, lt, p_row0, p_nrows, n0, A1);
