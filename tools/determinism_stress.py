@@ -22,11 +22,13 @@ def main():
     ap.add_argument("--reps", type=int, default=200)
     ap.add_argument("--meshes", type=int, default=16)
     ap.add_argument("--verts", type=int, default=10000)
+    ap.add_argument("--cwidth", type=int, default=128)
+    ap.add_argument("--keig", type=int, default=128)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     sizes = bench.mesh_sizes(a.meshes, a.verts, 0)
-    meshes, mb, gather, x3 = bench.build_batch(sizes, 128, dev, 0)
-    V, C, K = sum(sizes), 128, 128
+    meshes, mb, gather, x3 = bench.build_batch(sizes, a.keig, dev, 0)
+    V, C, K = sum(sizes), a.cwidth, a.keig
     g = torch.Generator().manual_seed(0)
     R = lambda *s: torch.randn(*s, generator=g).to(dev)
     x, y, w = R(V, C), R(V, C), R(V, C)
