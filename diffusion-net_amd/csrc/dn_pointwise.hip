@@ -234,38 +234,50 @@ int dn_launch_dtanh(const float* dg, const float* g, float* out, long long n, hi
 // ---- thin products with a tiny contraction / output width (first_lin: C_in = 3 or 16; last_lin backward) ----
 // A thread owns 4 output columns for all the rows it visits and keeps their K <= 16 weights in registers; per row it
 // reads the K inputs (wave-broadcast) and writes one float4.  Bandwidth-bound on the output stream.
+template <int KMAX>
 __global__ __launch_bounds__(256) void smallk_rows_kernel(const float* x, int K, const float* W, int w_kn, const float* bias,
                                                           int N, float* out, long long rows) {
+    constexpr int UR = KMAX <= 4 ? 4 : 2;       // independent row passes in flight per thread
     const int n4 = (N + 3) / 4;                 // column groups per row
     const int cg = threadIdx.x % n4, rl = threadIdx.x / n4;
     const int rows_per_pass = 256 / n4;         // rows a block covers per pass (threads beyond rows_per_pass*n4 idle)
     if (rl >= rows_per_pass) return;
     const int n = cg * 4;
-    float w[4][16], b4[4];
+    float w[4][KMAX], b4[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         b4[e] = (bias && n + e < N) ? bias[n + e] : 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
+        for (int k = 0; k < KMAX; ++k)
             w[e][k] = (k < K && n + e < N) ? (w_kn ? W[(long long)k * N + n + e] : W[(long long)(n + e) * K + k]) : 0.f;
     }
     const bool vec = (N % 4 == 0) && (((uintptr_t)out & 15) == 0);
-    for (long long r = (long long)blockIdx.x * rows_per_pass + rl; r < rows; r += (long long)gridDim.x * rows_per_pass) {
-        float acc[4] = {b4[0], b4[1], b4[2], b4[3]};
+    const long long stride = (long long)gridDim.x * rows_per_pass;
+    for (long long r0 = (long long)blockIdx.x * rows_per_pass + rl; r0 < rows; r0 += UR * stride) {
+        float xv[UR][KMAX];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            if (k < K) {
-                const float xv = x[r * K + k];
+        for (int u = 0; u < UR; ++u) {           // all input loads of the UR passes first (clamped row, no branch)
+            const long long r = r0 + u * stride < rows ? r0 + u * stride : r0;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = fmaf(xv, w[e][k], acc[e]);
-            }
+            for (int k = 0; k < KMAX; ++k) xv[u][k] = x[r * K + (k < K ? k : 0)];
         }
-        if (vec) {
-            *reinterpret_cast<float4*>(out + r * N + n) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (n + e < N) out[r * N + n + e] = acc[e];
+        for (int u = 0; u < UR; ++u) {
+            const long long r = r0 + u * stride;
+            float acc[4] = {b4[0], b4[1], b4[2], b4[3]};
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(xv[u][k], w[e][k], acc[e]);   // w is 0 for k >= K
+            if (r < rows) {
+                if (vec) {
+                    *reinterpret_cast<float4*>(out + r * N + n) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < N) out[r * N + n + e] = acc[e];
+                }
+            }
         }
     }
 }
@@ -279,7 +291,13 @@ int dn_launch_smallk_rows(const float* x, int K, const float* W, int w_kn, const
     long long nb = (rows + rpp - 1) / rpp;
     if (nb > 4096) nb = 4096;
     dn_prof_begin(DN_K_SMALL, stream);
-    DN_LAUNCH(smallk_rows_kernel, dim3((unsigned)nb, 1, 1), dim3(256, 1, 1), 0, stream, x, K, W, w_kn, bias, N, out, rows);
+    if (K <= 4) {
+        DN_LAUNCH(smallk_rows_kernel<4>, dim3((unsigned)nb, 1, 1), dim3(256, 1, 1), 0, stream, x, K, W, w_kn, bias, N, out, rows);
+    } else if (K <= 8) {
+        DN_LAUNCH(smallk_rows_kernel<8>, dim3((unsigned)nb, 1, 1), dim3(256, 1, 1), 0, stream, x, K, W, w_kn, bias, N, out, rows);
+    } else {
+        DN_LAUNCH(smallk_rows_kernel<16>, dim3((unsigned)nb, 1, 1), dim3(256, 1, 1), 0, stream, x, K, W, w_kn, bias, N, out, rows);
+    }
     dn_prof_end(DN_K_SMALL, stream, 2.0 * rows * K * N, 4.0 * rows * (K + N));
     return (int)hipGetLastError();
 }
