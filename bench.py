@@ -281,7 +281,7 @@ def main():
                        "streams_per_gpu": nsub},
             "roofline": roof, "kernel_families": fam, "diffusion_block": diff,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only (the other ranks would sit idle behind it)
             res["cpu_baseline"] = cpu_baseline(args, C_out)
         print(json.dumps(res))
     if world > 1:
