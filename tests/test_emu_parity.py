@@ -84,3 +84,10 @@ def test_gradient_sinks_on_emulator(emu):
 def test_inkernel_dropout_on_emulator(emu, C):
     import parity_cases
     parity_cases.run_inkernel_dropout(emu, C=C)
+
+
+@pytest.mark.parametrize("sizes,K,C", [((17,), 8, 16), ((16, 33, 128, 129), 16, 32), ((40,), 32, 128)])
+def test_boundary_sizes_on_emulator(emu, sizes, K, C):
+    """Meshes smaller than one 32-row slice / one 128-row tile, exact tile multiples and one-past, K = V/2."""
+    import parity_cases
+    parity_cases.run_ragged_net(emu, sizes=sizes, K=K, C=C, N_block=1)
