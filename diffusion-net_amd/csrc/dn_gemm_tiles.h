@@ -282,15 +282,18 @@ struct X3Planes {
     uint2 b[NOUT][B_IT][3];   // BCOLK: one 8-byte chunk per float4; PAIRK: dword e of column group h is (i = 2h + (e >> 1), .x/.y = e & 1)
 };
 
-template <int NOUT, bool BCOLK, bool HASQ, int A_IT, int B_IT>
+template <int NOUT, bool BCOLK, bool HASQ, int A_IT, int B_IT, bool DO_A = true, bool DO_B = true>
 __device__ __forceinline__ void rg_split_x3(const RgRegs<NOUT, A_IT, B_IT>& R, X3Planes<NOUT, A_IT, B_IT>& P) {
+    if (DO_A) {
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-        // no row mask here: a row past the unit's end (its address was clamped) only feeds its own, never stored, output row
-        float4 v = R.a[i];
-        if (HASQ) v = dn_f4_mul(v, R.q[i]);
-        dn_split3_f4(v, P.a[i][0], P.a[i][1], P.a[i][2]);
+        for (int i = 0; i < A_IT; ++i) {
+            // no row mask here: a row past the unit's end (its address was clamped) only feeds its own, never stored, output row
+            float4 v = R.a[i];
+            if (HASQ) v = dn_f4_mul(v, R.q[i]);
+            dn_split3_f4(v, P.a[i][0], P.a[i][1], P.a[i][2]);
+        }
     }
+    if (!DO_B) return;
 #if defined(DN_X3_ABLATE_BSTAGE)   // development ablation: B operand neither loaded, split nor written
     return;
 #endif

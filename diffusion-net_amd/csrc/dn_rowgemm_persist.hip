@@ -392,6 +392,9 @@ static int dn_num_cus() {
 #define DN_WS_SPLIT_SIMD 0   // 1: MFMA waves on two SIMDs, loaders on the other two -- measured slower (58 vs 51 us, C->C product)
 #endif
 #define DN_WS_LTHR (64 * DN_WS_LW)             // loader threads
+#ifndef DN_WS_BCACHE
+#define DN_WS_BCACHE 1   // keep the split B strip in loader registers when B is the same for every unit (see rowgemm_ws_kernel)
+#endif
 #ifndef DN_WS_PW
 #define DN_WS_PW DN_WS_LW                     // loader waves that also stream the parked unit out; measured: 4 or 2 (the oldest) instead of all 8 is slower (C->C 47-52 / 59 us vs 46-49)
 #endif
@@ -457,17 +460,20 @@ __device__ __forceinline__ void ws_mma(const X3Frags<2, 2, 1>& F, int s, f32x16 
 
 // loader-side fetch of one slice with every descriptor already in registers (no kernel-argument or tile-table loads on the
 // path to the global loads: a dependent scalar load costs a few hundred cycles, and the lock-step kernel paid four per slice)
-template <bool BCOLK, int A_IT, int B_IT>
+template <bool BCOLK, int A_IT, int B_IT, bool LOAD_A = true, bool LOAD_B = true>
 __device__ __forceinline__ void ws_load(const float* ap, int ald, const float* bp, int ldb, int N, int row0, int nrows, int n0,
                                         int koff, int lt, RgRegs<1, A_IT, B_IT>& R) {
     constexpr int LTHR = DN_WS_LTHR;
+    if (LOAD_A) {
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-        const int idx = lt + i * LTHR;
-        const int row = idx >> 3, q = idx & 7;
-        const long long off = (long long)(row0 + (row < nrows ? row : 0)) * ald + koff + 4 * q;
-        R.a[i] = *reinterpret_cast<const float4*>(ap + off);
+        for (int i = 0; i < A_IT; ++i) {
+            const int idx = lt + i * LTHR;
+            const int row = idx >> 3, q = idx & 7;
+            const long long off = (long long)(row0 + (row < nrows ? row : 0)) * ald + koff + 4 * q;
+            R.a[i] = *reinterpret_cast<const float4*>(ap + off);
+        }
     }
+    if (!LOAD_B) return;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
         const int idx = lt + i * LTHR;
@@ -484,7 +490,10 @@ __device__ __forceinline__ void ws_load(const float* ap, int ald, const float* b
     }
 }
 
-template <int MODE, bool BCOLK, bool FLAG, int PPI>
+// BC ("B cached"): products with ONE 128-wide segment (4 slices) and the same B for every unit (nn.Linear weights): every loader
+// thread stages the same B elements of slice s for every unit, so it splits them once, before the loop, and keeps the 4 x 12
+// plane dwords in registers -- the per-slice B work shrinks from 2 loads + 44 VALU + 6 LDS writes to the 6 LDS writes.
+template <int MODE, bool BCOLK, bool FLAG, int PPI, bool BC>
 __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2 : 3) void rowgemm_ws_kernel(RgArgs g, int ntiles) {
     constexpr int TN = 128, NOUT = 1, LTHR = DN_WS_LTHR;
     constexpr int A_IT = DN_TM * 8 / LTHR;            // 4 float4 of the A slice per loader thread
@@ -614,13 +623,17 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
         ltile_next = g.tiles[lu + G < ntiles ? lu + G : lu];   /* consumed at the next unit switch at the earliest */    \
     } while (0)
 #define WS_LOAD(RS)                                                                                                     \
-    ws_load<BCOLK, A_IT, B_IT>(lseg == 0 ? sp0 : (lseg == 1 ? sp1 : sp2), lseg == 0 ? sl0 : (lseg == 1 ? sl1 : sl2),     \
+    ws_load<BCOLK, A_IT, B_IT, true, !BC>(lseg == 0 ? sp0 : (lseg == 1 ? sp1 : sp2), lseg == 0 ? sl0 : (lseg == 1 ? sl1 : sl2), \
                                (lseg == 0 ? sb0 : (lseg == 1 ? sb1 : sb2)) + (long long)ltile.mesh * bms, ldb, Ncols,    \
                                ltile.row0, ltile.nrows, n0, lkoff, lt, RS)
-#define WS_STAGE(buf, RS)                                                                                               \
+#define WS_STAGE(buf, RS, SIDX)                                                                                         \
     do {                                                                                                                \
         X3Planes<NOUT, A_IT, B_IT> PLN;                                                                                 \
-        rg_split_x3<NOUT, BCOLK, HASQ, A_IT, B_IT>(RS, PLN);                                                            \
+        rg_split_x3<NOUT, BCOLK, HASQ, A_IT, B_IT, true, !BC>(RS, PLN);                                                 \
+        if constexpr (BC) {                                                                                             \
+            _Pragma("unroll") for (int i_ = 0; i_ < B_IT; ++i_)                                                         \
+                _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_) PLN.b[0][i_][p_] = Bc[SIDX][i_][p_];                   \
+        }                                                                                                               \
         rg_put_x3<LTHR, NOUT, BCOLK, A_IT, B_IT>(reinterpret_cast<unsigned char*>(buf),                                 \
                                                  reinterpret_cast<unsigned char*>((buf) + SA), lt, PLN);                \
     } while (0)
@@ -628,11 +641,11 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
 // Order inside an iteration: stage -> deferred pieces (their operands were requested an iteration ago) -> operands of the
 // next iteration's pieces -> slice prefetch.  (Measured: a second register set / fetching two slices ahead, and requesting
 // the piece operands before the prefetch, were both slower -- 60/48/135 us vs 53/51/127 us for the NN, C->C, 3C->C products.)
-#define WS_ITER(j, RS)                                                                                                  \
+#define WS_ITER(j, RS, SIDX)                                                                                            \
     do {                                                                                                                \
         float* nxt = smem + (((j) & 1) ^ 1) * SBUF;                                                                     \
         WS_T(DN_WS_TRACE_TID);                                                                                                      \
-        WS_STAGE(nxt, RS);             /* slice j+1 (the last iteration stages a stale copy nobody reads) */            \
+        WS_STAGE(nxt, RS, SIDX);       /* slice j+1 (the last iteration stages a stale copy nobody reads) */            \
         WS_T(DN_WS_TRACE_TID);                                                                                                      \
         if (piece_wave) {              /* wave-uniform: only the first DN_WS_PW loader waves stream the parked unit out */ \
             _Pragma("unroll") for (int k = 0; k < PPI; ++k) ws_piece_out<MODE, FLAG>(g, sE, bias, AX[k]);               \
@@ -657,23 +670,47 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
         __syncthreads();                                                                                                \
     } while (0)
 
+    uint2 Bc[BC ? 4 : 1][B_IT][3];
+    if constexpr (BC) {   // split the whole B strip of this workgroup once (4 slices of the one segment)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            RgRegs<NOUT, A_IT, B_IT> Rb;
+            ws_load<BCOLK, A_IT, B_IT, false, true>(sp0, sl0, sb0, ldb, Ncols, 0, 0, n0, DN_KB * s4, lt, Rb);
+            X3Planes<NOUT, A_IT, B_IT> Pb;
+            rg_split_x3<NOUT, BCOLK, HASQ, A_IT, B_IT, false, true>(Rb, Pb);
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i)
+#pragma unroll
+                for (int p3 = 0; p3 < 3; ++p3) Bc[s4][i][p3] = Pb.b[0][i][p3];
+        }
+    }
     WS_LOAD(R0);
-    WS_STAGE(smem, R0);
+    WS_STAGE(smem, R0, 0);
 #if DN_WS_DEPTH == 2
+    static_assert(!BC, "the cached-B form is written for the one-set prefetch");
     WS_ADVANCE(T > 1);
     WS_LOAD(R1);                       // slice 1
     WS_ADVANCE(T > 2);
     WS_LOAD(R0);                       // slice 2
     __syncthreads();                   // slice 0 staged
     for (int j = 0; j < T; j += 2) {
-        WS_ITER(j, R1);
-        if (j + 1 < T) WS_ITER(j + 1, R0);
+        WS_ITER(j, R1, 0);
+        if (j + 1 < T) WS_ITER(j + 1, R0, 0);
     }
 #else
     WS_ADVANCE(T > 1);
     WS_LOAD(R0);                       // slice 1
     __syncthreads();                   // slice 0 staged
-    for (int j = 0; j < T; ++j) WS_ITER(j, R0);
+    if constexpr (BC) {                // T is a multiple of 4: iteration j stages slice (j + 1) % 4 of its unit
+        for (int j = 0; j < T; j += 4) {
+            WS_ITER(j, R0, 1);
+            WS_ITER(j + 1, R0, 2);
+            WS_ITER(j + 2, R0, 3);
+            WS_ITER(j + 3, R0, 0);
+        }
+    } else {
+        for (int j = 0; j < T; ++j) WS_ITER(j, R0, 0);
+    }
 #endif
 #undef WS_ITER
 #undef WS_STAGE
@@ -691,20 +728,20 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     }
 }
 
-template <int MODE, bool BCOLK, bool FLAG, int PPI>
+template <int MODE, bool BCOLK, bool FLAG, int PPI, bool BC>
 static int ws_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
     const size_t smem = (size_t)(2 * (DN_TM * 64 * 3 + 128 * 64 * 3) + 128 * 128 * 4);   // 160 KiB
 #ifndef DN_EMULATE
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_ws_kernel<MODE, BCOLK, FLAG, PPI>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_ws_kernel<MODE, BCOLK, FLAG, PPI, BC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         lds_opt_in = true;
     }
 #endif
     int gx = dn_num_cus();
     if (gx > ntiles) gx = ntiles;
-    DN_LAUNCH((rowgemm_ws_kernel<MODE, BCOLK, FLAG, PPI>), dim3(gx, (g.N + 127) / 128, 1), dim3(256 + DN_WS_LTHR, 1, 1), smem, stream, g, ntiles);
+    DN_LAUNCH((rowgemm_ws_kernel<MODE, BCOLK, FLAG, PPI, BC>), dim3(gx, (g.N + 127) / 128, 1), dim3(256 + DN_WS_LTHR, 1, 1), smem, stream, g, ntiles);
     return (int)hipGetLastError();
 }
 
@@ -1034,8 +1071,10 @@ static int pt_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
         int nsl = 0;
         for (int s = 0; s < g.nseg; ++s) nsl += g.a[s].w / DN_KB;
         // PPI = ceil(NP / (nsl - 1)) for the two slice counts that matter (K = 128: 4 slices, K = 384: 12)
-        if (nsl >= 9) return ws_launch<MODE, BCOLK, FLAG, (DN_WS_NP + 7) / 8>(g, ntiles, stream);
-        if (nsl >= 4) return ws_launch<MODE, BCOLK, FLAG, (DN_WS_NP + 2) / 3>(g, ntiles, stream);
+        if (nsl >= 9) return ws_launch<MODE, BCOLK, FLAG, (DN_WS_NP + 7) / 8, false>(g, ntiles, stream);
+        if (DN_WS_BCACHE && DN_WS_DEPTH == 1 && nsl == 4 && g.nseg == 1 && g.b_mesh_stride == 0)
+            return ws_launch<MODE, BCOLK, FLAG, (DN_WS_NP + 2) / 3, true>(g, ntiles, stream);
+        if (nsl >= 4) return ws_launch<MODE, BCOLK, FLAG, (DN_WS_NP + 2) / 3, false>(g, ntiles, stream);
     }
     // slice buffers (2x) + parked accumulators: 128 KiB with f32 tiles, exactly 160 KiB with bf16x3 planes
     const size_t smem = X3 ? (size_t)(2 * (DN_PT_ROWS * 64 * 3 + 128 * 64 * 3) + DN_PT_ROWS * 128 * 4)
