@@ -571,6 +571,13 @@ int dn_nll_loss_bwd_f32(const int64_t* labels, int64_t n, int C, const float* d_
     return dn_launch_nll_bwd((const long long*)labels, n, C, d_loss, d_logp, S(stream));
 }
 
+// ------------------------------------------------------------------ input features next to the path
+int dn_hks_f32(const float* evals, const float* evecs, const float* scales, int B, int V, int K, int n_scales, int scales_per_batch,
+               float* out, void* stream) {
+    if (!evals || !evecs || !scales || !out || B < 0 || V < 0 || K <= 0 || n_scales <= 0) return DN_ERR_INVALID;
+    return dn_launch_hks(evals, evecs, scales, B, V, K, n_scales, scales_per_batch ? (long long)n_scales : 0LL, out, S(stream));
+}
+
 // ------------------------------------------------------------------ output remaps
 int dn_csr_mean_f32(const int32_t* rowptr, const int32_t* col, int n_rows, const float* x, int C, float div, float* out,
                     void* stream) {

@@ -297,6 +297,8 @@ int dn_launch_nll_fwd(const float* logp, const long long* labels, long long n, i
                       hipStream_t stream);
 int dn_launch_nll_bwd(const long long* labels, long long n, int C, const float* gout, float* dlogp, hipStream_t stream);
 int dn_launch_dtanh(const float* dg, const float* g, float* out, long long n, hipStream_t stream);
+int dn_launch_hks(const float* evals, const float* evecs, const float* scales, int B, int V, int K, int S, long long scale_stride,
+                  float* out, hipStream_t stream);
 // launchers (host), defined in the .hip files; all return hipError_t as int
 int dn_launch_rowgemm(const RgArgs& g, int ntiles, int nout, hipStream_t stream);
 int dn_launch_tngemm(const TnArgs& g, int nchunks, hipStream_t stream);

@@ -384,3 +384,57 @@ int dn_launch_nll_bwd(const long long* labels, long long n, int C, const float* 
     DN_LAUNCH(nll_bwd_kernel, dim3((unsigned)nb, 1, 1), dim3(256, 1, 1), 0, stream, labels, n, C, gout, 1.f / (float)n, dlogp);
     return (int)hipGetLastError();
 }
+
+// ---- heat kernel signature (geometry.py:600-633): out[b][v][s] = sum_k exp(-lambda[b][k] * t[s]) * evecs[b][v][k]^2.
+//      One streaming pass over the eigenbasis (the input feature of the "hks" experiments); block = 64 rows x 4 groups of
+//      4 scales, 32-wide k chunks staged through LDS (coalesced float4 loads of Phi, exp() once per (k, scale) and block).
+__global__ __launch_bounds__(256) void hks_kernel(const float* evals, const float* evecs, const float* scales, int V, int K, int S,
+                                                  long long scale_stride, float* out) {
+    __shared__ float sphi[64][33];
+    __shared__ float scoef[32][17];
+    const int b = blockIdx.z, s_base = blockIdx.y * 16;
+    const int tid = threadIdx.x, rl = tid >> 2, g4 = tid & 3;
+    const long long row0 = (long long)blockIdx.x * 64;
+    const float* ev = evals + (long long)b * K;
+    const float* ph = evecs + (long long)b * V * K;
+    const float* sc = scales + (long long)b * scale_stride;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        for (int i = tid; i < 64 * 32; i += 256) {           // Phi chunk, squared
+            const int r = i >> 5, kk = i & 31;
+            const long long row = row0 + r;
+            const float v = (row < V && k0 + kk < K) ? ph[row * K + k0 + kk] : 0.f;
+            sphi[r][kk] = v * v;
+        }
+        for (int i = tid; i < 32 * 16; i += 256) {           // exp(-lambda t) for the chunk
+            const int kk = i >> 4, ss = i & 15;
+            scoef[kk][ss] = (k0 + kk < K && s_base + ss < S) ? expf(-ev[k0 + kk] * sc[s_base + ss]) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < 32; ++kk) {
+            const float p2 = sphi[rl][kk];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(p2, scoef[kk][4 * g4 + e], acc[e]);
+        }
+        __syncthreads();
+    }
+    const long long row = row0 + rl;
+    if (row < V) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ss = s_base + 4 * g4 + e;
+            if (ss < S) out[((long long)b * V + row) * S + ss] = acc[e];
+        }
+    }
+}
+
+int dn_launch_hks(const float* evals, const float* evecs, const float* scales, int B, int V, int K, int S, long long scale_stride,
+                  float* out, hipStream_t stream) {
+    if (B <= 0 || V <= 0 || K <= 0 || S <= 0) return 0;
+    dn_prof_begin(DN_K_SMALL, stream);
+    DN_LAUNCH(hks_kernel, dim3((unsigned)((V + 63) / 64), (unsigned)((S + 15) / 16), (unsigned)B), dim3(256, 1, 1), 0, stream, evals, evecs,
+              scales, V, K, S, scale_stride, out);
+    dn_prof_end(DN_K_SMALL, stream, 3.0 * B * (double)V * K * S, 4.0 * B * ((double)V * K + (double)V * S));
+    return (int)hipGetLastError();
+}

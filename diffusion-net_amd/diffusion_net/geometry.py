@@ -10,8 +10,8 @@ import torch
 
 from . import ops
 from .batch import MeshBatch
-from .precompute import (compute_hks, compute_hks_autoscale, compute_operators, get_all_operators,  # noqa: F401
-                         get_operators, normalize_positions)
+from .precompute import compute_operators, get_all_operators, get_operators, normalize_positions  # noqa: F401
+from . import precompute as _pre
 
 
 def _spectral_batch(basis, massvec):
@@ -40,3 +40,18 @@ def from_basis(values, basis):
     D = values.shape[-1]
     out = ops.FromBasisFn.apply(values.reshape(mb.n_mesh, -1, D), mb)
     return out.reshape(*basis.shape[:-1], D)
+
+
+def compute_hks(evals, evecs, scales):
+    """Heat kernel signature (geometry.py:600-628): (K),(V,K),(S) -> (V,S), or batched (B,K),(B,V,K),(B,S) -> (B,V,S).
+    On a ROCm device and outside autograd this is one streaming HIP pass over the eigenbasis (``dn_hks_f32``); host
+    tensors (the reference computes it in its CPU dataset loaders) and differentiable calls use the torch formula."""
+    on_dev = evecs.is_cuda and evals.is_cuda and scales.is_cuda and evecs.dtype == torch.float32
+    if not on_dev or evecs.requires_grad or evals.requires_grad or scales.requires_grad:
+        return _pre.compute_hks(evals, evecs, scales)
+    return ops.hks(evals, evecs, scales)
+
+
+def compute_hks_autoscale(evals, evecs, count):
+    scales = torch.logspace(-2, 0.0, steps=count, device=evals.device, dtype=evals.dtype)   # geometry.py:630-633
+    return compute_hks(evals, evecs, scales)

@@ -169,6 +169,22 @@ class GradFeatFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------
 # nn.Linear on the row axis (first_lin / last_lin / stand-alone MiniMLP layers)
 # ----------------------------------------------------------------------------------------------
+def hks(evals, evecs, scales):
+    """out[.., v, s] = sum_k exp(-evals[.., k] * scales[.., s]) * evecs[.., v, k]^2 (geometry.py:600-628), forward only."""
+    _hip.require_device(evecs)
+    squeeze = evals.dim() == 1
+    if squeeze:
+        evals, evecs, scales = evals[None], evecs[None], scales[None]
+    evals, evecs, scales = _f32c(evals), _f32c(evecs), _f32c(scales)
+    B, V, K = evecs.shape
+    S = scales.shape[-1]
+    out = torch.empty(B, V, S, dtype=torch.float32, device=evecs.device)
+    per_batch = int(scales.dim() == 2 and scales.shape[0] == B and B > 1)
+    _hip.check(_hip.lib().dn_hks_f32(evals.data_ptr(), evecs.data_ptr(), scales.data_ptr(), B, V, K, S, per_batch, out.data_ptr(),
+                                     _hip.stream_of(evecs)), "dn_hks_f32")
+    return out[0] if squeeze else out
+
+
 # ----------------------------------------------------------------------------------------------
 # gradient sinks: a parameter may carry ``_dn_grad_sink`` (set by dist.FlatParams: its slice of the flat
 # gradient bucket).  Backward then ACCUMULATES the parameter gradients of a whole op into their sinks with

@@ -11,3 +11,18 @@ def nll_loss(log_probs, labels):
     """Drop-in for ``torch.nn.functional.nll_loss(log_probs, labels)`` (mean reduction, rows x classes) on the HIP path."""
     from . import ops
     return ops.NllLossFn.apply(log_probs, labels)
+
+
+def label_smoothing_log_loss(pred, labels, smoothing=0.0):
+    """Reference ``utils.label_smoothing_log_loss`` (utils.py:18-24): cross entropy of log-probabilities against the
+    smoothed one-hot target, mean over rows.  The reference builds its one-hot with ``one_hot[labels] = 1``, which is a
+    proper one-hot only for the 1-D prediction of its single caller (classification_shrec11.py: one mesh, scalar label);
+    that case is reproduced exactly, and 2-D predictions get the per-row one-hot the formula intends."""
+    n_class = pred.shape[-1]
+    one_hot = torch.zeros_like(pred)
+    if pred.dim() == 1:
+        one_hot[labels] = 1.0
+    else:
+        one_hot.scatter_(-1, labels.reshape(*pred.shape[:-1], 1).long(), 1.0)
+    one_hot = one_hot * (1 - smoothing) + (1 - one_hot) * smoothing / (n_class - 1)
+    return -(one_hot * pred).sum(dim=-1).mean()

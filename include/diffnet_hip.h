@@ -162,6 +162,12 @@ int dn_nll_loss_fwd_f32(const float* logp, const int64_t* labels, int64_t n, int
                         void* stream);
 int dn_nll_loss_bwd_f32(const int64_t* labels, int64_t n, int C, const float* d_loss, float* d_logp, void* stream);
 
+/* ---- geometry.compute_hks (geometry.py:600-628; compute_hks_autoscale :630-633 passes scales = logspace(-2, 0, S)):
+ *      out[b][v][s] = sum_k exp(-evals[b][k] * scales[.][s]) * evecs[b][v][k]^2.  evals [B,K], evecs [B,V,K], out [B,V,S];
+ *      scales [S] shared by the batch (scales_per_batch = 0) or [B,S] (scales_per_batch = 1).  Forward only (an input feature). */
+int dn_hks_f32(const float* evals, const float* evecs, const float* scales, int B, int V, int K, int S, int scales_per_batch,
+               float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -226,3 +226,18 @@ def net_forward_backward(params, inputs, outputs_at="vertices", last_activation=
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}
     grads["x_in"] = x_in.grad
     return out.detach(), grads
+
+
+def hks(evals, evecs, scales):
+    """geometry.py:600-628: heat kernel signature, out[v, s] = sum_k exp(-evals[k] * scales[s]) * evecs[v, k]^2
+    (unbatched restatement; the reference broadcasts a (B,V,S,K) term tensor and sums over K)."""
+    coefs = torch.exp(-evals[None, :] * scales[:, None])                 # (S,K)
+    return (evecs * evecs) @ coefs.t()                                   # (V,S)
+
+
+def label_smoothing_log_loss(pred, label, smoothing):
+    """utils.py:18-24 for the 1-D prediction of its only caller: -(q . pred) with q the smoothed one-hot."""
+    n_class = pred.shape[-1]
+    q = torch.full_like(pred, smoothing / (n_class - 1))
+    q[label] = 1.0 - smoothing
+    return -(q * pred).sum()

@@ -169,13 +169,39 @@ def run_geometry_case(ref, V=300, seed=5):
     print("geom_sphere%d: frames %s, grad nnz %d -> %.0f kB" % (V, tuple(frames.shape), grad.nnz, os.path.getsize(path) / 1e3))
 
 
+def run_feature_cases(ref, V=300, K=32, seed=9):
+    """heat kernel signatures (geometry.py:600-633, single and batched) and the label-smoothing loss
+    (utils.py:18-24, in the 1-D form of its only caller) straight from the reference functions."""
+    items = [synthetic.make_mesh_operators(V, K, seed=seed + b) for b in range(2)]
+    arrays = {}
+    for b, it in enumerate(items):
+        arrays["mesh%d.evals" % b] = it["evals"].numpy()
+        arrays["mesh%d.evecs" % b] = it["evecs"].numpy()
+        arrays["hks16.mesh%d" % b] = ref.geometry.compute_hks_autoscale(it["evals"], it["evecs"], 16).numpy()
+    ev = torch.stack([it["evals"] for it in items]); ph = torch.stack([it["evecs"] for it in items])
+    scales = torch.tensor([[0.01, 0.1, 0.5], [0.02, 0.2, 1.0]])
+    arrays["scales_batched"] = scales.numpy()
+    arrays["hks_batched"] = ref.geometry.compute_hks(ev, ph, scales).numpy()
+    g = torch.Generator().manual_seed(seed)
+    pred = torch.log_softmax(torch.randn(30, generator=g), -1)
+    arrays["ls.pred"] = pred.numpy()
+    arrays["ls.label"] = np.array(7)
+    arrays["ls.loss_s0"] = ref.utils.label_smoothing_log_loss(pred, torch.tensor(7), 0.0).numpy()
+    arrays["ls.loss_s02"] = ref.utils.label_smoothing_log_loss(pred, torch.tensor(7), 0.2).numpy()
+    path = os.path.join(HERE, "feat_hks_ls.npz")
+    np.savez_compressed(path, **arrays)
+    print("feat_hks_ls: hks %s, batched %s -> %.0f kB" % (arrays["hks16.mesh0"].shape, arrays["hks_batched"].shape, os.path.getsize(path) / 1e3))
+
+
 def main():
     ref = import_reference()
     print("reference imported from", ref.__file__, "torch", torch.__version__)
-    if "--geometry-only" not in sys.argv:
+    if "--geometry-only" not in sys.argv and "--features-only" not in sys.argv:
         for name, case in CASES.items():
             run_case(ref, name, case)
-    run_geometry_case(ref)
+    if "--features-only" not in sys.argv:
+        run_geometry_case(ref)
+    run_feature_cases(ref)
 
 
 if __name__ == "__main__":

@@ -7,6 +7,8 @@ Tolerances (fp32, north_star: 1e-5 relative):
   * gradients: rel-L2 <= 2e-4 (the reference's own fp32-vs-fp64 gradient floor is 1e-4..7e-4,
     SURVEY.md section 7).
 """
+import os
+
 import torch
 
 import helpers
@@ -343,6 +345,34 @@ def run_inkernel_dropout(device, sizes=(300, 140), K=32, C=128, seed=6):
     assert lag(m[:, 1:], m[:, :-1]) < 5 / m.numel() ** 0.5 and lag(m[1:], m[:-1]) < 5 / m.numel() ** 0.5
     assert not torch.equal(ops.keep_mask_reference(drop_seed, 1, 64, C), ops.keep_mask_reference(drop_seed, 2, 64, C))
     assert not torch.equal(ops.keep_mask_reference(drop_seed, 1, 64, C), ops.keep_mask_reference(drop_seed + 1, 1, 64, C))
+
+
+def run_features(device):
+    """SURVEY 8f-3/4 against the reference's own outputs (tests/golden/feat_hks_ls.npz) and the oracle restatement."""
+    import numpy as np
+    from diffusion_net import geometry, ops, utils
+    g = np.load(os.path.join(helpers.GOLDEN_DIR, "feat_hks_ls.npz"))
+    T = lambda k: torch.from_numpy(g[k])
+    for b in range(2):
+        ev, ph = T("mesh%d.evals" % b), T("mesh%d.evecs" % b)
+        ref = T("hks16.mesh%d" % b)
+        assert helpers.rel_max(orc.hks(ev, ph, torch.logspace(-2, 0.0, steps=16)), ref) < 1e-5          # oracle pinned
+        got = geometry.compute_hks_autoscale(ev.to(device), ph.to(device), 16).cpu()
+        assert got.shape == ref.shape and helpers.rel_max(got, ref) < 1e-5, helpers.rel_max(got, ref)
+        raw = ops.hks(ev.to(device), ph.to(device), torch.logspace(-2, 0.0, steps=16).to(device)).cpu()   # the kernel itself
+        assert helpers.rel_max(raw, ref) < 1e-5, helpers.rel_max(raw, ref)
+    ev = torch.stack([T("mesh0.evals"), T("mesh1.evals")]).to(device)
+    ph = torch.stack([T("mesh0.evecs"), T("mesh1.evecs")]).to(device)
+    got = geometry.compute_hks(ev, ph, T("scales_batched").to(device)).cpu()
+    assert helpers.rel_max(got, T("hks_batched")) < 1e-5
+    assert helpers.rel_max(ops.hks(ev, ph, T("scales_batched").to(device)).cpu(), T("hks_batched")) < 1e-5
+    pred, lab = T("ls.pred"), torch.tensor(int(g["ls.label"]))
+    for key, sm in (("ls.loss_s0", 0.0), ("ls.loss_s02", 0.2)):
+        ref = float(g[key])
+        assert abs(float(orc.label_smoothing_log_loss(pred, lab, sm)) - ref) < 1e-6 * max(1.0, abs(ref))
+        assert abs(float(utils.label_smoothing_log_loss(pred.to(device), lab.to(device), sm)) - ref) < 1e-5 * max(1.0, abs(ref))
+    rows = utils.label_smoothing_log_loss(pred[None].repeat(3, 1).to(device), torch.tensor([7, 7, 7]).to(device), 0.2)
+    assert abs(float(rows) - float(g["ls.loss_s02"])) < 1e-5 * max(1.0, abs(float(g["ls.loss_s02"])))
 
 
 def run_nll(device, n=1234, C=8, seed=0):

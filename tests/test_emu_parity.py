@@ -91,3 +91,8 @@ def test_boundary_sizes_on_emulator(emu, sizes, K, C):
     """Meshes smaller than one 32-row slice / one 128-row tile, exact tile multiples and one-past, K = V/2."""
     import parity_cases
     parity_cases.run_ragged_net(emu, sizes=sizes, K=K, C=C, N_block=1)
+
+
+def test_hks_and_label_smoothing_on_emulator(emu):
+    import parity_cases
+    parity_cases.run_features(emu)

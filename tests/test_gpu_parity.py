@@ -89,6 +89,11 @@ def test_inkernel_dropout_matches_explicit_masks(dev, C):
     parity_cases.run_inkernel_dropout(dev, sizes=(3000, 1400), K=64, C=C)
 
 
+def test_hks_and_label_smoothing(dev):
+    import parity_cases
+    parity_cases.run_features(dev)
+
+
 def test_gradient_sinks_accumulate_into_flat_bucket(dev):
     import parity_cases
     parity_cases.run_grad_sinks(dev, V=3000, K=64, C=128)
