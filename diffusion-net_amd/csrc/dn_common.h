@@ -1,7 +1,8 @@
 // dn_common.h -- shared definitions for the gfx950 (MI355X / CDNA4) DiffusionNet kernels.
 //
-// The kernels are written for wave64 + exact-f32 MFMA (v_mfma_f32_32x32x2_f32).  The only
-// concession to portability is the DN_EMULATE switch, which lets tests/emu compile the same
+// The kernels are written for wave64 and the gfx950 matrix pipe: split-bf16 MFMA (v_mfma_f32_32x32x16_bf16 on a 3-term
+// split of fp32 operands, fp32 accumulation) on the aligned 128-wide paths, exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
+// everywhere else.  The only concession to portability is the DN_EMULATE switch, which lets tests/emu compile the same
 // sources for the host to check index logic; the product build never defines it.
 #pragma once
 #include <stdint.h>
