@@ -234,6 +234,18 @@ struct TnArgs {
     int nchunks;                // filled by the launcher
     int acct_rows;              // host-side accounting only
 };
+// Allow more than 64 KiB of dynamic LDS for one kernel instantiation, once per DEVICE (function attributes are per device;
+// `done` is the instantiation's own 64-bit device bitmap).  Not thread-safe beyond "setting it twice is harmless".
+#ifndef DN_EMULATE
+static inline void dn_lds_opt_in(const void* fn, size_t smem, unsigned long long* done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+    if (!((*done >> dev) & 1ull)) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        *done |= 1ull << dev;
+    }
+}
+#endif
 // number of partial results a tngemm launch over `nchunks` chunks with grouping `group` writes
 static inline int dn_tn_npartial(int nchunks, int group) { return (nchunks + (group < 1 ? 1 : group) - 1) / (group < 1 ? 1 : group); }
 // grouping for sums over ALL rows (weight gradients): about two workgroups per CU

@@ -237,12 +237,8 @@ static int rg_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
     const size_t smem = X3 ? (size_t)(DN_RG2_SINGLE ? 1 : 2) * (DN_TM * 64 * 3 + NOUT * 128 * 64 * 3)
                            : (size_t)2 * (DN_TM * DN_KB + NOUT * DN_KB * TN) * sizeof(float);
 #ifndef DN_EMULATE
-    static bool lds_opt_in = false;   // idempotent: allow > 64 KiB of dynamic LDS for this instantiation
-    if (!lds_opt_in) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_kernel<TN, WR, WC, NOUT, MODE, ALIGNED, BCOLK>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        lds_opt_in = true;
-    }
+    static unsigned long long lds_opt_in = 0;   // per-device bitmap
+    dn_lds_opt_in(reinterpret_cast<const void*>(&rowgemm_kernel<TN, WR, WC, NOUT, MODE, ALIGNED, BCOLK>), smem, &lds_opt_in);
 #endif
     DN_LAUNCH((rowgemm_kernel<TN, WR, WC, NOUT, MODE, ALIGNED, BCOLK>), dim3(ntiles, ncol, 1), dim3(WR * WC * 64, 1, 1), smem,
               stream, g);

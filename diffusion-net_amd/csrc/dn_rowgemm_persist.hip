@@ -349,18 +349,18 @@ __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_pers
     }
 }
 
-static int dn_num_cus() {
+static int dn_num_cus() {   // CUs of the CURRENT device (one workgroup per CU in the persistent kernels)
 #ifdef DN_EMULATE
     return 3;
 #else
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-        else n = 256;
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+    if (cus[dev] == 0) {
+        int v = 0;
+        cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
     }
-    return n;
+    return cus[dev];
 #endif
 }
 
@@ -732,12 +732,8 @@ template <int MODE, bool BCOLK, bool FLAG, int PPI, bool BC>
 static int ws_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
     const size_t smem = (size_t)(2 * (DN_TM * 64 * 3 + 128 * 64 * 3) + 128 * 128 * 4);   // 160 KiB
 #ifndef DN_EMULATE
-    static bool lds_opt_in = false;
-    if (!lds_opt_in) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_ws_kernel<MODE, BCOLK, FLAG, PPI, BC>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        lds_opt_in = true;
-    }
+    static unsigned long long lds_opt_in = 0;   // per-device bitmap
+    dn_lds_opt_in(reinterpret_cast<const void*>(&rowgemm_ws_kernel<MODE, BCOLK, FLAG, PPI, BC>), smem, &lds_opt_in);
 #endif
     int gx = dn_num_cus();
     if (gx > ntiles) gx = ntiles;
@@ -1034,12 +1030,8 @@ template <int MODE, bool BCOLK>
 static int ws2_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
     const size_t smem = (size_t)(2 * (3 * 128 * 64 + 6 * 64 * 64) + 2 * 128 * 64 * 4);   // 160 KiB
 #ifndef DN_EMULATE
-    static bool lds_opt_in = false;
-    if (!lds_opt_in) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_ws2_kernel<MODE, BCOLK>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        lds_opt_in = true;
-    }
+    static unsigned long long lds_opt_in = 0;   // per-device bitmap
+    dn_lds_opt_in(reinterpret_cast<const void*>(&rowgemm_ws2_kernel<MODE, BCOLK>), smem, &lds_opt_in);
 #endif
     int gx = dn_num_cus();
     if (gx > ntiles) gx = ntiles;
@@ -1080,12 +1072,8 @@ static int pt_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
     const size_t smem = X3 ? (size_t)(2 * (DN_PT_ROWS * 64 * 3 + 128 * 64 * 3) + DN_PT_ROWS * 128 * 4)
                            : (size_t)(2 * (DN_PT_ROWS * DN_KB + DN_KB * 128) + DN_PT_ROWS * 128) * sizeof(float);
 #ifndef DN_EMULATE
-    static bool lds_opt_in = false;
-    if (!lds_opt_in) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_persist_kernel<MODE, BCOLK, FLAG, X3>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        lds_opt_in = true;
-    }
+    static unsigned long long lds_opt_in = 0;   // per-device bitmap
+    dn_lds_opt_in(reinterpret_cast<const void*>(&rowgemm_persist_kernel<MODE, BCOLK, FLAG, X3>), smem, &lds_opt_in);
 #endif
     const int upt = DN_TM / DN_PT_ROWS;
     int gx = upt * dn_num_cus();   // one 128-row workgroup per CU (two 64-row ones)

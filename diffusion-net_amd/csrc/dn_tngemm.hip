@@ -421,12 +421,8 @@ template <int FLAVOR>
 static int tx_launch(const TnArgs& g, dim3 grid, hipStream_t stream) {
     const size_t smem = (size_t)(DN_TX_SINGLE ? 1 : 2) * 6 * DN_TX_PLANE;   // 120 KiB (60 KiB single-buffered)
 #ifndef DN_EMULATE
-    static bool lds_opt_in = false;
-    if (!lds_opt_in) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tngemm_x3_kernel<FLAVOR>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)smem);
-        lds_opt_in = true;
-    }
+    static unsigned long long lds_opt_in = 0;   // per-device bitmap
+    dn_lds_opt_in(reinterpret_cast<const void*>(&tngemm_x3_kernel<FLAVOR>), smem, &lds_opt_in);
 #endif
     DN_LAUNCH((tngemm_x3_kernel<FLAVOR>), grid, dim3(DN_TX_THREADS, 1, 1), smem, stream, g);
     return (int)hipGetLastError();
