@@ -18,7 +18,7 @@ import bench
 from diffusion_net import _hip, ops
 
 PHASES_MFMA = ["reads+MFMA k16 #0", "MFMA k16 #1", "park", "barrier wait"]
-PHASES_LOAD = ["wait+split+LDS writes", "cursor+prefetch issue", "pieces out", "piece operands+barrier"]
+PHASES_LOAD = ["wait+split+LDS writes", "pieces out", "piece operands+cursor+prefetch issue", "barrier"]
 
 
 def dump(name):
