@@ -192,9 +192,8 @@ int linear_bwd_weights(const dn_mesh_batch_t* mb, const float* d_a, int C_out, c
     tn_finish(g);
     const int npart = dn_tn_npartial(mb->n_chunks, g.group);
     DN_CHECK(dn_launch_tngemm(g, mb->n_chunks, st));
-    DN_CHECK(dn_launch_reduce(partial, dW, npart, (long long)g.M * g.N, (long long)g.M * g.N, st));
-    if (db) DN_CHECK(dn_launch_reduce(colsum, db, npart, g.M, g.M, st));
-    return 0;
+    if (db) return dn_launch_reduce_pair(partial, dW, (long long)g.M * g.N, colsum, db, g.M, npart, st);   // one launch for both
+    return dn_launch_reduce(partial, dW, npart, (long long)g.M * g.N, (long long)g.M * g.N, st);
 }
 // per-layer key of the in-kernel dropout (0 stays 0 = off; never maps a live seed to 0)
 unsigned long long layer_seed(unsigned long long seed, int layer) {

@@ -310,6 +310,7 @@ int dn_launch_nll_fwd(const float* logp, const long long* labels, long long n, i
                       hipStream_t stream);
 int dn_launch_nll_bwd(const long long* labels, long long n, int C, const float* gout, float* dlogp, hipStream_t stream);
 int dn_launch_dtanh(const float* dg, const float* g, float* out, long long n, hipStream_t stream);
+int dn_launch_reduce_pair(const float* pa, float* oa, long long la, const float* pb, float* ob, long long lb, int n, hipStream_t stream);
 int dn_launch_hks(const float* evals, const float* evecs, const float* scales, int B, int V, int K, int S, long long scale_stride,
                   float* out, hipStream_t stream);
 // launchers (host), defined in the .hip files; all return hipError_t as int

@@ -73,11 +73,8 @@ int dn_launch_spec_bwd(float* dys, const float* evals, const float* time, const 
 // block = 32 column groups x 8 chunk lanes: lane kl sums chunks beg+kl, beg+kl+8, ... (several loads in flight),
 // the 8 lane sums are then combined in order through LDS -> bitwise reproducible, bandwidth-bound.
 template <int VEC>
-__global__ __launch_bounds__(256) void seg_reduce_kernel(const float* partial, const int* seg_off, int n, float* out,
-                                                         long long len) {
+__device__ __forceinline__ void seg_reduce_body(const float* partial, int s, int beg, int end, float* out, long long len) {
     __shared__ float red[8][32 * VEC];
-    const int s = blockIdx.y;
-    const int beg = seg_off ? seg_off[s] : 0, end = seg_off ? seg_off[s + 1] : n;
     const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
     const long long i = ((long long)blockIdx.x * 32 + cl) * VEC;
     float a[VEC];
@@ -126,6 +123,20 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const float* partial, c
     }
 }
 
+template <int VEC>
+__global__ __launch_bounds__(256) void seg_reduce_kernel(const float* partial, const int* seg_off, int n, float* out,
+                                                         long long len) {
+    const int s = blockIdx.y;
+    seg_reduce_body<VEC>(partial, s, seg_off ? seg_off[s] : 0, seg_off ? seg_off[s + 1] : n, out, len);
+}
+
+// two independent whole-range sums in one launch (a weight gradient, float4 path, and its bias gradient): blockIdx.y picks the job
+__global__ __launch_bounds__(256) void seg_reduce_pair_kernel(const float* pa, float* oa, long long la, const float* pb, float* ob,
+                                                              long long lb, int n) {
+    if (blockIdx.y == 0) seg_reduce_body<4>(pa, 0, 0, n, oa, la);
+    else seg_reduce_body<1>(pb, 0, 0, n, ob, lb);
+}
+
 int dn_launch_seg_reduce(const float* partial, const int* seg_off, int nseg, int n, float* out, long long len,
                          hipStream_t stream) {
     if (len <= 0 || nseg <= 0) return 0;
@@ -139,6 +150,21 @@ int dn_launch_seg_reduce(const float* partial, const int* seg_off, int nseg, int
         DN_LAUNCH(seg_reduce_kernel<1>, grid, dim3(256, 1, 1), 0, stream, partial, seg_off, n, out, len);
     }
     dn_prof_end(DN_K_SMALL, stream, 0.0, 4.0 * (double)len * ((double)(seg_off ? 0 : n) + 1.0));
+    return (int)hipGetLastError();
+}
+
+int dn_launch_reduce_pair(const float* pa, float* oa, long long la, const float* pb, float* ob, long long lb, int n,
+                          hipStream_t stream) {
+    if (n <= 0 || la <= 0 || lb <= 0) return DN_ERR_BAD_MODE;
+    const bool vec = (la % 4 == 0) && ((uintptr_t)pa % 16 == 0) && ((uintptr_t)oa % 16 == 0);
+    if (!vec) {   // odd sizes: two plain launches
+        int e = dn_launch_seg_reduce(pa, nullptr, 1, n, oa, la, stream);
+        return e ? e : dn_launch_seg_reduce(pb, nullptr, 1, n, ob, lb, stream);
+    }
+    const long long ba = (la / 4 + 31) / 32, bb = (lb + 31) / 32;
+    dn_prof_begin(DN_K_SMALL, stream);
+    DN_LAUNCH(seg_reduce_pair_kernel, dim3((unsigned)(ba > bb ? ba : bb), 2, 1), dim3(256, 1, 1), 0, stream, pa, oa, la, pb, ob, lb, n);
+    dn_prof_end(DN_K_SMALL, stream, 0.0, 4.0 * (double)(la + lb) * ((double)n + 1.0));
     return (int)hipGetLastError();
 }
 
