@@ -31,6 +31,9 @@ bool dn_rowgemm_try_persistent(const RgArgs& g, int ntiles, int nout, hipStream_
 #ifndef DN_RG2_SINGLE
 #define DN_RG2_SINGLE 0
 #endif
+#ifndef DN_RG2_REORDER
+#define DN_RG2_REORDER 0   // 1: reads -> split || MFMA -> writes inside a slice iteration of the two-output kernel; measured 192 vs 174 us -> off
+#endif
 #ifndef DN_RG2_VEC_EPI
 #define DN_RG2_VEC_EPI 1   // parked float4 epilogue of the two-output split-bf16 kernel (0: per-element dword epilogue)
 #endif
@@ -102,6 +105,34 @@ void rowgemm_kernel(RgArgs g) {
     }
     __syncthreads();
     int sl = 0;
+    if constexpr (X3 && DN_RG2_REORDER) {
+        // Split-bf16 order (as in the persistent kernels): the LDS reads of slice sl come FIRST, then the pure-VALU split of
+        // slice sl+1 next to the MFMAs of the first k16 step, then the LDS writes.  With the writes first the compiler has to
+        // keep every MFMA behind them (may-alias LDS): 178 staging VALU instructions ran before the first MFMA of a slice.
+        const int arow0 = wr * MT * 32, bcol0 = wc * NT * 32;
+        for (; sl < nslices; ++sl) {
+            const unsigned char* cA = reinterpret_cast<const unsigned char*>(smem + (sl & 1) * SBUF);
+            const unsigned char* cB = cA + SA * 4;
+            unsigned char* nA = reinterpret_cast<unsigned char*>(smem + ((sl & 1) ^ 1) * SBUF);
+            const bool stage = sl + 1 < nslices;      // uniform
+            X3Frags<MT, NT, NOUT> F;
+            X3Planes<NOUT, A_IT, B_IT> PLN;
+            rg_frag_x3<MT, NT, NOUT>(cA, cB, arow0, bcol0, li, ls, 0, F);
+            rg_split_x3<NOUT, BCOLK, HASQ, A_IT, B_IT>(R, PLN);          // stale registers on the last slice: never written
+            rg_mma_x3<MT, NT, NOUT>(F, 0, acc);
+            if (sl + 2 < nslices) {
+                koff += DN_KB;
+                if (koff >= g.a[seg].w) { koff = 0; ++seg; }
+                rg_load<TN, NTHR, NOUT, ALIGNED, BCOLK, HASQ, A_IT, B_IT, PAIRK>(g, tile, n0, seg, koff, tid, R);
+            }
+            rg_frag_x3<MT, NT, NOUT>(cA, cB, arow0, bcol0, li, ls, 1, F);
+            rg_mma_x3<MT, NT, NOUT>(F, 1, acc);
+            if (stage) {
+                rg_put_x3<NTHR, NOUT, BCOLK, A_IT, B_IT>(nA, nA + SA * 4, tid, PLN);
+                __syncthreads();
+            }
+        }
+    } else {
     for (; sl + 2 < nslices; ++sl) {
         float* cur = smem + (sl & 1) * SBUF;
         float* nxt = smem + ((sl & 1) ^ 1) * SBUF;
@@ -129,6 +160,7 @@ void rowgemm_kernel(RgArgs g) {
     {
         float* cur = smem + (sl & 1) * SBUF;
         RG_COMPUTE(cur);
+    }
     }
     }
 
