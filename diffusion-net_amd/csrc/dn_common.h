@@ -17,6 +17,8 @@
 #define DN_WAVES_PER_EU(n)
 #define DN_MIN_WAVES_PER_EU(n)
 #define DN_SETPRIO(n) do {} while (0)
+#define DN_SCHED_FENCE() do {} while (0)
+#define DN_UNIFORM(x) (x)
 #else
 #include <hip/hip_runtime.h>
 #define DN_LAUNCH(kernel, grid, block, smem, stream, ...) \
@@ -27,6 +29,10 @@
 #define DN_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #define DN_MIN_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
 #define DN_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#define DN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// a wave-uniform value the compiler cannot prove uniform (e.g. threadIdx.x >> 6): forces it into an SGPR, so that table
+// lookups indexed by it become scalar loads (lgkmcnt) instead of vector loads (vmcnt, which would drain the prefetch)
+#define DN_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -246,6 +252,21 @@ static inline void dn_lds_opt_in(const void* fn, size_t smem, unsigned long long
     }
 }
 #endif
+// CUs of the CURRENT device (one workgroup per CU in the persistent kernels)
+static inline int dn_num_cus() {
+#ifdef DN_EMULATE
+    return 3;
+#else
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+    if (cus[dev] == 0) {
+        int v = 0;
+        cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    return cus[dev];
+#endif
+}
 // number of partial results a tngemm launch over `nchunks` chunks with grouping `group` writes
 static inline int dn_tn_npartial(int nchunks, int group) { return (nchunks + (group < 1 ? 1 : group) - 1) / (group < 1 ? 1 : group); }
 // grouping for sums over ALL rows (weight gradients): about two workgroups per CU

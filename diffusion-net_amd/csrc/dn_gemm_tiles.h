@@ -441,3 +441,38 @@ __device__ __forceinline__ void rg_compute_x3(const unsigned char* sA, const uns
     }
 }
 
+// ---- float4 "piece" epilogue shared by the persistent kernels (parked accumulators) and the direct kernel (accumulator registers):
+//      FLAG: STORE -> a bias vector is added; BIAS_RELU -> a dropout keep-mask is applied; unused otherwise.
+struct PtPiece {
+    float4 v, a0, bias;
+    uint32_t mk;
+    float rs;
+    long long off;
+    bool ok;
+};
+
+// phase 2 (after the MFMAs): epilogue maths + one coalesced float4 store
+template <int MODE, bool FLAG>
+__device__ __forceinline__ void pt_piece_store(const RgArgs& g, const PtPiece& P) {
+    constexpr bool need_bias = (MODE == DN_EPI_STORE && FLAG) || MODE == DN_EPI_BIAS_RELU || MODE == DN_EPI_BIAS_RESID;
+    float x[4] = {P.v.x, P.v.y, P.v.z, P.v.w};
+    if (need_bias) { x[0] += P.bias.x; x[1] += P.bias.y; x[2] += P.bias.z; x[3] += P.bias.w; }
+    const float r[4] = {P.a0.x, P.a0.y, P.a0.z, P.a0.w};
+    float y[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (MODE == DN_EPI_STORE) y[e] = x[e];
+        else if (MODE == DN_EPI_BIAS_RELU) {
+            const float h = x[e] > 0.f ? x[e] : 0.f;
+            y[e] = FLAG ? (((P.mk >> (8 * e)) & 0xffu) ? h * g.scale : 0.f) : h;
+        }
+        else if (MODE == DN_EPI_BIAS_RESID) y[e] = x[e] + r[e];
+        else if (MODE == DN_EPI_MUL_DFAC) y[e] = r[e] > 0.f ? x[e] * g.scale : 0.f;
+        else if (MODE == DN_EPI_ADD) y[e] = x[e] + r[e];
+        else if (MODE == DN_EPI_DTANH) y[e] = x[e] * (1.f - r[e] * r[e]);
+        else if (MODE == DN_EPI_MASS_ADD) y[e] = r[e] + P.rs * x[e];
+        else y[e] = x[e];
+    }
+    if (P.ok) *reinterpret_cast<float4*>(g.o0 + P.off) = make_float4(y[0], y[1], y[2], y[3]);
+}
+

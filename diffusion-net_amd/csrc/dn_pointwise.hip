@@ -7,27 +7,6 @@
 //   mass_mean : mass-weighted global mean pooling and its gradient              (layers.py:397)
 #include "dn_common.h"
 
-__global__ __launch_bounds__(256) void spec_fwd_kernel(const float* partial, const int* mco, const float* evals,
-                                                       const float* time, float* xs, float* ys, int K, int C) {
-    const int m = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int KC = K * C;
-    if (i >= KC) return;
-    const int k = i / C, c = i % C;
-    float s = 0.f;
-    for (int ch = mco[m]; ch < mco[m + 1]; ++ch) s += partial[(long long)ch * KC + i];
-    if (xs) xs[(long long)m * KC + i] = s;
-    if (ys) ys[(long long)m * KC + i] = time ? expf(-evals[m * K + k] * time[c]) * s : s;
-}
-
-int dn_launch_spec_fwd(const float* partial, const int* mesh_chunk_off, const float* evals, const float* time,
-                       float* xs, float* ys, int n_mesh, int K, int C, hipStream_t stream) {
-    if (n_mesh <= 0 || K <= 0 || C <= 0) return 0;
-    dim3 grid((K * C + 255) / 256, n_mesh, 1);
-    DN_LAUNCH(spec_fwd_kernel, grid, dim3(256, 1, 1), 0, stream, partial, mesh_chunk_off, evals, time, xs, ys, K, C);
-    return (int)hipGetLastError();
-}
-
 // dys: [n_mesh,K,C] = evecs^T d_xd (already reduced over chunks).  In place: dys <- exp(-lambda t) * dys (the
 // spectrum handed to from_basis), and d_t partial per (mesh, channel).  block = 32 channels x 8 k-lanes.
 __global__ __launch_bounds__(256) void spec_bwd_kernel(float* dys, const float* evals, const float* time, const float* xs,
@@ -72,8 +51,12 @@ int dn_launch_spec_bwd(float* dys, const float* evals, const float* time, const 
 // Fixed-order segmented sum of split-V partials: out[s][i] = sum_{ch in segment s} partial[ch][i].
 // block = 32 column groups x 8 chunk lanes: lane kl sums chunks beg+kl, beg+kl+8, ... (several loads in flight),
 // the 8 lane sums are then combined in order through LDS -> bitwise reproducible, bandwidth-bound.
-template <int VEC>
-__device__ __forceinline__ void seg_reduce_body(const float* partial, int s, int beg, int end, float* out, long long len) {
+struct SegStore {   // plain epilogue: out[s][i + e] = sum
+    float* out; long long len;
+    __device__ __forceinline__ void operator()(int s, long long i, int e, float t) const { out[(long long)s * len + i + e] = t; }
+};
+template <int VEC, class EPI>
+__device__ __forceinline__ void seg_reduce_body(const float* partial, int s, int beg, int end, long long len, const EPI& epi) {
     __shared__ float red[8][32 * VEC];
     const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
     const long long i = ((long long)blockIdx.x * 32 + cl) * VEC;
@@ -118,7 +101,7 @@ __device__ __forceinline__ void seg_reduce_body(const float* partial, int s, int
             float t = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) t += red[j][cl * VEC + e];
-            out[(long long)s * len + i + e] = t;
+            epi(s, i, e, t);
         }
     }
 }
@@ -127,14 +110,49 @@ template <int VEC>
 __global__ __launch_bounds__(256) void seg_reduce_kernel(const float* partial, const int* seg_off, int n, float* out,
                                                          long long len) {
     const int s = blockIdx.y;
-    seg_reduce_body<VEC>(partial, s, seg_off ? seg_off[s] : 0, seg_off ? seg_off[s + 1] : n, out, len);
+    seg_reduce_body<VEC>(partial, s, seg_off ? seg_off[s] : 0, seg_off ? seg_off[s + 1] : n, len, SegStore{out, len});
+}
+
+// spec_fwd: the per-mesh sum of the to_basis partials (same parallel fixed-order reduction) with the spectral scaling as its
+// epilogue: xs[m] = sum, ys[m][k][c] = exp(-lambda_mk t_c) * sum  (layers.py:62-64).  Either output may be null.
+struct SpecEpi {
+    const float* evals; const float* time; float* xs; float* ys; int K, C;
+    __device__ __forceinline__ void operator()(int m, long long i, int e, float t) const {
+        const long long o = (long long)m * K * C + i + e;
+        if (xs) xs[o] = t;
+        if (ys) {
+            const int k = (int)((i + e) / C), c = (int)((i + e) % C);
+            ys[o] = time ? expf(-evals[m * K + k] * time[c]) * t : t;
+        }
+    }
+};
+template <int VEC>
+__global__ __launch_bounds__(256) void spec_fwd_kernel(const float* partial, const int* mco, SpecEpi epi) {
+    const int m = blockIdx.y;
+    seg_reduce_body<VEC>(partial, m, mco[m], mco[m + 1], (long long)epi.K * epi.C, epi);
+}
+
+int dn_launch_spec_fwd(const float* partial, const int* mesh_chunk_off, const float* evals, const float* time,
+                       float* xs, float* ys, int n_mesh, int K, int C, hipStream_t stream) {
+    if (n_mesh <= 0 || K <= 0 || C <= 0) return 0;
+    const long long len = (long long)K * C;
+    const bool vec = (len % 4 == 0) && ((uintptr_t)partial % 16 == 0);
+    const SpecEpi epi{evals, time, xs, ys, K, C};
+    dn_prof_begin(DN_K_SMALL, stream);
+    if (vec) {
+        DN_LAUNCH(spec_fwd_kernel<4>, dim3((unsigned)((len / 4 + 31) / 32), n_mesh, 1), dim3(256, 1, 1), 0, stream, partial, mesh_chunk_off, epi);
+    } else {
+        DN_LAUNCH(spec_fwd_kernel<1>, dim3((unsigned)((len + 31) / 32), n_mesh, 1), dim3(256, 1, 1), 0, stream, partial, mesh_chunk_off, epi);
+    }
+    dn_prof_end(DN_K_SMALL, stream, 0.0, 0.0);
+    return (int)hipGetLastError();
 }
 
 // two independent whole-range sums in one launch (a weight gradient, float4 path, and its bias gradient): blockIdx.y picks the job
 __global__ __launch_bounds__(256) void seg_reduce_pair_kernel(const float* pa, float* oa, long long la, const float* pb, float* ob,
                                                               long long lb, int n) {
-    if (blockIdx.y == 0) seg_reduce_body<4>(pa, 0, 0, n, oa, la);
-    else seg_reduce_body<1>(pb, 0, 0, n, ob, lb);
+    if (blockIdx.y == 0) seg_reduce_body<4>(pa, 0, 0, n, la, SegStore{oa, la});
+    else seg_reduce_body<1>(pb, 0, 0, n, lb, SegStore{ob, lb});
 }
 
 int dn_launch_seg_reduce(const float* partial, const int* seg_off, int nseg, int n, float* out, long long len,

@@ -8,6 +8,8 @@
 
 // implemented in dn_rowgemm_persist.hip: launches a persistent kernel if the product is eligible (returns true) ...
 bool dn_rowgemm_try_persistent(const RgArgs& g, int ntiles, int nout, hipStream_t stream, int* err);
+// dn_rowgemm_direct.hip: the K = 128 one-output products (A fragments straight from HBM, B resident in LDS)
+bool dn_rowgemm_try_direct(const RgArgs& g, int ntiles, int nout, hipStream_t stream, int* err);
 
 #ifndef DN_RG_X3
 #define DN_RG_X3 1   // -DDN_RG_X3=0: exact-f32 MFMA in the two-output kernels
@@ -297,6 +299,10 @@ int dn_launch_rowgemm(const RgArgs& g, int ntiles, int nout, hipStream_t stream)
     dn_prof_begin(kind, stream);
     int err = DN_ERR_BAD_MODE;
     const bool ck = g.b_colk != 0;
+    if (dn_rowgemm_try_direct(g, ntiles, nout, stream, &err)) {
+        dn_prof_end(kind, stream, flops, bytes);
+        return err;
+    }
 #ifndef DN_NO_PERSIST
     if (dn_rowgemm_try_persistent(g, ntiles, nout, stream, &err)) {
         dn_prof_end(kind, stream, flops, bytes);

@@ -43,14 +43,6 @@
 #define DN_PT_THREADS (4 * DN_PT_ROWS)   // 64x32 outputs per wave
 #define DN_PT_NP (DN_PT_ROWS * 128 / 4 / DN_PT_THREADS)   // float4 pieces per thread per unit (8)
 
-struct PtPiece {
-    float4 v, a0, bias;
-    uint32_t mk;
-    float rs;
-    long long off;
-    bool ok;
-};
-
 // FLAG: STORE -> a bias vector is added; BIAS_RELU -> a dropout keep-mask is applied; unused otherwise.
 // phase 1 of a deferred piece: ISSUE the LDS read of the parked accumulators and the global loads of the auxiliary
 // operands.  Branch-free, and nothing loaded here is used before the MFMA block (a use would put a vmcnt wait --
@@ -78,31 +70,6 @@ __device__ __forceinline__ void pt_piece_load(const RgArgs& g, const float* sE, 
         P.mk = g.mask ? ld : dn_keep_bytes(dn_keep_bits(g.rng_seed, grow, ccol >> 2, (g.N + 3) >> 2));
     }
     if (MODE == DN_EPI_MASS_ADD) P.rs = g.rowv[grow];
-}
-
-// phase 2 (after the MFMAs): epilogue maths + one coalesced float4 store
-template <int MODE, bool FLAG>
-__device__ __forceinline__ void pt_piece_store(const RgArgs& g, const PtPiece& P) {
-    constexpr bool need_bias = (MODE == DN_EPI_STORE && FLAG) || MODE == DN_EPI_BIAS_RELU || MODE == DN_EPI_BIAS_RESID;
-    float x[4] = {P.v.x, P.v.y, P.v.z, P.v.w};
-    if (need_bias) { x[0] += P.bias.x; x[1] += P.bias.y; x[2] += P.bias.z; x[3] += P.bias.w; }
-    const float r[4] = {P.a0.x, P.a0.y, P.a0.z, P.a0.w};
-    float y[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (MODE == DN_EPI_STORE) y[e] = x[e];
-        else if (MODE == DN_EPI_BIAS_RELU) {
-            const float h = x[e] > 0.f ? x[e] : 0.f;
-            y[e] = FLAG ? (((P.mk >> (8 * e)) & 0xffu) ? h * g.scale : 0.f) : h;
-        }
-        else if (MODE == DN_EPI_BIAS_RESID) y[e] = x[e] + r[e];
-        else if (MODE == DN_EPI_MUL_DFAC) y[e] = r[e] > 0.f ? x[e] * g.scale : 0.f;
-        else if (MODE == DN_EPI_ADD) y[e] = x[e] + r[e];
-        else if (MODE == DN_EPI_DTANH) y[e] = x[e] * (1.f - r[e] * r[e]);
-        else if (MODE == DN_EPI_MASS_ADD) y[e] = r[e] + P.rs * x[e];
-        else y[e] = x[e];
-    }
-    if (P.ok) *reinterpret_cast<float4*>(g.o0 + P.off) = make_float4(y[0], y[1], y[2], y[3]);
 }
 
 #if defined(DN_PT_TRACE)   // development build only: per-phase timestamps of workgroup 0 (waves 0 and 7), tools/trace_pt.py
@@ -347,21 +314,6 @@ __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_pers
         pt_piece_load<MODE, FLAG>(g, sE, p_next, tid, p_row0, p_nrows, n0, P1);
         pt_piece_store<MODE, FLAG>(g, P1);
     }
-}
-
-static int dn_num_cus() {   // CUs of the CURRENT device (one workgroup per CU in the persistent kernels)
-#ifdef DN_EMULATE
-    return 3;
-#else
-    static int cus[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
-    if (cus[dev] == 0) {
-        int v = 0;
-        cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-    }
-    return cus[dev];
-#endif
 }
 
 #ifndef DN_PT_X3

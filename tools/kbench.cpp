@@ -1,0 +1,254 @@
+// kbench.cpp -- standalone timing + spot-check harness for the C ABI of libdiffnet_hip.so (development aid, GPU only).
+// No torch: starts in milliseconds, so one GPU call can compare many library build variants.
+//   hipcc -O2 -std=c++17 tools/kbench.cpp -o tools/kbench -ldl
+//   tools/kbench [--lib path.so] [--meshes 16] [--verts 10000] [--C 128] [--K 128] [--reps 20] [--ops a,b,..] [--check]
+// Ops: to_basis from_basis diffusion diffusion_bwd spmm gradfeat gradfeat_bwd linear linear_relu linear_bwd
+//      block_inf block_fwd block_bwd copy
+// Every op line: avg us (hipEvents around `reps` back-to-back calls), algorithmic GB/s and, with --check, the worst error of a
+// row sample against an fp64 host evaluation of the same formula (relative to the largest reference magnitude).
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <random>
+#include <string>
+#include <vector>
+#include "../include/diffnet_hip.h"
+
+#define HC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %d (%s) at %s:%d\n", (int)e_, hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+#define DC(x) do { int e_ = (x); if (e_) { fprintf(stderr, "library error %d at %s:%d: %s\n", e_, __FILE__, __LINE__, #x); exit(3); } } while (0)
+
+struct Lib {
+    void* h;
+    template <class F> F sym(const char* n) { void* p = dlsym(h, n); if (!p) { fprintf(stderr, "missing symbol %s\n", n); exit(4); } return (F)p; }
+};
+
+template <class T> T* dev(const std::vector<T>& v) {
+    T* p = nullptr;
+    HC(hipMalloc(&p, std::max<size_t>(v.size(), 1) * sizeof(T)));
+    if (!v.empty()) HC(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return p;
+}
+static float* devz(size_t n) { float* p; HC(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(float))); HC(hipMemset(p, 0, n * sizeof(float))); return p; }
+static std::vector<float> host(const float* d, size_t n) { std::vector<float> v(n); HC(hipMemcpy(v.data(), d, n * sizeof(float), hipMemcpyDeviceToHost)); return v; }
+
+int main(int argc, char** argv) {
+    std::string libpath = "diffusion-net_amd/diffusion_net/libdiffnet_hip.so", ops = "all";
+    int n_mesh = 16, verts = 10000, C = 128, K = 128, reps = 20, chunk_rows = 0;
+    bool check = false, trace = false;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto nxt = [&]() { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(1); } return std::string(argv[++i]); };
+        if (a == "--lib") libpath = nxt(); else if (a == "--meshes") n_mesh = atoi(nxt().c_str()); else if (a == "--verts") verts = atoi(nxt().c_str());
+        else if (a == "--C") C = atoi(nxt().c_str()); else if (a == "--K") K = atoi(nxt().c_str()); else if (a == "--reps") reps = atoi(nxt().c_str());
+        else if (a == "--ops") ops = nxt(); else if (a == "--check") check = true; else if (a == "--trace") trace = true; else if (a == "--chunk") chunk_rows = atoi(nxt().c_str());
+        else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 1; }
+    }
+    auto want = [&](const char* o) { return ops == "all" || ("," + ops + ",").find(std::string(",") + o + ",") != std::string::npos; };
+    Lib L{dlopen(libpath.c_str(), RTLD_NOW | RTLD_LOCAL)};
+    if (!L.h) { fprintf(stderr, "dlopen %s: %s\n", libpath.c_str(), dlerror()); return 4; }
+    auto tile_rows = L.sym<int (*)()>("dn_tile_rows")();
+
+    // ---- synthetic ragged batch
+    std::mt19937 rng(1234);
+    std::uniform_real_distribution<float> U(0.f, 1.f);
+    std::normal_distribution<float> Nrm(0.f, 1.f);
+    std::vector<int> sizes(n_mesh);
+    for (auto& s : sizes) s = (int)(verts * (0.9 + 0.2 * U(rng)));
+    long long V = 0; for (int s : sizes) V += s;
+    if (!chunk_rows) { chunk_rows = 32 * std::max<long long>(1, (V + 512 * 32 - 1) / (512 * 32)); chunk_rows = std::min(1024, std::max(128, chunk_rows)); }
+    std::vector<dn_tile_t> tiles, chunks, mrows; std::vector<int> mco{0};
+    { int row0 = 0; for (int m = 0; m < n_mesh; ++m) { int v = sizes[m]; mrows.push_back({row0, v, m, 0});
+        for (int r = 0; r < v; r += tile_rows) tiles.push_back({row0 + r, std::min(tile_rows, v - r), m, 0});
+        int i = 0; for (int r = 0; r < v; r += chunk_rows) chunks.push_back({row0 + r, std::min(chunk_rows, v - r), m, i++});
+        mco.push_back((int)chunks.size()); row0 += v; } }
+    std::vector<float> mass(V), evals((size_t)n_mesh * K), evecs((size_t)V * K);
+    for (auto& m : mass) m = (0.5f + U(rng)) * 12.566f / verts;
+    for (int m = 0; m < n_mesh; ++m) { std::vector<float> e(K); for (auto& x : e) x = 50.f * U(rng); e[0] = 0.f; std::sort(e.begin(), e.end()); std::copy(e.begin(), e.end(), evals.begin() + (size_t)m * K); }
+    { const float s = sqrtf((float)verts / 12.566f); for (auto& x : evecs) x = s * Nrm(rng) * 0.3f; }
+    // gradient pattern: ~7 entries per row, neighbours within the mesh and close in index (as a mesh ordering gives), row sums zero
+    std::vector<int> rowptr(V + 1, 0), col; std::vector<float> vx, vy;
+    { long long r = 0; for (int m = 0; m < n_mesh; ++m) { const int row0 = mrows[m].row0, v = sizes[m];
+        for (int i = 0; i < v; ++i, ++r) { int deg = 6 + (int)(U(rng) * 3); std::vector<int> cs{row0 + i};
+            for (int d = 0; d < deg - 1; ++d) { int j = i + (int)((U(rng) - 0.5f) * 256); j = std::min(v - 1, std::max(0, j)); cs.push_back(row0 + j); }
+            std::sort(cs.begin(), cs.end()); cs.erase(std::unique(cs.begin(), cs.end()), cs.end());
+            float sx = 0, sy = 0; size_t b = col.size();
+            for (int c : cs) { col.push_back(c); float a = 20.f * Nrm(rng), bb = 20.f * Nrm(rng); vx.push_back(a); vy.push_back(bb); sx += a; sy += bb; }
+            vx[b] -= sx; vy[b] -= sy; rowptr[r + 1] = (int)col.size(); } } }
+    const long long nnz = col.size();
+    std::vector<int> t_rowptr(V + 1, 0), t_col(nnz); std::vector<float> t_vx(nnz), t_vy(nnz);
+    { for (long long j = 0; j < nnz; ++j) t_rowptr[col[j] + 1]++; for (long long i = 0; i < V; ++i) t_rowptr[i + 1] += t_rowptr[i];
+      std::vector<int> fill(t_rowptr.begin(), t_rowptr.end() - 1);
+      for (long long r = 0; r < V; ++r) for (int j = rowptr[r]; j < rowptr[r + 1]; ++j) { int p = fill[col[j]]++; t_col[p] = (int)r; t_vx[p] = vx[j]; t_vy[p] = vy[j]; } }
+    dn_mesh_batch_t mb; memset(&mb, 0, sizeof(mb));
+    mb.n_mesh = n_mesh; mb.v_total = (int)V; mb.k_eig = K; mb.n_tiles = (int)tiles.size(); mb.n_chunks = (int)chunks.size(); mb.g_nnz = (int)nnz;
+    mb.tiles = dev(tiles); mb.chunks = dev(chunks); mb.mesh_chunk_off = dev(mco); mb.mesh_rows = dev(mrows);
+    mb.mass = dev(mass); mb.evals = dev(evals); mb.evecs = dev(evecs);
+    mb.g_rowptr = dev(rowptr); mb.g_col = dev(col); mb.g_vx = dev(vx); mb.g_vy = dev(vy);
+    mb.gt_rowptr = dev(t_rowptr); mb.gt_col = dev(t_col); mb.gt_vx = dev(t_vx); mb.gt_vy = dev(t_vy);
+
+    auto randv = [&](size_t n, float sc) { std::vector<float> v(n); for (auto& x : v) x = sc * Nrm(rng); return v; };
+    std::vector<float> hx = randv((size_t)V * C, 1.f), hy = randv((size_t)V * C, 1.f), hW = randv((size_t)C * C, 1.f / sqrtf((float)C)),
+                       hW2 = randv((size_t)C * C, 1.f / sqrtf((float)C)), hW3 = randv((size_t)3 * C * C, 1.f / sqrtf(3.f * C)), hb = randv(C, 0.1f),
+                       hspec = randv((size_t)n_mesh * K * C, 1.f), htime(C, 0.05f);
+    float *x = dev(hx), *y = dev(hy), *W = dev(hW), *W2 = dev(hW2), *W3 = dev(hW3), *b = dev(hb), *spec = dev(hspec), *tm = dev(htime);
+    float *o0 = devz((size_t)V * C), *o1 = devz((size_t)V * C), *o2 = devz((size_t)V * C), *o3 = devz((size_t)V * C), *o4 = devz((size_t)V * C);
+    float *specout = devz((size_t)n_mesh * K * C), *dW = devz((size_t)3 * C * C), *db = devz(C), *dW2 = devz((size_t)C * C), *dt = devz(C);
+
+    dn_block_params_t bp; memset(&bp, 0, sizeof(bp));
+    bp.C = C; bp.n_mlp = 3; bp.with_grad = 1; bp.with_rot = 1; bp.widths[0] = 3 * C; bp.widths[1] = bp.widths[2] = bp.widths[3] = C;
+    bp.time = tm; bp.A_re = W; bp.A_im = W2; bp.W[0] = W3; bp.W[1] = W; bp.W[2] = W2; bp.b[0] = bp.b[1] = bp.b[2] = b; bp.drop_seed = 0x1234567ull;
+    dn_block_saved_t sv; memset(&sv, 0, sizeof(sv));
+    sv.xs = devz((size_t)n_mesh * K * C); sv.xd = devz((size_t)V * C); sv.gx = devz((size_t)V * C); sv.gy = devz((size_t)V * C); sv.g = devz((size_t)V * C);
+    sv.bre = devz((size_t)V * C); sv.bim = devz((size_t)V * C); sv.h[0] = devz((size_t)V * C); sv.h[1] = devz((size_t)V * C);
+    dn_block_grads_t gr; memset(&gr, 0, sizeof(gr));
+    gr.d_x = o4; gr.d_time = dt; gr.dA_re = devz((size_t)C * C); gr.dA_im = devz((size_t)C * C);
+    gr.dW[0] = dW; gr.dW[1] = devz((size_t)C * C); gr.dW[2] = devz((size_t)C * C); gr.db[0] = db; gr.db[1] = devz(C); gr.db[2] = devz(C);
+
+    auto f_ws = [&](const char* n) { return L.sym<size_t (*)(const dn_mesh_batch_t*, int)>(n); };
+    size_t wsb = 0;
+    wsb = std::max(wsb, f_ws("dn_to_basis_workspace_bytes")(&mb, C));
+    wsb = std::max(wsb, f_ws("dn_diffusion_workspace_bytes")(&mb, C));
+    wsb = std::max(wsb, f_ws("dn_gradfeat_workspace_bytes")(&mb, C));
+    wsb = std::max(wsb, L.sym<size_t (*)(const dn_mesh_batch_t*, int, int)>("dn_linear_workspace_bytes")(&mb, C, C));
+    wsb = std::max(wsb, L.sym<size_t (*)(const dn_mesh_batch_t*, const dn_block_params_t*, int)>("dn_block_fwd_workspace_bytes")(&mb, &bp, 0));
+    wsb = std::max(wsb, L.sym<size_t (*)(const dn_mesh_batch_t*, const dn_block_params_t*)>("dn_block_bwd_workspace_bytes")(&mb, &bp));
+    void* ws; HC(hipMalloc(&ws, wsb));
+    hipStream_t st; HC(hipStreamCreate(&st));
+    hipEvent_t e0, e1; HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
+    printf("# lib=%s V=%lld meshes=%d K=%d C=%d tiles=%d chunks=%d (rows %d) nnz=%lld ws=%.0f MB\n", libpath.c_str(), V, n_mesh, K, C, mb.n_tiles, mb.n_chunks, chunk_rows, nnz, wsb / 1e6);
+
+    auto timeit = [&](const char* name, double bytes, double flops, auto fn) {
+        for (int i = 0; i < 3; ++i) fn();
+        HC(hipStreamSynchronize(st));
+        HC(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) fn();
+        HC(hipEventRecord(e1, st));
+        HC(hipEventSynchronize(e1));
+        float ms; HC(hipEventElapsedTime(&ms, e0, e1));
+        const double us = 1e3 * ms / reps;
+        printf("%-16s %9.1f us  %7.0f GB/s  %6.1f TF", name, us, bytes / us / 1e3, flops / us / 1e6);
+        fflush(stdout);
+        return us;
+    };
+    auto endl_ = [&]() { printf("\n"); fflush(stdout); };
+    // sample of rows for the fp64 spot checks
+    std::vector<long long> rows_s;
+    for (int i = 0; i < 48; ++i) rows_s.push_back((long long)(U(rng) * (V - 1)));
+    for (auto& t : tiles) if (t.nrows < tile_rows) { rows_s.push_back(t.row0); rows_s.push_back(t.row0 + t.nrows - 1); }   // ragged tile ends
+    rows_s.push_back(0); rows_s.push_back(V - 1);
+    auto mesh_of = [&](long long r) { int m = 0; while (r >= mrows[m].row0 + mrows[m].nrows) ++m; return m; };
+    auto report = [&](double err, double ref) { printf("  err %.2e", err / std::max(ref, 1e-30)); };
+
+    const double VC = (double)V * C * 4, VK = (double)V * K * 4;
+    if (want("copy")) { timeit("copy", 2 * VC, 0, [&] { HC(hipMemcpyAsync(o0, x, (size_t)V * C * 4, hipMemcpyDeviceToDevice, st)); }); endl_(); }
+    if (want("to_basis")) {
+        auto f = L.sym<int (*)(const dn_mesh_batch_t*, const float*, int, int, float*, void*, size_t, void*)>("dn_to_basis_f32");
+        timeit("to_basis", VC + VK + V * 4.0, 2.0 * V * K * C, [&] { DC(f(&mb, x, C, 1, specout, ws, wsb, st)); });
+        if (check) {
+            auto got = host(specout, (size_t)n_mesh * K * C); double err = 0, ref = 0;
+            for (int m : {0, n_mesh - 1}) for (int k : {0, 1, 37, K - 1}) for (int c : {0, 5, C - 1}) {
+                double s = 0; for (int r = mrows[m].row0; r < mrows[m].row0 + mrows[m].nrows; ++r) s += (double)evecs[(size_t)r * K + k] * ((double)mass[r] * hx[(size_t)r * C + c]);
+                err = std::max(err, fabs(s - got[((size_t)m * K + k) * C + c])); ref = std::max(ref, fabs(s)); }
+            report(err, ref);
+        }
+        endl_();
+    }
+    if (want("from_basis")) {
+        auto f = L.sym<int (*)(const dn_mesh_batch_t*, const float*, int, int, float*, void*)>("dn_from_basis_f32");
+        timeit("from_basis", VC + VK, 2.0 * V * K * C, [&] { DC(f(&mb, spec, C, 0, o0, st)); });
+        if (check) {
+            auto got = host(o0, (size_t)V * C); double err = 0, ref = 0;
+            for (long long r : rows_s) { int m = mesh_of(r); for (int c = 0; c < C; ++c) { double s = 0; for (int k = 0; k < K; ++k) s += (double)evecs[(size_t)r * K + k] * hspec[((size_t)m * K + k) * C + c];
+                err = std::max(err, fabs(s - got[(size_t)r * C + c])); ref = std::max(ref, fabs(s)); } }
+            report(err, ref);
+        }
+        endl_();
+        if (trace) {   // libraries built with -DDN_RD_TRACE=<block>: s_memtime stamps of that workgroup's eight waves
+            auto rd = (int (*)(unsigned long long*, int))dlsym(L.h, "dn_debug_rd_trace_read");
+            if (rd) {
+                DC(f(&mb, spec, C, 0, o0, st)); HC(hipStreamSynchronize(st));
+                std::vector<unsigned long long> tb(8 * 64); rd(tb.data(), 8 * 64);
+                unsigned long long t0 = ~0ull; for (int w = 0; w < 8; ++w) t0 = std::min(t0, tb[w * 64]);
+                for (int w = 0; w < 8; ++w) { printf("  wave %d:", w); for (int i = 0; i < 40 && (i == 0 || tb[w * 64 + i] >= tb[w * 64 + i - 1]) ; ++i) printf(" %llu", tb[w * 64 + i] - t0); printf("\n"); }
+            }
+        }
+    }
+    if (want("diffusion")) {
+        auto f = L.sym<int (*)(const dn_mesh_batch_t*, const float*, const float*, int, float*, float*, void*, size_t, void*)>("dn_diffusion_fwd_f32");
+        double byts = 0; for (int s : sizes) byts += 4.0 * ((double)s * (2 * C + 2 * K + 1) + 2.0 * K * C + K + C);
+        double us = timeit("diffusion", byts, 4.0 * V * K * C, [&] { DC(f(&mb, x, tm, C, sv.xs, o0, ws, wsb, st)); });
+        printf("  frac_hbm_8TBs %.3f", byts / us / 1e3 / 8000.0);
+        endl_();
+    }
+    if (want("diffusion_bwd")) {
+        auto f = L.sym<int (*)(const dn_mesh_batch_t*, const float*, const float*, const float*, int, const float*, float*, float*, void*, size_t, void*)>("dn_diffusion_bwd_f32");
+        timeit("diffusion_bwd", 3 * VC + 2 * VK, 4.0 * V * K * C, [&] { DC(f(&mb, y, sv.xs, tm, C, x, o1, dt, ws, wsb, st)); });
+        endl_();
+    }
+    if (want("spmm")) {
+        auto f = L.sym<int (*)(const dn_mesh_batch_t*, const float*, int, float*, float*, void*)>("dn_grad_apply_fwd_f32");
+        timeit("spmm", 4.0 * (V + 3.0 * nnz) + 3 * VC, 4.0 * nnz * C, [&] { DC(f(&mb, x, C, o1, o2, st)); });
+        endl_();
+    }
+    if (want("gradfeat")) {
+        auto f = L.sym<int (*)(const dn_mesh_batch_t*, const float*, const float*, const float*, const float*, int, float*, float*, float*, void*)>("dn_gradfeat_fwd_f32");
+        timeit("gradfeat", 5 * VC, 8.0 * V * C * C, [&] { DC(f(&mb, x, y, W, W2, C, o0, o1, o2, st)); });
+        if (check) {
+            auto got = host(o0, (size_t)V * C); double err = 0, ref = 0;
+            for (long long r : rows_s) for (int c = 0; c < C; ++c) { double bre = 0, bim = 0;
+                for (int k = 0; k < C; ++k) { double gx = hx[(size_t)r * C + k], gy = hy[(size_t)r * C + k]; bre += gx * hW[(size_t)c * C + k] - gy * hW2[(size_t)c * C + k]; bim += gx * hW2[(size_t)c * C + k] + gy * hW[(size_t)c * C + k]; }
+                double s = tanh(hx[(size_t)r * C + c] * bre + hy[(size_t)r * C + c] * bim);
+                err = std::max(err, fabs(s - got[(size_t)r * C + c])); ref = 1.0; }
+            report(err, ref);
+        }
+        endl_();
+    }
+    if (want("gradfeat_bwd")) {
+        auto f = L.sym<int (*)(const dn_mesh_batch_t*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, int,
+                               float*, float*, float*, float*, void*, size_t, void*)>("dn_gradfeat_bwd_f32");
+        timeit("gradfeat_bwd", 9 * VC, 16.0 * V * C * C, [&] { DC(f(&mb, y, sv.g, x, y, o1, o2, W, W2, C, o3, o4, gr.dA_re, gr.dA_im, ws, wsb, st)); });
+        endl_();
+    }
+    auto lin = L.sym<int (*)(const dn_mesh_batch_t*, const float*, int, const float*, const float*, int, int, const uint8_t*, float*, void*)>("dn_linear_fwd_f32");
+    for (int relu = 0; relu < 2; ++relu) {
+        if (!want(relu ? "linear_relu" : "linear")) continue;
+        timeit(relu ? "linear_relu" : "linear", 2 * VC, 2.0 * V * C * C, [&] { DC(lin(&mb, x, C, W, b, C, relu, nullptr, o0, st)); });
+        if (check) {
+            auto got = host(o0, (size_t)V * C); double err = 0, ref = 0;
+            for (long long r : rows_s) for (int c = 0; c < C; ++c) { double s = hb[c]; for (int k = 0; k < C; ++k) s += (double)hx[(size_t)r * C + k] * hW[(size_t)c * C + k];
+                if (relu) s = s > 0 ? s : 0; err = std::max(err, fabs(s - got[(size_t)r * C + c])); ref = std::max(ref, fabs(s)); }
+            report(err, ref);
+        }
+        endl_();
+    }
+    if (want("linear_bwd")) {
+        auto f = L.sym<int (*)(const dn_mesh_batch_t*, const float*, const float*, const float*, int, int, float*, float*, float*, void*, size_t, void*)>("dn_linear_bwd_f32");
+        timeit("linear_bwd", 5 * VC, 4.0 * V * C * C, [&] { DC(f(&mb, y, x, W, C, C, o1, dW2, db, ws, wsb, st)); });
+        if (check) {
+            auto got = host(o1, (size_t)V * C); double err = 0, ref = 0;
+            for (long long r : rows_s) for (int c = 0; c < C; ++c) { double s = 0; for (int k = 0; k < C; ++k) s += (double)hy[(size_t)r * C + k] * hW[(size_t)k * C + c];
+                err = std::max(err, fabs(s - got[(size_t)r * C + c])); ref = std::max(ref, fabs(s)); }
+            report(err, ref);
+            auto gw = host(dW2, (size_t)C * C); err = ref = 0;
+            for (int o : {0, 3, C - 1}) for (int i : {0, 7, C - 1}) { double s = 0; for (long long r = 0; r < V; ++r) s += (double)hy[(size_t)r * C + o] * hx[(size_t)r * C + i];
+                err = std::max(err, fabs(s - gw[(size_t)o * C + i])); ref = std::max(ref, fabs(s)); }
+            report(err, ref);
+        }
+        endl_();
+    }
+    auto blk_f = L.sym<int (*)(const dn_mesh_batch_t*, const dn_block_params_t*, const float*, float*, const dn_block_saved_t*, void*, size_t, void*)>("dn_block_fwd_f32");
+    if (want("block_inf")) { dn_block_params_t p2 = bp; p2.drop_seed = 0; timeit("block_inf", 12 * VC, 0, [&] { DC(blk_f(&mb, &p2, x, o0, nullptr, ws, wsb, st)); }); endl_(); }
+    if (want("block_fwd")) { timeit("block_fwd", 20 * VC, 0, [&] { DC(blk_f(&mb, &bp, x, o0, &sv, ws, wsb, st)); }); endl_(); }
+    if (want("block_bwd")) {
+        auto f = L.sym<int (*)(const dn_mesh_batch_t*, const dn_block_params_t*, const float*, const dn_block_saved_t*, const float*, const dn_block_grads_t*, void*, size_t, void*)>("dn_block_bwd_f32");
+        DC(blk_f(&mb, &bp, x, o0, &sv, ws, wsb, st));
+        timeit("block_bwd", 40 * VC, 0, [&] { DC(f(&mb, &bp, x, &sv, y, &gr, ws, wsb, st)); }); endl_();
+    }
+    HC(hipStreamSynchronize(st));
+    return 0;
+}
