@@ -17,8 +17,6 @@
 #define DN_WAVES_PER_EU(n)
 #define DN_MIN_WAVES_PER_EU(n)
 #define DN_SETPRIO(n) do {} while (0)
-#define DN_SCHED_FENCE() do {} while (0)
-#define DN_UNIFORM(x) (x)
 #else
 #include <hip/hip_runtime.h>
 #define DN_LAUNCH(kernel, grid, block, smem, stream, ...) \
@@ -29,10 +27,6 @@
 #define DN_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #define DN_MIN_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
 #define DN_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
-#define DN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-// a wave-uniform value the compiler cannot prove uniform (e.g. threadIdx.x >> 6): forces it into an SGPR, so that table
-// lookups indexed by it become scalar loads (lgkmcnt) instead of vector loads (vmcnt, which would drain the prefetch)
-#define DN_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -205,7 +199,7 @@ struct RgArgs {
     const uint8_t* mask;
     unsigned long long rng_seed;   // != 0 with mask == null: Bernoulli(1/2) keep bits drawn in the epilogue (dn_keep_bits)
     float scale;
-    int acct_rows;         // host-side accounting only (rows covered by the launch)
+    int acct_rows;         // rows covered by the launch (= v_total of the mesh batch)
 };
 enum {
     DN_EPI_STORE = 0,        // o0 = acc (+bias)

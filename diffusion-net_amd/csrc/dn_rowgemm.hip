@@ -8,8 +8,6 @@
 
 // implemented in dn_rowgemm_persist.hip: launches a persistent kernel if the product is eligible (returns true) ...
 bool dn_rowgemm_try_persistent(const RgArgs& g, int ntiles, int nout, hipStream_t stream, int* err);
-// dn_rowgemm_direct.hip: the K = 128 one-output products (A fragments straight from HBM, B resident in LDS)
-bool dn_rowgemm_try_direct(const RgArgs& g, int ntiles, int nout, hipStream_t stream, int* err);
 
 #ifndef DN_RG_X3
 #define DN_RG_X3 1   // -DDN_RG_X3=0: exact-f32 MFMA in the two-output kernels
@@ -43,6 +41,7 @@ constexpr bool rg_is_x3(int TN, int NTHR, int NOUT, bool ALIGNED) { return DN_RG
 template <int TN, int WR, int WC, int NOUT, int MODE, bool ALIGNED, bool BCOLK>
 __global__ __launch_bounds__(WR* WC * 64) DN_MIN_WAVES_PER_EU((rg_is_x3(TN, WR * WC * 64, NOUT, ALIGNED) && DN_RG2_SINGLE) ? 4 : 1)
 void rowgemm_kernel(RgArgs g) {
+
     constexpr int NTHR = WR * WC * 64;
     constexpr int MT = DN_TM / (32 * WR);
     constexpr int NT = TN / (32 * WC);
@@ -299,10 +298,6 @@ int dn_launch_rowgemm(const RgArgs& g, int ntiles, int nout, hipStream_t stream)
     dn_prof_begin(kind, stream);
     int err = DN_ERR_BAD_MODE;
     const bool ck = g.b_colk != 0;
-    if (dn_rowgemm_try_direct(g, ntiles, nout, stream, &err)) {
-        dn_prof_end(kind, stream, flops, bytes);
-        return err;
-    }
 #ifndef DN_NO_PERSIST
     if (dn_rowgemm_try_persistent(g, ntiles, nout, stream, &err)) {
         dn_prof_end(kind, stream, flops, bytes);

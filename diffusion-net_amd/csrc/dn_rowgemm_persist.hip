@@ -103,6 +103,7 @@ extern "C" int dn_debug_trace_read(unsigned long long* out, int n) {
 #endif
 template <int MODE, bool BCOLK, bool FLAG, bool X3>
 __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_persist_kernel(RgArgs g, int ntiles) {
+
     constexpr int TN = 128, WR = DN_PT_ROWS / 64, WC = 4, NOUT = 1, NTHR = DN_PT_THREADS, TMU = DN_PT_ROWS;
     constexpr int UPT = DN_TM / TMU;                 // work units per 128-row tile (1 or 2)
     constexpr int MT = TMU / (32 * WR);              // 2
@@ -447,6 +448,7 @@ __device__ __forceinline__ void ws_load(const float* ap, int ald, const float* b
 // plane dwords in registers -- the per-slice B work shrinks from 2 loads + 44 VALU + 6 LDS writes to the 6 LDS writes.
 template <int MODE, bool BCOLK, bool FLAG, int PPI, bool BC>
 __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2 : 3) void rowgemm_ws_kernel(RgArgs g, int ntiles) {
+
     constexpr int TN = 128, NOUT = 1, LTHR = DN_WS_LTHR;
     constexpr int A_IT = DN_TM * 8 / LTHR;            // 4 float4 of the A slice per loader thread
     constexpr int B_IT = DN_KB * TN / 4 / LTHR;       // 4 float4 of the B slice

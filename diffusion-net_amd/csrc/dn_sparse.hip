@@ -17,6 +17,7 @@
 
 template <int VEC>
 __global__ __launch_bounds__(256) void spmm_kernel(SpArgs s, int tpr) {
+
     const int tid = threadIdx.x;
     const int rl = tid / tpr, cg = tid % tpr;
     const int rows_per_block = 256 / tpr;

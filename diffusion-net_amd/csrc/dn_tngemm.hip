@@ -307,6 +307,7 @@ __device__ __forceinline__ void tx_compute(const unsigned char* sA, const unsign
 #endif
 template <int FLAVOR>
 __global__ __launch_bounds__(DN_TX_THREADS, DN_TX_SINGLE ? 4 : 2) void tngemm_x3_kernel(TnArgs g) {
+
     constexpr int SBUF = 6 * DN_TX_PLANE;   // bytes of one (A,B) step buffer (3 planes each); two buffers in LDS
     DN_DYN_SMEM(smem_raw);
     unsigned char* smem = reinterpret_cast<unsigned char*>(smem_raw);

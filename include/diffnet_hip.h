@@ -19,6 +19,8 @@
  * A "mesh batch" is a ragged batch of independent meshes whose vertex axes are concatenated:
  * mesh m owns rows [mesh_rows[m].row0, +nrows) of every [v_total, *] array; the sparse gradient
  * operators use global (concatenated) row/column indices, i.e. they are block-diagonal.
+ * Table invariants: meshes, tiles and chunks are listed in row order and each table covers [0, v_total) without gaps or
+ * overlap; a tile / chunk never straddles two meshes.
  */
 #ifndef DIFFNET_HIP_H
 #define DIFFNET_HIP_H

@@ -95,8 +95,14 @@ int main(int argc, char** argv) {
     std::vector<float> hx = randv((size_t)V * C, 1.f), hy = randv((size_t)V * C, 1.f), hW = randv((size_t)C * C, 1.f / sqrtf((float)C)),
                        hW2 = randv((size_t)C * C, 1.f / sqrtf((float)C)), hW3 = randv((size_t)3 * C * C, 1.f / sqrtf(3.f * C)), hb = randv(C, 0.1f),
                        hspec = randv((size_t)n_mesh * K * C, 1.f), htime(C, 0.05f);
-    float *x = dev(hx), *y = dev(hy), *W = dev(hW), *W2 = dev(hW2), *W3 = dev(hW3), *b = dev(hb), *spec = dev(hspec), *tm = dev(htime);
-    float *o0 = devz((size_t)V * C), *o1 = devz((size_t)V * C), *o2 = devz((size_t)V * C), *o3 = devz((size_t)V * C), *o4 = devz((size_t)V * C);
+    // Inputs / outputs rotate over NROT buffer sets, so that consecutive repetitions never find their operands in the 256 MiB
+    // Infinity Cache (one 81 MB pair re-read 20 times does: a copy of it "runs" at 7 TB/s) -- in the network every operand comes
+    // from another kernel and ~1.3 GB of activations stream between two uses of the same buffer.
+    constexpr int NROT = 4;
+    float *xr[NROT], *yr[NROT], *o0r[NROT], *o1r[NROT];
+    for (int i = 0; i < NROT; ++i) { xr[i] = dev(hx); yr[i] = dev(hy); o0r[i] = devz((size_t)V * C); o1r[i] = devz((size_t)V * C); }
+    float *x = xr[0], *y = yr[0], *W = dev(hW), *W2 = dev(hW2), *W3 = dev(hW3), *b = dev(hb), *spec = dev(hspec), *tm = dev(htime);
+    float *o0 = o0r[0], *o1 = o1r[0], *o2 = devz((size_t)V * C), *o3 = devz((size_t)V * C), *o4 = devz((size_t)V * C);
     float *specout = devz((size_t)n_mesh * K * C), *dW = devz((size_t)3 * C * C), *db = devz(C), *dW2 = devz((size_t)C * C), *dt = devz(C);
 
     dn_block_params_t bp; memset(&bp, 0, sizeof(bp));
@@ -123,10 +129,10 @@ int main(int argc, char** argv) {
     printf("# lib=%s V=%lld meshes=%d K=%d C=%d tiles=%d chunks=%d (rows %d) nnz=%lld ws=%.0f MB\n", libpath.c_str(), V, n_mesh, K, C, mb.n_tiles, mb.n_chunks, chunk_rows, nnz, wsb / 1e6);
 
     auto timeit = [&](const char* name, double bytes, double flops, auto fn) {
-        for (int i = 0; i < 3; ++i) fn();
+        for (int i = 0; i < 3; ++i) fn(i);
         HC(hipStreamSynchronize(st));
         HC(hipEventRecord(e0, st));
-        for (int i = 0; i < reps; ++i) fn();
+        for (int i = 0; i < reps; ++i) fn(i + 3);
         HC(hipEventRecord(e1, st));
         HC(hipEventSynchronize(e1));
         float ms; HC(hipEventElapsedTime(&ms, e0, e1));
@@ -145,10 +151,10 @@ int main(int argc, char** argv) {
     auto report = [&](double err, double ref) { printf("  err %.2e", err / std::max(ref, 1e-30)); };
 
     const double VC = (double)V * C * 4, VK = (double)V * K * 4;
-    if (want("copy")) { timeit("copy", 2 * VC, 0, [&] { HC(hipMemcpyAsync(o0, x, (size_t)V * C * 4, hipMemcpyDeviceToDevice, st)); }); endl_(); }
+    if (want("copy")) { timeit("copy", 2 * VC, 0, [&](int it) { HC(hipMemcpyAsync(o0r[it % NROT], xr[it % NROT], (size_t)V * C * 4, hipMemcpyDeviceToDevice, st)); }); endl_(); }
     if (want("to_basis")) {
         auto f = L.sym<int (*)(const dn_mesh_batch_t*, const float*, int, int, float*, void*, size_t, void*)>("dn_to_basis_f32");
-        timeit("to_basis", VC + VK + V * 4.0, 2.0 * V * K * C, [&] { DC(f(&mb, x, C, 1, specout, ws, wsb, st)); });
+        timeit("to_basis", VC + VK + V * 4.0, 2.0 * V * K * C, [&](int it) { DC(f(&mb, xr[it % NROT], C, 1, specout, ws, wsb, st)); });
         if (check) {
             auto got = host(specout, (size_t)n_mesh * K * C); double err = 0, ref = 0;
             for (int m : {0, n_mesh - 1}) for (int k : {0, 1, 37, K - 1}) for (int c : {0, 5, C - 1}) {
@@ -160,7 +166,7 @@ int main(int argc, char** argv) {
     }
     if (want("from_basis")) {
         auto f = L.sym<int (*)(const dn_mesh_batch_t*, const float*, int, int, float*, void*)>("dn_from_basis_f32");
-        timeit("from_basis", VC + VK, 2.0 * V * K * C, [&] { DC(f(&mb, spec, C, 0, o0, st)); });
+        timeit("from_basis", VC + VK, 2.0 * V * K * C, [&](int it) { DC(f(&mb, spec, C, 0, o0r[it % NROT], st)); });
         if (check) {
             auto got = host(o0, (size_t)V * C); double err = 0, ref = 0;
             for (long long r : rows_s) { int m = mesh_of(r); for (int c = 0; c < C; ++c) { double s = 0; for (int k = 0; k < K; ++k) s += (double)evecs[(size_t)r * K + k] * hspec[((size_t)m * K + k) * C + c];
@@ -181,23 +187,23 @@ int main(int argc, char** argv) {
     if (want("diffusion")) {
         auto f = L.sym<int (*)(const dn_mesh_batch_t*, const float*, const float*, int, float*, float*, void*, size_t, void*)>("dn_diffusion_fwd_f32");
         double byts = 0; for (int s : sizes) byts += 4.0 * ((double)s * (2 * C + 2 * K + 1) + 2.0 * K * C + K + C);
-        double us = timeit("diffusion", byts, 4.0 * V * K * C, [&] { DC(f(&mb, x, tm, C, sv.xs, o0, ws, wsb, st)); });
+        double us = timeit("diffusion", byts, 4.0 * V * K * C, [&](int it) { DC(f(&mb, xr[it % NROT], tm, C, sv.xs, o0r[it % NROT], ws, wsb, st)); });
         printf("  frac_hbm_8TBs %.3f", byts / us / 1e3 / 8000.0);
         endl_();
     }
     if (want("diffusion_bwd")) {
         auto f = L.sym<int (*)(const dn_mesh_batch_t*, const float*, const float*, const float*, int, const float*, float*, float*, void*, size_t, void*)>("dn_diffusion_bwd_f32");
-        timeit("diffusion_bwd", 3 * VC + 2 * VK, 4.0 * V * K * C, [&] { DC(f(&mb, y, sv.xs, tm, C, x, o1, dt, ws, wsb, st)); });
+        timeit("diffusion_bwd", 3 * VC + 2 * VK, 4.0 * V * K * C, [&](int it) { DC(f(&mb, yr[it % NROT], sv.xs, tm, C, xr[it % NROT], o1r[it % NROT], dt, ws, wsb, st)); });
         endl_();
     }
     if (want("spmm")) {
         auto f = L.sym<int (*)(const dn_mesh_batch_t*, const float*, int, float*, float*, void*)>("dn_grad_apply_fwd_f32");
-        timeit("spmm", 4.0 * (V + 3.0 * nnz) + 3 * VC, 4.0 * nnz * C, [&] { DC(f(&mb, x, C, o1, o2, st)); });
+        timeit("spmm", 4.0 * (V + 3.0 * nnz) + 3 * VC, 4.0 * nnz * C, [&](int it) { DC(f(&mb, xr[it % NROT], C, o1r[it % NROT], o2, st)); });
         endl_();
     }
     if (want("gradfeat")) {
         auto f = L.sym<int (*)(const dn_mesh_batch_t*, const float*, const float*, const float*, const float*, int, float*, float*, float*, void*)>("dn_gradfeat_fwd_f32");
-        timeit("gradfeat", 5 * VC, 8.0 * V * C * C, [&] { DC(f(&mb, x, y, W, W2, C, o0, o1, o2, st)); });
+        timeit("gradfeat", 5 * VC, 8.0 * V * C * C, [&](int it) { DC(f(&mb, xr[it % NROT], yr[it % NROT], W, W2, C, o0r[it % NROT], o1r[it % NROT], o2, st)); });
         if (check) {
             auto got = host(o0, (size_t)V * C); double err = 0, ref = 0;
             for (long long r : rows_s) for (int c = 0; c < C; ++c) { double bre = 0, bim = 0;
@@ -211,13 +217,13 @@ int main(int argc, char** argv) {
     if (want("gradfeat_bwd")) {
         auto f = L.sym<int (*)(const dn_mesh_batch_t*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, int,
                                float*, float*, float*, float*, void*, size_t, void*)>("dn_gradfeat_bwd_f32");
-        timeit("gradfeat_bwd", 9 * VC, 16.0 * V * C * C, [&] { DC(f(&mb, y, sv.g, x, y, o1, o2, W, W2, C, o3, o4, gr.dA_re, gr.dA_im, ws, wsb, st)); });
+        timeit("gradfeat_bwd", 9 * VC, 16.0 * V * C * C, [&](int it) { DC(f(&mb, yr[it % NROT], sv.g, xr[it % NROT], yr[it % NROT], o1r[it % NROT], o2, W, W2, C, o3, o4, gr.dA_re, gr.dA_im, ws, wsb, st)); });
         endl_();
     }
     auto lin = L.sym<int (*)(const dn_mesh_batch_t*, const float*, int, const float*, const float*, int, int, const uint8_t*, float*, void*)>("dn_linear_fwd_f32");
     for (int relu = 0; relu < 2; ++relu) {
         if (!want(relu ? "linear_relu" : "linear")) continue;
-        timeit(relu ? "linear_relu" : "linear", 2 * VC, 2.0 * V * C * C, [&] { DC(lin(&mb, x, C, W, b, C, relu, nullptr, o0, st)); });
+        timeit(relu ? "linear_relu" : "linear", 2 * VC, 2.0 * V * C * C, [&](int it) { DC(lin(&mb, xr[it % NROT], C, W, b, C, relu, nullptr, o0r[it % NROT], st)); });
         if (check) {
             auto got = host(o0, (size_t)V * C); double err = 0, ref = 0;
             for (long long r : rows_s) for (int c = 0; c < C; ++c) { double s = hb[c]; for (int k = 0; k < C; ++k) s += (double)hx[(size_t)r * C + k] * hW[(size_t)c * C + k];
@@ -228,7 +234,7 @@ int main(int argc, char** argv) {
     }
     if (want("linear_bwd")) {
         auto f = L.sym<int (*)(const dn_mesh_batch_t*, const float*, const float*, const float*, int, int, float*, float*, float*, void*, size_t, void*)>("dn_linear_bwd_f32");
-        timeit("linear_bwd", 5 * VC, 4.0 * V * C * C, [&] { DC(f(&mb, y, x, W, C, C, o1, dW2, db, ws, wsb, st)); });
+        timeit("linear_bwd", 5 * VC, 4.0 * V * C * C, [&](int it) { DC(f(&mb, yr[it % NROT], xr[it % NROT], W, C, C, o1r[it % NROT], dW2, db, ws, wsb, st)); });
         if (check) {
             auto got = host(o1, (size_t)V * C); double err = 0, ref = 0;
             for (long long r : rows_s) for (int c = 0; c < C; ++c) { double s = 0; for (int k = 0; k < C; ++k) s += (double)hy[(size_t)r * C + k] * hW[(size_t)k * C + c];
@@ -242,12 +248,12 @@ int main(int argc, char** argv) {
         endl_();
     }
     auto blk_f = L.sym<int (*)(const dn_mesh_batch_t*, const dn_block_params_t*, const float*, float*, const dn_block_saved_t*, void*, size_t, void*)>("dn_block_fwd_f32");
-    if (want("block_inf")) { dn_block_params_t p2 = bp; p2.drop_seed = 0; timeit("block_inf", 12 * VC, 0, [&] { DC(blk_f(&mb, &p2, x, o0, nullptr, ws, wsb, st)); }); endl_(); }
-    if (want("block_fwd")) { timeit("block_fwd", 20 * VC, 0, [&] { DC(blk_f(&mb, &bp, x, o0, &sv, ws, wsb, st)); }); endl_(); }
+    if (want("block_inf")) { dn_block_params_t p2 = bp; p2.drop_seed = 0; timeit("block_inf", 12 * VC, 0, [&](int it) { DC(blk_f(&mb, &p2, xr[it % NROT], o0r[it % NROT], nullptr, ws, wsb, st)); }); endl_(); }
+    if (want("block_fwd")) { timeit("block_fwd", 20 * VC, 0, [&](int it) { DC(blk_f(&mb, &bp, xr[it % NROT], o0r[it % NROT], &sv, ws, wsb, st)); }); endl_(); }
     if (want("block_bwd")) {
         auto f = L.sym<int (*)(const dn_mesh_batch_t*, const dn_block_params_t*, const float*, const dn_block_saved_t*, const float*, const dn_block_grads_t*, void*, size_t, void*)>("dn_block_bwd_f32");
         DC(blk_f(&mb, &bp, x, o0, &sv, ws, wsb, st));
-        timeit("block_bwd", 40 * VC, 0, [&] { DC(f(&mb, &bp, x, &sv, y, &gr, ws, wsb, st)); }); endl_();
+        timeit("block_bwd", 40 * VC, 0, [&](int it) { DC(f(&mb, &bp, x, &sv, yr[it % NROT], &gr, ws, wsb, st)); }); endl_();
     }
     HC(hipStreamSynchronize(st));
     return 0;
