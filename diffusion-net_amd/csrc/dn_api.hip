@@ -577,6 +577,21 @@ int dn_hks_f32(const float* evals, const float* evecs, const float* scales, int 
     return dn_launch_hks(evals, evecs, scales, B, V, K, n_scales, scales_per_batch ? (long long)n_scales : 0LL, out, S(stream));
 }
 
+// ------------------------------------------------------------------ operator packing
+size_t dn_coo_to_csr_workspace_bytes(int64_t nnz, int n_cols) { return dn_pack_ws_bytes(nnz, n_cols) + 512; }
+int dn_coo_to_csr_i64(const int64_t* rows, int row_div, const int64_t* cols, const float* vx, const float* vy, int64_t nnz, int n_rows, int n_cols,
+                      int32_t* rowptr, int32_t* col, int32_t* t_rowptr, int32_t* t_col, float* t_vx, float* t_vy, int32_t* status,
+                      void* ws, size_t ws_bytes, void* stream) {
+    if (nnz < 0 || n_rows < 0 || n_cols < 0 || nnz >= 2147483647LL || (!rows && row_div <= 0) || !rowptr || !t_rowptr || !status ||
+        (nnz > 0 && (!cols || !col || !t_col || (vx && !t_vx) || (vy && !t_vy))))
+        return DN_ERR_INVALID;
+    Bump b(ws, ws_bytes);
+    int* w = (int*)b.f((size_t)n_cols + 1 + (size_t)nnz);
+    if (!b.ok) return DN_ERR_INVALID;
+    return dn_launch_coo_to_csr((const long long*)rows, row_div, (const long long*)cols, vx, vy, nnz, n_rows, n_cols, rowptr, col, t_rowptr, t_col,
+                                t_vx, t_vy, status, w, S(stream));
+}
+
 // ------------------------------------------------------------------ output remaps
 int dn_csr_mean_f32(const int32_t* rowptr, const int32_t* col, int n_rows, const float* x, int C, float div, float* out,
                     void* stream) {

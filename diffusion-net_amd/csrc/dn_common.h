@@ -328,6 +328,11 @@ int dn_launch_dtanh(const float* dg, const float* g, float* out, long long n, hi
 int dn_launch_reduce_pair(const float* pa, float* oa, long long la, const float* pb, float* ob, long long lb, int n, hipStream_t stream);
 int dn_launch_hks(const float* evals, const float* evecs, const float* scales, int B, int V, int K, int S, long long scale_stride,
                   float* out, hipStream_t stream);
+// COO -> CSR + CSR of the transpose (dn_pack.hip).  rows == nullptr: entry j belongs to row j / row_div (gather patterns)
+size_t dn_pack_ws_bytes(long long nnz, int n_cols);
+int dn_launch_coo_to_csr(const long long* rows, int row_div, const long long* cols, const float* vx, const float* vy, long long nnz, int n_rows,
+                         int n_cols, int* rowptr, int* col32, int* t_rowptr, int* t_col, float* t_vx, float* t_vy, int* status, int* ws,
+                         hipStream_t stream);
 // launchers (host), defined in the .hip files; all return hipError_t as int
 int dn_launch_rowgemm(const RgArgs& g, int ntiles, int nout, hipStream_t stream);
 int dn_launch_tngemm(const TnArgs& g, int nchunks, hipStream_t stream);

@@ -9,6 +9,7 @@ tables the HIP kernels walk are built on the host.  The struct handed to the C A
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 from typing import List, Optional, Sequence
 
@@ -54,11 +55,29 @@ def _tables_on(device, sizes, chunk_rows):
     return hit
 
 
-def _csr_from_sorted_rows(rows: torch.Tensor, n_rows: int) -> torch.Tensor:
-    counts = torch.bincount(rows, minlength=n_rows)
-    rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=rows.device)
-    torch.cumsum(counts, 0, out=rowptr[1:])
-    return rowptr.to(torch.int32)
+def coo_to_csr(rows, row_div, cols, vx, vy, n_rows, n_cols):
+    """int64 COO -> int32 CSR of the pattern + CSR of its transpose, on the device (``dn_coo_to_csr_i64``, dn_pack.hip).
+    rows: [nnz] non-decreasing int64 row ids, or None: entry j belongs to row j // row_div.  Raises ValueError on an index outside
+    the operator (the one host synchronisation of a pack; the reference's ``torch.gather`` / sparse mm would fault there too)."""
+    if n_rows >= 2 ** 31 - 1 or n_cols >= 2 ** 31 - 1 or cols.numel() >= 2 ** 31 - 1:
+        raise ValueError("operator too large for int32 CSR indices")
+    _hip.require_device(cols)
+    L, dev, nnz = _hip.lib(), cols.device, int(cols.numel())
+    cols = cols.to(torch.int64).contiguous()
+    rows = rows.to(torch.int64).contiguous() if rows is not None else None
+    i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
+    f32 = lambda v: torch.empty(nnz, dtype=torch.float32, device=dev) if v is not None else None
+    vx = vx.to(torch.float32).contiguous() if vx is not None else None
+    vy = vy.to(torch.float32).contiguous() if vy is not None else None
+    rowptr, col, t_rowptr, t_col, t_vx, t_vy = i32(n_rows + 1), i32(nnz), i32(n_cols + 1), i32(nnz), f32(vx), f32(vy)
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = _hip.workspace(dev, L.dn_coo_to_csr_workspace_bytes(nnz, n_cols))
+    _hip.check(L.dn_coo_to_csr_i64(_hip.ptr(rows), int(row_div), cols.data_ptr(), _hip.ptr(vx), _hip.ptr(vy), nnz, n_rows, n_cols,
+                                   rowptr.data_ptr(), col.data_ptr(), t_rowptr.data_ptr(), t_col.data_ptr(), _hip.ptr(t_vx), _hip.ptr(t_vy),
+                                   status.data_ptr(), ws.data_ptr(), ws.numel(), _hip.stream_of(cols)), "dn_coo_to_csr_i64")
+    if int(status.item()) != 0:
+        raise ValueError("sparse operator / gather index out of range (rows must be sorted, 0 <= index < %d x %d)" % (n_rows, n_cols))
+    return rowptr, col, vx, vy, t_rowptr, t_col, t_vx, t_vy
 
 
 class MeshBatch:
@@ -129,16 +148,13 @@ class MeshBatch:
     def _set_grad(self, rows, cols, vx, vy):
         """rows/cols: global int64 COO (row-sorted, coalesced); builds CSR and CSR of the transpose."""
         vt = sum(self.sizes)
-        self.g_rowptr = _csr_from_sorted_rows(rows, vt)
-        self.g_col = cols.to(torch.int32).contiguous()
-        self.g_vx, self.g_vy = vx.to(torch.float32).contiguous(), vy.to(torch.float32).contiguous()
-        perm = torch.argsort(cols, stable=True)
-        self.gt_rowptr = _csr_from_sorted_rows(cols[perm], vt)
-        self.gt_col = rows[perm].to(torch.int32).contiguous()
-        self.gt_vx, self.gt_vy = self.g_vx[perm].contiguous(), self.g_vy[perm].contiguous()
+        (self.g_rowptr, self.g_col, self.g_vx, self.g_vy,
+         self.gt_rowptr, self.gt_col, self.gt_vx, self.gt_vy) = coo_to_csr(rows, 1, cols, vx, vy, vt, vt)
 
     def _finish(self, chunk_rows):
         vt = sum(self.sizes)
+        if vt >= 2 ** 31 - 1:
+            raise ValueError("more than 2^31 vertices in one batch")
         self.chunk_rows = int(chunk_rows or default_chunk_rows(vt))
         self.tiles, self.chunks, self.mesh_chunk_off, self.mesh_rows = _tables_on(self.device, self.sizes, self.chunk_rows)
         s = _hip.MeshBatchStruct()
@@ -199,11 +215,89 @@ class GatherPattern:
     def __init__(self, index: torch.Tensor, n_src_rows: int):
         # index: [n_out, n_per] int64, global row ids into the [n_src_rows, C] source
         n_out, n_per = index.shape
-        dev = index.device
-        flat = index.reshape(-1)
         self.n_out, self.n_per, self.n_src = int(n_out), int(n_per), int(n_src_rows)
-        self.rowptr = torch.arange(0, n_out * n_per + 1, n_per, dtype=torch.int32, device=dev)
-        self.col = flat.to(torch.int32).contiguous()
-        perm = torch.argsort(flat, stable=True)
-        self.t_rowptr = _csr_from_sorted_rows(flat[perm], n_src_rows)
-        self.t_col = (perm // n_per).to(torch.int32).contiguous()
+        self.rowptr, self.col, _, _, self.t_rowptr, self.t_col, _, _ = coo_to_csr(None, n_per, index.reshape(-1), None, None,
+                                                                                  self.n_out, self.n_src)
+
+
+class OperatorCache:
+    """Device-resident operator cache behind the REFERENCE signature.  The experiment scripts hand the same meshes'
+    operators to ``forward`` again and again -- and move them to the device anew every step
+    (human_segmentation_original.py:111-120) -- so re-packing them per call (COO -> CSR, transpose, tile tables) made the
+    unmodified loop host-bound.  Two levels:
+      1. identity: (data_ptr, version, shape) of every operand.  Hits when the caller keeps its device tensors; no host sync.  The
+         entry holds references to the keyed tensors, so an address cannot be recycled under a live key.
+      2. content fingerprint: shapes, nnz, ALL eigenvalues and 16 mass entries (plus 32 entries of the faces/edges array), fetched with
+         one small device-to-host copy.  Hits when the caller re-uploads the same mesh.  Two different meshes with the same vertex
+         count and the same K eigenvalues to the last bit do not occur in practice; set ``operator_cache.fingerprint = False`` to
+         rely on identity only, ``operator_cache.enabled = False`` to pack on every call as round 1 did.
+    LRU over both levels, bounded by entries and by the bytes of eigenbasis they keep alive."""
+
+    def __init__(self, max_entries=256, max_bytes=16 << 30):
+        self.enabled, self.fingerprint = True, True
+        self.max_entries, self.max_bytes = max_entries, max_bytes
+        self._by_id = collections.OrderedDict()
+        self._by_fp = collections.OrderedDict()
+        self.hits_id = self.hits_fp = self.misses = 0
+
+    @staticmethod
+    def _ident(t):
+        if t is None:
+            return None
+        if t.is_sparse:
+            i, v = t._indices(), t._values()
+            return (i.data_ptr(), v.data_ptr(), v._version, tuple(t.shape), int(v.shape[0]))
+        return (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+
+    def clear(self):
+        self._by_id.clear()
+        self._by_fp.clear()
+
+    def _trim(self, d):
+        total = 0
+        for k in reversed(list(d.keys())):
+            total += d[k][2]
+            if total > self.max_bytes and len(d) > 1:
+                del d[k]
+        while len(d) > self.max_entries:
+            d.popitem(last=False)
+
+    def lookup(self, mass, evals, evecs, gradX, gradY, index, tag, build, key_operands=None):
+        """build() -> (MeshBatch, GatherPattern or None).  Tensors are the batched reference operands; ``tag`` the static part;
+        ``key_operands``: the tensors as the caller handed them over (``unsqueeze`` of a sparse tensor copies it), for the identity key."""
+        if not self.enabled:
+            return build()
+        operands = key_operands if key_operands is not None else (mass, evals, evecs, gradX, gradY, index)
+        kid = (tag,) + tuple(self._ident(t) for t in operands)
+        hit = self._by_id.get(kid)
+        if hit is not None:
+            self._by_id.move_to_end(kid)
+            self.hits_id += 1
+            return hit[0]
+        kfp = None
+        if self.fingerprint and evals is not None and evals.numel() > 0:
+            m = mass.reshape(-1)
+            parts = [evals.reshape(-1).to(torch.float32), m[:8].to(torch.float32), m[-8:].to(torch.float32)]
+            if index is not None:
+                ix = index.reshape(-1)
+                parts += [ix[:16].to(torch.float32), ix[-16:].to(torch.float32)]
+            fp = torch.cat(parts).cpu().numpy().tobytes()          # the one host synchronisation of a level-2 lookup
+            nnz = int(gradX._values().shape[0]) if gradX is not None else -1
+            kfp = (tag, tuple(evecs.shape), nnz, tuple(index.shape) if index is not None else None, fp)
+            hit = self._by_fp.get(kfp)
+            if hit is not None:
+                self._by_fp.move_to_end(kfp)
+                self.hits_fp += 1
+                return hit[0]
+        self.misses += 1
+        value = build()
+        nbytes = int(evecs.numel()) * 4
+        self._by_id[kid] = (value, operands, nbytes)
+        self._trim(self._by_id)
+        if kfp is not None:
+            self._by_fp[kfp] = (value, None, nbytes)
+            self._trim(self._by_fp)
+        return value
+
+
+operator_cache = OperatorCache()

@@ -1,6 +1,7 @@
 """Data-parallel training over the GPUs of one node: one process per GPU, meshes sharded across
-ranks as independent batch items, ONE RCCL all-reduce of a single flat fp32 gradient bucket per step
-(SURVEY.md 8e).  The reference has no distributed code at all; this is new.
+ranks as independent batch items, the gradient sync is an RCCL all-reduce over ONE flat fp32 gradient buffer
+(SURVEY.md 8e): per-block ranges go out on a side stream as soon as their backward is done, the small rest after it.
+The reference has no distributed code at all; this is new.
 
 ``FlatParams`` re-homes every parameter (and its .grad) of a module into one contiguous buffer so
 that (a) the gradient sync is a single collective over xGMI instead of 40 small ones (the whole
@@ -15,10 +16,12 @@ import torch.distributed as dist
 
 
 class FlatParams:
-    def __init__(self, module: torch.nn.Module, direct_sinks: bool = True):
+    def __init__(self, module: torch.nn.Module, direct_sinks: bool = True, overlap: bool = True):
         """direct_sinks: let the HIP ops accumulate parameter gradients straight into the bucket (ops._deliver).  Turn it off
         when backward passes run concurrently on several streams: the direct adds are not ordered across streams, autograd's
-        AccumulateGrad is."""
+        AccumulateGrad is.
+        overlap: in a multi-rank job, all-reduce the gradient range of a DiffusionNetBlock as soon as its backward has delivered it
+        (on a side stream, under the backward of the blocks before it); all_reduce_mean() then only sends what is left."""
         self.direct_sinks = bool(direct_sinks)
         params = [p for p in module.parameters()]
         if not params:
@@ -41,6 +44,42 @@ class FlatParams:
         self.params, self.offsets, self.sizes = params, offs, sizes
         self.master = torch.nn.Parameter(self.flat, requires_grad=True)   # what the optimizer updates
         self.master.grad = self.grad
+        # ---- per-block buckets: the contiguous flat range of every DiffusionNetBlock, in parameter order
+        self.buckets: List[tuple] = []
+        self._pending, self._sent = [], []
+        self._side = None
+        index_of = {id(p): i for i, p in enumerate(params)}
+        blocks = getattr(module, "blocks", None) if overlap else None
+        if blocks and self.direct_sinks:
+            for bi, blk in enumerate(blocks):
+                ids = sorted(index_of[id(p)] for p in blk.parameters())
+                if not ids or ids != list(range(ids[0], ids[-1] + 1)):
+                    self.buckets = []
+                    break
+                lo, hi = offs[ids[0]], offs[ids[-1]] + (sizes[ids[-1]] + 3) // 4 * 4
+                self.buckets.append((lo, hi))
+                blk._cfg.grad_hook = (lambda k: (lambda: self._bucket_ready(k)))(bi)
+        self._force_collectives = False   # tests: run the collective path at world size 1
+
+    # ------------------------------------------------------------------ overlap machinery
+    def _active(self, group=None):
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or self._force_collectives)
+
+    def _bucket_ready(self, k):
+        """Called by ops.BlockFn.backward once block k's gradients sit in the flat bucket (stream-ordered on the current stream)."""
+        if not self._active() or k in self._sent:
+            return
+        lo, hi = self.buckets[k]
+        self._sent.append(k)
+        view = self.grad[lo:hi]
+        if self.grad.is_cuda:
+            if self._side is None:
+                self._side = torch.cuda.Stream(self.grad.device)
+            self._side.wait_stream(torch.cuda.current_stream(self.grad.device))   # the bucket's adds have been enqueued
+            with torch.cuda.stream(self._side):
+                self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
 
     def rebind(self):
         """Re-point parameters at the flat buffers (needed after code that re-binds ``p.data``,
@@ -56,12 +95,30 @@ class FlatParams:
 
     def zero_grad(self):
         self.grad.zero_()
+        self._sent, self._pending = [], []
 
     def all_reduce_mean(self, group=None):
-        """One collective for the whole model: sum over ranks, then divide by the world size."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
-            self.grad.div_(dist.get_world_size(group))
+        """Sum over ranks, then divide by the world size.  Blocks whose range went out during backward are skipped; what is left
+        (head / tail linears, or everything when nothing was overlapped) goes in as few contiguous collectives as possible."""
+        if not self._active(group):
+            return
+        world = dist.get_world_size(group)
+        done = sorted(self.buckets[k] for k in self._sent)
+        cur, rest = 0, []
+        for lo, hi in done:
+            if lo > cur:
+                rest.append((cur, lo))
+            cur = max(cur, hi)
+        if cur < self.grad.numel():
+            rest.append((cur, self.grad.numel()))
+        for lo, hi in rest:
+            dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=group)
+        for w in self._pending:
+            w.wait()          # orders the current stream behind the side-stream collectives
+        if self._side is not None:
+            torch.cuda.current_stream(self.grad.device).wait_stream(self._side)
+        self._pending, self._sent = [], []
+        self.grad.div_(world)
 
 
 def shard_by_cost(costs: Sequence[float], world: int) -> List[List[int]]:

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .batch import GatherPattern, MeshBatch
+from .batch import GatherPattern, MeshBatch, operator_cache
 
 _MIN_TIME = 1e-8
 
@@ -59,7 +59,8 @@ def _batch_of(mass, evals, evecs, gradX=None, gradY=None):
         mass, evals, evecs = mass[None], evals[None], evecs[None]
         if gradX is not None and gradX.dim() == 2:
             gradX, gradY = gradX.unsqueeze(0), gradY.unsqueeze(0)
-    return MeshBatch.from_reference_args(mass, evals, evecs, gradX, gradY)
+    return operator_cache.lookup(mass, evals, evecs, gradX, gradY, None, ("ops", gradX is not None),
+                                 lambda: (MeshBatch.from_reference_args(mass, evals, evecs, gradX, gradY), None))[0]
 
 
 class LearnedTimeDiffusion(nn.Module):
@@ -180,7 +181,11 @@ class DiffusionNetBlock(nn.Module):
         if self.mask_provider is None:
             if self.drop_seed_provider is not None:
                 return int(self.drop_seed_provider())
-            return int(torch.randint(1, 2 ** 62, (1,), dtype=torch.int64).item())
+            seed = int(torch.randint(1, 2 ** 62, (1,), dtype=torch.int64).item())
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                # replicas are seeded identically; their dropout masks must not be
+                seed = (seed + 0x9E3779B97F4A7C15 * (torch.distributed.get_rank() + 1)) % (2 ** 62) or 1
+            return seed
         masks = [None]
         for i in range(1, self._cfg.n_mlp):
             shape = (n_rows, self._cfg.widths[i])
@@ -290,6 +295,7 @@ class DiffusionNet(nn.Module):
         if x_in.shape[-1] != self.C_in:
             raise ValueError("DiffusionNet was constructed with C_in={}, but x_in has last dim={}".format(
                 self.C_in, x_in.shape[-1]))
+        key_ops = (mass, evals, evecs, gradX, gradY, edges if self.outputs_at == "edges" else faces)   # identity key: as handed over
         if x_in.dim() == 2:
             squeeze = True
             x_in, mass = x_in.unsqueeze(0), mass.unsqueeze(0)
@@ -310,13 +316,21 @@ class DiffusionNet(nn.Module):
 
         B, V, _ = x_in.shape
         use_grad = self.with_gradient_features
-        mb = MeshBatch.from_reference_args(mass, evals, evecs, gradX if use_grad else None, gradY if use_grad else None)
-        gather = None
+        idx = None
         if self.outputs_at in ("edges", "faces"):
-            idx = edges if self.outputs_at == "edges" else faces      # AttributeError on None, as the reference
-            offs = (torch.arange(B, device=idx.device, dtype=idx.dtype) * V).view(B, 1, 1)
-            gather = GatherPattern((idx + offs).reshape(-1, idx.shape[-1]), B * V)
-            n_per_mesh = idx.shape[1]
+            idx = edges if self.outputs_at == "edges" else faces
+            n_per_mesh = idx.shape[1]                                  # AttributeError on None, as the reference
+
+        def pack():
+            mb_ = MeshBatch.from_reference_args(mass, evals, evecs, gradX if use_grad else None, gradY if use_grad else None)
+            gather_ = None
+            if idx is not None:
+                offs = (torch.arange(B, device=idx.device, dtype=idx.dtype) * V).view(B, 1, 1)
+                gather_ = GatherPattern((idx + offs).reshape(-1, idx.shape[-1]), B * V)
+            return mb_, gather_
+        # the packed operators of a mesh are built once and found again on later calls (batch.OperatorCache)
+        mb, gather = operator_cache.lookup(mass, evals, evecs, gradX if use_grad else None, gradY if use_grad else None, idx,
+                                           ("net", use_grad, self.outputs_at), pack, key_ops)
         out = self.forward_packed(x_in.reshape(B * V, self.C_in), mb, gather)
         if self.outputs_at == "vertices":
             out = out.reshape(B, V, -1)

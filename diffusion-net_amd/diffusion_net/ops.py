@@ -6,12 +6,27 @@ activations the hand-written backward needs.  No op has a torch/CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 from typing import List, Optional
 
 import torch
 
 from . import _hip
 from .batch import GatherPattern, MeshBatch
+
+
+def _on_device(fn):
+    """Run a Function's forward/backward with the tensors' device current: the library reads the current device for its
+    per-device function attributes and CU counts, and a launch on another device's stream is an error -- `model.to('cuda:1')`
+    without a surrounding `torch.cuda.device` must just work, as it does for torch's own ops."""
+    @functools.wraps(fn)
+    def wrapped(ctx, *args):
+        dev = next((a.device for a in args if isinstance(a, torch.Tensor) and a.is_cuda), None)
+        if dev is None or torch.cuda.current_device() == dev.index:
+            return fn(ctx, *args)
+        with torch.cuda.device(dev):
+            return fn(ctx, *args)
+    return wrapped
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -51,12 +66,14 @@ class ToBasisFn(torch.autograd.Function):
     """spec[m] = evecs_m^T (x_m * mass_m)  -> [n_mesh, K, C]"""
 
     @staticmethod
+    @_on_device
     def forward(ctx, x, mb):
         _hip.require_device(x)
         ctx.mb = mb
         return _to_basis_raw(mb, _f32c(x), True)
 
     @staticmethod
+    @_on_device
     def backward(ctx, d_spec):
         return _from_basis_raw(ctx.mb, _f32c(d_spec), scale_by_mass=True), None
 
@@ -65,12 +82,14 @@ class FromBasisFn(torch.autograd.Function):
     """x_m = evecs_m spec[m]  -> [v_total, C]"""
 
     @staticmethod
+    @_on_device
     def forward(ctx, spec, mb):
         _hip.require_device(spec)
         ctx.mb = mb
         return _from_basis_raw(mb, _f32c(spec))
 
     @staticmethod
+    @_on_device
     def backward(ctx, d_x):
         return _to_basis_raw(ctx.mb, _f32c(d_x), False), None
 
@@ -80,6 +99,7 @@ class FromBasisFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------
 class DiffusionFn(torch.autograd.Function):
     @staticmethod
+    @_on_device
     def forward(ctx, x, time, mb):
         _hip.require_device(x)
         L = _hip.lib()
@@ -95,6 +115,7 @@ class DiffusionFn(torch.autograd.Function):
         return xd
 
     @staticmethod
+    @_on_device
     def backward(ctx, d_xd):
         L = _hip.lib()
         mb = ctx.mb
@@ -115,6 +136,7 @@ class DiffusionFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------
 class GradApplyFn(torch.autograd.Function):
     @staticmethod
+    @_on_device
     def forward(ctx, x, mb):
         _hip.require_device(x)
         x = _f32c(x)
@@ -125,6 +147,7 @@ class GradApplyFn(torch.autograd.Function):
         return gx, gy
 
     @staticmethod
+    @_on_device
     def backward(ctx, d_gx, d_gy):
         d_gx, d_gy = _f32c(d_gx), _f32c(d_gy)
         d_x = torch.empty_like(d_gx)
@@ -135,6 +158,7 @@ class GradApplyFn(torch.autograd.Function):
 
 class GradFeatFn(torch.autograd.Function):
     @staticmethod
+    @_on_device
     def forward(ctx, gx, gy, A_re, A_im, mb):
         _hip.require_device(gx)
         gx, gy, A_re = _f32c(gx), _f32c(gy), _f32c(A_re)
@@ -149,6 +173,7 @@ class GradFeatFn(torch.autograd.Function):
         return g
 
     @staticmethod
+    @_on_device
     def backward(ctx, d_g):
         L = _hip.lib()
         mb = ctx.mb
@@ -192,7 +217,15 @@ def hks(evals, evecs, scales):
 # autograd's AccumulateGrad (one 5 us add kernel each: 40 launches per step of the 4-block network).
 # ----------------------------------------------------------------------------------------------
 def _sinks(params):
-    return [getattr(p, "_dn_grad_sink", None) if p is not None else None for p in params]
+    """The sink of a parameter counts only while the parameter still owns it: it requires grad and its ``.grad`` IS the sink
+    (``zero_grad(set_to_none=True)`` or a frozen parameter switch back to returning the gradient to autograd)."""
+    out = []
+    for p in params:
+        s = getattr(p, "_dn_grad_sink", None) if p is not None else None
+        if s is not None and not (p.requires_grad and p.grad is not None and p.grad.data_ptr() == s.data_ptr()):
+            s = None
+        out.append(s)
+    return out
 
 
 def _deliver(sinks, grads):
@@ -204,6 +237,7 @@ def _deliver(sinks, grads):
 
 class LinearFn(torch.autograd.Function):
     @staticmethod
+    @_on_device
     def forward(ctx, x, W, b, mb):
         _hip.require_device(x)
         ctx.sinks = _sinks([W, b])
@@ -216,6 +250,7 @@ class LinearFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_on_device
     def backward(ctx, d_out):
         L = _hip.lib()
         mb = ctx.mb
@@ -241,6 +276,7 @@ class BlockConfig:
     def __init__(self, C, widths, with_grad, with_rot):
         self.C, self.widths, self.with_grad, self.with_rot = int(C), [int(w) for w in widths], bool(with_grad), bool(with_rot)
         self.n_mlp = len(self.widths) - 1
+        self.grad_hook = None
         if self.n_mlp > _hip.MAX_MLP:
             raise ValueError("MiniMLP deeper than %d layers is not supported by the HIP block" % _hip.MAX_MLP)
 
@@ -283,6 +319,7 @@ class BlockFn(torch.autograd.Function):
     """forward(x, time, A_re, A_im, *W_and_b) with non-tensor (mb, cfg, masks) first."""
 
     @staticmethod
+    @_on_device
     def forward(ctx, mb, cfg, masks, x, time, A_re, A_im, *wb):
         _hip.require_device(x)
         ctx.sinks = _sinks([time, A_re, A_im, *wb])
@@ -322,6 +359,7 @@ class BlockFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_on_device
     def backward(ctx, d_out):
         L = _hip.lib()
         mb, cfg, masks = ctx.mb, ctx.cfg, ctx.masks
@@ -360,6 +398,9 @@ class BlockFn(torch.autograd.Function):
         for dw, db in zip(dWs, dbs):
             wb += [dw, db]
         d_time, dA_re, dA_im, *wb = _deliver(ctx.sinks, [d_time, dA_re, dA_im, *wb])
+        hook = getattr(cfg, "grad_hook", None)
+        if hook is not None:          # dist.FlatParams: this block's gradient range may go out now
+            hook()
         return (None, None, None, d_x, d_time, dA_re, dA_im, *wb)
 
 
@@ -370,6 +411,7 @@ class GatherMeanFn(torch.autograd.Function):
     """out[i] = mean_j x[index[i, j]]  (faces: 3 rows, edges: 2 rows)"""
 
     @staticmethod
+    @_on_device
     def forward(ctx, x, pat: GatherPattern):
         _hip.require_device(x)
         x = _f32c(x)
@@ -380,6 +422,7 @@ class GatherMeanFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_on_device
     def backward(ctx, d_out):
         pat = ctx.pat
         d_out = _f32c(d_out)
@@ -394,6 +437,7 @@ class MassMeanFn(torch.autograd.Function):
     """out[m] = sum_v mass_v x_v / sum_v mass_v over the vertices of mesh m (layers.py:397)"""
 
     @staticmethod
+    @_on_device
     def forward(ctx, x, mb):
         _hip.require_device(x)
         x = _f32c(x)
@@ -406,6 +450,7 @@ class MassMeanFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_on_device
     def backward(ctx, d_out):
         (msum,) = ctx.saved_tensors
         d_out = _f32c(d_out)
@@ -420,6 +465,7 @@ class MassMeanFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------
 class NllLossFn(torch.autograd.Function):
     @staticmethod
+    @_on_device
     def forward(ctx, logp, labels):
         _hip.require_device(logp)
         L = _hip.lib()
@@ -437,6 +483,7 @@ class NllLossFn(torch.autograd.Function):
         return loss
 
     @staticmethod
+    @_on_device
     def backward(ctx, d_loss):
         (labels,) = ctx.saved_tensors
         n, Cc = ctx.shape

@@ -147,6 +147,18 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
                      const dn_block_saved_t* saved, const float* d_out, const dn_block_grads_t* grads,
                      void* ws, size_t ws_bytes, void* stream);
 
+/* ---- operator packing: sparse COO (int64 indices, as the reference holds gradX/gradY: utils.py:55, geometry.py:375-382) -> int32 CSR of
+ *      the pattern and CSR of its transpose, values carried along; also builds the gather patterns of the faces/edges remap.
+ *      rows: [nnz] non-decreasing row ids (coalesced COO order), or NULL: entry j belongs to row j / row_div (a dense [n_rows, row_div]
+ *      index array such as faces).  cols: [nnz].  vx / vy: [nnz] values on the shared pattern (either may be NULL).
+ *      Out: rowptr [n_rows+1], col [nnz]; transpose: t_rowptr [n_cols+1], t_col [nnz] (row ids, ascending inside a transposed row),
+ *      t_vx / t_vy [nnz].  status: one device int32, non-zero afterwards if an index was outside [0,n_rows) x [0,n_cols) or the
+ *      rows were not sorted (the outputs are then undefined; the caller checks it at its next synchronisation point). */
+size_t dn_coo_to_csr_workspace_bytes(int64_t nnz, int n_cols);
+int dn_coo_to_csr_i64(const int64_t* rows, int row_div, const int64_t* cols, const float* vx, const float* vy, int64_t nnz, int n_rows,
+                      int n_cols, int32_t* rowptr, int32_t* col, int32_t* t_rowptr, int32_t* t_col, float* t_vx, float* t_vy,
+                      int32_t* status, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- output remaps (layers.py:379-397).
  *      csr_mean: out[i] = (sum_{j in row i} x[col[j]]) / div  -- faces (div=3) / edges (div=2) gather-mean, and with the
  *      transposed pattern its gradient.  mass_mean: out[m] = sum_v mass*x / sum_v mass per mesh (global_mean). */

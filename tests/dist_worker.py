@@ -22,9 +22,10 @@ def run(rank, world, port, emu_so, sizes, out_dir):
     import parity_cases
     _hip._use_library_for_tests(emu_so, True)
     torch.manual_seed(0)                                   # identical replicas
-    model = diffusion_net.layers.DiffusionNet(3, 4, C_width=32, N_block=1, dropout=False)
+    model = diffusion_net.layers.DiffusionNet(3, 4, C_width=32, N_block=2, dropout=False)   # two per-block gradient buckets
     model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=0))
     flat = FlatParams(model)
+    assert len(flat.buckets) == 2
     opt = torch.optim.Adam([flat.master], lr=1e-2)
     mine = shard_by_cost(sizes, world)[rank]
     meshes, feats = parity_cases.make_ragged(sizes, 16, 3, seed=1)

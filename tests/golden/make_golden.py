@@ -151,6 +151,51 @@ def run_case(ref, name, case, seed=7):
           f"masks={len(masks)} -> {os.path.getsize(path)/1e3:.0f} kB")
 
 
+def run_checkpoint_case(ref, name, ckpt, C_in, V=600, K=128, seed=21):
+    """SURVEY 4 (iv) / VERDICT r1 item 1c: the SHIPPED trained weights of the human-segmentation experiment
+    (experiments/human_segmentation_original/pretrained_models/*.pth, constructed as the script does at
+    human_segmentation_original.py:69-75: C_out=8, C_width=128, N_block=4, per-face log-softmax, dropout=True) on a real
+    triangle mesh run through get_operators (ours: potpourri3d is not installable), eval mode as in the script's
+    test loop.  The npz carries the checkpoint's tensors, so the strict=True load of the reference keys is part of the test."""
+    path_ckpt = os.path.join("/root/reference/experiments/human_segmentation_original/pretrained_models", ckpt)
+    sd = torch.load(path_ckpt, map_location="cpu")
+    act = lambda t: torch.nn.functional.log_softmax(t, dim=-1)
+    ctor = dict(C_in=C_in, C_out=8, C_width=128, N_block=4, outputs_at="faces", dropout=True)
+    model = ref.layers.DiffusionNet(last_activation=act, **ctor)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    verts, faces = synthetic.sphere_mesh(V, seed=seed)
+    verts = my_precompute.normalize_positions(torch.from_numpy(verts).float()).numpy()
+    frames, mass, L, evals, evecs, gradX, gradY = my_precompute.compute_operators(torch.from_numpy(verts).float(), torch.from_numpy(faces), K)
+    if C_in == 3:
+        feats = torch.from_numpy(verts).float()
+    else:
+        feats = ref.geometry.compute_hks_autoscale(evals, evecs, C_in)   # human_segmentation_original.py:130
+    x_in = feats.clone().requires_grad_(True)
+    ft = torch.from_numpy(faces).long()
+    out = model(x_in, mass, L=L, evals=evals, evecs=evecs, gradX=gradX, gradY=gradY, faces=ft)
+    wgen = torch.Generator().manual_seed(seed + 1)
+    w = torch.randn(out.shape, generator=wgen)
+    (out * w).sum().backward()
+    arrays = {"out": out.detach().numpy(), "loss_w": w.numpy(), "x_in": x_in.detach().numpy(), "grad.x_in": x_in.grad.numpy()}
+    for k, v in model.state_dict().items():
+        arrays["param." + k] = v.detach().numpy()
+    for k, p in model.named_parameters():
+        arrays["grad." + k] = p.grad.numpy()
+    gX, gY = gradX.coalesce(), gradY.coalesce()
+    assert torch.equal(gX.indices(), gY.indices())
+    edges = torch.cat([ft[:, [0, 1]], ft[:, [1, 2]], ft[:, [2, 0]]], 0)[:8]
+    arrays.update({"mesh0.mass": mass.numpy(), "mesh0.evals": evals.numpy(), "mesh0.evecs": evecs.numpy(),
+                   "mesh0.grad_idx": gX.indices().numpy().astype(np.int32), "mesh0.gradX_val": gX.values().numpy(),
+                   "mesh0.gradY_val": gY.values().numpy(), "mesh0.faces": faces.astype(np.int32), "mesh0.edges": edges.numpy().astype(np.int32)})
+    meta = dict(V=V, K=K, B=None, ctor=ctor, act="log_softmax", train=False, checkpoint=ckpt)
+    arrays["meta"] = np.array(repr(meta))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {ckpt} out{tuple(out.shape)} |out|max={out.abs().max():.3g} t in [{min(float(v.min()) for k, v in sd.items() if k.endswith('diffusion_time')):.2e}, "
+          f"{max(float(v.max()) for k, v in sd.items() if k.endswith('diffusion_time')):.2e}] -> {os.path.getsize(path)/1e3:.0f} kB")
+
+
 def run_geometry_case(ref, V=300, seed=5):
     """Golden for the host precompute: tangent frames and the complex gradient operator from the reference's
     own pure-numpy/torch functions (geometry.py:114-273).  The Laplacian itself comes from potpourri3d in the reference
@@ -167,6 +212,34 @@ def run_geometry_case(ref, V=300, seed=5):
                         grad_row=grad.row.astype(np.int32), grad_col=grad.col.astype(np.int32),
                         grad_re=grad.data.real.astype(np.float64), grad_im=grad.data.imag.astype(np.float64))
     print("geom_sphere%d: frames %s, grad nnz %d -> %.0f kB" % (V, tuple(frames.shape), grad.nnz, os.path.getsize(path) / 1e3))
+
+
+def run_refcache_case(ref, V=200, K=16, seed=31):
+    """an operator-cache file written by the REFERENCE's own writer (geometry.get_operators, geometry.py:426-570),
+    committed as a fixture so that the npz reader of diffusion_net.precompute.get_operators is tested against the reference's
+    layout and file naming, not against its own writer.  potpourri3d is not installable, so its two functions used at
+    geometry.py:322-323 are stubbed with the restatement of SURVEY's appendix (ours); everything else -- hashing, key names,
+    CSC triplets, dtypes -- is the reference's code."""
+    import shutil
+    import tempfile
+    pp3d = sys.modules["potpourri3d"]
+    pp3d.cotan_laplacian = lambda v, f, denom_eps=1e-10: my_precompute.cotan_laplacian(np.asarray(v), np.asarray(f), denom_eps)
+    pp3d.vertex_areas = lambda v, f: my_precompute.vertex_areas(np.asarray(v), np.asarray(f))
+    verts, faces = synthetic.sphere_mesh(V, seed=seed)
+    vt, ft = torch.from_numpy(verts).float(), torch.from_numpy(faces).long()
+    tmp = tempfile.mkdtemp()
+    try:
+        ref.geometry.get_operators(vt, ft, k_eig=K, op_cache_dir=tmp)
+        files = os.listdir(tmp)
+        assert len(files) == 1 and files[0].endswith("_0.npz"), files
+        dst = os.path.join(HERE, "refcache_" + files[0])
+        for old in [f for f in os.listdir(HERE) if f.startswith("refcache_")]:
+            os.remove(os.path.join(HERE, old))
+        shutil.copy(os.path.join(tmp, files[0]), dst)
+        z = np.load(dst, allow_pickle=True)
+        print("refcache: %s keys=%s -> %.0f kB" % (os.path.basename(dst), sorted(z.files), os.path.getsize(dst) / 1e3))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def run_feature_cases(ref, V=300, K=32, seed=9):
@@ -196,11 +269,21 @@ def run_feature_cases(ref, V=300, K=32, seed=9):
 def main():
     ref = import_reference()
     print("reference imported from", ref.__file__, "torch", torch.__version__)
+    if "--refcache-only" in sys.argv:
+        run_refcache_case(ref)
+        return
+    if "--checkpoints-only" in sys.argv:
+        run_checkpoint_case(ref, "ckpt_human_seg_xyz_v600", "human_seg_xyz_4x128.pth", 3)
+        run_checkpoint_case(ref, "ckpt_human_seg_hks_v600", "human_seg_hks_4x128.pth", 16)
+        return
     if "--geometry-only" not in sys.argv and "--features-only" not in sys.argv:
         for name, case in CASES.items():
             run_case(ref, name, case)
+        run_checkpoint_case(ref, "ckpt_human_seg_xyz_v600", "human_seg_xyz_4x128.pth", 3)
+        run_checkpoint_case(ref, "ckpt_human_seg_hks_v600", "human_seg_hks_4x128.pth", 16)
     if "--features-only" not in sys.argv:
         run_geometry_case(ref)
+        run_refcache_case(ref)
     run_feature_cases(ref)
 
 

@@ -52,13 +52,28 @@ def run_golden(name, device):
                 gradX=dev(gX), gradY=dev(gY), edges=dev(inputs["edges"]), faces=dev(inputs["faces"]))
     assert out.shape == expect["out"].shape
     err = helpers.rel_max(out.detach().cpu(), expect["out"])
-    assert err < FWD_TOL, (name, "forward", err)
     (out * expect["loss_w"].to(device)).sum().backward()
-    errs = {"x_in": helpers.rel_l2(x.grad.cpu(), expect["grads"]["x_in"])}
+    got = {"x_in": x.grad.cpu()}
     for k, p in model.named_parameters():
-        errs[k] = helpers.rel_l2(p.grad.cpu(), expect["grads"][k])
-    bad = {k: v for k, v in errs.items() if not v < GRAD_TOL}
-    assert not bad, (name, bad)
+        got[k] = p.grad.cpu()
+    errs = {k: helpers.rel_l2(v, expect["grads"][k]) for k, v in got.items()}
+    if meta.get("checkpoint"):
+        # Trained weights, four blocks, |log-softmax| up to 40: here the fp32 REFERENCE itself sits 1.1-1.2e-5 (rel-max) from the
+        # fp64 evaluation of the same net, and any other fp32 summation order lands 2-3e-5 from the reference.  Judged against the
+        # fp64 oracle, allowed twice the distance the reference keeps from it (the rule of the headline-shape test).
+        _, p64, i64, _, e64 = helpers.load_golden(name, dtype=torch.float64)
+        o64, g64 = orc.net_forward_backward(p64, i64, outputs_at=meta["ctor"]["outputs_at"], last_activation=helpers.activation_of(meta),
+                                            keep_masks=None, loss_weights=e64["loss_w"])
+        e_new, e_ref = helpers.rel_max(out.detach().cpu().double(), o64), helpers.rel_max(expect["out"].double(), o64)
+        assert e_new < max(FWD_TOL, 2 * e_ref), (name, "forward vs fp64", e_new, e_ref)
+        assert err < 4e-5, (name, "forward vs fp32 reference", err)
+        for k, v in got.items():
+            gn, gr = helpers.rel_l2(v.double(), g64[k]), helpers.rel_l2(expect["grads"][k].double(), g64[k])
+            assert gn < max(GRAD_TOL, 2 * gr), (name, k, gn, gr)
+    else:
+        assert err < FWD_TOL, (name, "forward", err)
+        bad = {k: v for k, v in errs.items() if not v < GRAD_TOL}
+        assert not bad, (name, bad)
     # the clamp side effect on the Parameter (layers.py:48-49)
     for k, p in model.named_parameters():
         if k.endswith("diffusion_time"):
@@ -84,7 +99,7 @@ def pack(meshes, device, with_grad=True, chunk_rows=None):
 
 
 def run_ragged_net(device, sizes=(130, 257, 64), K=24, C=32, C_in=3, C_out=5, N_block=2, outputs_at="vertices",
-                   chunk_rows=None, seed=3, dropout=False, fp64_bracket=False):
+                   chunk_rows=None, seed=3, dropout=False, fp64_bracket=False, fwd_tol=FWD_TOL):
     torch.manual_seed(seed)
     model = diffusion_net.layers.DiffusionNet(C_in, C_out, C_width=C, N_block=N_block, outputs_at=outputs_at, dropout=dropout)
     sd = synthetic.randomize_times(model.state_dict(), seed=seed)
@@ -147,7 +162,7 @@ def run_ragged_net(device, sizes=(130, 257, 64), K=24, C=32, C_in=3, C_out=5, N_
     got = {k: p.grad.cpu() for k, p in model.named_parameters()}
     got["x_in"] = x.grad.cpu()
     e_out = helpers.rel_max(out.detach().cpu(), ref_out)
-    assert e_out < FWD_TOL, ("out", e_out)
+    assert e_out < fwd_tol, ("out", e_out)
     if not fp64_bracket:
         for k, gk in got.items():
             e = helpers.rel_l2(gk, ref_grads[k])
@@ -156,7 +171,9 @@ def run_ragged_net(device, sizes=(130, 257, 64), K=24, C=32, C_in=3, C_out=5, N_
     # Deep train-mode nets sit at the fp32 oracle's own noise floor (its multi-threaded CPU reductions are not even
     # run-to-run identical: 1 run in 10 moved first_lin.weight's gradient across 2e-4), so gradients are judged against the
     # fp64 oracle and allowed twice the distance the fp32 oracle itself keeps from it.
-    _, ref64 = oracle_pass(torch.float64)
+    out64, ref64 = oracle_pass(torch.float64)
+    e_new, e_ref = helpers.rel_max(out.detach().cpu().double(), out64), helpers.rel_max(ref_out.double(), out64)
+    assert e_new < max(FWD_TOL, 2 * e_ref), ("out vs fp64", e_new, e_ref)
     for k, gk in got.items():
         e_new, e_ref = helpers.rel_l2(gk.double(), ref64[k]), helpers.rel_l2(ref_grads[k].double(), ref64[k])
         assert e_new < max(GRAD_TOL, 2 * e_ref), (k, e_new, e_ref)
@@ -413,3 +430,83 @@ def run_real_mesh_pipeline(device, V=400, K=16, C=32, seed=0):
     assert helpers.rel_l2(x.grad.cpu(), g["x_in"]) < GRAD_TOL
     for k, p in model.named_parameters():
         assert helpers.rel_l2(p.grad.cpu(), g[k]) < GRAD_TOL, k
+
+
+# ------------------------------------------------------------------------------------------
+# operator packing on the device (dn_coo_to_csr_i64) and the operator cache behind the reference signature
+# ------------------------------------------------------------------------------------------
+def run_packing(device, V=500, seed=13):
+    import numpy as np
+    import pytest
+    import scipy.sparse as sp
+    from diffusion_net.batch import coo_to_csr
+    rng = np.random.RandomState(seed)
+    for n_rows, n_cols, density in ((V, V, 7.0 / V), (37, 211, 0.05), (64, 64, 0.0)):
+        m = sp.random(n_rows, n_cols, density=density, random_state=rng, format="coo", dtype=np.float32)
+        m.sum_duplicates()
+        order = np.lexsort((m.col, m.row))                      # coalesced COO order
+        rows, cols, vx = m.row[order].astype(np.int64), m.col[order].astype(np.int64), m.data[order]
+        vy = rng.randn(vx.shape[0]).astype(np.float32)
+        t = lambda a: torch.from_numpy(a).to(device)
+        rowptr, col, gx, gy, t_rowptr, t_col, t_vx, t_vy = coo_to_csr(t(rows), 1, t(cols), t(vx), t(vy), n_rows, n_cols)
+        csr = sp.csr_matrix((vx, (rows, cols)), shape=(n_rows, n_cols))
+        csr.sort_indices()
+        assert np.array_equal(rowptr.cpu().numpy(), csr.indptr) and np.array_equal(col.cpu().numpy(), csr.indices)
+        for vals, tv in ((vx, t_vx), (vy, t_vy)):
+            tr = sp.csr_matrix((vals, (cols, rows)), shape=(n_cols, n_rows))
+            tr.sort_indices()                                   # ascending row ids inside a transposed row
+            assert np.array_equal(t_rowptr.cpu().numpy(), tr.indptr) and np.array_equal(t_col.cpu().numpy(), tr.indices)
+            assert np.array_equal(tv.cpu().numpy(), tr.data)
+    # dense index array (faces): row j // 3
+    faces = torch.from_numpy(rng.randint(0, 90, size=(200, 3)).astype(np.int64)).to(device)
+    pat = GatherPattern(faces, 90)
+    assert np.array_equal(pat.rowptr.cpu().numpy(), np.arange(0, 601, 3)) and torch.equal(pat.col.cpu().long(), faces.reshape(-1).cpu())
+    cnt = np.bincount(faces.reshape(-1).cpu().numpy(), minlength=90)          # a vertex repeated inside a face counts twice
+    assert np.array_equal(pat.t_rowptr.cpu().numpy(), np.concatenate([[0], np.cumsum(cnt)]))
+    got = [sorted(pat.t_col.cpu().numpy()[pat.t_rowptr[i]:pat.t_rowptr[i + 1]].tolist()) for i in range(90)]
+    want = [sorted(np.repeat(np.arange(200), 3)[faces.reshape(-1).cpu().numpy() == i].tolist()) for i in range(90)]
+    assert got == want
+    # an index outside the operator is an error, not an out-of-bounds gather on the device
+    bad = faces.clone()
+    bad[5, 1] = 90
+    with pytest.raises(ValueError):
+        GatherPattern(bad, 90)
+    bad[5, 1] = -1
+    with pytest.raises(ValueError):
+        GatherPattern(bad, 90)
+
+
+def run_operator_cache(device, V=300, K=16, C=32, seed=6):
+    """The reference-signature forward packs a mesh once: identical tensors hit by identity, re-uploaded copies of the same mesh by
+    content fingerprint, a changed operator misses; the results are bitwise those of an uncached pack."""
+    from diffusion_net.batch import operator_cache
+    torch.manual_seed(seed)
+    model = diffusion_net.layers.DiffusionNet(3, 4, C_width=C, N_block=1, outputs_at="faces", dropout=False).to(device).eval()
+    m = synthetic.make_mesh_operators(V, K, seed=seed)
+    up = lambda: {k: m[k].to(device).clone() if not m[k].is_sparse else m[k].to(device).coalesce() for k in ("verts", "mass", "evals", "evecs", "gradX", "gradY", "faces")}
+    call = lambda a: model(a["verts"], a["mass"], evals=a["evals"], evecs=a["evecs"], gradX=a["gradX"], gradY=a["gradY"], faces=a["faces"])
+    operator_cache.clear()
+    operator_cache.enabled = False
+    with torch.no_grad():
+        base = call(up())
+    operator_cache.enabled = True
+    h0 = (operator_cache.hits_id, operator_cache.hits_fp, operator_cache.misses)
+    a = up()
+    with torch.no_grad():
+        o1 = call(a)          # miss: packs
+        o2 = call(a)          # same tensors: identity hit
+        o3 = call(up())       # the scripts' pattern: the same mesh moved to the device again -> fingerprint hit
+    h1 = (operator_cache.hits_id, operator_cache.hits_fp, operator_cache.misses)
+    assert (h1[0] - h0[0], h1[1] - h0[1], h1[2] - h0[2]) == (1, 1, 1), (h0, h1)
+    for o in (o1, o2, o3):
+        assert torch.equal(o, base)
+    b = up()
+    b["evals"].mul_(1.5)      # another spectrum: must not be served from the cache
+    with torch.no_grad():
+        o4 = call(b)
+    assert operator_cache.misses == h1[2] + 1 and not torch.equal(o4, base)
+    a["evals"].mul_(1.5)      # in-place change of a keyed tensor bumps its version: identity key no longer matches
+    with torch.no_grad():
+        o5 = call(a)
+    assert torch.equal(o5, o4)
+    operator_cache.clear()

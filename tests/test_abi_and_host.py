@@ -104,3 +104,19 @@ def test_synthetic_operators_are_consistent():
     assert m["gradX"].to_dense().sum(1).abs().max() < 1e-3                                 # zero row sums
     nnz_per_row = np.bincount(m["gradX"].indices()[0].numpy(), minlength=500)
     assert (nnz_per_row == 7).all() and m["faces"].shape == (1000, 3)
+
+
+@pytest.mark.parametrize("name", ["ckpt_human_seg_xyz_v600", "ckpt_human_seg_hks_v600"])
+def test_shipped_checkpoints_load_strict(name):
+    """The reference's trained checkpoints (human_segmentation_original/pretrained_models/*.pth, tensors carried by the golden
+    fixtures) load into the drop-in module with strict=True, as human_segmentation_original.py:83 does, key for key."""
+    import helpers
+    import diffusion_net
+    meta, params, _, _, _ = helpers.load_golden(name)
+    assert meta["checkpoint"].endswith(".pth") and len(params) == 40
+    model = diffusion_net.layers.DiffusionNet(last_activation=helpers.activation_of(meta), **meta["ctor"])
+    missing = model.load_state_dict(params, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, params[k]), k
+    assert sum(p.numel() for p in model.parameters()) == 462344 + (meta["ctor"]["C_in"] - 3) * 128

@@ -78,3 +78,36 @@ def test_hks_and_normalize():
     sc = torch.logspace(-2, 0.0, steps=4)
     ref = torch.stack([(torch.exp(-ev * s) * ph * ph).sum(-1) for s in sc], -1)
     assert hks.shape == (50, 4) and torch.allclose(hks, ref, atol=1e-6)
+
+
+def test_reads_operator_cache_written_by_the_reference(tmp_path):
+    """tests/golden/refcache_<sha1>_0.npz was written by the reference's geometry.get_operators (make_golden.py, its own hashing,
+    key names and CSC triplets).  Ours must find it under the same file name for the same mesh and return its content -- the
+    eigenvectors of a recomputation would differ by signs/rotations, so equality proves the file was read."""
+    import glob
+    import shutil
+    import scipy.sparse as sp
+    from diffusion_net import precompute, synthetic
+    src = glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refcache_*_0.npz"))
+    assert len(src) == 1
+    name = os.path.basename(src[0])[len("refcache_"):]
+    shutil.copy(src[0], tmp_path / name)
+    z = np.load(src[0], allow_pickle=True)
+    verts, faces = torch.from_numpy(z["verts"]).float(), torch.from_numpy(z["faces"]).long()
+    K = int(z["k_eig"].item())
+    assert precompute.hash_arrays((z["verts"], z["faces"])) + "_0.npz" == name          # same key derivation (utils.py:71-76)
+    before = sorted(os.listdir(tmp_path))
+    frames, mass, L, evals, evecs, gX, gY = precompute.get_operators(verts, faces, k_eig=K, op_cache_dir=str(tmp_path))
+    assert sorted(os.listdir(tmp_path)) == before                                           # nothing rebuilt or rewritten
+    assert np.array_equal(evecs.numpy(), z["evecs"][:, :K]) and np.array_equal(evals.numpy(), z["evals"][:K])
+    assert np.array_equal(mass.numpy(), z["mass"]) and np.array_equal(frames.numpy(), z["frames"])
+    ref_gx = sp.csc_matrix((z["gradX_data"], z["gradX_indices"], z["gradX_indptr"]), shape=tuple(z["gradX_shape"])).toarray()
+    assert np.array_equal(gX.to_dense().numpy(), ref_gx)
+    # and the other direction: a file written by ours carries the same keys and dtypes the reference's reader indexes
+    out_dir = tmp_path / "mine"
+    v2, f2 = synthetic.sphere_mesh(150, seed=3)
+    precompute.get_operators(torch.from_numpy(v2).float(), torch.from_numpy(f2).long(), k_eig=8, op_cache_dir=str(out_dir))
+    mine = np.load(str(out_dir / os.listdir(out_dir)[0]), allow_pickle=True)
+    assert sorted(mine.files) == sorted(z.files)
+    for k in z.files:
+        assert mine[k].dtype == z[k].dtype, (k, mine[k].dtype, z[k].dtype)
