@@ -29,6 +29,7 @@ import torch.nn.functional as F
 PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: exact-f32 MFMA = f32 vector peak
 PEAK_HBM_GBPS = 8000.0            # HBM3E spec (6.29 TB/s measured copy ceiling)
 PEAK_MFMA_BF16_TFLOPS = 2500.0    # dense bf16 MFMA (no sparsity)
+TRAFFIC_JSON = "r02_traffic.json"  # PMC FETCH/WRITE passes of the same command (tools/pmc_run.sh + tools/traffic_summary.py)
 
 
 def mesh_sizes(n_meshes, v_mean, rank):
@@ -54,42 +55,223 @@ def build_batch(sizes, K, device, seed0):
     return meshes, mb, gather, x
 
 
-def cpu_baseline(args, C_out):
-    """CPU oracle (kind 'port'): fwd + loss + bwd + Adam on ONE mesh of the workload per step."""
+def _import_reference():
+    """The reference package itself, when its sources are reachable (dev container only; never on the GPU box)."""
+    import types
+    if not os.path.isdir("/root/reference/src/diffusion_net"):
+        return None
+    try:
+        import importlib.util
+        for name in ("potpourri3d", "robust_laplacian"):
+            sys.modules.setdefault(name, types.ModuleType(name))
+        spec = importlib.util.spec_from_file_location("ref_diffusion_net", "/root/reference/src/diffusion_net/__init__.py",
+                                                      submodule_search_locations=["/root/reference/src/diffusion_net"])
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules["ref_diffusion_net"] = mod
+        spec.loader.exec_module(mod)
+        return mod
+    except Exception:      # noqa: BLE001
+        return None
+
+
+def cpu_baseline(args, C_out, sizes):
+    """The reference's training loop on the host CPU: one mesh per optimizer step (DataLoader(batch_size=None),
+    human_segmentation_original.py:61), fwd + NLL + bwd + Adam, the first meshes of THIS benchmark batch.  Timed with the imported
+    reference module when its sources are reachable (kind "reference"), else with the in-repo oracle restatement (kind "port");
+    swept over thread counts, the best is reported with its core count."""
     import diffusion_net
     from diffusion_net import synthetic
     from oracle import diffusionnet_oracle as orc
+    ref = _import_reference()
+    n_sample = min(3, len(sizes))
+    meshes = [synthetic.make_mesh_operators(v, args.keig, seed=i) for i, v in enumerate(sizes[:n_sample])]
+    labels = [torch.randint(0, C_out, (m["faces"].shape[0],)) for m in meshes]
+    lsm = lambda t: F.log_softmax(t, dim=-1)
     torch.manual_seed(0)
-    V = args.verts
-    m = synthetic.make_mesh_operators(V, args.keig, seed=99)
-    model = diffusion_net.layers.DiffusionNet(3, C_out, C_width=args.cwidth, N_block=args.blocks, outputs_at="faces")
-    params = {k: v.clone().requires_grad_(True) for k, v in synthetic.randomize_times(model.state_dict(), seed=0).items()}
-    opt = torch.optim.Adam(list(params.values()), lr=1e-3)
-    labels = torch.randint(0, C_out, (m["faces"].shape[0],))
-    n_mask = 2
+    sd = synthetic.randomize_times(diffusion_net.layers.DiffusionNet(3, C_out, C_width=args.cwidth, N_block=args.blocks, outputs_at="faces").state_dict(), seed=0)
+    if ref is not None:
+        model = ref.layers.DiffusionNet(3, C_out, C_width=args.cwidth, N_block=args.blocks, outputs_at="faces", dropout=True, last_activation=lsm)
+        model.load_state_dict(sd)
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
 
-    def step():
-        opt.zero_grad()
-        masks = [[torch.bernoulli(torch.full((V, args.cwidth), 0.5)) for _ in range(n_mask)] for _ in range(args.blocks)]
-        p = dict(params)
-        for k in p:
-            if k.endswith("diffusion_time"):
-                p[k] = orc.clamp_time(p[k])
-        out = orc.net_forward(p, m["verts"], m["mass"], m["evals"], m["evecs"], m["gradX"], m["gradY"], faces=m["faces"],
-                              outputs_at="faces", last_activation=lambda t: F.log_softmax(t, dim=-1), keep_masks=masks)
-        F.nll_loss(out, labels).backward()
-        opt.step()
+        def step(i):
+            m = meshes[i % n_sample]
+            opt.zero_grad()
+            out = model(m["verts"], m["mass"], L=None, evals=m["evals"], evecs=m["evecs"], gradX=m["gradX"], gradY=m["gradY"], faces=m["faces"])
+            F.nll_loss(out, labels[i % n_sample]).backward()
+            opt.step()
+    else:
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        opt = torch.optim.Adam(list(params.values()), lr=1e-3)
 
-    for _ in range(2):
-        step()
-    t0, n = time.perf_counter(), 0
-    while n < 40 and (time.perf_counter() - t0 < 15.0 or n < 3):
-        step()
-        n += 1
-    dt = (time.perf_counter() - t0) / n
-    return {"value": V / dt, "unit": "vertices/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} train steps of one {V}-vertex mesh (same net/config, torch-CPU oracle, fp32)",
-            "ms_per_step": dt * 1e3}
+        def step(i):
+            m = meshes[i % n_sample]
+            V = m["verts"].shape[0]
+            opt.zero_grad()
+            masks = [[torch.bernoulli(torch.full((V, args.cwidth), 0.5)) for _ in range(2)] for _ in range(args.blocks)]
+            p = {k: (orc.clamp_time(v) if k.endswith("diffusion_time") else v) for k, v in params.items()}
+            out = orc.net_forward(p, m["verts"], m["mass"], m["evals"], m["evecs"], m["gradX"], m["gradY"], faces=m["faces"],
+                                  outputs_at="faces", last_activation=lsm, keep_masks=masks)
+            F.nll_loss(out, labels[i % n_sample]).backward()
+            opt.step()
+    ncpu = os.cpu_count() or 1
+    sweep, best = {}, None
+    prev_threads = torch.get_num_threads()
+    for nt in sorted({min(8, ncpu), min(32, ncpu), ncpu}):
+        torch.set_num_threads(nt)
+        step(0)                                              # warm-up (thread pool, allocator)
+        t0, n, v = time.perf_counter(), 0, 0
+        while n < 2 * n_sample and (time.perf_counter() - t0 < 6.0 or n < n_sample):
+            step(n)
+            v += sizes[n % n_sample]
+            n += 1
+        rate = v / (time.perf_counter() - t0)
+        sweep[str(nt)] = round(rate, 1)
+        if best is None or rate > best[0]:
+            best = (rate, nt, n)
+    torch.set_num_threads(prev_threads)
+    return {"value": best[0], "unit": "vertices/s", "cores": best[1], "kind": "reference" if ref is not None else "port",
+            "sample": "%d train steps, one mesh per step as the reference's loop, over the first %d meshes (%s vertices) of the benchmark batch, "
+                      "fp32, same net/config; best of thread counts %s (vertices/s per count: %s); host has %d logical CPUs"
+                      % (best[2], n_sample, "/".join(str(s_) for s_ in sizes[:n_sample]), sorted(int(k) for k in sweep), sweep, ncpu)}
+
+
+def kernel_family_report(lib):
+    """Per-kernel-family timing from the library's hipEvent brackets (this rank, timed region) and the roofline object of the family
+    with the largest share."""
+    fam = []
+    buf = (ctypes.c_double * 4)()
+    for k in range(5):
+        lib.dn_prof_read(k, buf)
+        ms, n, fl, by = buf[0], buf[1], buf[2], buf[3]
+        if n > 0:
+            fam.append({"kernel": lib.dn_prof_kind_name(k).decode(), "ms_total": ms, "launches": int(n),
+                        "avg_us": 1e3 * ms / n, "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                        "gbps": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                        "flops_per_launch": fl / n, "bytes_per_launch": by / n})
+    dom = max(fam, key=lambda f: f["ms_total"])
+    # Binding roof of a family = the lower of the two roofs at its arithmetic intensity.  The GEMM families run on
+    # split-bf16 MFMA (6 bf16 MFMAs per fp32 product: effective fp32 peak = 2.5 PF / 6); the sparse family is HBM-bound.
+    def bind(f):
+        eff_peak = PEAK_MFMA_BF16_TFLOPS / 6.0 if "gemm" in f["kernel"] else PEAK_MFMA_F32_TFLOPS
+        ai = f["flops_per_launch"] / max(f["bytes_per_launch"], 1.0)
+        ridge = eff_peak * 1e12 / (PEAK_HBM_GBPS * 1e9)
+        if f["flops_per_launch"] > 0 and ai > ridge:
+            return {"bound": "mfma", "achieved": f["tflops"], "peak": eff_peak, "unit": "TFLOP/s", "frac": f["tflops"] / eff_peak}
+        return {"bound": "hbm", "achieved": f["gbps"], "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": f["gbps"] / PEAK_HBM_GBPS}
+    roof = bind(dom)
+    roof["traffic"] = None
+    roof["arithmetic_intensity_flop_per_byte"] = dom["flops_per_launch"] / max(dom["bytes_per_launch"], 1.0)
+    roof["effective_fp32_tflops"] = dom["tflops"]
+    # HBM bytes per launch of that family from the committed FETCH_SIZE / WRITE_SIZE PMC passes (separate rocprofv3
+    # --pmc runs of the same workload, gfx950 x2 read correction applied; tools/traffic_summary.py)
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_JSON)))
+        roof["traffic"] = tr[dom["kernel"]]["hbm_bytes_per_launch"]
+        roof["traffic_note"] = "PMC (2*FETCH_SIZE+WRITE_SIZE)*1024 B per launch; algorithmic bytes per launch = %.4g" % dom["bytes_per_launch"]
+    except Exception:
+        pass
+    roof.update({"kernel": dom["kernel"], "avg_launch_us": dom["avg_us"], "launches": dom["launches"],
+                 "share_of_kernel_time": dom["ms_total"] / sum(f["ms_total"] for f in fam)})
+
+    return fam, roof
+
+
+def run_other_config(args, device, lib, world, rank):
+    """The other BASELINE.json configs through the same timing contract (1 GPU; they are parity-test shapes, reported for reference):
+      cfg2  human_segmentation_original as the script runs it: ONE ~7k-vertex mesh per step through the reference-signature forward,
+            operators moved to the device every step, torch Adam, F.nll_loss (human_segmentation_original.py:105-148)
+      cfg3  classification_shrec11 shape: 64 ragged ~2k-vertex meshes per step, C_width=64 (the script's), K=128, global-mean pooling,
+            30 classes, label-smoothing loss, packed batch
+      cfg4  one 200 000-vertex mesh, C_width=K=256, inference (no_grad, eval) through the reference-signature forward"""
+    import diffusion_net
+    from diffusion_net import synthetic
+    assert world == 1, "the alternative configs are single-GPU workloads"
+    lsm = lambda t: F.log_softmax(t, dim=-1)
+    torch.manual_seed(0)
+    cfg = args.config
+    if cfg == "cfg2":
+        V, K, C = 7000, 128, 128
+        meshes = [synthetic.make_mesh_operators(V + 17 * i, K, seed=i) for i in range(8)]
+        labels = [torch.randint(0, 8, (m["faces"].shape[0],)) for m in meshes]
+        model = diffusion_net.layers.DiffusionNet(3, 8, C_width=C, N_block=4, outputs_at="faces", dropout=True, last_activation=lsm).to(device)
+        model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=0))
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        sizes = [m["verts"].shape[0] for m in meshes]
+
+        def step(i):
+            m, lab = meshes[i % 8], labels[i % 8]
+            d = {k: m[k].to(device) for k in ("verts", "faces", "mass", "evals", "evecs", "gradX", "gradY")}
+            opt.zero_grad()
+            preds = model(d["verts"], d["mass"], L=None, evals=d["evals"], evecs=d["evecs"], gradX=d["gradX"], gradY=d["gradY"], faces=d["faces"])
+            loss = F.nll_loss(preds, lab.to(device))
+            loss.backward()
+            opt.step()
+            return loss, sizes[i % 8]
+        desc = ("unmodified human_segmentation_original train loop: one ~%d-vertex mesh per step through DiffusionNet.forward(x, mass, L, evals, evecs, "
+                "gradX, gradY, faces), operators re-sent to the device every step (operator cache hits by content), C_width=128 K=128 N_block=4, "
+                "dropout on, torch Adam + F.nll_loss" % V)
+        Cw = C
+    elif cfg == "cfg3":
+        K, C, n = 128, 64, 64
+        g = torch.Generator().manual_seed(3)
+        sizes = [int(1500 + 1000 * torch.rand(1, generator=g).item()) for _ in range(n)]
+        from diffusion_net.batch import MeshBatch
+        ms = [synthetic.make_mesh_operators(v, K, seed=100 + i) for i, v in enumerate(sizes)]
+        mb = MeshBatch.from_operators([m["mass"] for m in ms], [m["evals"] for m in ms], [m["evecs"] for m in ms], [m["gradX"] for m in ms],
+                                      [m["gradY"] for m in ms], device=device)
+        x = torch.cat([m["verts"] for m in ms], 0).to(device)
+        lab = torch.randint(0, 30, (n,), device=device)
+        model = diffusion_net.layers.DiffusionNet(3, 30, C_width=C, N_block=4, outputs_at="global_mean", dropout=False, last_activation=lsm).to(device)
+        model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=0))
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+
+        def step(i):
+            opt.zero_grad()
+            preds = model.forward_packed(x, mb)
+            loss = diffusion_net.utils.label_smoothing_log_loss(preds, lab, 0.2)
+            loss.backward()
+            opt.step()
+            return loss, sum(sizes)
+        desc = ("classification_shrec11 shape: packed batch of %d ragged meshes (1500..2500 vertices, %d in total) per step, C_in=3 C_out=30 C_width=64 K=128 "
+                "N_block=4 outputs_at=global_mean, label-smoothing loss 0.2, torch Adam" % (n, sum(sizes)))
+        Cw = C
+    else:
+        V, K, C = 200000, 256, 256
+        m = synthetic.make_mesh_operators(V, K, seed=4)
+        d = {k: m[k].to(device) for k in ("verts", "mass", "evals", "evecs", "gradX", "gradY")}
+        model = diffusion_net.layers.DiffusionNet(3, 16, C_width=C, N_block=4, dropout=True).to(device).eval()
+        model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=1))
+
+        def step(i):
+            with torch.no_grad():
+                out = model(d["verts"], d["mass"], evals=d["evals"], evecs=d["evecs"], gradX=d["gradX"], gradY=d["gradY"])
+            return out.sum(), V
+        desc = "inference (eval, no_grad) on one %d-vertex mesh through the reference-signature forward, C_in=3 C_out=16 C_width=256 K=256 N_block=4" % V
+        Cw = C
+    for i in range(max(args.warmup, 8 if cfg == "cfg2" else 1)):
+        step(i)
+    torch.cuda.synchronize()
+    lib.dn_prof_reset()
+    lib.dn_prof_enable(1)
+    t0, verts = time.perf_counter(), 0
+    for i in range(args.steps):
+        loss, v = step(i)
+        verts += v
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    lib.dn_prof_enable(0)
+    assert torch.isfinite(loss).item()
+    fam, roof = kernel_family_report(lib)
+    print(json.dumps({
+        "metric": "vertices/sec %s, C_width=%d K=%d" % ("fwd" if cfg == "cfg4" else "fwd+bwd", Cw, K),
+        "value": verts / elapsed, "unit": "vertices/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic", "config": {"workload": desc, "baseline_config": cfg, "parallelism": "dp1"},
+        "roofline": roof, "kernel_families": fam}))
 
 
 def main():
@@ -104,6 +286,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=4)
     ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch into this many sub-batches run on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default="headline", choices=["headline", "cfg2", "cfg3", "cfg4"],
+                    help="headline: BASELINE metric workload (default, what the driver runs); cfg2/cfg3/cfg4: the other BASELINE.json configs, same JSON contract")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -139,10 +323,12 @@ def main():
             dist.barrier()
     lib = _hip.lib()
 
+    if args.config != "headline":
+        return run_other_config(args, device, lib, world, rank)
     C_in, C_out = 3, 8
     torch.manual_seed(0)                       # identical replicas on every rank
-    model = diffusion_net.layers.DiffusionNet(C_in, C_out, C_width=args.cwidth, N_block=args.blocks,
-                                              outputs_at="faces", dropout=True)
+    model = diffusion_net.layers.DiffusionNet(C_in, C_out, C_width=args.cwidth, N_block=args.blocks, outputs_at="faces", dropout=True,
+                                              last_activation=lambda t: F.log_softmax(t, dim=-1))   # as human_segmentation_original.py:69-75
     model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=0))
     model.to(device).train()
     nsub = max(1, min(args.streams, args.meshes))
@@ -167,8 +353,7 @@ def main():
         flat.zero_grad()
         if nsub == 1:
             mb_j, gather_j, x_j, labels_j, _ = subs[0]
-            out = model.forward_packed(x_j, mb_j, gather_j)
-            loss = diffusion_net.utils.nll_loss(F.log_softmax(out, dim=-1), labels_j)
+            _, loss = model.forward_packed_loss(x_j, mb_j, gather_j, labels_j)     # per-face log-softmax + NLL: one kernel each way
             loss.backward()
         else:
             # sub-batches on separate streams: the store phase of one overlaps the MFMA phase of the other;
@@ -178,8 +363,7 @@ def main():
             for st, (mb_j, gather_j, x_j, labels_j, v_j) in zip(streams, subs):
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):
-                    out = model.forward_packed(x_j, mb_j, gather_j)
-                    losses.append(diffusion_net.utils.nll_loss(F.log_softmax(out, dim=-1), labels_j) * (1.0 / nsub))
+                    losses.append(model.forward_packed_loss(x_j, mb_j, gather_j, labels_j)[1] * (1.0 / nsub))
             for st, l in zip(streams, losses):
                 with torch.cuda.stream(st):
                     l.backward()
@@ -217,41 +401,7 @@ def main():
         v_all = float(v_step)
     assert torch.isfinite(loss).item()
 
-    # ---- per-kernel-family timing from the library's hipEvent brackets (this rank, timed region)
-    fam = []
-    buf = (ctypes.c_double * 4)()
-    for k in range(5):
-        lib.dn_prof_read(k, buf)
-        ms, n, fl, by = buf[0], buf[1], buf[2], buf[3]
-        if n > 0:
-            fam.append({"kernel": lib.dn_prof_kind_name(k).decode(), "ms_total": ms, "launches": int(n),
-                        "avg_us": 1e3 * ms / n, "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
-                        "gbps": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
-                        "flops_per_launch": fl / n, "bytes_per_launch": by / n})
-    dom = max(fam, key=lambda f: f["ms_total"])
-    # Binding roof of a family = the lower of the two roofs at its arithmetic intensity.  The GEMM families run on
-    # split-bf16 MFMA (6 bf16 MFMAs per fp32 product: effective fp32 peak = 2.5 PF / 6); the sparse family is HBM-bound.
-    def bind(f):
-        eff_peak = PEAK_MFMA_BF16_TFLOPS / 6.0 if "gemm" in f["kernel"] else PEAK_MFMA_F32_TFLOPS
-        ai = f["flops_per_launch"] / max(f["bytes_per_launch"], 1.0)
-        ridge = eff_peak * 1e12 / (PEAK_HBM_GBPS * 1e9)
-        if f["flops_per_launch"] > 0 and ai > ridge:
-            return {"bound": "mfma", "achieved": f["tflops"], "peak": eff_peak, "unit": "TFLOP/s", "frac": f["tflops"] / eff_peak}
-        return {"bound": "hbm", "achieved": f["gbps"], "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": f["gbps"] / PEAK_HBM_GBPS}
-    roof = bind(dom)
-    roof["traffic"] = None
-    roof["arithmetic_intensity_flop_per_byte"] = dom["flops_per_launch"] / max(dom["bytes_per_launch"], 1.0)
-    roof["effective_fp32_tflops"] = dom["tflops"]
-    # HBM bytes per launch of that family from the committed FETCH_SIZE / WRITE_SIZE PMC passes (separate rocprofv3
-    # --pmc runs of the same workload, gfx950 x2 read correction applied; tools/traffic_summary.py)
-    try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        roof["traffic"] = tr[dom["kernel"]]["hbm_bytes_per_launch"]
-        roof["traffic_note"] = "PMC (2*FETCH_SIZE+WRITE_SIZE)*1024 B per launch; algorithmic bytes per launch = %.4g" % dom["bytes_per_launch"]
-    except Exception:
-        pass
-    roof.update({"kernel": dom["kernel"], "avg_launch_us": dom["avg_us"], "launches": dom["launches"],
-                 "share_of_kernel_time": dom["ms_total"] / sum(f["ms_total"] for f in fam)})
+    fam, roof = kernel_family_report(lib)
 
     # ---- diffusion block (to_basis + exp(-lambda t) + from_basis) on the same batch: HBM GB/s of BASELINE.json
     from diffusion_net import ops
@@ -294,7 +444,7 @@ def main():
             "roofline": roof, "kernel_families": fam, "diffusion_block": diff,
         }
         if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only (the other ranks would sit idle behind it)
-            res["cpu_baseline"] = cpu_baseline(args, C_out)
+            res["cpu_baseline"] = cpu_baseline(args, C_out, mesh_sizes(args.meshes, args.verts, 0))
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -556,18 +556,32 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     return from_basis(mb, dxs, C, gr->d_x, d_xacc, true, st);
 }
 
-// ------------------------------------------------------------------ loss next to the path
-#define DN_NLL_BLOCKS 1024
-size_t dn_nll_workspace_bytes(void) { return pad256(DN_NLL_BLOCKS) + 512; }
-int dn_nll_loss_fwd_f32(const float* logp, const int64_t* labels, int64_t n, int C, float* loss, void* ws, size_t ws_bytes,
-                        void* stream) {
+// ------------------------------------------------------------------ head / loss next to the path (dn_head.hip)
+#define DN_HEAD_BLOCKS 2048
+size_t dn_head_workspace_bytes(void) { return pad256(2 * DN_HEAD_BLOCKS) + 512; }
+int dn_head_fwd_f32(const float* x, int n_src, int C, const int32_t* rowptr, const int32_t* col, int n_out, float div, int log_softmax,
+                    const int64_t* labels, float smoothing, float* logp, float* loss, float* count, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || n_src < 0 || n_out < 0 || C <= 0 || (rowptr && !col) || div <= 0.f || (labels && (!loss || !count))) return DN_ERR_INVALID;
+    if (!rowptr && n_out != n_src) return DN_ERR_INVALID;
     Bump b(ws, ws_bytes);
-    float* partial = b.f(DN_NLL_BLOCKS);
+    float* partial = b.f(2 * DN_HEAD_BLOCKS);
     if (!b.ok) return DN_ERR_INVALID;
-    return dn_launch_nll_fwd(logp, (const long long*)labels, n, C, partial, DN_NLL_BLOCKS, loss, S(stream));
+    HeadArgs a; memset(&a, 0, sizeof(a));
+    a.x = x; a.ldx = C; a.rowptr = rowptr; a.col = col; a.inv_div = 1.f / div; a.labels = (const long long*)labels; a.smoothing = smoothing;
+    a.n_out = n_out; a.n_src = n_src; a.C = C; a.lsm = log_softmax != 0; a.logp = logp; a.partial = partial;
+    return dn_launch_head_fwd(a, DN_HEAD_BLOCKS, loss, count, S(stream));
 }
-int dn_nll_loss_bwd_f32(const int64_t* labels, int64_t n, int C, const float* d_loss, float* d_logp, void* stream) {
-    return dn_launch_nll_bwd((const long long*)labels, n, C, d_loss, d_logp, S(stream));
+int dn_head_bwd_f32(const float* logp, int n_out, int C, const int32_t* t_rowptr, const int32_t* t_col, int n_src, float div, int log_softmax,
+                    const int64_t* labels, float smoothing, const float* d_logp, const float* d_loss, const float* count, float* d_x,
+                    void* stream) {
+    if (n_src < 0 || n_out < 0 || C <= 0 || !d_x || (t_rowptr && !t_col) || div <= 0.f || (log_softmax && !logp) ||
+        (labels && d_loss && !count) || (!t_rowptr && n_out != n_src))
+        return DN_ERR_INVALID;
+    HeadArgs a; memset(&a, 0, sizeof(a));
+    a.inv_div = 1.f / div; a.labels = (const long long*)labels; a.smoothing = smoothing; a.n_out = n_out; a.n_src = n_src; a.C = C;
+    a.lsm = log_softmax != 0; a.logp = const_cast<float*>(logp); a.t_rowptr = t_rowptr; a.t_col = t_col; a.d_logp = d_logp; a.g_loss = d_loss;
+    a.count = count; a.d_x = d_x;
+    return dn_launch_head_bwd(a, S(stream));
 }
 
 // ------------------------------------------------------------------ input features next to the path

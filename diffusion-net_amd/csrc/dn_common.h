@@ -91,10 +91,6 @@ __device__ __forceinline__ void dn_split3_pair(float x, float y, unsigned& hi, u
     typedef float dn_f2 __attribute__((ext_vector_type(2)));
     typedef __bf16 dn_bf2 __attribute__((ext_vector_type(2)));
     hi = __builtin_bit_cast(unsigned, __builtin_convertvector(dn_f2{x, y}, dn_bf2));
-#if defined(DN_X3_ABLATE_SPLIT)   // development ablation: no residual arithmetic
-    mid = lo = hi;
-    return;
-#endif
     const float rx = x - __uint_as_float(hi << 16), ry = y - __uint_as_float(hi & 0xffff0000u);
     mid = __builtin_bit_cast(unsigned, __builtin_convertvector(dn_f2{rx, ry}, dn_bf2));
     const float tx = rx - __uint_as_float(mid << 16), ty = ry - __uint_as_float(mid & 0xffff0000u);
@@ -237,13 +233,15 @@ struct TnArgs {
 // Allow more than 64 KiB of dynamic LDS for one kernel instantiation, once per DEVICE (function attributes are per device;
 // `done` is the instantiation's own 64-bit device bitmap).  Not thread-safe beyond "setting it twice is harmless".
 #ifndef DN_EMULATE
-static inline void dn_lds_opt_in(const void* fn, size_t smem, unsigned long long* done) {
+static inline int dn_lds_opt_in(const void* fn, size_t smem, unsigned long long* done) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
     if (!((*done >> dev) & 1ull)) {
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;   // reported by the launcher instead of surfacing later as an opaque launch failure
         *done |= 1ull << dev;
     }
+    return 0;
 }
 #endif
 // CUs of the CURRENT device (one workgroup per CU in the persistent kernels)
@@ -321,9 +319,25 @@ int dn_launch_smallk_rows(const float* x, int K, const float* W, int w_kn, const
 // partial-free small-N vertex contraction: out[m, n] = sum_r A[r,m] * B[r,n], N <= 16, via per-block partials in ws
 int dn_launch_smalln_tn(const float* A, int M, const float* B, int N, long long rows, float* out, float* ws, int nblk,
                         hipStream_t stream);
-int dn_launch_nll_fwd(const float* logp, const long long* labels, long long n, int C, float* partial, int nb, float* out,
-                      hipStream_t stream);
-int dn_launch_nll_bwd(const long long* labels, long long n, int C, const float* gout, float* dlogp, hipStream_t stream);
+// head / loss kernels (dn_head.hip)
+struct HeadArgs {
+    const float* x; int ldx;               // [n_src, C] logits (or log-probabilities when !lsm)
+    const int* rowptr; const int* col;     // gather pattern of the outputs (null: output i = row i)
+    float inv_div;                         // 1 / entries per output (mean)
+    const long long* labels;               // [n_out] or null
+    float smoothing;
+    int n_out, n_src, C, lsm;
+    float* logp;                           // [n_out, C] or null
+    float* partial;                        // [2 * gridDim.x]: loss sums, valid counts
+    // backward
+    const int* t_rowptr; const int* t_col; // transposed gather (null: identity)
+    const float* d_logp;                   // [n_out, C] or null
+    const float* g_loss;                   // device scalar or null
+    const float* count;                    // device scalar: valid rows of the forward
+    float* d_x;                            // [n_src, C]
+};
+int dn_launch_head_fwd(const HeadArgs& a, int nb, float* loss, float* count, hipStream_t stream);
+int dn_launch_head_bwd(const HeadArgs& a, hipStream_t stream);
 int dn_launch_dtanh(const float* dg, const float* g, float* out, long long n, hipStream_t stream);
 int dn_launch_reduce_pair(const float* pa, float* oa, long long la, const float* pb, float* ob, long long lb, int n, hipStream_t stream);
 int dn_launch_hks(const float* evals, const float* evecs, const float* scales, int B, int V, int K, int S, long long scale_stride,

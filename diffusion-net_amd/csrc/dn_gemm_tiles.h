@@ -126,9 +126,6 @@ __device__ __forceinline__ void rg_load(const RgArgs& g, const DnTile& tile, int
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) R.q[i] = *reinterpret_cast<const float4*>(sg.q + off[i]);
         }
-#if defined(DN_X3_ABLATE_BSTAGE)
-        if (NTHR == 512) return;
-#endif
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) {
             const float* bp = g.b[o][seg] + (long long)tile.mesh * g.b_mesh_stride;
@@ -262,11 +259,7 @@ __device__ __forceinline__ void rg_compute(const float* sA, const float* sB, int
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int o = 0; o < NOUT; ++o) {
-#if defined(DN_ABLATE_MFMA)   // development ablation: operands stay live, no matrix work
-                        acc[o][mt][nt][0] += dn_f4_get(af[mt], t) * bv[o][nt][t];
-#else
                         acc[o][mt][nt] = dn_mfma(dn_f4_get(af[mt], t), bv[o][nt][t], acc[o][mt][nt]);
-#endif
                     }
     }
 }
@@ -294,9 +287,6 @@ __device__ __forceinline__ void rg_split_x3(const RgRegs<NOUT, A_IT, B_IT>& R, X
         }
     }
     if (!DO_B) return;
-#if defined(DN_X3_ABLATE_BSTAGE)   // development ablation: B operand neither loaded, split nor written
-    return;
-#endif
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
         if (BCOLK) {
@@ -334,9 +324,6 @@ __device__ __forceinline__ void rg_put_x3(unsigned char* sA, unsigned char* sB, 
 #pragma unroll
         for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(sA + p * PL + off) = P.a[i][p];
     }
-#if defined(DN_X3_ABLATE_BSTAGE)
-    return;
-#endif
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
         unsigned char* sBo = sB + o * 3 * PLB;
@@ -386,14 +373,6 @@ template <int MT, int NT, int NOUT>
 __device__ __forceinline__ void rg_frag_x3(const unsigned char* sA, const unsigned char* sB, int arow0, int bcol0, int li, int lg,
                                            int s, X3Frags<MT, NT, NOUT>& F) {
     constexpr int PL = DN_TM * 64, PLB = 128 * 64;
-#if defined(DN_X3_ABLATE_LDSR)   // development ablation: one LDS read feeds every fragment
-    const uint4 one = *reinterpret_cast<const uint4*>(sA + dn_plane_off(arow0 + li, 2 * s + lg));
-    for (int p = 0; p < 3; ++p) {
-        for (int mt = 0; mt < MT; ++mt) F.a[s][p][mt] = one;
-        for (int o = 0; o < NOUT; ++o)
-            for (int nt = 0; nt < NT; ++nt) F.b[s][o][p][nt] = one;
-    }
-#else
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
 #pragma unroll
@@ -405,7 +384,6 @@ __device__ __forceinline__ void rg_frag_x3(const unsigned char* sA, const unsign
             for (int nt = 0; nt < NT; ++nt)
                 F.b[s][o][p][nt] = *reinterpret_cast<const uint4*>(sB + (o * 3 + p) * PLB + dn_plane_off(bcol0 + nt * 32 + li, 2 * s + lg));
     }
-#endif
 }
 
 // The six cross products of one k16 step, smallest terms first.  Product-major issue order: consecutive MFMAs go to
@@ -422,11 +400,7 @@ __device__ __forceinline__ void rg_mma_x3(const X3Frags<MT, NT, NOUT>& F, int s,
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-#if defined(DN_X3_ABLATE_MFMA)   // development ablation: operands stay live, no matrix work
-                    acc[o][mt][nt][0] += __uint_as_float((F.a[s][PA[p]][mt].x & F.b[s][o][PB[p]][nt].x) & 0x3f800000u);
-#else
                     acc[o][mt][nt] = dn_mfma_bf16(F.a[s][PA[p]][mt], F.b[s][o][PB[p]][nt], acc[o][mt][nt]);
-#endif
                 }
 }
 

@@ -5,6 +5,7 @@
 //   reduce    : fixed-order sum of weight/bias-gradient partials
 //   reduce_dA : same, plus the complex-structured recombination for A_re / A_im (layers.py:122-123)
 //   mass_mean : mass-weighted global mean pooling and its gradient              (layers.py:397)
+// (the loss / head kernels live in dn_head.hip)
 #include "dn_common.h"
 
 // dys: [n_mesh,K,C] = evecs^T d_xd (already reduced over chunks).  In place: dys <- exp(-lambda t) * dys (the
@@ -370,63 +371,6 @@ int dn_launch_smalln_tn(const float* A, int M, const float* B, int N, long long 
     DN_LAUNCH(smalln_tn_kernel, dim3(nblk, 1, 1), dim3(256, 1, 1), 0, stream, A, M, B, N, rows, ws);
     dn_prof_end(DN_K_SMALL, stream, 2.0 * rows * M * N, 4.0 * rows * (M + N));
     return dn_launch_seg_reduce(ws, nullptr, 1, nblk, out, (long long)M * N, stream);
-}
-
-// ---- NLL of log-probabilities, mean reduction (the loss on the far side of the path: F.nll_loss in the experiment
-//      scripts, e.g. human_segmentation_original.py:136).  fwd: block partials of -logp[i, label_i], fixed-order finish;
-//      bwd: d_logp[i, c] = -(g / n) * [c == label_i].  Labels int64 as torch passes them.
-__global__ __launch_bounds__(256) void nll_fwd_kernel(const float* logp, const long long* labels, long long n, int C,
-                                                      float* partial) {
-    __shared__ float red[256];
-    float s = 0.f;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const long long l = labels[i];
-        if (l >= 0 && l < C) s -= logp[i * C + l];
-    }
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
-}
-__global__ __launch_bounds__(256) void nll_finish_kernel(const float* partial, int nb, float inv_n, float* out) {
-    __shared__ float red[256];
-    float s = 0.f;
-    for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = red[0] * inv_n;
-}
-__global__ __launch_bounds__(256) void nll_bwd_kernel(const long long* labels, long long n, int C, const float* gout,
-                                                      float inv_n, float* dlogp) {
-    const float gv = -gout[0] * inv_n;
-    const long long total = n * C;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long r = i / C;
-        const int c = (int)(i - r * C);
-        dlogp[i] = (labels[r] == c) ? gv : 0.f;
-    }
-}
-
-int dn_launch_nll_fwd(const float* logp, const long long* labels, long long n, int C, float* partial, int nb, float* out,
-                      hipStream_t stream) {
-    if (n <= 0 || C <= 0) return 0;
-    DN_LAUNCH(nll_fwd_kernel, dim3(nb, 1, 1), dim3(256, 1, 1), 0, stream, logp, labels, n, C, partial);
-    DN_LAUNCH(nll_finish_kernel, dim3(1, 1, 1), dim3(256, 1, 1), 0, stream, partial, nb, 1.f / (float)n, out);
-    return (int)hipGetLastError();
-}
-int dn_launch_nll_bwd(const long long* labels, long long n, int C, const float* gout, float* dlogp, hipStream_t stream) {
-    if (n <= 0 || C <= 0) return 0;
-    long long nb = (n * C + 255) / 256;
-    if (nb > 4096) nb = 4096;
-    DN_LAUNCH(nll_bwd_kernel, dim3((unsigned)nb, 1, 1), dim3(256, 1, 1), 0, stream, labels, n, C, gout, 1.f / (float)n, dlogp);
-    return (int)hipGetLastError();
 }
 
 // ---- heat kernel signature (geometry.py:600-633): out[b][v][s] = sum_k exp(-lambda[b][k] * t[s]) * evecs[b][v][k]^2.

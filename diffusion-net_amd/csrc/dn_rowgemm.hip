@@ -25,21 +25,12 @@ bool dn_rowgemm_try_persistent(const RgArgs& g, int ntiles, int nout, hipStream_
                                                       wc * NT * 32, li, ls, acc);                                              \
         else rg_compute<TN, MT, NT, NOUT, BCOLK>((buf), (buf) + SA, wr * MT * 32, wc * NT * 32, li, ls, acc);                  \
     } while (0)
-// DN_RG2_SINGLE=1: the split-bf16 two-output configuration keeps ONE 72 KiB slice buffer, so that two workgroups share a CU
-// (<= 128 VGPRs) and one's MFMAs run under the other's loads and epilogue; two barriers per slice.  Measured 267 us vs 180 us
-// for the double-buffered form (45-71 spilled registers at the 128 cap) -> off.
-#ifndef DN_RG2_SINGLE
-#define DN_RG2_SINGLE 0
-#endif
-#ifndef DN_RG2_REORDER
-#define DN_RG2_REORDER 0   // 1: reads -> split || MFMA -> writes inside a slice iteration of the two-output kernel; measured 192 vs 174 us -> off
-#endif
 #ifndef DN_RG2_VEC_EPI
 #define DN_RG2_VEC_EPI 1   // parked float4 epilogue of the two-output split-bf16 kernel (0: per-element dword epilogue)
 #endif
 constexpr bool rg_is_x3(int TN, int NTHR, int NOUT, bool ALIGNED) { return DN_RG_X3 && ALIGNED && NOUT == 2 && TN == 128 && NTHR == 512; }
 template <int TN, int WR, int WC, int NOUT, int MODE, bool ALIGNED, bool BCOLK>
-__global__ __launch_bounds__(WR* WC * 64) DN_MIN_WAVES_PER_EU((rg_is_x3(TN, WR * WC * 64, NOUT, ALIGNED) && DN_RG2_SINGLE) ? 4 : 1)
+__global__ __launch_bounds__(WR* WC * 64) DN_MIN_WAVES_PER_EU(1)
 void rowgemm_kernel(RgArgs g) {
 
     constexpr int NTHR = WR * WC * 64;
@@ -85,19 +76,6 @@ void rowgemm_kernel(RgArgs g) {
     // The steady-state body has no branch, so the LDS writes and the global loads can be scheduled under the MFMAs.
     int seg = 0, koff = 0;
     rg_load<TN, NTHR, NOUT, ALIGNED, BCOLK, HASQ, A_IT, B_IT, PAIRK>(g, tile, n0, seg, koff, tid, R);
-    if constexpr (X3 && DN_RG2_SINGLE) {
-        for (int s1 = 0; s1 < nslices; ++s1) {
-            RG_STORE(smem);                       // slice s1
-            if (s1 + 1 < nslices) {               // slice s1+1 into the registers just freed; in flight under the MFMAs
-                koff += DN_KB;
-                if (koff >= g.a[seg].w) { koff = 0; ++seg; }
-                rg_load<TN, NTHR, NOUT, ALIGNED, BCOLK, HASQ, A_IT, B_IT, PAIRK>(g, tile, n0, seg, koff, tid, R);
-            }
-            __syncthreads();
-            RG_COMPUTE(smem);
-            __syncthreads();
-        }
-    } else {
     RG_STORE(smem);
     if (nslices > 1) {
         koff += DN_KB;
@@ -106,49 +84,15 @@ void rowgemm_kernel(RgArgs g) {
     }
     __syncthreads();
     int sl = 0;
-    if constexpr (X3 && DN_RG2_REORDER) {
-        // Split-bf16 order (as in the persistent kernels): the LDS reads of slice sl come FIRST, then the pure-VALU split of
-        // slice sl+1 next to the MFMAs of the first k16 step, then the LDS writes.  With the writes first the compiler has to
-        // keep every MFMA behind them (may-alias LDS): 178 staging VALU instructions ran before the first MFMA of a slice.
-        const int arow0 = wr * MT * 32, bcol0 = wc * NT * 32;
-        for (; sl < nslices; ++sl) {
-            const unsigned char* cA = reinterpret_cast<const unsigned char*>(smem + (sl & 1) * SBUF);
-            const unsigned char* cB = cA + SA * 4;
-            unsigned char* nA = reinterpret_cast<unsigned char*>(smem + ((sl & 1) ^ 1) * SBUF);
-            const bool stage = sl + 1 < nslices;      // uniform
-            X3Frags<MT, NT, NOUT> F;
-            X3Planes<NOUT, A_IT, B_IT> PLN;
-            rg_frag_x3<MT, NT, NOUT>(cA, cB, arow0, bcol0, li, ls, 0, F);
-            rg_split_x3<NOUT, BCOLK, HASQ, A_IT, B_IT>(R, PLN);          // stale registers on the last slice: never written
-            rg_mma_x3<MT, NT, NOUT>(F, 0, acc);
-            if (sl + 2 < nslices) {
-                koff += DN_KB;
-                if (koff >= g.a[seg].w) { koff = 0; ++seg; }
-                rg_load<TN, NTHR, NOUT, ALIGNED, BCOLK, HASQ, A_IT, B_IT, PAIRK>(g, tile, n0, seg, koff, tid, R);
-            }
-            rg_frag_x3<MT, NT, NOUT>(cA, cB, arow0, bcol0, li, ls, 1, F);
-            rg_mma_x3<MT, NT, NOUT>(F, 1, acc);
-            if (stage) {
-                rg_put_x3<NTHR, NOUT, BCOLK, A_IT, B_IT>(nA, nA + SA * 4, tid, PLN);
-                __syncthreads();
-            }
-        }
-    } else {
     for (; sl + 2 < nslices; ++sl) {
         float* cur = smem + (sl & 1) * SBUF;
         float* nxt = smem + ((sl & 1) ^ 1) * SBUF;
-#if !defined(DN_ABLATE_LOADS)
         RG_STORE(nxt);
         koff += DN_KB;
         if (koff >= g.a[seg].w) { koff = 0; ++seg; }
         rg_load<TN, NTHR, NOUT, ALIGNED, BCOLK, HASQ, A_IT, B_IT, PAIRK>(g, tile, n0, seg, koff, tid, R);
-#else
-        (void)nxt;
-#endif
         RG_COMPUTE(cur);
-#if !defined(DN_ABLATE_BARRIER)
         __syncthreads();
-#endif
     }
     if (sl + 1 < nslices) {   // second-to-last slice: stage the last one, nothing left to load
         float* cur = smem + (sl & 1) * SBUF;
@@ -162,25 +106,8 @@ void rowgemm_kernel(RgArgs g) {
         float* cur = smem + (sl & 1) * SBUF;
         RG_COMPUTE(cur);
     }
-    }
-    }
 
     // ---------------- epilogue ----------------
-#if defined(DN_ABLATE_EPILOGUE)   // development ablation: keep the accumulators live, store one value per wave
-    {
-        float keep = 0.f;
-#pragma unroll
-        for (int o = 0; o < NOUT; ++o)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) keep += acc[o][mt][nt][r];
-        if (lane == 0 && wave_active) g.o0[(long long)tile.row0 * g.ldo + n0 + wave] = keep;
-        return;
-    }
-#endif
     if constexpr (X3 && DN_RG2_VEC_EPI) {
         // Two-output split-bf16 configuration: the slice buffers are dead now, so both 128 x 128 accumulator tiles are parked in
         // them (2 x 64 KiB of the 144 KiB) and the epilogue runs on float4 pieces with coalesced 16-byte loads and stores --
@@ -267,11 +194,11 @@ template <int TN, int WR, int WC, int NOUT, int MODE, bool ALIGNED, bool BCOLK>
 static int rg_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
     const int ncol = (g.N + TN - 1) / TN;
     constexpr bool X3 = DN_RG_X3 && ALIGNED && NOUT == 2 && TN == 128 && WR * WC == 8;
-    const size_t smem = X3 ? (size_t)(DN_RG2_SINGLE ? 1 : 2) * (DN_TM * 64 * 3 + NOUT * 128 * 64 * 3)
+    const size_t smem = X3 ? (size_t)2 * (DN_TM * 64 * 3 + NOUT * 128 * 64 * 3)
                            : (size_t)2 * (DN_TM * DN_KB + NOUT * DN_KB * TN) * sizeof(float);
 #ifndef DN_EMULATE
     static unsigned long long lds_opt_in = 0;   // per-device bitmap
-    dn_lds_opt_in(reinterpret_cast<const void*>(&rowgemm_kernel<TN, WR, WC, NOUT, MODE, ALIGNED, BCOLK>), smem, &lds_opt_in);
+    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&rowgemm_kernel<TN, WR, WC, NOUT, MODE, ALIGNED, BCOLK>), smem, &lds_opt_in); if (oe_) return oe_; }
 #endif
     DN_LAUNCH((rowgemm_kernel<TN, WR, WC, NOUT, MODE, ALIGNED, BCOLK>), dim3(ntiles, ncol, 1), dim3(WR * WC * 64, 1, 1), smem,
               stream, g);
@@ -298,12 +225,10 @@ int dn_launch_rowgemm(const RgArgs& g, int ntiles, int nout, hipStream_t stream)
     dn_prof_begin(kind, stream);
     int err = DN_ERR_BAD_MODE;
     const bool ck = g.b_colk != 0;
-#ifndef DN_NO_PERSIST
     if (dn_rowgemm_try_persistent(g, ntiles, nout, stream, &err)) {
         dn_prof_end(kind, stream, flops, bytes);
         return err;
     }
-#endif
     if (nout == 1) {
         switch (g.mode) {
             case DN_EPI_STORE:

@@ -21,19 +21,6 @@
 #ifndef DN_PT_MAX_SLICES
 #define DN_PT_MAX_SLICES 12  // up to K = 384 (the 3C -> C MLP layer); measured 177 -> 155 us with the bf16x3 path
 #endif
-#ifndef DN_PT_DEPTH
-#define DN_PT_DEPTH 1   // register sets in the prefetch ring (slice s+DEPTH is loaded once slice s has been split)
-#endif
-#if defined(DN_PT_ABLATE_OUT)   // development ablation: parked units are never streamed out
-#define DN_PT_OUT_START DN_PT_NP
-#else
-#define DN_PT_OUT_START 0
-#endif
-#if defined(DN_PT_ABLATE_LOADS)
-#define DN_PT_SKIP_LOADS 1
-#else
-#define DN_PT_SKIP_LOADS 0
-#endif
 // Work-unit geometry.  Measured on MI355X (K = N = 128 product, 158k rows): 128-row units with 8 waves and one
 // workgroup per CU: 68 us; 64-row units with 4 waves and two workgroups per CU (2 x 80 KiB LDS): 71-75 us (twice the
 // B-operand staging per MFMA); non-persistent kernel: 75-80 us.
@@ -72,35 +59,6 @@ __device__ __forceinline__ void pt_piece_load(const RgArgs& g, const float* sE, 
     if (MODE == DN_EPI_MASS_ADD) P.rs = g.rowv[grow];
 }
 
-#if defined(DN_PT_TRACE)   // development build only: per-phase timestamps of workgroup 0 (waves 0 and 7), tools/trace_pt.py
-__device__ unsigned long long dn_pt_trace_buf[2 * 4096];
-#define PT_T()                                                                                                          \
-    do {                                                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                              \
-        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                     \
-        if (blockIdx.x == 0 && blockIdx.y == 0 && (tid == 0 || tid == 448) && trn < 4096)                              \
-            dn_pt_trace_buf[(tid ? 4096 : 0) + trn] = t_;                                                              \
-        ++trn;                                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                                              \
-    } while (0)
-extern "C" int dn_debug_trace_read(unsigned long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dn_pt_trace_buf), sizeof(unsigned long long) * n);
-}
-#ifndef DN_WS_TRACE_TID
-#define DN_WS_TRACE_TID 256   // first lane of the traced loader wave
-#endif
-#define WS_T(who)                                                                                                       \
-    do {                                                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                              \
-        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                     \
-        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == (who) && trn < 4096) dn_pt_trace_buf[((who) ? 4096 : 0) + trn] = t_; \
-        ++trn;                                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                                              \
-    } while (0)
-#else
-#define PT_T() do {} while (0)
-#define WS_T(who) do {} while (0)
-#endif
 template <int MODE, bool BCOLK, bool FLAG, bool X3>
 __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_persist_kernel(RgArgs g, int ntiles) {
 
@@ -153,16 +111,10 @@ __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_pers
         return t;
     };
 
-    // DN_PT_DEPTH register sets form the prefetch ring: slice s travels in set s % DEPTH and is loaded DEPTH iterations
+    // 1 register sets form the prefetch ring: slice s travels in set s % DEPTH and is loaded DEPTH iterations
     // before it is written to LDS, so DEPTH x 16 KiB of reads per CU are in flight (one slice ahead covers only ~1 us of HBM
     // latency once the split-bf16 MFMAs made an iteration that short).
-#if DN_PT_DEPTH == 3
-    RgRegs<NOUT, A_IT, B_IT> R0, R1, R2;
-#elif DN_PT_DEPTH == 2
-    RgRegs<NOUT, A_IT, B_IT> R0, R1;
-#else
     RgRegs<NOUT, A_IT, B_IT> R0;
-#endif
     // load cursor (runs ahead of the compute cursor, across unit boundaries)
     int lu = blockIdx.x, lseg = 0, lkoff = 0;
     DnTile ltile = unit_tile(lu);
@@ -171,12 +123,6 @@ __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_pers
     DnTile ctile = ltile;
     // parked unit being streamed out
     int p_row0 = ctile.row0, p_nrows = 0, p_next = DN_PT_NP;   // p_next >= NP: nothing pending
-#if DN_PT_SKIP_LOADS
-    bool pt_first_load = true;
-#endif
-#if defined(DN_PT_TRACE)
-    int trn = 0;
-#endif
 
 #define PT_ADVANCE()                                                                                                    \
     do {                                                                                                                \
@@ -199,11 +145,7 @@ __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_pers
         lkoff = ok_ ? nk_ : lkoff; lseg = ok_ ? ns_ : lseg; lu = ok_ ? nu_ : lu;                                        \
         ltile = unit_tile(lu);                                                                                          \
     } while (0)
-#if DN_PT_SKIP_LOADS   // development ablation: only the prologue fetches
-#define PT_LOAD(RS) do { if (pt_first_load) rg_load<TN, NTHR, NOUT, true, BCOLK, HASQ, A_IT, B_IT, PAIRK>(g, ltile, n0, lseg, lkoff, tid, RS); pt_first_load = false; } while (0)
-#else
 #define PT_LOAD(RS) rg_load<TN, NTHR, NOUT, true, BCOLK, HASQ, A_IT, B_IT, PAIRK>(g, ltile, n0, lseg, lkoff, tid, RS)
-#endif
 #define PT_STORE(buf, RS)                                                                                               \
     do {                                                                                                                \
         if constexpr (X3) rg_store_x3<NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>(reinterpret_cast<unsigned char*>(buf),        \
@@ -220,7 +162,6 @@ __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_pers
         float* nxt = smem + (((j) & 1) ^ 1) * SBUF;                                                                     \
         PtPiece P[PPI];                                                                                                 \
         const bool pending = p_next < DN_PT_NP;                                                                         \
-        PT_T();                                                                                                         \
         if constexpr (X3) {                                                                                             \
             const unsigned char* cA = reinterpret_cast<const unsigned char*>(cur);                                      \
             const unsigned char* cB = reinterpret_cast<const unsigned char*>(cur + SA);                                 \
@@ -233,24 +174,19 @@ __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_pers
             /* so a piece that waited on a younger load would wait for the prefetch too                              */ \
             _Pragma("unroll") for (int k = 0; k < PPI; ++k)                                                             \
                 pt_piece_load<MODE, FLAG>(g, sE, p_next + k, tid, p_row0, p_nrows, n0, P[k]);                           \
-            PT_T();                                                                                                     \
             rg_split_x3<NOUT, BCOLK, HASQ, A_IT, B_IT>(RS, PLN);                                                        \
             rg_mma_x3<MT, NT, NOUT>(F, 0, acc);                                                                         \
-            PT_T();                                                                                                     \
-            PT_ADVANCE_SEL((j) + 1 + DN_PT_DEPTH < T);                                                                  \
+            PT_ADVANCE_SEL((j) + 1 + 1 < T);                                                                  \
             PT_LOAD(RS);                                                                                                \
             rg_frag_x3<MT, NT, NOUT>(cA, cB, wr * MT * 32, wc * NT * 32, li, ls, 1, F);                                 \
-            PT_T();                                                                                                     \
             rg_mma_x3<MT, NT, NOUT>(F, 1, acc);                                                                         \
-            PT_T();                                                                                                     \
             rg_put_x3<NTHR, NOUT, BCOLK, A_IT, B_IT>(reinterpret_cast<unsigned char*>(nxt),                             \
                                                      reinterpret_cast<unsigned char*>(nxt + SA), tid, PLN);             \
             _Pragma("unroll") for (int k = 0; k < PPI; ++k) pt_piece_store<MODE, FLAG>(g, P[k]);                        \
             p_next = (p_next + PPI < DN_PT_NP) ? p_next + PPI : DN_PT_NP;                                               \
-            PT_T();                                                                                                     \
         } else {                                                                                                        \
             if ((j) + 1 < T) PT_STORE(nxt, RS);                                                                         \
-            if ((j) + 1 + DN_PT_DEPTH < T) { PT_ADVANCE(); PT_LOAD(RS); }                                               \
+            if ((j) + 1 + 1 < T) { PT_ADVANCE(); PT_LOAD(RS); }                                               \
             if (pending) {                                                                                              \
                 _Pragma("unroll") for (int k = 0; k < PPI; ++k)                                                         \
                     pt_piece_load<MODE, FLAG>(g, sE, p_next + k, tid, p_row0, p_nrows, n0, P[k]);                       \
@@ -267,49 +203,25 @@ __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_pers
                     sE[((wr * MT + mt) * 32 + dn_acc_row(r, lane)) * 128 + wc * 32 + li] = acc[0][mt][0][r];            \
                     acc[0][mt][0][r] = 0.f;                                                                             \
                 }                                                                                                       \
-            p_row0 = ctile.row0; p_nrows = ctile.nrows; p_next = DN_PT_OUT_START;                                       \
+            p_row0 = ctile.row0; p_nrows = ctile.nrows; p_next = 0;                                       \
             cs = 0;                                                                                                     \
             cu += G;                                                                                                    \
             if (cu < nunits) ctile = unit_tile(cu);                                                                     \
         }                                                                                                               \
-        PT_T();                                                                                                         \
         __syncthreads(); /* slice buffer hand-off + visibility of the parked unit */                                    \
     } while (0)
 
     // prologue: slice 0 -> LDS, slices 1..DEPTH -> ring sets (slice % DEPTH)
     PT_LOAD(R0);
     PT_STORE(smem, R0);
-#if DN_PT_DEPTH == 3
-    if (T > 1) { PT_ADVANCE(); PT_LOAD(R1); }
-    if (T > 2) { PT_ADVANCE(); PT_LOAD(R2); }
-    if (T > 3) { PT_ADVANCE(); PT_LOAD(R0); }
-    __syncthreads();
-    for (int j = 0; j < T; j += 3) {
-        PT_ITER(j, R1);
-        if (j + 1 < T) PT_ITER(j + 1, R2);
-        if (j + 2 < T) PT_ITER(j + 2, R0);
-    }
-#elif DN_PT_DEPTH == 2
-    if (T > 1) { PT_ADVANCE(); PT_LOAD(R1); }
-    if (T > 2) { PT_ADVANCE(); PT_LOAD(R0); }
-    __syncthreads();
-    for (int j = 0; j < T; j += 2) {
-        PT_ITER(j, R1);
-        if (j + 1 < T) PT_ITER(j + 1, R0);
-    }
-#else
     if (T > 1) { PT_ADVANCE(); PT_LOAD(R0); }
     __syncthreads();
     for (int j = 0; j < T; ++j) PT_ITER(j, R0);
-#endif
 #undef PT_ITER
 #undef PT_STORE
 #undef PT_LOAD
 #undef PT_ADVANCE
     // flush what is still parked (the last unit)
-#if defined(DN_PT_ABLATE_OUT)
-    p_next = DN_PT_NP - 1;
-#endif
     for (; p_next < DN_PT_NP; ++p_next) {
         PtPiece P1;
         pt_piece_load<MODE, FLAG>(g, sE, p_next, tid, p_row0, p_nrows, n0, P1);
@@ -335,14 +247,8 @@ __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_pers
 #ifndef DN_WS_LW
 #define DN_WS_LW 8                            // loader waves per workgroup (4 or 8); measured: 4 loader waves made the loaders the pole
 #endif
-#ifndef DN_WS_DEPTH
-#define DN_WS_DEPTH 1                         // register sets of the loader's prefetch ring
-#endif
 #ifndef DN_WS_LOADER_PRIO
 #define DN_WS_LOADER_PRIO 0   // s_setprio of the loader waves (the MFMA waves are the older ones and win arbitration at equal priority)
-#endif
-#ifndef DN_WS_SPLIT_SIMD
-#define DN_WS_SPLIT_SIMD 0   // 1: MFMA waves on two SIMDs, loaders on the other two -- measured slower (58 vs 51 us, C->C product)
 #endif
 #define DN_WS_LTHR (64 * DN_WS_LW)             // loader threads
 #ifndef DN_WS_BCACHE
@@ -403,11 +309,7 @@ __device__ __forceinline__ void ws_mma(const X3Frags<2, 2, 1>& F, int s, f32x16 
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-#if defined(DN_X3_ABLATE_MFMA)
-                acc[0][mt][nt][0] += __uint_as_float((F.a[s][PA[p]][mt].x & F.b[s][0][PB[p]][nt].x) & 0x3f800000u);
-#else
                 acc[0][mt][nt] = dn_mfma_bf16(F.a[s][PA[p]][mt], F.b[s][0][PB[p]][nt], acc[0][mt][nt]);
-#endif
             }
 }
 
@@ -470,20 +372,11 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     const int my_units = ((int)blockIdx.x < ntiles) ? (ntiles - (int)blockIdx.x + G - 1) / G : 0;
     const int T = my_units * nsl;
     if (T == 0) return;
-#if defined(DN_PT_TRACE)
-    int trn = 0;
-#endif
 
     // Roles.  Default: waves 0-3 (one per SIMD) multiply, waves 4-11 load.  DN_WS_SPLIT_SIMD=1 instead puts the four MFMA
     // waves on two SIMDs (a workgroup's waves are dealt to the SIMDs cyclically) and leaves the other two to the loaders.
-#if DN_WS_SPLIT_SIMD
-    const bool is_mfma = wave < 8 && (wave & 3) < 2;
-    const int mw = wave < 4 ? wave : wave - 2;          // 0, 1, 4, 5 -> 0..3
-    const int lw = wave < 4 ? wave - 2 : wave - 4;      // 2, 3, 6, 7, 8..11 -> 0..7
-#else
     const bool is_mfma = wave < 4;
     const int mw = wave, lw = wave - 4;
-#endif
     if (is_mfma) {
         // ------------------------------------------------ MFMA waves ------------------------------------------------
         const int wr = mw >> 1, wc = mw & 1;
@@ -501,13 +394,10 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
             const unsigned char* cA = reinterpret_cast<const unsigned char*>(smem + (j & 1) * SBUF);
             const unsigned char* cB = cA + SA * 4;
             X3Frags<2, 2, 1> F;
-            WS_T(0);
             rg_frag_x3<2, 2, 1>(cA, cB, wr * 64, wc * 64, li, lg, 0, F);
             rg_frag_x3<2, 2, 1>(cA, cB, wr * 64, wc * 64, li, lg, 1, F);
             ws_mma(F, 0, acc);
-            WS_T(0);
             ws_mma(F, 1, acc);
-            WS_T(0);
             if (++cs == nsl) {   // unit complete: park it (fragment layout -> row-major) for the loader waves to stream out
                 cs = 0;
 #pragma unroll
@@ -520,7 +410,6 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
                             acc[0][mt][nt][r] = 0.f;
                         }
             }
-            WS_T(0);
             __syncthreads();
         }
         return;
@@ -535,9 +424,6 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
         if (need_bias) bias = *reinterpret_cast<const float4*>(g.bias + (col < g.N ? col : 0));
     }
     RgRegs<NOUT, A_IT, B_IT> R0;
-#if DN_WS_DEPTH == 2
-    RgRegs<NOUT, A_IT, B_IT> R1;
-#endif
     // segment descriptors in registers (nseg <= 3); the B operand of segment s starts koff = 0 again
     const float* sp0 = g.a[0].p; const float* sp1 = g.a[1].p; const float* sp2 = g.a[2].p;
     const int sl0 = g.a[0].ld, sl1 = g.a[1].ld, sl2 = g.a[2].ld;
@@ -598,17 +484,14 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
 #define WS_ITER(j, RS, SIDX)                                                                                            \
     do {                                                                                                                \
         float* nxt = smem + (((j) & 1) ^ 1) * SBUF;                                                                     \
-        WS_T(DN_WS_TRACE_TID);                                                                                                      \
         WS_STAGE(nxt, RS, SIDX);       /* slice j+1 (the last iteration stages a stale copy nobody reads) */            \
-        WS_T(DN_WS_TRACE_TID);                                                                                                      \
         if (piece_wave) {              /* wave-uniform: only the first DN_WS_PW loader waves stream the parked unit out */ \
             _Pragma("unroll") for (int k = 0; k < PPI; ++k) ws_piece_out<MODE, FLAG>(g, sE, bias, AX[k]);               \
-            WS_T(DN_WS_TRACE_TID);                                                                                      \
             p_next = (p_next + PPI < DN_WS_NP) ? p_next + PPI : DN_WS_NP;                                               \
             {   /* the MFMA waves park unit cu at the end of the iteration that multiplies its last slice */            \
                 const bool park = ++cs == nsl;                                                                          \
                 p_row0 = park ? ctile.row0 : p_row0; p_nrows = park ? ctile.nrows : p_nrows;                            \
-                p_next = park ? (DN_PT_OUT_START ? DN_WS_NP : 0) : p_next;                                              \
+                p_next = park ? 0 : p_next;                                                                      \
                 cs = park ? 0 : cs;                                                                                     \
                 cu = park ? cu + G : cu;                                                                                \
                 ctile.row0 = park ? ctile_next.row0 : ctile.row0; ctile.nrows = park ? ctile_next.nrows : ctile.nrows;  \
@@ -618,9 +501,8 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
             _Pragma("unroll") for (int k = 0; k < PPI; ++k)                                                             \
                 ws_aux_load<MODE, FLAG>(g, p_next + k, lt, p_row0, p_nrows, n0, AX[k]);                                 \
         }                                                                                                               \
-        WS_ADVANCE((j) + 1 + DN_WS_DEPTH < T);                                                                          \
+        WS_ADVANCE((j) + 1 + 1 < T);                                                                          \
         WS_LOAD(RS);                   /* slice j+1+DEPTH */                                                            \
-        WS_T(DN_WS_TRACE_TID);                                                                                          \
         __syncthreads();                                                                                                \
     } while (0)
 
@@ -640,18 +522,6 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     }
     WS_LOAD(R0);
     WS_STAGE(smem, R0, 0);
-#if DN_WS_DEPTH == 2
-    static_assert(!BC, "the cached-B form is written for the one-set prefetch");
-    WS_ADVANCE(T > 1);
-    WS_LOAD(R1);                       // slice 1
-    WS_ADVANCE(T > 2);
-    WS_LOAD(R0);                       // slice 2
-    __syncthreads();                   // slice 0 staged
-    for (int j = 0; j < T; j += 2) {
-        WS_ITER(j, R1, 0);
-        if (j + 1 < T) WS_ITER(j + 1, R0, 0);
-    }
-#else
     WS_ADVANCE(T > 1);
     WS_LOAD(R0);                       // slice 1
     __syncthreads();                   // slice 0 staged
@@ -665,15 +535,11 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     } else {
         for (int j = 0; j < T; ++j) WS_ITER(j, R0, 0);
     }
-#endif
 #undef WS_ITER
 #undef WS_STAGE
 #undef WS_LOAD
 #undef WS_ADVANCE
     // flush the last parked unit
-#if defined(DN_PT_ABLATE_OUT)
-    p_next = DN_WS_NP;
-#endif
     if (!piece_wave) return;
     for (; p_next < DN_WS_NP; ++p_next) {
         WsAux A1;
@@ -687,327 +553,12 @@ static int ws_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
     const size_t smem = (size_t)(2 * (DN_TM * 64 * 3 + 128 * 64 * 3) + 128 * 128 * 4);   // 160 KiB
 #ifndef DN_EMULATE
     static unsigned long long lds_opt_in = 0;   // per-device bitmap
-    dn_lds_opt_in(reinterpret_cast<const void*>(&rowgemm_ws_kernel<MODE, BCOLK, FLAG, PPI, BC>), smem, &lds_opt_in);
+    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&rowgemm_ws_kernel<MODE, BCOLK, FLAG, PPI, BC>), smem, &lds_opt_in); if (oe_) return oe_; }
 #endif
     int gx = dn_num_cus();
     if (gx > ntiles) gx = ntiles;
     DN_LAUNCH((rowgemm_ws_kernel<MODE, BCOLK, FLAG, PPI, BC>), dim3(gx, (g.N + 127) / 128, 1), dim3(256 + DN_WS_LTHR, 1, 1), smem, stream, g, ntiles);
     return (int)hipGetLastError();
-}
-
-// ---- wave-specialised TWO-output row GEMM (the gradient-feature products, split-bf16) --------------------------------------
-// Same roles as rowgemm_ws_kernel.  A work unit is 128 rows x 64 output columns of BOTH outputs, so that two slice buffers
-// (A planes 24 KiB + 2 x 12 KiB B planes each) and the two parked 128 x 64 accumulator tiles (2 x 32 KiB) fill the 160 KiB of
-// LDS exactly; the column halves of a row tile are consecutive units of the same workgroup (the second pass over the A rows is
-// an L2 / MALL hit).  The epilogue runs on parked float4 pieces: the lock-step kernel it replaces did it with per-element
-// dword loads and stores after its main loop, with one workgroup per CU and nothing to overlap them with.
-#ifndef DN_RG_WS2
-#define DN_RG_WS2 0   // measured on MI355X: 228 us vs 187 us for the lock-step two-output kernel (gradient features, 158k rows) -> off
-#endif
-#define DN_WS2_NP (128 * 64 / 4 / 512)   // float4 pieces (of each output) per loader thread and unit (4)
-
-struct Ws2Aux {
-    float4 r0, r1, r2;
-    long long off;
-    int lds;
-    bool ok;
-};
-
-template <int MODE>
-__device__ __forceinline__ void ws2_aux_load(const RgArgs& g, int piece, int lt, int row0, int nrows, int n0, Ws2Aux& A) {
-    const bool live = piece < DN_WS2_NP;
-    const int idx = lt + (live ? piece : 0) * 512;
-    const int row = idx >> 4, c4 = idx & 15;
-    const int col = n0 + 4 * c4;
-    A.ok = live && row < nrows && col < g.N;
-    A.lds = row * 64 + 4 * c4;
-    const long long grow = row0 + (A.ok ? row : 0);
-    const int ccol = A.ok ? col : 0;
-    A.off = grow * g.ldo + ccol;
-    const long long roff = grow * g.ldr + ccol;
-    A.r0 = *reinterpret_cast<const float4*>(g.r0 + roff);
-    A.r1 = *reinterpret_cast<const float4*>(g.r1 + roff);
-    if (MODE == DN_EPI_GRADFEAT_BWD) A.r2 = *reinterpret_cast<const float4*>(g.r2 + roff);
-}
-
-template <int MODE>
-__device__ __forceinline__ void ws2_piece_out(const RgArgs& g, const float* sE0, const float* sE1, const Ws2Aux& A) {
-    const float4 a0 = *reinterpret_cast<const float4*>(&sE0[A.lds]);
-    const float4 a1 = *reinterpret_cast<const float4*>(&sE1[A.lds]);
-    if (MODE == DN_EPI_GRADFEAT) {   // o0 = tanh(r0*acc0 + r1*acc1); o1 = acc0; o2 = acc1 (if wanted)
-        const float4 y = make_float4(tanhf(A.r0.x * a0.x + A.r1.x * a1.x), tanhf(A.r0.y * a0.y + A.r1.y * a1.y),
-                                     tanhf(A.r0.z * a0.z + A.r1.z * a1.z), tanhf(A.r0.w * a0.w + A.r1.w * a1.w));
-        if (A.ok) {
-            *reinterpret_cast<float4*>(g.o0 + A.off) = y;
-            if (g.o1) {
-                *reinterpret_cast<float4*>(g.o1 + A.off) = a0;
-                *reinterpret_cast<float4*>(g.o2 + A.off) = a1;
-            }
-        }
-    } else {                         // o0 = acc0 + r0*r1 ; o1 = acc1 + r0*r2
-        const float4 y0 = make_float4(a0.x + A.r0.x * A.r1.x, a0.y + A.r0.y * A.r1.y, a0.z + A.r0.z * A.r1.z, a0.w + A.r0.w * A.r1.w);
-        const float4 y1 = make_float4(a1.x + A.r0.x * A.r2.x, a1.y + A.r0.y * A.r2.y, a1.z + A.r0.z * A.r2.z, a1.w + A.r0.w * A.r2.w);
-        if (A.ok) {
-            *reinterpret_cast<float4*>(g.o0 + A.off) = y0;
-            *reinterpret_cast<float4*>(g.o1 + A.off) = y1;
-        }
-    }
-}
-
-template <int MODE, bool BCOLK>
-__global__ __launch_bounds__(768) DN_WAVES_PER_EU(3) void rowgemm_ws2_kernel(RgArgs g, int ntiles) {
-    constexpr bool HASQ = MODE == DN_EPI_GRADFEAT_BWD;   // its A operand is an elementwise product
-    constexpr int PLA = 128 * 64, PLB = 64 * 64;         // bytes of one A / B plane of a slice
-    constexpr int SA_B = 3 * PLA, SBUF_B = SA_B + 2 * 3 * PLB;   // 24 KiB + 24 KiB per slice buffer
-
-    DN_DYN_SMEM(smem_raw);
-    unsigned char* smem = reinterpret_cast<unsigned char*>(smem_raw);
-    float* sE0 = reinterpret_cast<float*>(smem + 2 * SBUF_B);   // parked accumulators [128][64] of output 0 ...
-    float* sE1 = sE0 + 128 * 64;                                 // ... and of output 1
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int G = gridDim.x;
-    const int NH = (g.N + 63) / 64;
-    int nsl = 0;
-    for (int s = 0; s < g.nseg; ++s) nsl += g.a[s].w / DN_KB;   // host guarantees nsl >= 5 and whole slices
-    const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - (int)blockIdx.x + G - 1) / G : 0;
-    const int T = my_tiles * NH * nsl;
-    if (T == 0) return;
-
-    if (wave < 4) {
-        // ------------------------------------------------ MFMA waves ------------------------------------------------
-        const int wr = wave >> 1, wc = wave & 1;   // 64 rows x 32 columns of both outputs
-        const int li = lane & 31, lg = lane >> 5;
-        f32x16 acc[2][2];
-#pragma unroll
-        for (int o = 0; o < 2; ++o)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[o][mt][r] = 0.f;
-        int cs = 0;
-        __syncthreads();   // slice 0 staged
-        for (int j = 0; j < T; ++j) {
-            const unsigned char* cA = smem + (j & 1) * SBUF_B;
-            const unsigned char* cB = cA + SA_B;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                uint4 a[3][2], b[2][3];
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-                        a[p][mt] = *reinterpret_cast<const uint4*>(cA + p * PLA + dn_plane_off(wr * 64 + mt * 32 + li, 2 * s + lg));
-#pragma unroll
-                    for (int o = 0; o < 2; ++o)
-                        b[o][p] = *reinterpret_cast<const uint4*>(cB + (o * 3 + p) * PLB + dn_plane_off(wc * 32 + li, 2 * s + lg));
-                }
-                constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};   // smallest terms first
-#pragma unroll
-                for (int p = 0; p < 6; ++p)
-#pragma unroll
-                    for (int o = 0; o < 2; ++o)
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) acc[o][mt] = dn_mfma_bf16(a[PA[p]][mt], b[o][PB[p]], acc[o][mt]);
-            }
-            if (++cs == nsl) {   // unit complete: park both accumulator tiles
-                cs = 0;
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int e = (wr * 64 + mt * 32 + dn_acc_row(r, lane)) * 64 + wc * 32 + li;
-                        sE0[e] = acc[0][mt][r]; sE1[e] = acc[1][mt][r];
-                        acc[0][mt][r] = 0.f; acc[1][mt][r] = 0.f;
-                    }
-            }
-            __syncthreads();
-        }
-        return;
-    }
-
-    // ---------------------------------------------------- loader waves ----------------------------------------------------
-    DN_SETPRIO(DN_WS_LOADER_PRIO);
-    const int lt = tid - 256;
-    const int ob = lt >> 8, l8 = lt & 255;   // each loader thread stages the B operand of ONE output
-    // segment descriptors in registers (two segments in both users; a third is carried for generality)
-    const float* sp0 = g.a[0].p; const float* sp1 = g.a[1].p; const float* sp2 = g.a[2].p;
-    const float* sq0 = g.a[0].q; const float* sq1 = g.a[1].q; const float* sq2 = g.a[2].q;
-    const int sl0 = g.a[0].ld, sl1 = g.a[1].ld, sl2 = g.a[2].ld;
-    const int sw0 = g.a[0].w, sw1 = g.a[1].w, sw2 = g.a[2].w;
-    const float* sb0 = g.b[ob][0]; const float* sb1 = g.b[ob][1]; const float* sb2 = g.b[ob][2];
-    const float sg0 = g.bsign[ob][0], sg1 = g.bsign[ob][1], sg2 = g.bsign[ob][2];
-    const int nseg = g.nseg, ldb = g.ldb, Ncols = g.N;
-    const long long bms = g.b_mesh_stride;
-    // load cursor: tile, column half, segment, k offset; the next tile's descriptor is fetched one tile ahead
-    int lti = blockIdx.x, lh = 0, lseg = 0, lkoff = 0;
-    DnTile ltile = g.tiles[lti];
-    DnTile ltile_next = g.tiles[lti + G < ntiles ? lti + G : lti];
-    // mirror of the compute cursor and the parked unit being streamed out
-    int cti = blockIdx.x, ch = 0, cs = 0;
-    DnTile ctile = ltile, ctile_next = ltile_next;
-    int p_row0 = ctile.row0, p_nrows = 0, p_n0 = 0, p_next = DN_WS2_NP;
-    Ws2Aux AX;
-    ws2_aux_load<MODE>(g, DN_WS2_NP, lt, p_row0, p_nrows, p_n0, AX);   // dead piece
-
-    float4 Ra[2], Rq[2], Rb[2];
-    float Rsg = 0.f;
-
-#define WS2_ADVANCE(commit)                                                                                             \
-    do {                                                                                                                \
-        const int cw_ = lseg == 0 ? sw0 : (lseg == 1 ? sw1 : sw2);                                                      \
-        int nk_ = lkoff + DN_KB, ns_ = lseg, nh_ = lh, nt_ = lti;                                                       \
-        const bool se_ = nk_ >= cw_;                                                                                    \
-        nk_ = se_ ? 0 : nk_;                                                                                            \
-        ns_ = se_ ? ns_ + 1 : ns_;                                                                                      \
-        const bool ue_ = ns_ >= nseg;                                                                                   \
-        ns_ = ue_ ? 0 : ns_;                                                                                            \
-        nh_ = ue_ ? nh_ + 1 : nh_;                                                                                      \
-        const bool te_ = nh_ >= NH;                                                                                     \
-        nh_ = te_ ? 0 : nh_;                                                                                            \
-        nt_ = te_ ? nt_ + G : nt_;                                                                                      \
-        const bool ok_ = (commit) && nt_ < ntiles;                                                                      \
-        const bool sw_ = ok_ && te_;                                                                                    \
-        lkoff = ok_ ? nk_ : lkoff; lseg = ok_ ? ns_ : lseg; lh = ok_ ? nh_ : lh; lti = ok_ ? nt_ : lti;                 \
-        ltile.row0 = sw_ ? ltile_next.row0 : ltile.row0; ltile.nrows = sw_ ? ltile_next.nrows : ltile.nrows;            \
-        ltile.mesh = sw_ ? ltile_next.mesh : ltile.mesh;                                                                \
-        ltile_next = g.tiles[lti + G < ntiles ? lti + G : lti];                                                         \
-    } while (0)
-#define WS2_LOAD()                                                                                                      \
-    do {                                                                                                                \
-        const float* ap_ = lseg == 0 ? sp0 : (lseg == 1 ? sp1 : sp2);                                                   \
-        const float* aq_ = lseg == 0 ? sq0 : (lseg == 1 ? sq1 : sq2);                                                   \
-        const int ald_ = lseg == 0 ? sl0 : (lseg == 1 ? sl1 : sl2);                                                     \
-        const float* bp_ = (lseg == 0 ? sb0 : (lseg == 1 ? sb1 : sb2)) + (long long)ltile.mesh * bms;                   \
-        Rsg = lseg == 0 ? sg0 : (lseg == 1 ? sg1 : sg2);                                                                \
-        const int n0_ = lh * 64;                                                                                        \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                 \
-            const int idx = lt + i * 512;                                                                               \
-            const int row = idx >> 3, q = idx & 7;                                                                      \
-            const long long off = (long long)(ltile.row0 + (row < ltile.nrows ? row : 0)) * ald_ + lkoff + 4 * q;       \
-            Ra[i] = *reinterpret_cast<const float4*>(ap_ + off);                                                        \
-            if (HASQ) Rq[i] = *reinterpret_cast<const float4*>(aq_ + off);                                              \
-        }                                                                                                               \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                 \
-            long long boff;                                                                                             \
-            if (BCOLK) {                                                                                                \
-                const int idx = l8 + i * 256;                                                                           \
-                const int nrow = idx >> 3, q = idx & 7;                                                                 \
-                boff = (long long)(n0_ + nrow < Ncols ? n0_ + nrow : 0) * ldb + lkoff + 4 * q;                          \
-            } else {                                                                                                    \
-                const int pr = l8 & 15, q4 = l8 >> 4;                                                                   \
-                boff = (long long)(lkoff + 2 * pr + i) * ldb + (n0_ + 4 * q4 < Ncols ? n0_ + 4 * q4 : 0);               \
-            }                                                                                                           \
-            Rb[i] = *reinterpret_cast<const float4*>(bp_ + boff);                                                       \
-        }                                                                                                               \
-    } while (0)
-#define WS2_STAGE(buf)                                                                                                  \
-    do {                                                                                                                \
-        unsigned char* sA_ = (buf);                                                                                     \
-        unsigned char* sB_ = (buf) + SA_B + ob * 3 * PLB;                                                               \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                 \
-            const int idx = lt + i * 512;                                                                               \
-            const int row = idx >> 3, q = idx & 7;                                                                      \
-            float4 v = Ra[i];                                                                                           \
-            if (HASQ) v = dn_f4_mul(v, Rq[i]);                                                                          \
-            uint2 h_, m_, l_;                                                                                           \
-            dn_split3_f4(v, h_, m_, l_);                                                                                \
-            const int off = dn_plane_off(row, q >> 1) + (q & 1) * 8;                                                    \
-            *reinterpret_cast<uint2*>(sA_ + off) = h_;                                                                  \
-            *reinterpret_cast<uint2*>(sA_ + PLA + off) = m_;                                                            \
-            *reinterpret_cast<uint2*>(sA_ + 2 * PLA + off) = l_;                                                        \
-        }                                                                                                               \
-        if (BCOLK) {                                                                                                    \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                             \
-                const int idx = l8 + i * 256;                                                                           \
-                const int nrow = idx >> 3, q = idx & 7;                                                                 \
-                uint2 h_, m_, l_;                                                                                       \
-                dn_split3_f4(dn_f4_scale(Rb[i], Rsg), h_, m_, l_);                                                      \
-                const int off = dn_plane_off(nrow, q >> 1) + (q & 1) * 8;                                               \
-                *reinterpret_cast<uint2*>(sB_ + off) = h_;                                                              \
-                *reinterpret_cast<uint2*>(sB_ + PLB + off) = m_;                                                        \
-                *reinterpret_cast<uint2*>(sB_ + 2 * PLB + off) = l_;                                                    \
-            }                                                                                                           \
-        } else {   /* rows 2p and 2p+1 of column group q4 -> packed (k, k+1) dwords of the transposed planes */          \
-            const int pr = l8 & 15, q4 = l8 >> 4;                                                                       \
-            const float4 v0 = dn_f4_scale(Rb[0], Rsg), v1 = dn_f4_scale(Rb[1], Rsg);                                    \
-            const float e0[4] = {v0.x, v0.y, v0.z, v0.w}, e1[4] = {v1.x, v1.y, v1.z, v1.w};                             \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                             \
-                unsigned h_, m_, l_;                                                                                    \
-                dn_split3_pair(e0[e], e1[e], h_, m_, l_);                                                               \
-                const int off = dn_plane_off(4 * q4 + e, pr >> 2) + (pr & 3) * 4;                                       \
-                *reinterpret_cast<unsigned*>(sB_ + off) = h_;                                                           \
-                *reinterpret_cast<unsigned*>(sB_ + PLB + off) = m_;                                                     \
-                *reinterpret_cast<unsigned*>(sB_ + 2 * PLB + off) = l_;                                                 \
-            }                                                                                                           \
-        }                                                                                                               \
-    } while (0)
-
-    WS2_LOAD();
-    WS2_STAGE(smem);
-    WS2_ADVANCE(T > 1);
-    WS2_LOAD();                        // slice 1
-    __syncthreads();                   // slice 0 staged
-    for (int j = 0; j < T; ++j) {
-        WS2_STAGE(smem + ((j & 1) ^ 1) * SBUF_B);   // slice j+1 (the last iteration stages a stale copy nobody reads)
-        WS2_ADVANCE(j + 2 < T);
-        WS2_LOAD();                    // slice j+2
-        ws2_piece_out<MODE>(g, sE0, sE1, AX);   // its operands were requested an iteration ago
-        p_next = (p_next + 1 < DN_WS2_NP) ? p_next + 1 : DN_WS2_NP;
-        {   // the MFMA waves park the unit whose last slice they multiply in this iteration (selects only)
-            const bool park = ++cs == nsl;
-            p_row0 = park ? ctile.row0 : p_row0; p_nrows = park ? ctile.nrows : p_nrows; p_n0 = park ? ch * 64 : p_n0;
-            p_next = park ? 0 : p_next;
-            cs = park ? 0 : cs;
-            const int nh = park ? ch + 1 : ch;
-            const bool te = nh >= NH;
-            ch = te ? 0 : nh;
-            cti = te ? cti + G : cti;
-            ctile.row0 = te ? ctile_next.row0 : ctile.row0; ctile.nrows = te ? ctile_next.nrows : ctile.nrows;
-            const int cn = cti + G < ntiles ? cti + G : ntiles - 1;
-            ctile_next = g.tiles[cn];
-        }
-        ws2_aux_load<MODE>(g, p_next, lt, p_row0, p_nrows, p_n0, AX);
-        __syncthreads();
-    }
-#undef WS2_STAGE
-#undef WS2_LOAD
-#undef WS2_ADVANCE
-    for (; p_next < DN_WS2_NP; ++p_next) {   // flush the last parked unit
-        Ws2Aux A1;
-        ws2_aux_load<MODE>(g, p_next, lt, p_row0, p_nrows, p_n0, A1);
-        ws2_piece_out<MODE>(g, sE0, sE1, A1);
-    }
-}
-
-template <int MODE, bool BCOLK>
-static int ws2_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
-    const size_t smem = (size_t)(2 * (3 * 128 * 64 + 6 * 64 * 64) + 2 * 128 * 64 * 4);   // 160 KiB
-#ifndef DN_EMULATE
-    static unsigned long long lds_opt_in = 0;   // per-device bitmap
-    dn_lds_opt_in(reinterpret_cast<const void*>(&rowgemm_ws2_kernel<MODE, BCOLK>), smem, &lds_opt_in);
-#endif
-    int gx = dn_num_cus();
-    if (gx > ntiles) gx = ntiles;
-    DN_LAUNCH((rowgemm_ws2_kernel<MODE, BCOLK>), dim3(gx, 1, 1), dim3(768, 1, 1), smem, stream, g, ntiles);
-    return (int)hipGetLastError();
-}
-
-// eligibility of the two-output wave-specialised path
-static bool ws2_eligible(const RgArgs& g, int nout) {
-    if (!DN_RG_WS2 || !DN_RG_X3 || nout != 2 || !g.aligned || g.N < 64 || g.N % 4 != 0 || g.ldo % 4 != 0 || g.ldr % 4 != 0) return false;
-    if (g.mode != DN_EPI_GRADFEAT && g.mode != DN_EPI_GRADFEAT_BWD) return false;
-    int nsl = 0;
-    for (int s = 0; s < g.nseg; ++s) {
-        nsl += g.a[s].w / DN_KB;
-        if ((g.a[s].q != nullptr) != (g.mode == DN_EPI_GRADFEAT_BWD)) return false;
-    }
-    if (nsl < 5) return false;   // one deferred piece per slice must drain a parked unit: (nsl - 1) >= DN_WS2_NP
-    auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-    if (!g.r0 || !g.r1 || !al(g.o0) || !al(g.o1) || !al(g.o2) || !al(g.r0) || !al(g.r1) || !al(g.r2)) return false;
-    if (g.mode == DN_EPI_GRADFEAT_BWD && (!g.r2 || !g.o1)) return false;
-    if ((g.o1 == nullptr) != (g.o2 == nullptr) && g.mode == DN_EPI_GRADFEAT) return false;
-    return true;
 }
 
 template <int MODE, bool BCOLK, bool FLAG>
@@ -1018,7 +569,7 @@ static int pt_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
         for (int s = 0; s < g.nseg; ++s) nsl += g.a[s].w / DN_KB;
         // PPI = ceil(NP / (nsl - 1)) for the two slice counts that matter (K = 128: 4 slices, K = 384: 12)
         if (nsl >= 9) return ws_launch<MODE, BCOLK, FLAG, (DN_WS_NP + 7) / 8, false>(g, ntiles, stream);
-        if (DN_WS_BCACHE && DN_WS_DEPTH == 1 && nsl == 4 && g.nseg == 1 && g.b_mesh_stride == 0)
+        if (DN_WS_BCACHE && nsl == 4 && g.nseg == 1 && g.b_mesh_stride == 0)
             return ws_launch<MODE, BCOLK, FLAG, (DN_WS_NP + 2) / 3, true>(g, ntiles, stream);
         if (nsl >= 4) return ws_launch<MODE, BCOLK, FLAG, (DN_WS_NP + 2) / 3, false>(g, ntiles, stream);
     }
@@ -1027,7 +578,7 @@ static int pt_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
                            : (size_t)(2 * (DN_PT_ROWS * DN_KB + DN_KB * 128) + DN_PT_ROWS * 128) * sizeof(float);
 #ifndef DN_EMULATE
     static unsigned long long lds_opt_in = 0;   // per-device bitmap
-    dn_lds_opt_in(reinterpret_cast<const void*>(&rowgemm_persist_kernel<MODE, BCOLK, FLAG, X3>), smem, &lds_opt_in);
+    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&rowgemm_persist_kernel<MODE, BCOLK, FLAG, X3>), smem, &lds_opt_in); if (oe_) return oe_; }
 #endif
     const int upt = DN_TM / DN_PT_ROWS;
     int gx = upt * dn_num_cus();   // one 128-row workgroup per CU (two 64-row ones)
@@ -1075,11 +626,6 @@ bool dn_rowgemm_try_persistent(const RgArgs& g, int ntiles, int nout, hipStream_
     const bool ck = g.b_colk != 0;
     if (pt_eligible(g, nout)) {
         *err = pt_dispatch(g, ntiles, stream);
-        return true;
-    }
-    if (ws2_eligible(g, nout)) {
-        if (g.mode == DN_EPI_GRADFEAT) *err = ck ? ws2_launch<DN_EPI_GRADFEAT, true>(g, ntiles, stream) : ws2_launch<DN_EPI_GRADFEAT, false>(g, ntiles, stream);
-        else *err = ck ? ws2_launch<DN_EPI_GRADFEAT_BWD, true>(g, ntiles, stream) : ws2_launch<DN_EPI_GRADFEAT_BWD, false>(g, ntiles, stream);
         return true;
     }
     return false;

@@ -302,11 +302,9 @@ __device__ __forceinline__ void tx_compute(const unsigned char* sA, const unsign
     }
 }
 
-#ifndef DN_TX_SINGLE
-#define DN_TX_SINGLE 1   // measured: 60.1 vs 62.2 us (to_basis, 158k rows) against the double-buffered 1-WG/CU form
-#endif
+// single 60 KiB step buffer, two workgroups per CU (measured 60.1 vs 62.2 us against a double-buffered one-workgroup form)
 template <int FLAVOR>
-__global__ __launch_bounds__(DN_TX_THREADS, DN_TX_SINGLE ? 4 : 2) void tngemm_x3_kernel(TnArgs g) {
+__global__ __launch_bounds__(DN_TX_THREADS, 4) void tngemm_x3_kernel(TnArgs g) {
 
     constexpr int SBUF = 6 * DN_TX_PLANE;   // bytes of one (A,B) step buffer (3 planes each); two buffers in LDS
     DN_DYN_SMEM(smem_raw);
@@ -350,7 +348,6 @@ __global__ __launch_bounds__(DN_TX_THREADS, DN_TX_SINGLE ? 4 : 2) void tngemm_x3
     for (int ci = c_beg; ci < c_end; ++ci) {
         const DnTile ch = g.chunks[ci];
         const int nsteps = (ch.nrows + DN_KB - 1) / DN_KB;
-#if DN_TX_SINGLE
         // single 60 KiB step buffer, two barriers per step: two workgroups (16 waves) share a CU and cover each other's
         // staging phases and HBM latency
         tx_load<FLAVOR>(g, ch, 0, kr0, a_ok, b_ok, ap, aq, ald, bp, bld, R);
@@ -365,34 +362,6 @@ __global__ __launch_bounds__(DN_TX_THREADS, DN_TX_SINGLE ? 4 : 2) void tngemm_x3
                 __syncthreads();
             }
         }
-#else
-        tx_load<FLAVOR>(g, ch, 0, kr0, a_ok, b_ok, ap, aq, ald, bp, bld, R);
-        tx_store<FLAVOR>(smem, smem + 3 * DN_TX_PLANE, kr0, q, R, csum);
-        if (nsteps > 1) tx_load<FLAVOR>(g, ch, 1, kr0, a_ok, b_ok, ap, aq, ald, bp, bld, R);
-        __syncthreads();
-        int st = 0;
-        for (; st + 2 < nsteps; ++st) {
-            unsigned char* cur = smem + (st & 1) * SBUF;
-            unsigned char* nxt = smem + ((st & 1) ^ 1) * SBUF;
-            tx_store<FLAVOR>(nxt, nxt + 3 * DN_TX_PLANE, kr0, q, R, csum);
-            tx_load<FLAVOR>(g, ch, st + 2, kr0, a_ok, b_ok, ap, aq, ald, bp, bld, R);
-            tx_compute(cur, cur + 3 * DN_TX_PLANE, wr, wc, lane, acc);
-            __syncthreads();
-        }
-        if (st + 1 < nsteps) {
-            unsigned char* cur = smem + (st & 1) * SBUF;
-            unsigned char* nxt = smem + ((st & 1) ^ 1) * SBUF;
-            tx_store<FLAVOR>(nxt, nxt + 3 * DN_TX_PLANE, kr0, q, R, csum);
-            tx_compute(cur, cur + 3 * DN_TX_PLANE, wr, wc, lane, acc);
-            __syncthreads();
-            ++st;
-        }
-        {
-            unsigned char* cur = smem + (st & 1) * SBUF;
-            tx_compute(cur, cur + 3 * DN_TX_PLANE, wr, wc, lane, acc);
-            __syncthreads();   // the next chunk's prologue overwrites buffer 0
-        }
-#endif
     }
     float* out = g.partial + (long long)blockIdx.x * g.M * g.N;
     if (wave_active) {
@@ -420,10 +389,10 @@ __global__ __launch_bounds__(DN_TX_THREADS, DN_TX_SINGLE ? 4 : 2) void tngemm_x3
 
 template <int FLAVOR>
 static int tx_launch(const TnArgs& g, dim3 grid, hipStream_t stream) {
-    const size_t smem = (size_t)(DN_TX_SINGLE ? 1 : 2) * 6 * DN_TX_PLANE;   // 120 KiB (60 KiB single-buffered)
+    const size_t smem = (size_t)6 * DN_TX_PLANE;   // 60 KiB
 #ifndef DN_EMULATE
     static unsigned long long lds_opt_in = 0;   // per-device bitmap
-    dn_lds_opt_in(reinterpret_cast<const void*>(&tngemm_x3_kernel<FLAVOR>), smem, &lds_opt_in);
+    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&tngemm_x3_kernel<FLAVOR>), smem, &lds_opt_in); if (oe_) return oe_; }
 #endif
     DN_LAUNCH((tngemm_x3_kernel<FLAVOR>), grid, dim3(DN_TX_THREADS, 1, 1), smem, stream, g);
     return (int)hipGetLastError();

@@ -85,9 +85,9 @@ _SIGNATURES = {
     "dn_block_fwd_f32": (C.c_int, [_P(MeshBatchStruct), _P(BlockParamsStruct), _vp, _vp, _P(BlockSavedStruct), _vp, C.c_size_t, _vp]),
     "dn_block_bwd_f32": (C.c_int, [_P(MeshBatchStruct), _P(BlockParamsStruct), _vp, _P(BlockSavedStruct), _vp,
                                    _P(BlockGradsStruct), _vp, C.c_size_t, _vp]),
-    "dn_nll_workspace_bytes": (C.c_size_t, []),
-    "dn_nll_loss_fwd_f32": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, C.c_size_t, _vp]),
-    "dn_nll_loss_bwd_f32": (C.c_int, [_vp, C.c_int64, C.c_int, _vp, _vp, _vp]),
+    "dn_head_workspace_bytes": (C.c_size_t, []),
+    "dn_head_fwd_f32": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_float, C.c_int, _vp, C.c_float, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "dn_head_bwd_f32": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_float, C.c_int, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     "dn_hks_f32": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "dn_coo_to_csr_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "dn_coo_to_csr_i64": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int] + [_vp] * 7 + [_vp, C.c_size_t, _vp]),

@@ -268,6 +268,46 @@ class DiffusionNet(nn.Module):
             self.blocks.append(blk)
             self.add_module("block_" + str(i), blk)
 
+    def _activation_is_log_softmax(self):
+        """The scripts pass ``last_activation=lambda x: torch.nn.functional.log_softmax(x, dim=-1)`` (human_segmentation_original.py:75):
+        an opaque callable.  It is recognised by what it does to a probe tensor, once per module and activation object, so that the
+        per-face / per-vertex head can run as ONE kernel (gather-mean + log_softmax, dn_head.hip) instead of three."""
+        act = self.last_activation
+        if act is None:
+            return False
+        hit = getattr(self, "_lsm_probe", None)
+        if hit is None or hit[0] is not act:
+            g = torch.Generator().manual_seed(0)
+            probe = torch.randn(3, max(self.C_out, 2), generator=g) * 3.0
+            try:
+                with torch.no_grad():
+                    ok = bool(torch.equal(act(probe), torch.nn.functional.log_softmax(probe, dim=-1)))
+            except Exception:      # noqa: BLE001  (an activation that does not take a [3, C] tensor is simply not log_softmax)
+                ok = False
+            hit = (act, ok)
+            object.__setattr__(self, "_lsm_probe", hit)
+        return hit[1]
+
+    def forward_packed_loss(self, x2d, mb: MeshBatch, gather: Optional[GatherPattern], labels, smoothing: float = 0.0):
+        """``forward_packed`` followed by the mean NLL (or label-smoothed log loss) against ``labels`` with the whole head -- remap,
+        log_softmax, loss -- in one kernel each way.  Needs a log_softmax ``last_activation`` (as the segmentation scripts have) and
+        outputs at vertices, edges or faces.  Returns (log-probabilities, loss)."""
+        if not self._activation_is_log_softmax() or self.outputs_at == "global_mean":
+            preds = self.forward_packed(x2d, mb, gather)
+            from .utils import label_smoothing_log_loss, nll_loss
+            return preds, (nll_loss(preds, labels) if smoothing == 0.0 else label_smoothing_log_loss(preds, labels, smoothing))
+        x = self._trunk(x2d, mb)
+        return ops.HeadFn.apply(x, gather if self.outputs_at in ("edges", "faces") else None, labels, True, float(smoothing), True)
+
+    def _trunk(self, x2d, mb):
+        if x2d.shape[-1] != self.C_in:
+            raise ValueError("DiffusionNet was constructed with C_in={}, but x_in has last dim={}".format(
+                self.C_in, x2d.shape[-1]))
+        x = self.first_lin.apply_rows(x2d, mb)
+        for blk in self.blocks:
+            x = blk.forward_packed(x, mb)
+        return self.last_lin.apply_rows(x, mb)
+
     # ------------------------------------------------------------------ ragged-batch entry point
     def forward_packed(self, x2d, mb: MeshBatch, gather: Optional[GatherPattern] = None):
         """x2d: [v_total, C_in] features on the concatenated vertex axis of ``mb``.
@@ -275,13 +315,10 @@ class DiffusionNet(nn.Module):
         Returns [v_total, C_out] ('vertices'), [n_faces_or_edges_total, C_out] ('faces'/'edges',
         ``gather`` built from global vertex ids) or [n_mesh, C_out] ('global_mean'); the last
         activation is applied as in ``forward``."""
-        if x2d.shape[-1] != self.C_in:
-            raise ValueError("DiffusionNet was constructed with C_in={}, but x_in has last dim={}".format(
-                self.C_in, x2d.shape[-1]))
-        x = self.first_lin.apply_rows(x2d, mb)
-        for blk in self.blocks:
-            x = blk.forward_packed(x, mb)
-        x = self.last_lin.apply_rows(x, mb)
+        x = self._trunk(x2d, mb)
+        if self.outputs_at != "global_mean" and self._activation_is_log_softmax():
+            # remap + log_softmax as one kernel (the scripts' per-face / per-vertex log-probabilities)
+            return ops.HeadFn.apply(x, gather if self.outputs_at in ("edges", "faces") else None, None, True, 0.0, True)[0]
         if self.outputs_at in ("edges", "faces"):
             x = ops.GatherMeanFn.apply(x, gather)
         elif self.outputs_at == "global_mean":

@@ -461,34 +461,58 @@ class MassMeanFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------------------
-# loss on the far side of the path: F.nll_loss(log_probs, labels) (mean), human_segmentation_original.py:136
+# the head on the far side of the path (dn_head.hip): [gather-mean] -> [log_softmax] -> log-probabilities -> [NLL / smoothed loss]
 # ----------------------------------------------------------------------------------------------
-class NllLossFn(torch.autograd.Function):
-    @staticmethod
-    @_on_device
-    def forward(ctx, logp, labels):
-        _hip.require_device(logp)
-        L = _hip.lib()
-        logp = _f32c(logp)
-        if labels.dtype != torch.int64:
-            raise TypeError("labels must be int64")
-        labels = labels.contiguous()
-        n, Cc = logp.shape
-        loss = torch.empty((), dtype=torch.float32, device=logp.device)
-        ws = _hip.workspace(logp.device, L.dn_nll_workspace_bytes())
-        _hip.check(L.dn_nll_loss_fwd_f32(logp.data_ptr(), labels.data_ptr(), n, Cc, loss.data_ptr(), ws.data_ptr(), ws.numel(),
-                                         _hip.stream_of(logp)), "dn_nll_loss_fwd_f32")
-        ctx.save_for_backward(labels)
-        ctx.shape = (n, Cc)
-        return loss
+class HeadFn(torch.autograd.Function):
+    """forward(x, pat, labels, log_softmax, smoothing, want_logp) -> (logp or None, loss or None)
+
+    x: [n_src, C] logits (log-probabilities when ``log_softmax`` is False); pat: GatherPattern of the faces/edges remap or None
+    (output i = row i); labels: int64 [n_out] or None.  One kernel forward (+ a 1-block finish when there is a loss), one kernel
+    backward for any combination of incoming d_logp / d_loss."""
 
     @staticmethod
     @_on_device
-    def backward(ctx, d_loss):
-        (labels,) = ctx.saved_tensors
-        n, Cc = ctx.shape
-        d_loss = _f32c(d_loss)
-        d_logp = torch.empty(n, Cc, dtype=torch.float32, device=d_loss.device)
-        _hip.check(_hip.lib().dn_nll_loss_bwd_f32(labels.data_ptr(), n, Cc, d_loss.data_ptr(), d_logp.data_ptr(),
-                                                  _hip.stream_of(d_loss)), "dn_nll_loss_bwd_f32")
-        return d_logp, None
+    def forward(ctx, x, pat, labels, log_softmax, smoothing, want_logp):
+        _hip.require_device(x)
+        L = _hip.lib()
+        x = _f32c(x)
+        n_src, Cc = x.shape
+        n_out = pat.n_out if pat is not None else n_src
+        if labels is not None:
+            if labels.dtype != torch.int64:
+                raise TypeError("labels must be int64")
+            labels = labels.reshape(-1).contiguous()
+            if labels.numel() != n_out:
+                raise ValueError("expected %d labels, got %d" % (n_out, labels.numel()))
+        need_logp = want_logp or (log_softmax and ctx.needs_input_grad[0])   # the backward of log_softmax needs the probabilities
+        logp = torch.empty(n_out, Cc, dtype=torch.float32, device=x.device) if need_logp else None
+        loss = torch.empty((), dtype=torch.float32, device=x.device) if labels is not None else None
+        count = torch.empty((), dtype=torch.float32, device=x.device) if labels is not None else None
+        ws = _hip.workspace(x.device, L.dn_head_workspace_bytes())
+        _hip.check(L.dn_head_fwd_f32(x.data_ptr(), n_src, Cc, _hip.ptr(pat.rowptr) if pat is not None else None,
+                                     _hip.ptr(pat.col) if pat is not None else None, n_out, float(pat.n_per) if pat is not None else 1.0,
+                                     int(bool(log_softmax)), _hip.ptr(labels), float(smoothing), _hip.ptr(logp), _hip.ptr(loss), _hip.ptr(count),
+                                     ws.data_ptr(), ws.numel(), _hip.stream_of(x)), "dn_head_fwd_f32")
+        ctx.pat, ctx.lsm, ctx.smoothing, ctx.shape = pat, bool(log_softmax), float(smoothing), (n_src, n_out, Cc)
+        ctx.save_for_backward(*[t for t in (logp, labels, count) if t is not None])
+        ctx.has = (logp is not None, labels is not None)
+        return (logp if want_logp else None), loss
+
+    @staticmethod
+    @_on_device
+    def backward(ctx, d_logp, d_loss):
+        sav = list(ctx.saved_tensors)
+        logp = sav.pop(0) if ctx.has[0] else None
+        labels = sav.pop(0) if ctx.has[1] else None
+        count = sav.pop(0) if ctx.has[1] else None
+        n_src, n_out, Cc = ctx.shape
+        pat = ctx.pat
+        ref = d_logp if d_logp is not None else d_loss
+        d_x = torch.empty(n_src, Cc, dtype=torch.float32, device=ref.device)
+        d_logp = _f32c(d_logp) if d_logp is not None else None
+        d_loss = _f32c(d_loss) if d_loss is not None else None
+        _hip.check(_hip.lib().dn_head_bwd_f32(_hip.ptr(logp), n_out, Cc, _hip.ptr(pat.t_rowptr) if pat is not None else None,
+                                              _hip.ptr(pat.t_col) if pat is not None else None, n_src, float(pat.n_per) if pat is not None else 1.0,
+                                              int(ctx.lsm), _hip.ptr(labels) if d_loss is not None else None, ctx.smoothing, _hip.ptr(d_logp),
+                                              _hip.ptr(d_loss), _hip.ptr(count), d_x.data_ptr(), _hip.stream_of(ref)), "dn_head_bwd_f32")
+        return d_x, None, None, None, None, None

@@ -14,7 +14,8 @@
  *   - dense arrays are row-major contiguous fp32; index arrays int32; masks uint8 (1 = keep);
  *   - `ws` is caller-provided device scratch of at least the size the matching
  *     dn_*_workspace_bytes() reports; contents are undefined on return;
- *   - re-entrant: no mutable global state.
+ *   - re-entrant: no mutable global state on the compute path.  Two process-wide pieces of bookkeeping exist: the opt-in timing of
+ *     dn_prof_* (off by default) and a per-device "large-LDS attribute set" bitmap per kernel instantiation (set-once, idempotent).
  *
  * A "mesh batch" is a ragged batch of independent meshes whose vertex axes are concatenated:
  * mesh m owns rows [mesh_rows[m].row0, +nrows) of every [v_total, *] array; the sparse gradient
@@ -168,13 +169,21 @@ int dn_mass_mean_fwd_f32(const dn_mesh_batch_t* mb, const float* x, int C, float
 int dn_mass_mean_bwd_f32(const dn_mesh_batch_t* mb, const float* mass_sum, const float* d_out, int C, float* d_x,
                          void* stream);
 
-/* ---- F.nll_loss(log_probs, labels) with mean reduction -- the loss the experiment scripts apply to the path's output
- *      (human_segmentation_original.py:136, rna_mesh_segmentation.py:135).  labels int64 (as torch holds them);
- *      loss: 1 float.  bwd: d_logp[i,c] = -(d_loss / n) * [c == labels[i]]. */
-size_t dn_nll_workspace_bytes(void);
-int dn_nll_loss_fwd_f32(const float* logp, const int64_t* labels, int64_t n, int C, float* loss, void* ws, size_t ws_bytes,
-                        void* stream);
-int dn_nll_loss_bwd_f32(const int64_t* labels, int64_t n, int C, const float* d_loss, float* d_logp, void* stream);
+/* ---- the head on the far side of the path, one pass each way (dn_head.hip): [gather-mean of the 2/3 vertices of an edge/face,
+ *      layers.py:379-391] -> [log_softmax, the scripts' last_activation, human_segmentation_original.py:75] -> log-probabilities ->
+ *      [NLL, F.nll_loss at human_segmentation_original.py:136 / rna_mesh_segmentation.py:135, or with smoothing > 0 the label-smoothed
+ *      log loss of utils.py:18-24; mean over the rows whose label lies in [0, C) -- others (ignore_index) neither contribute nor count].
+ *      Every bracketed stage is optional: rowptr = NULL: output i = row i (n_out == n_src); log_softmax = 0: x already holds
+ *      log-probabilities; labels = NULL: no loss; logp = NULL: log-probabilities not written.  div: entries per output (3 faces, 2 edges).
+ *      loss / count: device scalars (count = number of valid rows, needed by the backward).
+ *      bwd: d_x[v] = sum_{i gathered v} (1/div) (dlp_i - [log_softmax] exp(logp_i) sum_c dlp_i[c]),
+ *           dlp_i = d_logp_i (optional) - d_loss/count * smoothed-one-hot(label_i) (optional); t_rowptr/t_col: transposed gather. */
+size_t dn_head_workspace_bytes(void);
+int dn_head_fwd_f32(const float* x, int n_src, int C, const int32_t* rowptr, const int32_t* col, int n_out, float div, int log_softmax,
+                    const int64_t* labels, float smoothing, float* logp, float* loss, float* count, void* ws, size_t ws_bytes, void* stream);
+int dn_head_bwd_f32(const float* logp, int n_out, int C, const int32_t* t_rowptr, const int32_t* t_col, int n_src, float div, int log_softmax,
+                    const int64_t* labels, float smoothing, const float* d_logp, const float* d_loss, const float* count, float* d_x,
+                    void* stream);
 
 /* ---- geometry.compute_hks (geometry.py:600-628; compute_hks_autoscale :630-633 passes scales = logspace(-2, 0, S)):
  *      out[b][v][s] = sum_k exp(-evals[b][k] * scales[.][s]) * evecs[b][v][k]^2.  evals [B,K], evecs [B,V,K], out [B,V,S];

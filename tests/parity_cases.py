@@ -406,6 +406,92 @@ def run_nll(device, n=1234, C=8, seed=0):
     assert helpers.rel_l2(a.grad.cpu(), b.grad) < 1e-5
 
 
+def run_head(device, V=700, C=8, seed=0, smoothing=0.0, outputs="faces"):
+    """The fused head (dn_head.hip) against torch: gather-mean + log_softmax + NLL / label-smoothed loss, forward values and the
+    gradient w.r.t. the vertex logits for (a) loss only, (b) log-probabilities used downstream only, (c) both; ignored labels."""
+    from diffusion_net import utils
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(V, C, generator=g) * 2.0
+    if outputs == "faces":
+        faces = torch.randint(0, V, (2 * V, 3), generator=g)
+        pat = GatherPattern(faces.to(device), V)
+        remap = lambda t: t[faces].mean(dim=1)
+        n_out = 2 * V
+    else:
+        pat, remap, n_out = None, (lambda t: t), V
+    labels = torch.randint(0, C, (n_out,), generator=g)
+    labels[::7] = -100                                           # torch's default ignore_index
+    w = torch.randn(n_out, C, generator=g)
+
+    def ref_loss(lp):
+        if smoothing == 0.0:
+            return torch.nn.functional.nll_loss(lp, labels)
+        keep = labels >= 0
+        oh = torch.zeros_like(lp[keep]).scatter_(-1, labels[keep][:, None], 1.0)
+        oh = oh * (1 - smoothing) + (1 - oh) * smoothing / (C - 1)
+        return -(oh * lp[keep]).sum(-1).mean()
+    for use_loss, use_lp in ((True, False), (False, True), (True, True)):
+        a = x.clone().to(device).requires_grad_(True)
+        lp, loss = ops.HeadFn.apply(a, pat, labels.to(device) if use_loss else None, True, smoothing, True)
+        b = x.clone().requires_grad_(True)
+        rlp = torch.log_softmax(remap(b), -1)
+        tot, rtot = 0.0, 0.0
+        if use_loss:
+            rl = ref_loss(rlp)
+            assert abs(float(loss) - float(rl)) < 1e-5 * max(1.0, abs(float(rl))), (float(loss), float(rl))
+            tot, rtot = tot + 1.7 * loss, rtot + 1.7 * rl
+        if use_lp:
+            tot, rtot = tot + (lp * w.to(device)).sum(), rtot + (rlp * w).sum()
+        assert helpers.rel_max(lp.detach().cpu(), rlp.detach()) < 1e-5
+        tot.backward()
+        rtot.backward()
+        assert helpers.rel_l2(a.grad.cpu(), b.grad) < 1e-5, (use_loss, use_lp, helpers.rel_l2(a.grad.cpu(), b.grad))
+    # plain F.nll_loss drop-in on given log-probabilities, with ignored rows
+    lp0 = torch.log_softmax(torch.randn(n_out, C, generator=g), -1)
+    a = lp0.clone().to(device).requires_grad_(True)
+    l = utils.nll_loss(a, labels.to(device))
+    l.backward()
+    b = lp0.clone().requires_grad_(True)
+    rl = torch.nn.functional.nll_loss(b, labels)
+    rl.backward()
+    assert abs(float(l) - float(rl)) < 1e-5 * max(1.0, abs(float(rl))) and helpers.rel_l2(a.grad.cpu(), b.grad) < 1e-6
+
+
+def run_head_in_net(device, sizes=(300, 140), K=16, C=32, C_out=8, seed=5, outputs_at="faces"):
+    """DiffusionNet.forward_packed_loss (remap + log_softmax + NLL in one kernel each way) against the unfused sequence
+    forward_packed -> F.nll_loss on the same network: same log-probabilities, same loss, same parameter gradients."""
+    lsm = lambda t: torch.nn.functional.log_softmax(t, dim=-1)
+    meshes, feats = make_ragged(sizes, K, 3, seed)
+    mb = pack(meshes, device)
+    gather = None
+    if outputs_at == "faces":
+        offs, rows = 0, []
+        for m, v in zip(meshes, sizes):
+            rows.append(m["faces"] + offs)
+            offs += v
+        gather = GatherPattern(torch.cat(rows, 0).to(device), sum(sizes))
+    n_out = gather.n_out if gather is not None else sum(sizes)
+    labels = torch.randint(0, C_out, (n_out,), generator=torch.Generator().manual_seed(seed)).to(device)
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(seed)
+        model = diffusion_net.layers.DiffusionNet(3, C_out, C_width=C, N_block=1, outputs_at=outputs_at, dropout=False,
+                                                  last_activation=lsm if fused else None).to(device)
+        model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=seed))
+        x = torch.cat(feats, 0).to(device)
+        if fused:
+            assert model._activation_is_log_softmax()
+            preds, loss = model.forward_packed_loss(x, mb, gather, labels)
+        else:
+            preds = torch.log_softmax(model.forward_packed(x, mb, gather), -1)
+            loss = torch.nn.functional.nll_loss(preds, labels)
+        loss.backward()
+        res.append((preds.detach().cpu(), float(loss), [p.grad.cpu() for p in model.parameters()]))
+    assert helpers.rel_max(res[0][0], res[1][0]) < 1e-5 and abs(res[0][1] - res[1][1]) < 1e-5 * max(1.0, abs(res[1][1]))
+    for ga, gb in zip(res[0][2], res[1][2]):
+        assert helpers.rel_l2(ga, gb) < 1e-4
+
+
 def run_real_mesh_pipeline(device, V=400, K=16, C=32, seed=0):
     """End to end on a real triangle mesh: host precompute (diffusion_net.geometry.get_operators) -> reference-signature
     forward/backward on the HIP path vs the oracle on the same operators."""

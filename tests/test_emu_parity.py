@@ -66,6 +66,15 @@ def test_nll_loss_on_emulator(emu):
     parity_cases.run_nll(emu, n=70000, C=3, seed=1)
 
 
+def test_fused_head_on_emulator(emu):
+    import parity_cases
+    parity_cases.run_head(emu)
+    parity_cases.run_head(emu, V=90, C=260, seed=1, outputs="vertices")          # RNA-like wide head: 5 classes per lane
+    parity_cases.run_head(emu, V=120, C=30, seed=2, smoothing=0.2, outputs="vertices")
+    parity_cases.run_head_in_net(emu)
+    parity_cases.run_head_in_net(emu, outputs_at="vertices", C_out=5)
+
+
 def test_real_mesh_pipeline_on_emulator(emu):
     import parity_cases
     parity_cases.run_real_mesh_pipeline(emu)

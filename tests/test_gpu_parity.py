@@ -68,6 +68,16 @@ def test_nll_loss(dev):
     parity_cases.run_nll(dev, n=5000, C=260, seed=2)
 
 
+def test_fused_head(dev):
+    import parity_cases
+    parity_cases.run_head(dev, V=20000, C=8)
+    parity_cases.run_head(dev, V=5000, C=260, seed=1, outputs="vertices")
+    parity_cases.run_head(dev, V=3000, C=30, seed=2, smoothing=0.2, outputs="vertices")
+    parity_cases.run_head(dev, V=4000, C=8, seed=3, smoothing=0.1)
+    parity_cases.run_head_in_net(dev, sizes=(3000, 1400), K=64, C=128)
+    parity_cases.run_head_in_net(dev, sizes=(1500, 1100), K=64, C=128, C_out=260, outputs_at="vertices")
+
+
 def test_real_mesh_pipeline(dev):
     import parity_cases
     parity_cases.run_real_mesh_pipeline(dev, V=3000, K=64, C=128)
