@@ -189,6 +189,25 @@ int main(int argc, char** argv) {
         double byts = 0; for (int s : sizes) byts += 4.0 * ((double)s * (2 * C + 2 * K + 1) + 2.0 * K * C + K + C);
         double us = timeit("diffusion", byts, 4.0 * V * K * C, [&](int it) { DC(f(&mb, xr[it % NROT], tm, C, sv.xs, o0r[it % NROT], ws, wsb, st)); });
         printf("  frac_hbm_8TBs %.3f", byts / us / 1e3 / 8000.0);
+        if (check) {   // meshes 0 and last: fp64 spectrum on the host, then sampled rows of x_diffuse and sampled entries of xs
+            auto got = host(o0r[0], (size_t)V * C), gxs = host(sv.xs, (size_t)n_mesh * K * C);
+            double err = 0, ref = 0, errs = 0, refs = 0;
+            for (int m : {0, n_mesh - 1}) {
+                std::vector<double> sp((size_t)K * C, 0.0);
+                for (int r = mrows[m].row0; r < mrows[m].row0 + mrows[m].nrows; ++r)
+                    for (int k = 0; k < K; ++k) { const double w = (double)evecs[(size_t)r * K + k] * mass[r]; const float* xr = &hx[(size_t)r * C]; double* sk = &sp[(size_t)k * C];
+                        for (int c = 0; c < C; ++c) sk[c] += w * xr[c]; }
+                for (int k : {0, 5, K - 1}) for (int c : {0, 77, C - 1}) { errs = std::max(errs, fabs(sp[(size_t)k * C + c] - gxs[((size_t)m * K + k) * C + c])); refs = std::max(refs, fabs(sp[(size_t)k * C + c])); }
+                for (int k = 0; k < K; ++k) for (int c = 0; c < C; ++c) sp[(size_t)k * C + c] *= exp(-(double)evals[(size_t)m * K + k] * htime[c]);
+                for (int i = 0; i < 40; ++i) { const long long r = mrows[m].row0 + (long long)(i * 997 % mrows[m].nrows);
+                    for (int c = 0; c < C; ++c) { double s2 = 0; for (int k = 0; k < K; ++k) s2 += (double)evecs[(size_t)r * K + k] * sp[(size_t)k * C + c];
+                        err = std::max(err, fabs(s2 - got[(size_t)r * C + c])); ref = std::max(ref, fabs(s2)); } }
+                const long long rl = mrows[m].row0 + mrows[m].nrows - 1;   // last row of the mesh (ragged end)
+                for (int c = 0; c < C; ++c) { double s2 = 0; for (int k = 0; k < K; ++k) s2 += (double)evecs[(size_t)rl * K + k] * sp[(size_t)k * C + c];
+                    err = std::max(err, fabs(s2 - got[(size_t)rl * C + c])); ref = std::max(ref, fabs(s2)); }
+            }
+            report(errs, refs); report(err, ref);
+        }
         endl_();
     }
     if (want("diffusion_bwd")) {
