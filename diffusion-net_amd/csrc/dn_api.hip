@@ -156,7 +156,7 @@ int gradfeat_bwd_weights(const dn_mesh_batch_t* mb, const float* ddots, const fl
 // y = act(sum_s x_s W[:, off_s:off_s+w_s]^T + b)
 int linear_fwd(const dn_mesh_batch_t* mb, const float* const* xs, const int* ws_, int nseg, const float* W, int ldw,
                const float* b, int C_out, int mode, const uint8_t* mask, const float* resid, float* out, hipStream_t st,
-               unsigned long long rng_seed = 0) {
+               unsigned long long rng_seed = 0, const unsigned long long* rng_seed_dev = nullptr) {
     RgArgs g = rg_new(mb);
     int off = 0;
     for (int s = 0; s < nseg; ++s) {
@@ -165,7 +165,7 @@ int linear_fwd(const dn_mesh_batch_t* mb, const float* const* xs, const int* ws_
         off += ws_[s];
     }
     g.ldb = ldw; g.b_colk = 1; g.N = C_out;
-    g.mode = mode; g.bias = b; g.mask = mask; g.rng_seed = mask ? 0ull : rng_seed; g.scale = (mask || rng_seed) ? 2.f : 1.f; g.r0 = resid; g.ldr = C_out;
+    g.mode = mode; g.bias = b; g.mask = mask; g.rng_seed = mask ? 0ull : rng_seed; g.rng_seed_dev = rng_seed_dev; g.scale = (mask || rng_seed) ? 2.f : 1.f; g.r0 = resid; g.ldr = C_out;
     g.o0 = out; g.ldo = C_out;
     rg_finish(g, 1);
     return dn_launch_rowgemm(g, mb->n_tiles, 1, st);
@@ -480,7 +480,7 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
         float* dst = last ? out : (sv ? sv->h[j] : hbuf[j & 1]);
         DN_CHECK(linear_fwd(mb, in_ptr, in_w, nseg, p->W[j], p->widths[j], p->b[j], p->widths[j + 1],
                             last ? DN_EPI_BIAS_RESID : DN_EPI_BIAS_RELU, last ? nullptr : p->mask[j + 1],
-                            last ? x : nullptr, dst, st, last ? 0ull : layer_seed(p->drop_seed, j + 1)));
+                            last ? x : nullptr, dst, st, last ? 0ull : layer_seed(p->drop_seed, j + 1), (const unsigned long long*)p->drop_seed_dev));
         in_ptr[0] = dst; in_w[0] = p->widths[j + 1]; nseg = 1;
     }
     return 0;

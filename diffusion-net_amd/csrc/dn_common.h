@@ -194,6 +194,7 @@ struct RgArgs {
     const float* rowv;
     const uint8_t* mask;
     unsigned long long rng_seed;   // != 0 with mask == null: Bernoulli(1/2) keep bits drawn in the epilogue (dn_keep_bits)
+    const unsigned long long* rng_seed_dev;   // optional device word added to rng_seed by the kernel (a captured graph advances it per replay)
     float scale;
     int acct_rows;         // rows covered by the launch (= v_total of the mesh batch)
 };

@@ -32,6 +32,7 @@ constexpr bool rg_is_x3(int TN, int NTHR, int NOUT, bool ALIGNED) { return DN_RG
 template <int TN, int WR, int WC, int NOUT, int MODE, bool ALIGNED, bool BCOLK>
 __global__ __launch_bounds__(WR* WC * 64) DN_MIN_WAVES_PER_EU(1)
 void rowgemm_kernel(RgArgs g) {
+    if (g.rng_seed && g.rng_seed_dev) g.rng_seed += *g.rng_seed_dev;   // g is this kernel's own copy of the arguments
 
     constexpr int NTHR = WR * WC * 64;
     constexpr int MT = DN_TM / (32 * WR);

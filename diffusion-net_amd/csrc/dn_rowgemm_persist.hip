@@ -61,6 +61,7 @@ __device__ __forceinline__ void pt_piece_load(const RgArgs& g, const float* sE, 
 
 template <int MODE, bool BCOLK, bool FLAG, bool X3>
 __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_persist_kernel(RgArgs g, int ntiles) {
+    if (g.rng_seed && g.rng_seed_dev) g.rng_seed += *g.rng_seed_dev;   // g is this kernel's own copy of the arguments
 
     constexpr int TN = 128, WR = DN_PT_ROWS / 64, WC = 4, NOUT = 1, NTHR = DN_PT_THREADS, TMU = DN_PT_ROWS;
     constexpr int UPT = DN_TM / TMU;                 // work units per 128-row tile (1 or 2)
@@ -350,6 +351,7 @@ __device__ __forceinline__ void ws_load(const float* ap, int ald, const float* b
 // plane dwords in registers -- the per-slice B work shrinks from 2 loads + 44 VALU + 6 LDS writes to the 6 LDS writes.
 template <int MODE, bool BCOLK, bool FLAG, int PPI, bool BC>
 __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2 : 3) void rowgemm_ws_kernel(RgArgs g, int ntiles) {
+    if (g.rng_seed && g.rng_seed_dev) g.rng_seed += *g.rng_seed_dev;   // g is this kernel's own copy of the arguments
 
     constexpr int TN = 128, NOUT = 1, LTHR = DN_WS_LTHR;
     constexpr int A_IT = DN_TM * 8 / LTHR;            // 4 float4 of the A slice per loader thread

@@ -39,7 +39,7 @@ class BlockParamsStruct(C.Structure):
         ("C", C.c_int32), ("n_mlp", C.c_int32), ("with_grad", C.c_int32), ("with_rot", C.c_int32),
         ("widths", C.c_int32 * (MAX_MLP + 1)),
         ("time", _vp), ("A_re", _vp), ("A_im", _vp),
-        ("W", _vp * MAX_MLP), ("b", _vp * MAX_MLP), ("mask", _vp * MAX_MLP), ("drop_seed", C.c_uint64),
+        ("W", _vp * MAX_MLP), ("b", _vp * MAX_MLP), ("mask", _vp * MAX_MLP), ("drop_seed", C.c_uint64), ("drop_seed_dev", _vp),
     ]
 
 

@@ -1,0 +1,75 @@
+"""HIP-graph capture of the training step for the launch-bound regime.
+
+A DiffusionNet step is ~150 kernel launches.  At 160k vertices per step the GPU is the bottleneck and that is invisible; at the
+sizes of the reference's own experiments (one ~7k-vertex mesh per step; 64 x ~2k-vertex meshes) the host cannot enqueue them as fast
+as the GPU retires them.  ``GraphedTrainStep`` captures forward + loss + backward + optimizer update of ONE packed batch into a HIP
+graph (``torch.cuda.CUDAGraph``: the library's launches are plain stream work -- no allocation, no synchronisation -- so they capture
+like torch's own kernels) and replays it: one host call per step.
+
+What makes the step capturable:
+  * dropout masks are drawn inside the kernels from a seed; under capture the seed's varying part lives in a DEVICE word
+    (``dn_block_params_t.drop_seed_dev``) that the graph itself advances with its first node, so every replay draws fresh masks;
+  * the parameters live in ``dist.FlatParams`` (one buffer, gradients delivered by the ops straight into it), the optimizer is torch's
+    Adam with ``capturable=True``;
+  * inputs are static buffers owned by the object: ``step(x=..., labels=...)`` copies new values in before the replay.
+Single-GPU (the gradient all-reduce is not captured).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .batch import GatherPattern, MeshBatch
+from .dist import FlatParams
+
+_GOLDEN = 0x9E3779B97F4A7C15
+
+
+class GraphedTrainStep:
+    def __init__(self, model, flat: FlatParams, opt: torch.optim.Optimizer, mb: MeshBatch, gather: Optional[GatherPattern], x: torch.Tensor,
+                 labels: torch.Tensor, smoothing: float = 0.0, warmup: int = 3):
+        dev = x.device
+        if dev.type != "cuda":
+            raise RuntimeError("graph capture needs a ROCm device")
+        self.model, self.flat, self.opt, self.mb, self.gather, self.smoothing = model, flat, opt, mb, gather, float(smoothing)
+        self.x = x.detach().clone()
+        self.labels = labels.detach().clone()
+        # dropout: constant host part per block + one device word advanced by the graph
+        self.seed = torch.zeros(1, dtype=torch.int64, device=dev)
+        for bi, blk in enumerate(model.blocks):
+            blk._graph_seed = ((0x1234567 + 0x51ED27 * (bi + 1)) | 1, self.seed)
+        step = _GOLDEN - (1 << 64)                 # the 64-bit increment as a signed value
+        self._advance = lambda: self.seed.add_(step)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):              # eager warm-up on a side stream (allocator, per-device kernel attributes)
+            for _ in range(warmup):
+                self._body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.preds = self._body()
+        torch.cuda.synchronize(dev)
+
+    def _body(self):
+        self._advance()
+        self.flat.zero_grad()
+        preds, loss = self.model.forward_packed_loss(self.x, self.mb, self.gather, self.labels, self.smoothing)
+        loss.backward()
+        self.opt.step()
+        return loss, preds
+
+    def release(self):
+        for blk in self.model.blocks:
+            blk._graph_seed = None
+
+    def step(self, x: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None):
+        """One optimizer step.  Returns the (static) loss tensor of this replay; ``self.preds`` holds the log-probabilities."""
+        if x is not None:
+            self.x.copy_(x, non_blocking=True)
+        if labels is not None:
+            self.labels.copy_(labels, non_blocking=True)
+        self.graph.replay()
+        return self.loss

@@ -179,6 +179,9 @@ class DiffusionNetBlock(nn.Module):
         if not (self.training and self.dropout):
             return None
         if self.mask_provider is None:
+            gs = getattr(self, "_graph_seed", None)
+            if gs is not None:           # graphs.GraphedTrainStep: (constant host part, device word advanced by the graph itself)
+                return gs
             if self.drop_seed_provider is not None:
                 return int(self.drop_seed_provider())
             seed = int(torch.randint(1, 2 ** 62, (1,), dtype=torch.int64).item())

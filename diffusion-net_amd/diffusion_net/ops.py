@@ -287,8 +287,12 @@ def _params_struct(cfg: BlockConfig, time, A_re, A_im, Ws, bs, masks):
     for i, w in enumerate(cfg.widths):
         p.widths[i] = w
     p.time, p.A_re, p.A_im = time.data_ptr(), _hip.ptr(A_re), _hip.ptr(A_im)
+    dev_seed = None
+    if isinstance(masks, tuple):      # (host seed, device seed word): in-kernel dropout under a captured graph
+        masks, dev_seed = masks
     seeded = isinstance(masks, int)   # in-kernel dropout: `masks` is the 64-bit seed
     p.drop_seed = masks if seeded else 0
+    p.drop_seed_dev = dev_seed.data_ptr() if dev_seed is not None else None
     for i in range(cfg.n_mlp):
         p.W[i], p.b[i] = Ws[i].data_ptr(), bs[i].data_ptr()
         p.mask[i] = _hip.ptr(masks[i]) if (masks is not None and not seeded) else None

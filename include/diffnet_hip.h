@@ -66,6 +66,8 @@ typedef struct dn_block_params {
                                               producing kernel's epilogue, keep = bit of hash(drop_seed, i, row, column): no mask
                                               tensor is written or read (the backward needs none: a saved activation is > 0
                                               exactly where it was kept and active).  0 = no dropout where mask[i] == NULL. */
+    const uint64_t* drop_seed_dev;         /* optional DEVICE word added to drop_seed inside the kernels: a captured HIP graph of the training
+                                              step advances it with a graph node, so that every replay draws new masks without host work */
 } dn_block_params_t;
 
 /* Activations the forward saves for the backward (caller-allocated). */

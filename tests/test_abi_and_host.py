@@ -41,7 +41,7 @@ def test_struct_layouts_match_header():
     from diffusion_net import _hip
     P = ctypes.sizeof(ctypes.c_void_p)
     assert ctypes.sizeof(_hip.MeshBatchStruct) == 6 * 4 + 15 * P
-    assert ctypes.sizeof(_hip.BlockParamsStruct) == (4 + 9) * 4 + 4 + (3 + 3 * 8) * P + 8   # 4 B padding before the pointers, uint64 drop_seed last
+    assert ctypes.sizeof(_hip.BlockParamsStruct) == (4 + 9) * 4 + 4 + (3 + 3 * 8) * P + 8 + P   # 4 B padding before the pointers, uint64 drop_seed, then the device seed pointer
     assert ctypes.sizeof(_hip.BlockSavedStruct) == (7 + 8) * P
     assert ctypes.sizeof(_hip.BlockGradsStruct) == (4 + 16) * P
     assert _hip.TILE_DTYPE.itemsize == 16

@@ -156,6 +156,61 @@ def test_rccl_bucketed_all_reduce_world_size_one(dev):
         dist.destroy_process_group()
 
 
+def test_graph_captured_train_step(dev):
+    """diffusion_net.graphs.GraphedTrainStep: forward + loss + backward + Adam replayed from a captured HIP graph must follow the
+    eager path step for step (dropout off: identical arithmetic), and with dropout on every replay must draw new masks from the
+    device-side seed word."""
+    import diffusion_net
+    import parity_cases
+    from diffusion_net import synthetic
+    from diffusion_net.batch import GatherPattern
+    from diffusion_net.dist import FlatParams
+    from diffusion_net.graphs import GraphedTrainStep
+    lsm = lambda t: torch.nn.functional.log_softmax(t, dim=-1)
+    meshes, feats = parity_cases.make_ragged((1500, 900), 64, 3, seed=2)
+    mb = parity_cases.pack(meshes, dev)
+    offs, rows = 0, []
+    for m, v in zip(meshes, (1500, 900)):
+        rows.append(m["faces"] + offs)
+        offs += v
+    gather = GatherPattern(torch.cat(rows, 0).to(dev), 2400)
+    x = torch.cat(feats, 0).to(dev)
+    labels = torch.randint(0, 8, (gather.n_out,), generator=torch.Generator().manual_seed(0)).to(dev)
+    runs = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(4)
+        model = diffusion_net.layers.DiffusionNet(3, 8, C_width=128, N_block=2, outputs_at="faces", dropout=False, last_activation=lsm)
+        model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=4))
+        model.to(dev).train()
+        flat = FlatParams(model)
+        opt = torch.optim.Adam([flat.master], lr=1e-3, capturable=True)
+        losses = []
+        if mode == "graph":
+            gs = GraphedTrainStep(model, flat, opt, mb, gather, x, labels, warmup=0)
+            for _ in range(4):
+                losses.append(float(gs.step()))
+            gs.release()
+        else:
+            for _ in range(5):           # the capture itself executes nothing, but the graph object ran no warm-up: same number of updates
+                flat.zero_grad()
+                _, loss = model.forward_packed_loss(x, mb, gather, labels)
+                loss.backward()
+                opt.step()
+                losses.append(float(loss))
+            losses = losses[:4]
+        runs[mode] = (losses, flat.flat.detach().cpu().clone())
+    assert runs["eager"][0] == runs["graph"][0], (runs["eager"][0], runs["graph"][0])
+    # dropout on: successive replays see different masks (the loss of an unchanged model would repeat exactly otherwise)
+    torch.manual_seed(4)
+    model = diffusion_net.layers.DiffusionNet(3, 8, C_width=128, N_block=2, outputs_at="faces", dropout=True, last_activation=lsm).to(dev).train()
+    flat = FlatParams(model)
+    opt = torch.optim.Adam([flat.master], lr=0.0, capturable=True)     # frozen weights: only the masks change between replays
+    gs = GraphedTrainStep(model, flat, opt, mb, gather, x, labels)
+    vals = [float(gs.step()) for _ in range(4)]
+    assert len(set(vals)) == 4, vals
+    gs.release()
+
+
 def test_run_to_run_determinism_stress(dev):
     """Every op of the block, repeated on identical inputs at a multi-mesh 128-wide shape, must be bitwise identical every
     time (tools/determinism_stress.py; this is the test that exposes stale-register / packed-op hazards that stay far
