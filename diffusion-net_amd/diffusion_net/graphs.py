@@ -32,6 +32,8 @@ class GraphedTrainStep:
         dev = x.device
         if dev.type != "cuda":
             raise RuntimeError("graph capture needs a ROCm device")
+        if warmup < 1:
+            raise ValueError("at least one eager warm-up step is needed: it creates the optimizer state the captured update works on")
         self.model, self.flat, self.opt, self.mb, self.gather, self.smoothing = model, flat, opt, mb, gather, float(smoothing)
         self.x = x.detach().clone()
         self.labels = labels.detach().clone()

@@ -186,18 +186,18 @@ def test_graph_captured_train_step(dev):
         opt = torch.optim.Adam([flat.master], lr=1e-3, capturable=True)
         losses = []
         if mode == "graph":
-            gs = GraphedTrainStep(model, flat, opt, mb, gather, x, labels, warmup=0)
+            gs = GraphedTrainStep(model, flat, opt, mb, gather, x, labels, warmup=1)   # one eager update (creates the Adam state), then capture
             for _ in range(4):
                 losses.append(float(gs.step()))
             gs.release()
         else:
-            for _ in range(5):           # the capture itself executes nothing, but the graph object ran no warm-up: same number of updates
+            for _ in range(5):           # the same five updates eagerly; the graph's replays are updates 2..5
                 flat.zero_grad()
                 _, loss = model.forward_packed_loss(x, mb, gather, labels)
                 loss.backward()
                 opt.step()
                 losses.append(float(loss))
-            losses = losses[:4]
+            losses = losses[1:]
         runs[mode] = (losses, flat.flat.detach().cpu().clone())
     assert runs["eager"][0] == runs["graph"][0], (runs["eager"][0], runs["graph"][0])
     # dropout on: successive replays see different masks (the loss of an unchanged model would repeat exactly otherwise)
