@@ -318,7 +318,9 @@ def main():
     ap.add_argument("--blocks", type=int, default=4)
     ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch into this many sub-batches run on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="cfg2/cfg3: replay a captured HIP graph of the step (diffusion_net.graphs) instead of enqueueing ~150 launches per step")
+    ap.add_argument("--graph", action="store_true", help="cfg2/cfg3: replay a captured HIP graph of the step (diffusion_net.graphs) instead of enqueueing ~150 launches per step "
+                                                         "(the headline step is replayed from a graph by default; see --eager)")
+    ap.add_argument("--eager", action="store_true", help="headline: enqueue the ~190 launches of every step from the host instead of replaying the captured HIP graph")
     ap.add_argument("--config", default="headline", choices=["headline", "cfg2", "cfg3", "cfg4"],
                     help="headline: BASELINE metric workload (default, what the driver runs); cfg2/cfg3/cfg4: the other BASELINE.json configs, same JSON contract")
     args = ap.parse_args()
@@ -382,7 +384,38 @@ def main():
     v_step = sum(sizes)
     streams = [torch.cuda.Stream(device) for _ in range(nsub)] if nsub > 1 else [None]
 
+    gs, step_mode = None, "eager launches"
+    if not args.eager and nsub == 1:
+        # the whole step (zero grads + fwd + loss + bwd [+ bucketed RCCL all-reduce] + Adam) captured once into a HIP graph and replayed:
+        # one host call per step instead of ~190 launches (the host cannot enqueue them as fast as the GPU retires them)
+        from diffusion_net.graphs import GraphedTrainStep
+        ok, why = 1, ""
+        try:
+            try:
+                opt_g = torch.optim.Adam([flat.master], lr=1e-3, capturable=True, fused=True)
+            except (TypeError, RuntimeError):
+                opt_g = torch.optim.Adam([flat.master], lr=1e-3, capturable=True)
+            mb_j, gather_j, x_j, labels_j, _ = subs[0]
+            gs = GraphedTrainStep(model, flat, opt_g, mb_j, gather_j, x_j, labels_j, all_reduce=world > 1)
+            torch.cuda.synchronize()
+        except Exception as e:                 # never silently: the mode is reported in the bench line
+            ok, why = 0, repr(e)[:200]
+        if world > 1:                          # all ranks replay, or none does
+            t = torch.tensor([ok], device=device, dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = int(t.item())
+        if ok:
+            opt, step_mode = opt_g, "HIP-graph replay"
+        else:
+            if gs is not None:
+                gs.release()
+            for blk in model.blocks:
+                blk._graph_seed = None
+            gs, step_mode = None, "eager launches (graph capture failed: %s)" % why
+
     def step():
+        if gs is not None:
+            return gs.step()
         flat.zero_grad()
         if nsub == 1:
             mb_j, gather_j, x_j, labels_j, _ = subs[0]
@@ -434,7 +467,18 @@ def main():
         v_all = float(v_step)
     assert torch.isfinite(loss).item()
 
+    if gs is not None:      # the library's per-launch event brackets are host-side: time the same launches in a short eager pass
+        lib.dn_prof_reset()
+        lib.dn_prof_enable(1)
+        for _ in range(min(args.steps, 5)):
+            gs._body()
+        fence()
+        lib.dn_prof_enable(0)
     fam, roof = kernel_family_report(lib)
+    if roof is not None:
+        roof["timing"] = ("HIP events around every launch of %d eager steps run right after the timed graph replays (the event brackets are "
+                          "host-side; a replayed graph bypasses them); profiles/ holds the rocprofv3 kernel trace of the replays themselves"
+                          % min(args.steps, 5)) if gs is not None else "HIP events around every launch of the timed steps"
 
     # ---- diffusion block (to_basis + exp(-lambda t) + from_basis) on the same batch: HBM GB/s of BASELINE.json
     from diffusion_net import ops
@@ -473,7 +517,7 @@ def main():
                                    "DiffusionNet C_in=3 C_out=8 C_width=%d K=%d N_block=%d outputs_at=faces dropout=on"
                                    % ("+RCCL all-reduce" if world > 1 else "", args.meshes, args.verts, Cw, K, args.blocks),
                        "meshes_per_gpu": args.meshes, "verts_per_gpu_step": v_step, "parallelism": "dp%d" % world,
-                       "streams_per_gpu": nsub},
+                       "streams_per_gpu": nsub, "step_mode": step_mode},
             "roofline": roof, "kernel_families": fam, "diffusion_block": diff,
         }
         if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only (the other ranks would sit idle behind it)

@@ -32,7 +32,7 @@ constexpr bool rg_is_x3(int TN, int NTHR, int NOUT, bool ALIGNED) { return DN_RG
 template <int TN, int WR, int WC, int NOUT, int MODE, bool ALIGNED, bool BCOLK>
 __global__ __launch_bounds__(WR* WC * 64) DN_MIN_WAVES_PER_EU(1)
 void rowgemm_kernel(RgArgs g) {
-    if (g.rng_seed && g.rng_seed_dev) g.rng_seed += *g.rng_seed_dev;   // g is this kernel's own copy of the arguments
+    const unsigned long long seed = (MODE == DN_EPI_BIAS_RELU) ? rg_seed(g) : 0ull;
 
     constexpr int NTHR = WR * WC * 64;
     constexpr int MT = DN_TM / (32 * WR);
@@ -182,7 +182,7 @@ void rowgemm_kernel(RgArgs g) {
                 const int rbase = (wr * MT + mt) * 32;
                 const int col = n0 + (wc * NT + nt) * 32 + li;
                 if (rbase < tile.nrows)
-                    rg_epilogue_tile<MODE, NOUT>(g, tile.row0 + rbase, tile.nrows - rbase, col, col < g.N, lane,
+                    rg_epilogue_tile<MODE, NOUT>(g, seed, tile.row0 + rbase, tile.nrows - rbase, col, col < g.N, lane,
                                                  acc[0][mt][nt], acc[NOUT - 1][mt][nt]);
             }
     }

@@ -35,7 +35,7 @@
 // operands.  Branch-free, and nothing loaded here is used before the MFMA block (a use would put a vmcnt wait --
 // which also waits for the slice prefetch issued just before -- in front of the MFMAs).
 template <int MODE, bool FLAG>
-__device__ __forceinline__ void pt_piece_load(const RgArgs& g, const float* sE, int piece, int tid, int row0, int nrows,
+__device__ __forceinline__ void pt_piece_load(const RgArgs& g, unsigned long long seed, const float* sE, int piece, int tid, int row0, int nrows,
                                               int n0, PtPiece& P) {
     const bool live = piece < DN_PT_NP;
     const int idx = tid + (live ? piece : 0) * DN_PT_THREADS;
@@ -54,14 +54,14 @@ __device__ __forceinline__ void pt_piece_load(const RgArgs& g, const float* sE, 
     if (need_bias) P.bias = *reinterpret_cast<const float4*>(g.bias + ccol);
     if (MODE == DN_EPI_BIAS_RELU && FLAG) {   // explicit mask or drawn bits, without a branch: the load goes to a valid address either way
         const uint32_t ld = *reinterpret_cast<const uint32_t*>(g.mask ? g.mask + roff : reinterpret_cast<const uint8_t*>(g.bias));
-        P.mk = g.mask ? ld : dn_keep_bytes(dn_keep_bits(g.rng_seed, grow, ccol >> 2, (g.N + 3) >> 2));
+        P.mk = g.mask ? ld : dn_keep_bytes(dn_keep_bits(seed, grow, ccol >> 2, (g.N + 3) >> 2));
     }
     if (MODE == DN_EPI_MASS_ADD) P.rs = g.rowv[grow];
 }
 
 template <int MODE, bool BCOLK, bool FLAG, bool X3>
 __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_persist_kernel(RgArgs g, int ntiles) {
-    if (g.rng_seed && g.rng_seed_dev) g.rng_seed += *g.rng_seed_dev;   // g is this kernel's own copy of the arguments
+    const unsigned long long seed = (MODE == DN_EPI_BIAS_RELU && FLAG) ? rg_seed(g) : 0ull;
 
     constexpr int TN = 128, WR = DN_PT_ROWS / 64, WC = 4, NOUT = 1, NTHR = DN_PT_THREADS, TMU = DN_PT_ROWS;
     constexpr int UPT = DN_TM / TMU;                 // work units per 128-row tile (1 or 2)
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_pers
             /* every auxiliary load of this iteration's pieces goes out BEFORE the prefetch: loads retire in order,   */ \
             /* so a piece that waited on a younger load would wait for the prefetch too                              */ \
             _Pragma("unroll") for (int k = 0; k < PPI; ++k)                                                             \
-                pt_piece_load<MODE, FLAG>(g, sE, p_next + k, tid, p_row0, p_nrows, n0, P[k]);                           \
+                pt_piece_load<MODE, FLAG>(g, seed, sE, p_next + k, tid, p_row0, p_nrows, n0, P[k]);                           \
             rg_split_x3<NOUT, BCOLK, HASQ, A_IT, B_IT>(RS, PLN);                                                        \
             rg_mma_x3<MT, NT, NOUT>(F, 0, acc);                                                                         \
             PT_ADVANCE_SEL((j) + 1 + 1 < T);                                                                  \
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_pers
             if ((j) + 1 + 1 < T) { PT_ADVANCE(); PT_LOAD(RS); }                                               \
             if (pending) {                                                                                              \
                 _Pragma("unroll") for (int k = 0; k < PPI; ++k)                                                         \
-                    pt_piece_load<MODE, FLAG>(g, sE, p_next + k, tid, p_row0, p_nrows, n0, P[k]);                       \
+                    pt_piece_load<MODE, FLAG>(g, seed, sE, p_next + k, tid, p_row0, p_nrows, n0, P[k]);                       \
             }                                                                                                           \
             rg_compute<TN, MT, NT, NOUT, BCOLK>(cur, cur + SA, wr * MT * 32, wc * NT * 32, li, ls, acc);                \
             if (pending) {                                                                                              \
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_pers
     // flush what is still parked (the last unit)
     for (; p_next < DN_PT_NP; ++p_next) {
         PtPiece P1;
-        pt_piece_load<MODE, FLAG>(g, sE, p_next, tid, p_row0, p_nrows, n0, P1);
+        pt_piece_load<MODE, FLAG>(g, seed, sE, p_next, tid, p_row0, p_nrows, n0, P1);
         pt_piece_store<MODE, FLAG>(g, P1);
     }
 }
@@ -272,7 +272,7 @@ struct WsAux {
 
 // issue the auxiliary loads of one deferred piece (nothing here is used before the next slice iteration)
 template <int MODE, bool FLAG>
-__device__ __forceinline__ void ws_aux_load(const RgArgs& g, int piece, int lt, int row0, int nrows, int n0, WsAux& A) {
+__device__ __forceinline__ void ws_aux_load(const RgArgs& g, unsigned long long seed, int piece, int lt, int row0, int nrows, int n0, WsAux& A) {
     const bool live = piece < DN_WS_NP;
     const int idx = lt + (live ? piece : 0) * DN_WS_PTHR;
     const int row = idx >> 5, c4 = idx & 31;
@@ -288,7 +288,7 @@ __device__ __forceinline__ void ws_aux_load(const RgArgs& g, int piece, int lt, 
     if (need_r0) A.a0 = *reinterpret_cast<const float4*>(g.r0 + roff);
     if (MODE == DN_EPI_BIAS_RELU && FLAG) {   // explicit mask or drawn bits (see pt_piece_load)
         const uint32_t ld = *reinterpret_cast<const uint32_t*>(g.mask ? g.mask + roff : reinterpret_cast<const uint8_t*>(g.bias));
-        A.mk = g.mask ? ld : dn_keep_bytes(dn_keep_bits(g.rng_seed, grow, ccol >> 2, (g.N + 3) >> 2));
+        A.mk = g.mask ? ld : dn_keep_bytes(dn_keep_bits(seed, grow, ccol >> 2, (g.N + 3) >> 2));
     }
     if (MODE == DN_EPI_MASS_ADD) A.rs = g.rowv[grow];
 }
@@ -351,7 +351,7 @@ __device__ __forceinline__ void ws_load(const float* ap, int ald, const float* b
 // plane dwords in registers -- the per-slice B work shrinks from 2 loads + 44 VALU + 6 LDS writes to the 6 LDS writes.
 template <int MODE, bool BCOLK, bool FLAG, int PPI, bool BC>
 __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2 : 3) void rowgemm_ws_kernel(RgArgs g, int ntiles) {
-    if (g.rng_seed && g.rng_seed_dev) g.rng_seed += *g.rng_seed_dev;   // g is this kernel's own copy of the arguments
+    const unsigned long long seed = (MODE == DN_EPI_BIAS_RELU && FLAG) ? rg_seed(g) : 0ull;
 
     constexpr int TN = 128, NOUT = 1, LTHR = DN_WS_LTHR;
     constexpr int A_IT = DN_TM * 8 / LTHR;            // 4 float4 of the A slice per loader thread
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     const bool piece_wave = lt < DN_WS_PTHR;
     WsAux AX[PPI];
 #pragma unroll
-    for (int k = 0; k < PPI; ++k) ws_aux_load<MODE, FLAG>(g, DN_WS_NP, lt, p_row0, p_nrows, n0, AX[k]);   // dead pieces
+    for (int k = 0; k < PPI; ++k) ws_aux_load<MODE, FLAG>(g, seed, DN_WS_NP, lt, p_row0, p_nrows, n0, AX[k]);   // dead pieces
 
 // one step of the load cursor without control flow or memory access on the path; past the last slice it stays put
 #define WS_ADVANCE(commit)                                                                                              \
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
                 ctile_next = g.tiles[cn];   /* consumed at the next park at the earliest */                             \
             }                                                                                                           \
             _Pragma("unroll") for (int k = 0; k < PPI; ++k)                                                             \
-                ws_aux_load<MODE, FLAG>(g, p_next + k, lt, p_row0, p_nrows, n0, AX[k]);                                 \
+                ws_aux_load<MODE, FLAG>(g, seed, p_next + k, lt, p_row0, p_nrows, n0, AX[k]);                                 \
         }                                                                                                               \
         WS_ADVANCE((j) + 1 + 1 < T);                                                                          \
         WS_LOAD(RS);                   /* slice j+1+DEPTH */                                                            \
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     if (!piece_wave) return;
     for (; p_next < DN_WS_NP; ++p_next) {
         WsAux A1;
-        ws_aux_load<MODE, FLAG>(g, p_next, lt, p_row0, p_nrows, n0, A1);
+        ws_aux_load<MODE, FLAG>(g, seed, p_next, lt, p_row0, p_nrows, n0, A1);
         ws_piece_out<MODE, FLAG>(g, sE, bias, A1);
     }
 }

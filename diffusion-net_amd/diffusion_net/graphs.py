@@ -12,7 +12,8 @@ What makes the step capturable:
   * the parameters live in ``dist.FlatParams`` (one buffer, gradients delivered by the ops straight into it), the optimizer is torch's
     Adam with ``capturable=True``;
   * inputs are static buffers owned by the object: ``step(x=..., labels=...)`` copies new values in before the replay.
-Single-GPU (the gradient all-reduce is not captured).
+``all_reduce=True`` captures the bucketed RCCL gradient all-reduce of ``FlatParams`` with the step (data-parallel ranks each replay
+their own graph; the collectives inside keep them in lock step).
 """
 from __future__ import annotations
 
@@ -28,13 +29,14 @@ _GOLDEN = 0x9E3779B97F4A7C15
 
 class GraphedTrainStep:
     def __init__(self, model, flat: FlatParams, opt: torch.optim.Optimizer, mb: MeshBatch, gather: Optional[GatherPattern], x: torch.Tensor,
-                 labels: torch.Tensor, smoothing: float = 0.0, warmup: int = 3):
+                 labels: torch.Tensor, smoothing: float = 0.0, warmup: int = 3, all_reduce: bool = False):
         dev = x.device
         if dev.type != "cuda":
             raise RuntimeError("graph capture needs a ROCm device")
         if warmup < 1:
             raise ValueError("at least one eager warm-up step is needed: it creates the optimizer state the captured update works on")
         self.model, self.flat, self.opt, self.mb, self.gather, self.smoothing = model, flat, opt, mb, gather, float(smoothing)
+        self.all_reduce = bool(all_reduce)
         self.x = x.detach().clone()
         self.labels = labels.detach().clone()
         # dropout: constant host part per block + one device word advanced by the graph
@@ -60,6 +62,8 @@ class GraphedTrainStep:
         self.flat.zero_grad()
         preds, loss = self.model.forward_packed_loss(self.x, self.mb, self.gather, self.labels, self.smoothing)
         loss.backward()
+        if self.all_reduce:                        # RCCL collectives are stream work too: the per-block side-stream all-reduces fork
+            self.flat.all_reduce_mean()            # from and join the captured stream
         self.opt.step()
         return loss, preds
 

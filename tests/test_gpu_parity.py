@@ -211,6 +211,62 @@ def test_graph_captured_train_step(dev):
     gs.release()
 
 
+def test_graph_captures_the_rccl_gradient_all_reduce(dev):
+    """GraphedTrainStep(all_reduce=True) under backend "nccl" (= RCCL), world size 1 with the collective path forced: the per-block
+    side-stream all-reduces issued from inside backward and the tail all-reduce fork from / join the captured stream, and the
+    replays must follow the eager steps update for update (sum over one rank / 1 = the plain gradients)."""
+    import socket
+    import torch.distributed as dist
+    import diffusion_net
+    import parity_cases
+    from diffusion_net import synthetic
+    from diffusion_net.batch import GatherPattern
+    from diffusion_net.dist import FlatParams
+    from diffusion_net.graphs import GraphedTrainStep
+    lsm = lambda t: torch.nn.functional.log_softmax(t, dim=-1)
+    meshes, feats = parity_cases.make_ragged((1500, 900), 64, 3, seed=2)
+    mb = parity_cases.pack(meshes, dev)
+    offs, rows = 0, []
+    for m, v in zip(meshes, (1500, 900)):
+        rows.append(m["faces"] + offs)
+        offs += v
+    gather = GatherPattern(torch.cat(rows, 0).to(dev), 2400)
+    x = torch.cat(feats, 0).to(dev)
+    labels = torch.randint(0, 8, (gather.n_out,), generator=torch.Generator().manual_seed(0)).to(dev)
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    try:
+        runs = {}
+        for mode in ("eager", "graph"):
+            torch.manual_seed(4)
+            model = diffusion_net.layers.DiffusionNet(3, 8, C_width=128, N_block=2, outputs_at="faces", dropout=False, last_activation=lsm)
+            model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=4))
+            model.to(dev).train()
+            flat = FlatParams(model)
+            flat._force_collectives = True
+            opt = torch.optim.Adam([flat.master], lr=1e-3, capturable=True)
+            losses = []
+            if mode == "graph":
+                gs = GraphedTrainStep(model, flat, opt, mb, gather, x, labels, warmup=1, all_reduce=True)
+                for _ in range(4):
+                    losses.append(float(gs.step()))
+                gs.release()
+            else:
+                for _ in range(5):
+                    flat.zero_grad()
+                    _, loss = model.forward_packed_loss(x, mb, gather, labels)
+                    loss.backward()
+                    assert sorted(flat._sent) == [0, 1]
+                    flat.all_reduce_mean()
+                    opt.step()
+                    losses.append(float(loss))
+                losses = losses[1:]
+            runs[mode] = losses
+        assert runs["eager"] == runs["graph"], runs
+    finally:
+        dist.destroy_process_group()
+
+
 def test_run_to_run_determinism_stress(dev):
     """Every op of the block, repeated on identical inputs at a multi-mesh 128-wide shape, must be bitwise identical every
     time (tools/determinism_stress.py; this is the test that exposes stale-register / packed-op hazards that stay far

@@ -65,6 +65,17 @@ def main():
         rec("[calib] torch fill 81MB", timeit(lambda: z.fill_(1.0)), 0.0, 4.0 * V * C)
         rec("[calib] torch copy 81MB->81MB", timeit(lambda: z.copy_(x)), 0.0, 8.0 * V * C)
         rec("[calib] torch add 2x81MB->81MB", timeit(lambda: torch.add(x, y, out=z)), 0.0, 12.0 * V * C)
+        # the three lines above re-touch the same <=243 MB: they sit in the 256 MiB Infinity Cache and are NOT an HBM figure.
+        # HBM calibration: copies cycling through 8 source/destination pairs (1.3 GB), so that nothing is re-read from the cache
+        ring = [(torch.randn(V, C, device=dev), torch.empty(V, C, device=dev)) for _ in range(8)]
+        cnt = [0]
+
+        def rot_copy():
+            s_, d_ = ring[cnt[0] % 8]
+            cnt[0] += 1
+            d_.copy_(s_)
+        rec("[calib] HBM copy, 8 rotating 81MB pairs", timeit(rot_copy), 0.0, 8.0 * V * C)
+        del ring
         rec("to_basis (tngemm+reduce)", timeit(lambda: ops._to_basis_raw(mb, x, True)), 2.0 * V * K * C, 4.0 * V * (K + C + 1))
         rec("from_basis (rowgemm NN)", timeit(lambda: ops._from_basis_raw(mb, spec)), 2.0 * V * K * C, 4.0 * V * (K + C))
         rec("diffusion fwd (3 launches)", timeit(lambda: ops.DiffusionFn.apply(x, t, mb)), 4.0 * V * K * C, 4.0 * V * (2 * C + 2 * K + 1))
