@@ -141,6 +141,13 @@ int gradfeat_bwd_inputs(const dn_mesh_batch_t* mb, const float* ddots, const flo
 }
 int gradfeat_bwd_weights(const dn_mesh_batch_t* mb, const float* ddots, const float* gx, const float* gy, int C,
                          float* dA_re, float* dA_im, float* partial, float* psum, hipStream_t st) {
+    if (C == 128 && dA_im && al16(ddots) && al16(gx) && al16(gy) && al16(partial)) {
+        // one pass over ddots, gx, gy: every workgroup computes all four quadrants for its row range (dn_tn_da.hip)
+        int nwg = dn_num_cus();
+        if (nwg > 2 * mb->n_chunks) nwg = 2 * mb->n_chunks;      // the workspace holds n_chunks * 4 C^2 floats
+        DN_CHECK(dn_launch_tn_da(ddots, gx, gy, mb->v_total, partial, nwg, st));
+        return dn_launch_reduce_split(partial, nwg, dA_re, dA_im, (long long)C * C, st);
+    }
     TnArgs g = tn_new(mb);
     tn_a(g, ddots, gx, C, C);
     tn_a(g, ddots, gy, C, C);

@@ -309,6 +309,15 @@ int dn_launch_reduce(const float* partial, float* out, int n, long long stride, 
 // out[s][i] = sum_{ch in [seg_off[s], seg_off[s+1])} partial[ch][i]  (seg_off == nullptr: one segment [0,n))
 int dn_launch_seg_reduce(const float* partial, const int* seg_off, int nseg, int n, float* out, long long len, hipStream_t stream);
 int dn_launch_combine_dA(const float* P, float* dA_re, float* dA_im, int C, hipStream_t stream);
+int dn_launch_reduce_split(const float* partial, int n, float* o0, float* o1, long long half, hipStream_t stream);
+// dn_tn_da.hip: dA_re / dA_im partials of all four quadrants of [dd*gx | dd*gy]^T [gx | gy] from ONE pass over the three arrays (C = 128)
+struct DaArgs {
+    const float* dd; const float* gx; const float* gy;
+    float* partial;                 // [gridDim.x][2][128][128]
+    long long V;
+    int rows_per_wg;                // multiple of 16
+};
+int dn_launch_tn_da(const float* dd, const float* gx, const float* gy, long long V, float* partial, int nwg, hipStream_t stream);
 int dn_launch_mass_mean_fwd(const DnTile* meshrows, const float* mass, const float* x, float* out, float* msum,
                             int n_mesh, int C, hipStream_t stream);
 int dn_launch_mass_mean_bwd(const DnTile* tiles, int ntiles, const float* mass, const float* msum, const float* dout,

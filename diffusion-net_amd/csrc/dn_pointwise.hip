@@ -187,6 +187,25 @@ int dn_launch_reduce_pair(const float* pa, float* oa, long long la, const float*
     return (int)hipGetLastError();
 }
 
+// whole-range sum of [n][2 * half] partials whose two halves go to different arrays (dA_re | dA_im, dn_tn_da.hip)
+struct SegSplitStore {
+    float* o0; float* o1; long long half;
+    __device__ __forceinline__ void operator()(int, long long i, int e, float t) const {
+        const long long j = i + e;
+        if (j < half) o0[j] = t; else o1[j - half] = t;
+    }
+};
+__global__ __launch_bounds__(256) void seg_reduce_split_kernel(const float* partial, int n, float* o0, float* o1, long long half) {
+    seg_reduce_body<4>(partial, 0, 0, n, 2 * half, SegSplitStore{o0, o1, half});
+}
+int dn_launch_reduce_split(const float* partial, int n, float* o0, float* o1, long long half, hipStream_t stream) {
+    if (n <= 0 || half <= 0 || half % 4 != 0 || (uintptr_t)partial % 16 != 0) return DN_ERR_BAD_MODE;
+    dn_prof_begin(DN_K_SMALL, stream);
+    DN_LAUNCH(seg_reduce_split_kernel, dim3((unsigned)((2 * half / 4 + 31) / 32), 1, 1), dim3(256, 1, 1), 0, stream, partial, n, o0, o1, half);
+    dn_prof_end(DN_K_SMALL, stream, 0.0, 8.0 * (double)half * ((double)n + 1.0));
+    return (int)hipGetLastError();
+}
+
 int dn_launch_reduce(const float* partial, float* out, int n, long long stride, long long len, hipStream_t stream) {
     if (stride != len) return DN_ERR_BAD_MODE;
     return dn_launch_seg_reduce(partial, nullptr, 1, n, out, len, stream);
