@@ -25,7 +25,7 @@ def family(name):
     m = re.match(r"void rowgemm_kernel<\d+, \d+, \d+, (\d)", name)
     if m:
         return "rowgemm_kernel<*,%s>" % m.group(1)
-    if "tngemm_kernel" in name or "tngemm_x3_kernel" in name:
+    if "tngemm_kernel" in name or "tngemm_x3_kernel" in name or "tngemm_da_kernel" in name:
         return "tngemm_kernel"
     if "spmm_kernel" in name:
         return "spmm_kernel"
