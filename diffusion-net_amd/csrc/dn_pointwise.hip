@@ -301,7 +301,7 @@ int dn_launch_dtanh(const float* dg, const float* g, float* out, long long n, hi
 template <int KMAX>
 __global__ __launch_bounds__(256) void smallk_rows_kernel(const float* x, int K, const float* W, int w_kn, const float* bias,
                                                           int N, float* out, long long rows) {
-    constexpr int UR = KMAX <= 4 ? 4 : 2;       // independent row passes in flight per thread
+    constexpr int UR = KMAX <= 8 ? 4 : 2;       // independent row passes in flight per thread
     const int n4 = (N + 3) / 4;                 // column groups per row
     const int cg = threadIdx.x % n4, rl = threadIdx.x / n4;
     const int rows_per_pass = 256 / n4;         // rows a block covers per pass (threads beyond rows_per_pass*n4 idle)
