@@ -28,6 +28,9 @@ bool dn_rowgemm_try_persistent(const RgArgs& g, int ntiles, int nout, hipStream_
 #ifndef DN_RG2_VEC_EPI
 #define DN_RG2_VEC_EPI 1   // parked float4 epilogue of the two-output split-bf16 kernel (0: per-element dword epilogue)
 #endif
+#ifndef DN_RG2_EARLY_EPI
+#define DN_RG2_EARLY_EPI(MODE) 1   // epilogue operands fetched under the last two slices (measured: fwd 201 -> 186 us, bwd pair 360 -> 348 us; 0: after them)
+#endif
 constexpr bool rg_is_x3(int TN, int NTHR, int NOUT, bool ALIGNED) { return DN_RG_X3 && ALIGNED && NOUT == 2 && TN == 128 && NTHR == 512; }
 template <int TN, int WR, int WC, int NOUT, int MODE, bool ALIGNED, bool BCOLK>
 __global__ __launch_bounds__(WR* WC * 64) DN_MIN_WAVES_PER_EU(1)
@@ -72,6 +75,37 @@ void rowgemm_kernel(RgArgs g) {
     int nslices = 0;
     for (int s = 0; s < g.nseg; ++s) nslices += (g.a[s].w + DN_KB - 1) / DN_KB;
 
+    // Two-output split-bf16 configuration: the epilogue's elementwise operands (float4 pieces, see below) are fetched while the last
+    // two slices are still being multiplied -- with one workgroup per CU nothing else would cover that HBM round trip.
+    constexpr bool VEPI = X3 && DN_RG2_VEC_EPI;
+    constexpr int NPC = VEPI ? 128 * 128 / 4 / NTHR : 1;   // 8 pieces per thread
+    float4 er0[NPC], er1[NPC], er2[NPC];
+    long long eoff[NPC];
+    bool eok[NPC];
+    bool vec_ok = false;
+    if constexpr (VEPI)
+        vec_ok = (((uintptr_t)g.o0 | (uintptr_t)g.o1 | (uintptr_t)g.o2 | (uintptr_t)g.r0 | (uintptr_t)g.r1 | (uintptr_t)g.r2) & 15) == 0 &&
+                 g.ldo % 4 == 0 && g.ldr % 4 == 0 && g.N % 4 == 0;
+    auto epi_fetch = [&]() {
+        if constexpr (VEPI) {
+            if (vec_ok) {
+#pragma unroll
+                for (int k = 0; k < NPC; ++k) {
+                    const int idx = tid + k * NTHR;
+                    const int row = idx >> 5, c4 = idx & 31;
+                    const int col = n0 + 4 * c4;
+                    eok[k] = row < tile.nrows && col < g.N;
+                    const long long grow = tile.row0 + (eok[k] ? row : 0);
+                    const int ccol = eok[k] ? col : 0;
+                    eoff[k] = grow * g.ldo + ccol;
+                    const long long roff = grow * g.ldr + ccol;
+                    er0[k] = *reinterpret_cast<const float4*>(g.r0 + roff);
+                    er1[k] = *reinterpret_cast<const float4*>(g.r1 + roff);
+                }
+            }
+        }
+    };
+
     // Software pipeline over 32-wide slices of the contraction axis, two LDS buffers, ONE barrier per slice:
     //   iteration sl:  regs(slice sl+1) -> LDS[other] ; global loads of slice sl+2 -> regs ; MFMAs on LDS[cur] ; barrier
     // The steady-state body has no branch, so the LDS writes and the global loads can be scheduled under the MFMAs.
@@ -99,25 +133,35 @@ void rowgemm_kernel(RgArgs g) {
         float* cur = smem + (sl & 1) * SBUF;
         float* nxt = smem + ((sl & 1) ^ 1) * SBUF;
         RG_STORE(nxt);
+        if (DN_RG2_EARLY_EPI(MODE)) epi_fetch();   // (the slice loads have all been consumed: nothing younger is waited on before the epilogue)
         RG_COMPUTE(cur);
         __syncthreads();
         ++sl;
+    } else {
+        if (DN_RG2_EARLY_EPI(MODE)) epi_fetch();
     }
     {
         float* cur = smem + (sl & 1) * SBUF;
         RG_COMPUTE(cur);
     }
+    if (!DN_RG2_EARLY_EPI(MODE)) epi_fetch();
 
     // ---------------- epilogue ----------------
-    if constexpr (X3 && DN_RG2_VEC_EPI) {
-        // Two-output split-bf16 configuration: the slice buffers are dead now, so both 128 x 128 accumulator tiles are parked in
-        // them (2 x 64 KiB of the 144 KiB) and the epilogue runs on float4 pieces with coalesced 16-byte loads and stores --
-        // 8 pieces x (2-3 loads + 2-3 stores) per thread instead of 32 elements x (2-3 dword loads + 2-3 dword stores).
-        const bool vec_ok = (((uintptr_t)g.o0 | (uintptr_t)g.o1 | (uintptr_t)g.o2 | (uintptr_t)g.r0 | (uintptr_t)g.r1 | (uintptr_t)g.r2) & 15) == 0 &&
-                            g.ldo % 4 == 0 && g.ldr % 4 == 0 && g.N % 4 == 0;
+    if constexpr (VEPI) {
+        // The slice buffers are dead now, so both 128 x 128 accumulator tiles are parked in them (2 x 64 KiB of the 144 KiB) and the
+        // epilogue runs on float4 pieces with coalesced 16-byte loads (issued above) and stores -- 8 pieces x (2-3 loads + 2-3
+        // stores) per thread instead of 32 elements x (2-3 dword loads + 2-3 dword stores).
         if (vec_ok) {
             float* sE0 = smem;
             float* sE1 = smem + 128 * 128;
+            if (MODE == DN_EPI_GRADFEAT_BWD) {   // the third operand only now (register budget); the parking below covers part of its latency
+#pragma unroll
+                for (int k = 0; k < NPC; ++k) {
+                    const int idx = tid + k * NTHR;
+                    const long long grow = tile.row0 + (eok[k] ? (idx >> 5) : 0);
+                    er2[k] = *reinterpret_cast<const float4*>(g.r2 + grow * g.ldr + (eok[k] ? n0 + 4 * (idx & 31) : 0));
+                }
+            }
             __syncthreads();   // every wave is done with the slice buffers
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -128,24 +172,6 @@ void rowgemm_kernel(RgArgs g) {
                     sE1[e] = acc[NOUT - 1][mt][0][r];
                 }
             __syncthreads();
-            constexpr int NPC = 128 * 128 / 4 / NTHR;   // 8 pieces per thread
-            float4 r0[NPC], r1[NPC], r2[NPC];
-            long long off[NPC];
-            bool ok[NPC];
-#pragma unroll
-            for (int k = 0; k < NPC; ++k) {
-                const int idx = tid + k * NTHR;
-                const int row = idx >> 5, c4 = idx & 31;
-                const int col = n0 + 4 * c4;
-                ok[k] = row < tile.nrows && col < g.N;
-                const long long grow = tile.row0 + (ok[k] ? row : 0);
-                const int ccol = ok[k] ? col : 0;
-                off[k] = grow * g.ldo + ccol;
-                const long long roff = grow * g.ldr + ccol;
-                r0[k] = *reinterpret_cast<const float4*>(g.r0 + roff);
-                r1[k] = *reinterpret_cast<const float4*>(g.r1 + roff);
-                if (MODE == DN_EPI_GRADFEAT_BWD) r2[k] = *reinterpret_cast<const float4*>(g.r2 + roff);
-            }
 #pragma unroll
             for (int k = 0; k < NPC; ++k) {
                 const int idx = tid + k * NTHR;
@@ -153,21 +179,21 @@ void rowgemm_kernel(RgArgs g) {
                 const float4 a0 = *reinterpret_cast<const float4*>(&sE0[row * 128 + 4 * c4]);
                 const float4 a1 = *reinterpret_cast<const float4*>(&sE1[row * 128 + 4 * c4]);
                 if (MODE == DN_EPI_GRADFEAT) {
-                    const float4 y = make_float4(tanhf(r0[k].x * a0.x + r1[k].x * a1.x), tanhf(r0[k].y * a0.y + r1[k].y * a1.y),
-                                                 tanhf(r0[k].z * a0.z + r1[k].z * a1.z), tanhf(r0[k].w * a0.w + r1[k].w * a1.w));
-                    if (ok[k]) {
-                        *reinterpret_cast<float4*>(g.o0 + off[k]) = y;
+                    const float4 y = make_float4(tanhf(er0[k].x * a0.x + er1[k].x * a1.x), tanhf(er0[k].y * a0.y + er1[k].y * a1.y),
+                                                 tanhf(er0[k].z * a0.z + er1[k].z * a1.z), tanhf(er0[k].w * a0.w + er1[k].w * a1.w));
+                    if (eok[k]) {
+                        *reinterpret_cast<float4*>(g.o0 + eoff[k]) = y;
                         if (g.o1) {
-                            *reinterpret_cast<float4*>(g.o1 + off[k]) = a0;
-                            *reinterpret_cast<float4*>(g.o2 + off[k]) = a1;
+                            *reinterpret_cast<float4*>(g.o1 + eoff[k]) = a0;
+                            *reinterpret_cast<float4*>(g.o2 + eoff[k]) = a1;
                         }
                     }
                 } else {
-                    const float4 y0 = make_float4(a0.x + r0[k].x * r1[k].x, a0.y + r0[k].y * r1[k].y, a0.z + r0[k].z * r1[k].z, a0.w + r0[k].w * r1[k].w);
-                    const float4 y1 = make_float4(a1.x + r0[k].x * r2[k].x, a1.y + r0[k].y * r2[k].y, a1.z + r0[k].z * r2[k].z, a1.w + r0[k].w * r2[k].w);
-                    if (ok[k]) {
-                        *reinterpret_cast<float4*>(g.o0 + off[k]) = y0;
-                        *reinterpret_cast<float4*>(g.o1 + off[k]) = y1;
+                    const float4 y0 = make_float4(a0.x + er0[k].x * er1[k].x, a0.y + er0[k].y * er1[k].y, a0.z + er0[k].z * er1[k].z, a0.w + er0[k].w * er1[k].w);
+                    const float4 y1 = make_float4(a1.x + er0[k].x * er2[k].x, a1.y + er0[k].y * er2[k].y, a1.z + er0[k].z * er2[k].z, a1.w + er0[k].w * er2[k].w);
+                    if (eok[k]) {
+                        *reinterpret_cast<float4*>(g.o0 + eoff[k]) = y0;
+                        *reinterpret_cast<float4*>(g.o1 + eoff[k]) = y1;
                     }
                 }
             }
