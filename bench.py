@@ -338,6 +338,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "--gpus %d but the launcher started %d ranks" % (args.gpus, world)
+    if os.environ.get("DN_BENCH_LAUNCH_CHECK"):   # tests/test_dist_gloo.py: the launcher leg alone (runs without a GPU)
+        print(json.dumps({"rank": rank, "local": local, "world": world, "master": os.environ.get("MASTER_ADDR")}), flush=True)
+        return
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU path)"
     assert torch.cuda.device_count() >= (local + 1), "rank %d has no GPU (visible devices: %d)" % (rank, torch.cuda.device_count())
     torch.cuda.set_device(local)

@@ -52,3 +52,19 @@ def test_two_rank_gloo_matches_single_process():
         a, b = results[1][0]["grad"], results[2][0]["grad"]
         assert float((a - b).norm() / a.norm()) < 1e-5
         assert float((results[1][0]["flat"] - results[2][0]["flat"]).abs().max()) < 1e-3
+
+
+def test_bench_gpus_n_launches_n_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the driver's command) must become its own launcher: two ranks
+    under torch.distributed.run on 127.0.0.1, each seeing WORLD_SIZE == --gpus.  The DN_BENCH_LAUNCH_CHECK hook stops every rank
+    right after the rendezvous environment has been read (before the first GPU call), so the launcher leg is testable here."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DN_BENCH_LAUNCH_CHECK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    import json
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert sorted(l["rank"] for l in lines) == [0, 1], r.stdout
+    assert all(l["world"] == 2 and l["master"] == "127.0.0.1" for l in lines), lines
