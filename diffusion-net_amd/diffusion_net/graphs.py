@@ -53,7 +53,9 @@ class GraphedTrainStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread-local capture mode: the RCCL watchdog thread (event queries on finished collectives) or a data-loader thread may call
+        # into HIP while this thread captures; in the default global mode such a call invalidates the capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss, self.preds = self._body()
         torch.cuda.synchronize(dev)
 
