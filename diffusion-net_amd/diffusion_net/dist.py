@@ -96,6 +96,11 @@ class FlatParams:
     def zero_grad(self):
         self.grad.zero_()
         self._sent, self._pending = [], []
+        if self.direct_sinks:     # a zeroed sink may be written by the gradient kernel itself (ops._grad_out): store == accumulate
+            for p in self.params:
+                sink = getattr(p, "_dn_grad_sink", None)
+                if sink is not None:
+                    sink._dn_fresh = True
 
     def all_reduce_mean(self, group=None):
         """Sum over ranks, then divide by the world size.  Blocks whose range went out during backward are skipped; what is left

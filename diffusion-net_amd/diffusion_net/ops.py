@@ -228,10 +228,24 @@ def _sinks(params):
     return out
 
 
+def _grad_out(sink, like):
+    """Output buffer for a parameter gradient.  A sink that is known to hold zeros (``dist.FlatParams.zero_grad`` marks it fresh) is
+    handed to the kernel itself: its plain store IS the accumulation (0 + g), and the add launch of ``_deliver`` disappears.  The
+    mark is consumed, so a second gradient for the same parameter before the next zero_grad (shared weights, several backward
+    passes) goes through a temporary and is added."""
+    if like is None:
+        return None
+    if sink is not None and getattr(sink, "_dn_fresh", False) and sink.shape == like.shape and sink.is_contiguous() \
+            and sink.dtype == torch.float32 and sink.data_ptr() % 16 == 0:
+        sink._dn_fresh = False
+        return sink
+    return torch.empty_like(like, dtype=torch.float32)
+
+
 def _deliver(sinks, grads):
-    dst = [s for s, g in zip(sinks, grads) if s is not None and g is not None]
-    if dst:
-        torch._foreach_add_(dst, [g for s, g in zip(sinks, grads) if s is not None and g is not None])
+    pairs = [(s, g) for s, g in zip(sinks, grads) if s is not None and g is not None and g is not s]
+    if pairs:
+        torch._foreach_add_([s for s, g in pairs], [g for s, g in pairs])
     return [g if s is None else None for s, g in zip(sinks, grads)]
 
 
@@ -258,7 +272,8 @@ class LinearFn(torch.autograd.Function):
         d_out = _f32c(d_out)
         C_out, C_in = W.shape
         d_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dW, db = torch.empty_like(W), torch.empty(C_out, dtype=torch.float32, device=x.device)
+        dW = _grad_out(ctx.sinks[0], W)
+        db = _grad_out(ctx.sinks[1], W.new_empty(C_out))
         ws, n = _ws(mb, L.dn_linear_workspace_bytes(mb.ref(), C_in, C_out))
         _hip.check(L.dn_linear_bwd_f32(mb.ref(), d_out.data_ptr(), x.data_ptr(), W.data_ptr(), C_in, C_out, _hip.ptr(d_x),
                                        dW.data_ptr(), db.data_ptr(), ws.data_ptr(), n, _hip.stream_of(d_out)),
@@ -388,10 +403,11 @@ class BlockFn(torch.autograd.Function):
         for i, h in enumerate(hs):
             sv.h[i] = h.data_ptr()
         gr = _hip.BlockGradsStruct()
-        d_x, d_time = torch.empty_like(x), torch.empty_like(time)
-        dA_re = torch.empty_like(A_re) if A_re is not None else None
-        dA_im = torch.empty_like(A_im) if A_im is not None else None
-        dWs, dbs = [torch.empty_like(w) for w in Ws], [torch.empty_like(b) for b in bs]
+        sk = ctx.sinks                # order: time, A_re, A_im, W0, b0, W1, b1, ...
+        d_x, d_time = torch.empty_like(x), _grad_out(sk[0], time)
+        dA_re, dA_im = _grad_out(sk[1], A_re), _grad_out(sk[2], A_im)
+        dWs = [_grad_out(sk[3 + 2 * i], w) for i, w in enumerate(Ws)]
+        dbs = [_grad_out(sk[4 + 2 * i], b) for i, b in enumerate(bs)]
         gr.d_x, gr.d_time, gr.dA_re, gr.dA_im = d_x.data_ptr(), d_time.data_ptr(), _hip.ptr(dA_re), _hip.ptr(dA_im)
         for i in range(cfg.n_mlp):
             gr.dW[i], gr.db[i] = dWs[i].data_ptr(), dbs[i].data_ptr()

@@ -319,12 +319,22 @@ def run_grad_sinks(device, V=300, K=16, C=32, seed=4):
         flat = FlatParams(model) if use_flat else None
         m = synthetic.make_mesh_operators(V, K, seed=seed)
         kw = dict(evals=m["evals"].to(device), evecs=m["evecs"].to(device), gradX=m["gradX"].to(device), gradY=m["gradY"].to(device))
-        for scale in (1.0, 0.5):   # two accumulating backward passes
-            out = model(m["verts"].to(device), m["mass"].to(device), **kw)
-            (out.square().sum() * scale).backward()
-        if use_flat:
-            assert all(p.grad.data_ptr() == flat.grad.data_ptr() + o * 4 for p, o in zip(flat.params, flat.offsets))
-        grads.append([p.grad.detach().cpu().clone() for p in model.parameters()])
+        got = []
+        for rnd in range(2):
+            if rnd == 1:               # after zero_grad the sinks are "fresh": the first pass stores into them directly
+                if use_flat:           # (ops._grad_out), the second one goes through a temporary and is added
+                    flat.zero_grad()
+                else:
+                    for p in model.parameters():
+                        p.grad.zero_()
+            for scale in (1.0, 0.5):   # two accumulating backward passes
+                out = model(m["verts"].to(device), m["mass"].to(device), **kw)
+                (out.square().sum() * scale).backward()
+            if use_flat:
+                assert all(p.grad.data_ptr() == flat.grad.data_ptr() + o * 4 for p, o in zip(flat.params, flat.offsets))
+                assert not any(getattr(p._dn_grad_sink, "_dn_fresh", False) for p in flat.params if p.grad.abs().sum() > 0)
+            got += [p.grad.detach().cpu().clone() for p in model.parameters()]
+        grads.append(got)
     for a, b in zip(*grads):
         assert helpers.rel_l2(b, a) < 1e-6, helpers.rel_l2(b, a)
 
