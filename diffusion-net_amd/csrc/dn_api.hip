@@ -415,8 +415,15 @@ int dn_linear_bwd_f32(const dn_mesh_batch_t* mb, const float* d_out, const float
     if (!b.ok) return DN_ERR_INVALID;
     const float* ins[1] = {x};
     const int ws_[1] = {C_in};
-    if (C_in <= 16) {
-        // thin input (first_lin): dW = d_out^T x streams d_out once on the VALU
+    int nthin = mb->n_chunks < 512 ? mb->n_chunks : 512;    // workgroups of the thin products (their partials fit the regions above)
+    if (C_in <= 8 && C_out % 4 == 0 && al16(d_out) && (size_t)nthin * C_in * C_out <= linear_partial_elems(mb, C_in, C_out)) {
+        // thin input (first_lin, xyz features): dW = d_out^T x and db = column sums of d_out from ONE streaming pass over d_out
+        DN_CHECK(dn_launch_thin_tn(d_out, C_out, x, C_in, mb->v_total, 0, 1, dW, db, partial, colsum, nthin, S(stream)));
+    } else if (C_out <= 8 && C_in > 16 && C_in % 4 == 0 && al16(x)) {
+        // thin output (last_lin): dW = d_out^T x and db = column sums of d_out from one streaming pass over x
+        DN_CHECK(dn_launch_thin_tn(x, C_in, d_out, C_out, mb->v_total, 1, 0, dW, db, partial, colsum, nthin, S(stream)));
+    } else if (C_in <= 16) {
+        // thin input (hks features, C_in = 16): dW = d_out^T x streams d_out once on the VALU
         DN_CHECK(dn_launch_smalln_tn(d_out, C_out, x, C_in, mb->v_total, dW, partial, DN_SMALLN_BLOCKS, S(stream)));
         if (db) {   // db[o] = sum_r d_out[r,o]: column sums of a minimal (4-column) split-V product
             TnArgs g = tn_new(mb);

@@ -310,6 +310,8 @@ int dn_launch_reduce(const float* partial, float* out, int n, long long stride, 
 int dn_launch_seg_reduce(const float* partial, const int* seg_off, int nseg, int n, float* out, long long len, hipStream_t stream);
 int dn_launch_combine_dA(const float* P, float* dA_re, float* dA_im, int C, hipStream_t stream);
 int dn_launch_reduce_split(const float* partial, int n, float* o0, float* o1, long long half, hipStream_t stream);
+int dn_launch_thin_tn(const float* X, int M, const float* Y, int N, long long rows, int nm_major, int db_is_sx, float* dW, float* db,
+                      float* ws_p, float* ws_s, int nblk, hipStream_t stream);
 // dn_tn_da.hip: dA_re / dA_im partials of all four quadrants of [dd*gx | dd*gy]^T [gx | gy] from ONE pass over the three arrays (C = 128)
 struct DaArgs {
     const float* dd; const float* gx; const float* gy;

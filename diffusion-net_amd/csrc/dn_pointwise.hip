@@ -392,6 +392,99 @@ int dn_launch_smalln_tn(const float* A, int M, const float* B, int N, long long 
     return dn_launch_seg_reduce(ws, nullptr, 1, nblk, out, (long long)M * N, stream);
 }
 
+// ---- thin split-V product for the two ends of the network (first_lin: C_in = 3 inputs; last_lin: C_out <= 8 classes):
+//      P[m][n] = sum_r X[r,m] Y[r,n]   with X wide (M columns, float4 per thread) and Y thin (N <= 8),
+//      plus the column sums sx[m] = sum_r X[r,m] and sy[n] = sum_r Y[r,n] (whichever of them is the bias gradient) from the SAME pass.
+//      first_lin: X = d_out, Y = x      -> dW[o][i] = P[o][i] (m-major store), db = sx
+//      last_lin : X = x,     Y = d_out  -> dW[o][c] = P[c][o] (n-major store), db = sy
+//      Block = 8 row lanes x 32 column groups, two rows in flight per lane; partials per block, fixed-order reduce afterwards.
+#define DN_THIN_NMAX 8
+__global__ __launch_bounds__(256) void thin_tn_kernel(const float* X, int M, const float* Y, int N, long long rows, int nm_major,
+                                                      float* ws_p, float* ws_sx, float* ws_sy) {
+    __shared__ float red[8][128];
+    const int rl = threadIdx.x >> 5, c4 = threadIdx.x & 31;
+    const long long per = (rows + gridDim.x - 1) / gridDim.x;
+    const long long r_beg = (long long)blockIdx.x * per, r_end = (r_beg + per < rows) ? r_beg + per : rows;
+    float* wp = ws_p + (long long)blockIdx.x * M * N;
+    for (int m0 = 0; m0 < M; m0 += 128) {
+        const int m = m0 + 4 * c4;
+        const bool mok = m < M;
+        float acc[DN_THIN_NMAX][4], sx[4] = {0.f, 0.f, 0.f, 0.f}, sy[DN_THIN_NMAX];
+#pragma unroll
+        for (int n = 0; n < DN_THIN_NMAX; ++n) { sy[n] = 0.f; acc[n][0] = acc[n][1] = acc[n][2] = acc[n][3] = 0.f; }
+        for (long long r0 = r_beg + rl; r0 < r_end; r0 += 16) {
+            float4 xv[2];
+            float yv[2][DN_THIN_NMAX];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {          // both rows' loads first
+                const long long r = r0 + 8 * u;
+                const bool ok = r < r_end;
+                const long long rr = ok ? r : r0;
+                xv[u] = *reinterpret_cast<const float4*>(X + rr * M + (mok ? m : 0));
+                if (!ok || !mok) xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int n = 0; n < DN_THIN_NMAX; ++n) yv[u][n] = (ok && n < N) ? Y[rr * N + n] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                sx[0] += xv[u].x; sx[1] += xv[u].y; sx[2] += xv[u].z; sx[3] += xv[u].w;
+#pragma unroll
+                for (int n = 0; n < DN_THIN_NMAX; ++n) {
+                    sy[n] += yv[u][n];
+                    acc[n][0] = fmaf(xv[u].x, yv[u][n], acc[n][0]); acc[n][1] = fmaf(xv[u].y, yv[u][n], acc[n][1]);
+                    acc[n][2] = fmaf(xv[u].z, yv[u][n], acc[n][2]); acc[n][3] = fmaf(xv[u].w, yv[u][n], acc[n][3]);
+                }
+            }
+        }
+        // fixed-order sum over the 8 row lanes, one quantity at a time through 4 KiB of LDS
+#pragma unroll
+        for (int q = 0; q <= DN_THIN_NMAX; ++q) {      // q < NMAX: P[.][q];  q == NMAX: sx
+            if (q < DN_THIN_NMAX && q >= N) continue;
+            if (q == DN_THIN_NMAX && !ws_sx) continue;
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[rl][4 * c4 + e] = q < DN_THIN_NMAX ? acc[q][e] : sx[e];
+            __syncthreads();
+            if (threadIdx.x < 128 && m0 + (int)threadIdx.x < M) {
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+                const int mm = m0 + threadIdx.x;
+                if (q < DN_THIN_NMAX) wp[nm_major ? (long long)q * M + mm : (long long)mm * N + q] = t;
+                else ws_sx[(long long)blockIdx.x * M + mm] = t;
+            }
+        }
+        if (ws_sy && m0 == 0) {                        // sy: every column group holds the same sums; group 0 of each row lane reports
+            __syncthreads();
+            if (c4 == 0)
+#pragma unroll
+                for (int n = 0; n < DN_THIN_NMAX; ++n) red[rl][n] = sy[n];
+            __syncthreads();
+            if (threadIdx.x < N) {
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+                ws_sy[(long long)blockIdx.x * N + threadIdx.x] = t;
+            }
+        }
+    }
+}
+
+// dW (+ db) of a thin linear layer in two launches: the streaming pass above and one fixed-order reduce of both partial sets
+int dn_launch_thin_tn(const float* X, int M, const float* Y, int N, long long rows, int nm_major, int db_is_sx, float* dW, float* db,
+                      float* ws_p, float* ws_s, int nblk, hipStream_t stream) {
+    if (rows <= 0 || M <= 0 || N <= 0) return 0;
+    if (N > DN_THIN_NMAX || M % 4 != 0 || ((uintptr_t)X & 15) != 0 || nblk <= 0) return DN_ERR_BAD_MODE;
+    dn_prof_begin(DN_K_SMALL, stream);
+    DN_LAUNCH(thin_tn_kernel, dim3(nblk, 1, 1), dim3(256, 1, 1), 0, stream, X, M, Y, N, rows, nm_major,
+              ws_p, (db && db_is_sx) ? ws_s : (float*)nullptr, (db && !db_is_sx) ? ws_s : (float*)nullptr);
+    dn_prof_end(DN_K_SMALL, stream, 2.0 * rows * M * N, 4.0 * rows * (M + N));
+    int err = (int)hipGetLastError();
+    if (err) return err;
+    if (db) return dn_launch_reduce_pair(ws_p, dW, (long long)M * N, ws_s, db, db_is_sx ? M : N, nblk, stream);
+    return dn_launch_seg_reduce(ws_p, nullptr, 1, nblk, dW, (long long)M * N, stream);
+}
+
 // ---- heat kernel signature (geometry.py:600-633): out[b][v][s] = sum_k exp(-lambda[b][k] * t[s]) * evecs[b][v][k]^2.
 //      One streaming pass over the eigenbasis (the input feature of the "hks" experiments); block = 64 rows x 4 groups of
 //      4 scales, 32-wide k chunks staged through LDS (coalesced float4 loads of Phi, exp() once per (k, scale) and block).
