@@ -316,14 +316,23 @@ __global__ __launch_bounds__(256) void smallk_rows_kernel(const float* x, int K,
             w[e][k] = (k < K && n + e < N) ? (w_kn ? W[(long long)k * N + n + e] : W[(long long)(n + e) * K + k]) : 0.f;
     }
     const bool vec = (N % 4 == 0) && (((uintptr_t)out & 15) == 0);
+    const bool kvec = (K == KMAX) && (((uintptr_t)x & 15) == 0);
     const long long stride = (long long)gridDim.x * rows_per_pass;
     for (long long r0 = (long long)blockIdx.x * rows_per_pass + rl; r0 < rows; r0 += UR * stride) {
         float xv[UR][KMAX];
 #pragma unroll
         for (int u = 0; u < UR; ++u) {           // all input loads of the UR passes first (clamped row, no branch)
             const long long r = r0 + u * stride < rows ? r0 + u * stride : r0;
+            if (kvec) {            // K == KMAX, 16-byte aligned rows: KMAX / 4 vector loads instead of KMAX dword loads
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k) xv[u][k] = x[r * K + (k < K ? k : 0)];
+                for (int k = 0; k < KMAX; k += 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(x + r * K + k);
+                    xv[u][k] = t.x; xv[u][k + 1] = t.y; xv[u][k + 2] = t.z; xv[u][k + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) xv[u][k] = x[r * K + (k < K ? k : 0)];
+            }
         }
 #pragma unroll
         for (int u = 0; u < UR; ++u) {
