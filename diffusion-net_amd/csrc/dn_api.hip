@@ -140,12 +140,13 @@ int gradfeat_bwd_inputs(const dn_mesh_batch_t* mb, const float* ddots, const flo
     return dn_launch_rowgemm(g, mb->n_tiles, 2, st);
 }
 int gradfeat_bwd_weights(const dn_mesh_batch_t* mb, const float* ddots, const float* gx, const float* gy, int C,
-                         float* dA_re, float* dA_im, float* partial, float* psum, hipStream_t st) {
+                         float* dA_re, float* dA_im, float* partial, float* psum, hipStream_t st, MrJobs* defer = nullptr) {
     if (C == 128 && dA_im && al16(ddots) && al16(gx) && al16(gy) && al16(partial)) {
         // one pass over ddots, gx, gy: every workgroup computes all four quadrants for its row range (dn_tn_da.hip)
         int nwg = dn_num_cus();
         if (nwg > 2 * mb->n_chunks) nwg = 2 * mb->n_chunks;      // the workspace holds n_chunks * 4 C^2 floats
         DN_CHECK(dn_launch_tn_da(ddots, gx, gy, mb->v_total, partial, nwg, st));
+        if (defer && defer->push(partial, nwg, 2LL * C * C, dA_re, dA_im, (long long)C * C)) return 0;
         return dn_launch_reduce_split(partial, nwg, dA_re, dA_im, (long long)C * C, st);
     }
     TnArgs g = tn_new(mb);
@@ -190,7 +191,7 @@ int linear_bwd_input(const dn_mesh_batch_t* mb, const float* d_a, int C_out, con
 }
 // dW[o][i] = sum_r d_a[r,o] in[r,i] ; db[o] = sum_r d_a[r,o]
 int linear_bwd_weights(const dn_mesh_batch_t* mb, const float* d_a, int C_out, const float* const* ins, const int* ws_, int nseg,
-                       float* dW, float* db, float* partial, float* colsum, hipStream_t st) {
+                       float* dW, float* db, float* partial, float* colsum, hipStream_t st, MrJobs* defer = nullptr) {
     TnArgs g = tn_new(mb);
     tn_a(g, d_a, nullptr, C_out, C_out);
     for (int s = 0; s < nseg; ++s) tn_b(g, ins[s], nullptr, ws_[s], ws_[s]);
@@ -199,6 +200,11 @@ int linear_bwd_weights(const dn_mesh_batch_t* mb, const float* d_a, int C_out, c
     tn_finish(g);
     const int npart = dn_tn_npartial(mb->n_chunks, g.group);
     DN_CHECK(dn_launch_tngemm(g, mb->n_chunks, st));
+    if (defer && g.M % 4 == 0 && defer->count + 2 <= DN_MR_MAX_JOBS && al16(partial) && al16(colsum) &&
+        defer->push(partial, npart, (long long)g.M * g.N, dW)) {          // summed with the block's other gradients, one launch
+        if (db && !defer->push(colsum, npart, g.M, db)) return dn_launch_reduce(colsum, db, npart, g.M, g.M, st);
+        return 0;
+    }
     if (db) return dn_launch_reduce_pair(partial, dW, (long long)g.M * g.N, colsum, db, g.M, npart, st);   // one launch for both
     return dn_launch_reduce(partial, dW, npart, (long long)g.M * g.N, (long long)g.M * g.N, st);
 }
@@ -211,15 +217,6 @@ unsigned long long layer_seed(unsigned long long seed, int layer) {
 int max_width(const dn_block_params_t* p) {
     int m = p->C;
     for (int i = 1; i <= p->n_mlp; ++i) if (p->widths[i] > m) m = p->widths[i];
-    return m;
-}
-size_t max_wgrad_elems(const dn_mesh_batch_t* mb, const dn_block_params_t* p) {
-    size_t m = (size_t)mb->k_eig * p->C;
-    for (int i = 0; i < p->n_mlp; ++i) {
-        size_t e = (size_t)p->widths[i] * p->widths[i + 1];
-        if (e > m) m = e;
-    }
-    if (p->with_grad) { size_t e = (size_t)4 * p->C * p->C; if (e > m) m = e; }
     return m;
 }
 bool block_params_ok(const dn_block_params_t* p) {
@@ -505,8 +502,10 @@ size_t dn_block_bwd_workspace_bytes(const dn_mesh_batch_t* mb, const dn_block_pa
     const size_t VC = (size_t)mb->v_total * p->C;
     size_t n = 2 * pad256((size_t)mb->v_total * max_width(p));     // d_a ping-pong
     n += 5 * pad256(VC);                                            // d_xacc, d_xd, d_dots, d_gx, d_gy
-    n += pad256((size_t)mb->n_chunks * max_wgrad_elems(mb, p));     // TN partials
-    n += pad256((size_t)mb->n_chunks * max_width(p));               // bias partials
+    for (int j = 0; j < p->n_mlp; ++j)                               // TN partials + bias partials, one region per layer: the sums
+        n += pad256((size_t)mb->n_chunks * p->widths[j] * p->widths[j + 1]) + pad256((size_t)mb->n_chunks * p->widths[j + 1]);   // are deferred
+    if (p->with_grad) n += pad256((size_t)mb->n_chunks * 4 * p->C * p->C);
+    n += pad256((size_t)mb->n_chunks * mb->k_eig * p->C);           // split-V partials of the diffusion backward
     n += pad256((size_t)mb->n_mesh * mb->k_eig * p->C) + pad256((size_t)mb->n_mesh * p->C);
     n += pad256((size_t)4 * p->C * p->C);
     return n + 512;
@@ -524,13 +523,21 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     float* d_dots = b.f(VC);
     float* d_gx = b.f(VC);
     float* d_gy = b.f(VC);
-    float* partial = b.f((size_t)mb->n_chunks * max_wgrad_elems(mb, p));
-    float* colsum = b.f((size_t)mb->n_chunks * max_width(p));
+    float* part_w[DN_MAX_MLP_LAYERS]; float* part_b[DN_MAX_MLP_LAYERS];
+    for (int j = 0; j < p->n_mlp; ++j) {
+        part_w[j] = b.f((size_t)mb->n_chunks * p->widths[j] * p->widths[j + 1]);
+        part_b[j] = b.f((size_t)mb->n_chunks * p->widths[j + 1]);
+    }
+    float* part_a = p->with_grad ? b.f((size_t)mb->n_chunks * 4 * C * C) : nullptr;
+    float* partial = b.f((size_t)mb->n_chunks * K * C);
     float* dxs = b.f((size_t)mb->n_mesh * K * C);
     float* dtp = b.f((size_t)mb->n_mesh * C);
     float* psum = b.f((size_t)4 * C * C);
     if (!b.ok) return DN_ERR_INVALID;
 
+    // The fixed-order sums of the weight / bias / rotation-matrix partials are deferred: every product writes its partials to its
+    // own region and ONE launch reduces them all once the last one is written (5 launches -> 1 per block).
+    MrJobs jobs; jobs.count = 0;
     // ---- MiniMLP backward (autograd of layers.py:236); d_a = gradient w.r.t. a layer's pre-activation output
     const float* d_a = d_out;   // last layer has no activation; the residual branch is added into d_xacc below
     for (int j = p->n_mlp - 1; j >= 0; --j) {
@@ -538,7 +545,7 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
         if (j > 0) {
             const float* ins[1] = {sv->h[j - 1]};
             const int iw[1] = {wi};
-            DN_CHECK(linear_bwd_weights(mb, d_a, wo, ins, iw, 1, gr->dW[j], gr->db[j], partial, colsum, st));
+            DN_CHECK(linear_bwd_weights(mb, d_a, wo, ins, iw, 1, gr->dW[j], gr->db[j], part_w[j], part_b[j], st, &jobs));
             float* nxt = da[j & 1];
             // d(pre-act of layer j-1) = (d_a W_j) * relu'(.) * dropout scale; h>0 <=> kept and active
             DN_CHECK(linear_bwd_input(mb, d_a, wo, p->W[j], wi, 0, wi, DN_EPI_MUL_DFAC, sv->h[j - 1],
@@ -547,7 +554,7 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
         } else {
             const float* ins[3] = {x, sv->xd, sv->g};
             const int iw[3] = {C, C, C};
-            DN_CHECK(linear_bwd_weights(mb, d_a, wo, ins, iw, p->with_grad ? 3 : 2, gr->dW[0], gr->db[0], partial, colsum, st));
+            DN_CHECK(linear_bwd_weights(mb, d_a, wo, ins, iw, p->with_grad ? 3 : 2, gr->dW[0], gr->db[0], part_w[0], part_b[0], st, &jobs));
             // d_h0 = d_a W_0 split into its column groups [x | xd | g]
             DN_CHECK(linear_bwd_input(mb, d_a, wo, p->W[0], wi, 0, C, DN_EPI_ADD, d_out, 1.f, d_xacc, st));       // + residual
             DN_CHECK(linear_bwd_input(mb, d_a, wo, p->W[0], wi, C, C, DN_EPI_STORE, nullptr, 1.f, d_xd, st));
@@ -558,10 +565,11 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     // ---- gradient features + gradient apply backward
     if (p->with_grad) {
         const float* A_im = p->with_rot ? p->A_im : nullptr;
-        DN_CHECK(gradfeat_bwd_weights(mb, d_dots, sv->gx, sv->gy, C, gr->dA_re, p->with_rot ? gr->dA_im : nullptr, partial, psum, st));
+        DN_CHECK(gradfeat_bwd_weights(mb, d_dots, sv->gx, sv->gy, C, gr->dA_re, p->with_rot ? gr->dA_im : nullptr, part_a, psum, st, &jobs));
         DN_CHECK(gradfeat_bwd_inputs(mb, d_dots, sv->gx, sv->gy, sv->bre, sv->bim, p->A_re, A_im, C, d_gx, d_gy, st));
         DN_CHECK(grad_apply_bwd(mb, d_gx, d_gy, d_xd, C, d_xd, st));   // d_xd += gradX^T d_gx + gradY^T d_gy (in place)
     }
+    DN_CHECK(dn_launch_multi_reduce(jobs, st));
     // ---- diffusion backward
     DN_CHECK(to_basis_partials(mb, d_xd, C, false, partial, st));
     DN_CHECK(dn_launch_seg_reduce(partial, mb->mesh_chunk_off, mb->n_mesh, 0, dxs, (long long)K * C, st));

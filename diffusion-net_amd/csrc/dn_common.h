@@ -310,6 +310,20 @@ int dn_launch_reduce(const float* partial, float* out, int n, long long stride, 
 int dn_launch_seg_reduce(const float* partial, const int* seg_off, int nseg, int n, float* out, long long len, hipStream_t stream);
 int dn_launch_combine_dA(const float* P, float* dA_re, float* dA_im, int C, hipStream_t stream);
 int dn_launch_reduce_split(const float* partial, int n, float* o0, float* o1, long long half, hipStream_t stream);
+// several whole-range sums in ONE launch (the weight / bias / rotation gradients of a block's backward are reduced together once
+// their partials are all written): job j sums src[k][0..len) over k < n; element i goes to o0[i] (i < half) or o1[i - half].
+#define DN_MR_MAX_JOBS 20
+struct MrJob { const float* src; float* o0; float* o1; long long half, len; int n; };
+struct MrJobs {
+    MrJob j[DN_MR_MAX_JOBS];
+    int count;
+    bool push(const float* src, int n, long long len, float* o0, float* o1 = nullptr, long long half = -1) {
+        if (count >= DN_MR_MAX_JOBS || len % 4 != 0 || ((uintptr_t)src & 15) != 0 || (o1 && half % 4 != 0)) return false;
+        j[count++] = MrJob{src, o0, o1, o1 ? half : len, len, n};
+        return true;
+    }
+};
+int dn_launch_multi_reduce(const MrJobs& jobs, hipStream_t stream);
 int dn_launch_thin_tn(const float* X, int M, const float* Y, int N, long long rows, int nm_major, int db_is_sx, float* dW, float* db,
                       float* ws_p, float* ws_s, int nblk, hipStream_t stream);
 // dn_tn_da.hip: dA_re / dA_im partials of all four quadrants of [dd*gx | dd*gy]^T [gx | gy] from ONE pass over the three arrays (C = 128)

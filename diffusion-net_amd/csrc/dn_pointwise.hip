@@ -206,6 +206,26 @@ int dn_launch_reduce_split(const float* partial, int n, float* o0, float* o1, lo
     return (int)hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void multi_reduce_kernel(MrJobs J) {
+    const MrJob& j = J.j[blockIdx.y];
+    if ((long long)blockIdx.x * 128 >= j.len) return;          // (uniform per block)
+    seg_reduce_body<4>(j.src, 0, 0, j.n, j.len, SegSplitStore{j.o0, j.o1, j.half});
+}
+int dn_launch_multi_reduce(const MrJobs& jobs, hipStream_t stream) {
+    if (jobs.count <= 0) return 0;
+    long long nb = 0;
+    double bytes = 0.0;
+    for (int i = 0; i < jobs.count; ++i) {
+        const long long b = (jobs.j[i].len / 4 + 31) / 32;
+        nb = b > nb ? b : nb;
+        bytes += 4.0 * (double)jobs.j[i].len * ((double)jobs.j[i].n + 1.0);
+    }
+    dn_prof_begin(DN_K_SMALL, stream);
+    DN_LAUNCH(multi_reduce_kernel, dim3((unsigned)nb, jobs.count, 1), dim3(256, 1, 1), 0, stream, jobs);
+    dn_prof_end(DN_K_SMALL, stream, 0.0, bytes);
+    return (int)hipGetLastError();
+}
+
 int dn_launch_reduce(const float* partial, float* out, int n, long long stride, long long len, hipStream_t stream) {
     if (stride != len) return DN_ERR_BAD_MODE;
     return dn_launch_seg_reduce(partial, nullptr, 1, n, out, len, stream);
