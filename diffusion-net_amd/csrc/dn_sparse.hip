@@ -12,6 +12,13 @@
 #define DN_SP_XCD 1   // XCD-contiguous row blocks (block b runs on XCD b % 8): 76 vs 81 us on the bench batch (3 rounds)
 #endif
 #ifndef DN_SP_CHUNK
+#ifndef DN_SP_COOP
+#ifdef DN_EMULATE
+#define DN_SP_COOP 0   // (the fiber emulator's shuffles are whole-wave barriers; row groups of a wave leave the entry loop at different times)
+#else
+#define DN_SP_COOP 1   // pattern entries of a row fetched once per row group and shared by shuffles (0: every lane loads them)
+#endif
+#endif
 #define DN_SP_CHUNK 8   // non-zeros gathered per branch-free step (a mesh vertex has ~7 gradient entries)
 #endif
 
@@ -28,6 +35,9 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpArgs s, int tpr) {
 #else
     const int row = blockIdx.x * rows_per_block + rl;
 #endif
+    // cooperative index loads need every lane of the row's group alive in one wave (the row test below is uniform per group)
+    // (and every lane of the group must run every column pass: C a multiple of the group's span)
+    const bool coop = DN_SP_COOP && tpr >= DN_SP_CHUNK && tpr <= 64 && s.C % (tpr * VEC) == 0;
     if (row >= s.nrows) return;
     const int beg = s.rowptr[row], end = s.rowptr[row + 1];
     for (int c = cg * VEC; c < s.C; c += tpr * VEC) {
@@ -39,13 +49,30 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpArgs s, int tpr) {
         for (int j0 = beg; j0 < end; j0 += DN_SP_CHUNK) {
             long long src[DN_SP_CHUNK];
             float wa[DN_SP_CHUNK], wb[DN_SP_CHUNK];
+            if (coop) {
+                // The lanes of a row read the SAME DN_SP_CHUNK pattern entries: lane u of the row fetches entry u (one index load and
+                // one or two value loads per wave instead of 3 x DN_SP_CHUNK broadcast loads) and the row shares them by shuffles.
+                const bool mine = cg < DN_SP_CHUNK && j0 + cg < end;
+                const int jm = mine ? j0 + cg : end - 1;
+                const int colm = s.col[jm];
+                const float vam = mine ? (s.va ? s.va[jm] : 1.f) : 0.f;
+                const float vbm = (s.mode != DN_SP_ONE && mine) ? s.vb[jm] : 0.f;
+                const int gbase = (tid & 63) - cg;
 #pragma unroll
-            for (int u = 0; u < DN_SP_CHUNK; ++u) {
-                const bool in = j0 + u < end;
-                const int j = in ? j0 + u : end - 1;
-                src[u] = (long long)s.col[j] * s.ldx + c;
-                wa[u] = in ? (s.va ? s.va[j] : 1.f) : 0.f;
-                wb[u] = (s.mode != DN_SP_ONE && in) ? s.vb[j] : 0.f;
+                for (int u = 0; u < DN_SP_CHUNK; ++u) {
+                    src[u] = (long long)__shfl(colm, gbase + u, 64) * s.ldx + c;
+                    wa[u] = __shfl(vam, gbase + u, 64);
+                    wb[u] = s.mode != DN_SP_ONE ? __shfl(vbm, gbase + u, 64) : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < DN_SP_CHUNK; ++u) {
+                    const bool in = j0 + u < end;
+                    const int j = in ? j0 + u : end - 1;
+                    src[u] = (long long)s.col[j] * s.ldx + c;
+                    wa[u] = in ? (s.va ? s.va[j] : 1.f) : 0.f;
+                    wb[u] = (s.mode != DN_SP_ONE && in) ? s.vb[j] : 0.f;
+                }
             }
             float xv[DN_SP_CHUNK][VEC], yv[DN_SP_CHUNK][VEC];
 #pragma unroll
