@@ -142,6 +142,48 @@ def cpu_baseline(args, C_out, sizes):
                       % (best[2], n_sample, "/".join(str(s_) for s_ in sizes[:n_sample]), sorted(int(k) for k in sweep), sweep, ncpu)}
 
 
+def torch_rocm_baseline(args, C_out, sizes, device):
+    """SURVEY 8d's optional second baseline: the SAME restatement the CPU baseline times (oracle/, plain torch ops), but with its tensors on
+    the MI355X -- i.e. what stock PyTorch-ROCm (rocBLAS GEMMs, rocSPARSE COO products, elementwise kernels, autograd) makes of this
+    network on this GPU, in the reference's one-mesh-per-step loop.  Baseline only; returns None if an op is missing on this build."""
+    try:
+        import diffusion_net
+        from diffusion_net import synthetic
+        from oracle import diffusionnet_oracle as orc
+        n_sample = min(3, len(sizes))
+        meshes = [{k: (v.to(device) if torch.is_tensor(v) else v) for k, v in synthetic.make_mesh_operators(vv, args.keig, seed=i).items()}
+                  for i, vv in enumerate(sizes[:n_sample])]
+        labels = [torch.randint(0, C_out, (m["faces"].shape[0],), device=device) for m in meshes]
+        lsm = lambda t: F.log_softmax(t, dim=-1)
+        sd = synthetic.randomize_times(diffusion_net.layers.DiffusionNet(3, C_out, C_width=args.cwidth, N_block=args.blocks, outputs_at="faces").state_dict(), seed=0)
+        params = {k: v.clone().to(device).requires_grad_(True) for k, v in sd.items()}
+        opt = torch.optim.Adam(list(params.values()), lr=1e-3)
+
+        def step(i):
+            m = meshes[i % n_sample]
+            V = m["verts"].shape[0]
+            opt.zero_grad()
+            masks = [[torch.bernoulli(torch.full((V, args.cwidth), 0.5, device=device)) for _ in range(2)] for _ in range(args.blocks)]
+            p = {k: (orc.clamp_time(v) if k.endswith("diffusion_time") else v) for k, v in params.items()}
+            out = orc.net_forward(p, m["verts"], m["mass"], m["evals"], m["evecs"], m["gradX"], m["gradY"], faces=m["faces"],
+                                  outputs_at="faces", last_activation=lsm, keep_masks=masks)
+            F.nll_loss(out, labels[i % n_sample]).backward()
+            opt.step()
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+        t0, n, v = time.perf_counter(), 0, 0
+        while n < 30 and time.perf_counter() - t0 < 5.0:
+            step(n)
+            v += sizes[n % n_sample]
+            n += 1
+        torch.cuda.synchronize()
+        return {"value": v / (time.perf_counter() - t0), "unit": "vertices/s", "kind": "port on the GPU (stock PyTorch-ROCm ops, no code of this library)",
+                "sample": "%d train steps, one mesh per step, first %d meshes of the benchmark batch, fp32, same net/config" % (n, n_sample)}
+    except Exception as e:      # noqa: BLE001
+        return {"value": None, "unit": "vertices/s", "kind": "unavailable: %s" % repr(e)[:160]}
+
+
 def kernel_family_report(lib):
     """Per-kernel-family timing from the library's hipEvent brackets (this rank, timed region) and the roofline object of the family
     with the largest share."""
@@ -525,6 +567,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only (the other ranks would sit idle behind it)
             res["cpu_baseline"] = cpu_baseline(args, C_out, mesh_sizes(args.meshes, args.verts, 0))
+            res["torch_rocm_baseline"] = torch_rocm_baseline(args, C_out, mesh_sizes(args.meshes, args.verts, 0), device)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
