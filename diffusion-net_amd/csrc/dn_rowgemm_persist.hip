@@ -19,7 +19,7 @@
 // LDS: 2 x 32 KiB slice buffers + 64 KiB staging = 128 KiB.
 // =======================================================================================
 #ifndef DN_PT_MAX_SLICES
-#define DN_PT_MAX_SLICES 12  // up to K = 384 (the 3C -> C MLP layer); measured 177 -> 155 us with the bf16x3 path
+#define DN_PT_MAX_SLICES 32  // up to K = 1024 (the 3C -> C MLP layer: 12 slices at C = 128, 24 at C = 256; the lock-step exact-f32 fallback took 829 us per launch at C = 256: cfg4 18.9 -> 20.3 M vertices/s)
 #endif
 // Work-unit geometry.  Measured on MI355X (K = N = 128 product, 158k rows): 128-row units with 8 waves and one
 // workgroup per CU: 68 us; 64-row units with 4 waves and two workgroups per CU (2 x 80 KiB LDS): 71-75 us (twice the
