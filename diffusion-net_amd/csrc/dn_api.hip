@@ -413,11 +413,11 @@ int dn_linear_bwd_f32(const dn_mesh_batch_t* mb, const float* d_out, const float
     const float* ins[1] = {x};
     const int ws_[1] = {C_in};
     int nthin = mb->n_chunks < 512 ? mb->n_chunks : 512;    // workgroups of the thin products (their partials fit the regions above)
-    if (C_in <= 8 && C_out % 4 == 0 && al16(d_out) && (size_t)nthin * C_in * C_out <= linear_partial_elems(mb, C_in, C_out)) {
-        // thin input (first_lin, xyz features): dW = d_out^T x and db = column sums of d_out from ONE streaming pass over d_out
+    if (C_in <= 32 && C_out >= 32 && C_out % 4 == 0 && al16(d_out) && (size_t)nthin * C_in * C_out <= linear_partial_elems(mb, C_in, C_out)) {
+        // thin input (first_lin: xyz or hks features): dW = d_out^T x and db = column sums of d_out from one streaming pass over d_out per 8 inputs
         DN_CHECK(dn_launch_thin_tn(d_out, C_out, x, C_in, mb->v_total, 0, 1, dW, db, partial, colsum, nthin, S(stream)));
-    } else if (C_out <= 8 && C_in > 16 && C_in % 4 == 0 && al16(x)) {
-        // thin output (last_lin): dW = d_out^T x and db = column sums of d_out from one streaming pass over x
+    } else if (C_out <= 32 && C_in >= 32 && C_in % 4 == 0 && al16(x)) {
+        // thin output (last_lin, up to 32 classes): dW = d_out^T x and db = column sums of d_out from one streaming pass over x per 8 classes
         DN_CHECK(dn_launch_thin_tn(x, C_in, d_out, C_out, mb->v_total, 1, 0, dW, db, partial, colsum, nthin, S(stream)));
     } else if (C_in <= 16) {
         // thin input (hks features, C_in = 16): dW = d_out^T x streams d_out once on the VALU

@@ -251,25 +251,37 @@ int dn_launch_combine_dA(const float* P, float* dA_re, float* dA_im, int C, hipS
 
 // meshrows[m] = {row0, nrows, m, 0}.  block = 64 channels x 4 row lanes.
 __global__ __launch_bounds__(256) void mass_mean_fwd_kernel(const DnTile* meshrows, const float* mass, const float* x,
-                                                            float* out, float* msum, int C) {
-    __shared__ float red[4][64];
-    __shared__ float redm[4][64];
+                                                            float* out, float* msum, int C, int CL) {
+    // CL channel lanes x (256 / CL) row lanes; every row lane keeps four independent partial sums (four rows in flight), all
+    // combined in a fixed order: bitwise reproducible
+    __shared__ float red[8][64];
+    __shared__ float redm[8][64];
     const DnTile mr = meshrows[blockIdx.y];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    float s = 0.f, ms = 0.f;
-    for (int r = rl; r < mr.nrows; r += 4) {
-        const float mv = mass[mr.row0 + r];
-        ms += mv;
-        if (c < C) s += mv * x[(long long)(mr.row0 + r) * C + c];
+    const int RL = 256 / CL;
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+    const int c = blockIdx.x * CL + cl;
+    const bool cok = c < C;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, ms[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r0 = rl; r0 < mr.nrows; r0 += 4 * RL) {
+        float mv[4], xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u * RL;
+            const bool ok = r < mr.nrows;
+            const long long row = mr.row0 + (ok ? r : r0);
+            mv[u] = ok ? mass[row] : 0.f;
+            xv[u] = (ok && cok) ? x[row * C + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { ms[u] += mv[u]; s[u] = fmaf(mv[u], xv[u], s[u]); }
     }
-    red[rl][cl] = s;
-    redm[rl][cl] = ms;
+    red[rl][cl] = (s[0] + s[1]) + (s[2] + s[3]);
+    redm[rl][cl] = (ms[0] + ms[1]) + (ms[2] + ms[3]);
     __syncthreads();
     if (rl == 0) {
-        const float st = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
-        const float mt = (redm[0][cl] + redm[1][cl]) + (redm[2][cl] + redm[3][cl]);
-        if (c < C) out[blockIdx.y * C + c] = st / mt;
+        float st = 0.f, mt = 0.f;
+        for (int k = 0; k < RL; ++k) { st += red[k][cl]; mt += redm[k][cl]; }
+        if (cok) out[blockIdx.y * C + c] = st / mt;
         if (blockIdx.x == 0 && cl == 0) msum[blockIdx.y] = mt;
     }
 }
@@ -277,8 +289,9 @@ __global__ __launch_bounds__(256) void mass_mean_fwd_kernel(const DnTile* meshro
 int dn_launch_mass_mean_fwd(const DnTile* meshrows, const float* mass, const float* x, float* out, float* msum,
                             int n_mesh, int C, hipStream_t stream) {
     if (n_mesh <= 0 || C <= 0) return 0;
-    dim3 grid((C + 63) / 64, n_mesh, 1);
-    DN_LAUNCH(mass_mean_fwd_kernel, grid, dim3(256, 1, 1), 0, stream, meshrows, mass, x, out, msum, C);
+    const int CL = C <= 32 ? 32 : 64;
+    dim3 grid((C + CL - 1) / CL, n_mesh, 1);
+    DN_LAUNCH(mass_mean_fwd_kernel, grid, dim3(256, 1, 1), 0, stream, meshrows, mass, x, out, msum, C, CL);
     return (int)hipGetLastError();
 }
 
@@ -422,7 +435,7 @@ int dn_launch_smalln_tn(const float* A, int M, const float* B, int N, long long 
 }
 
 // ---- thin split-V product for the two ends of the network (first_lin: C_in = 3 inputs; last_lin: C_out <= 8 classes):
-//      P[m][n] = sum_r X[r,m] Y[r,n]   with X wide (M columns, float4 per thread) and Y thin (N <= 8),
+//      P[m][n] = sum_r X[r,m] Y[r,n]   with X wide (M columns, float4 per thread) and Y thin (N <= 32, eight columns per pass over X),
 //      plus the column sums sx[m] = sum_r X[r,m] and sy[n] = sum_r Y[r,n] (whichever of them is the bias gradient) from the SAME pass.
 //      first_lin: X = d_out, Y = x      -> dW[o][i] = P[o][i] (m-major store), db = sx
 //      last_lin : X = x,     Y = d_out  -> dW[o][c] = P[c][o] (n-major store), db = sy
@@ -435,7 +448,8 @@ __global__ __launch_bounds__(256) void thin_tn_kernel(const float* X, int M, con
     const long long per = (rows + gridDim.x - 1) / gridDim.x;
     const long long r_beg = (long long)blockIdx.x * per, r_end = (r_beg + per < rows) ? r_beg + per : rows;
     float* wp = ws_p + (long long)blockIdx.x * M * N;
-    for (int m0 = 0; m0 < M; m0 += 128) {
+    for (int m0 = 0; m0 < M; m0 += 128)
+    for (int n0 = 0; n0 < N; n0 += DN_THIN_NMAX) {       // N > 8 (e.g. 30 classes, 16 hks features): X is streamed once per 8 columns of Y
         const int m = m0 + 4 * c4;
         const bool mok = m < M;
         float acc[DN_THIN_NMAX][4], sx[4] = {0.f, 0.f, 0.f, 0.f}, sy[DN_THIN_NMAX];
@@ -452,7 +466,7 @@ __global__ __launch_bounds__(256) void thin_tn_kernel(const float* X, int M, con
                 xv[u] = *reinterpret_cast<const float4*>(X + rr * M + (mok ? m : 0));
                 if (!ok || !mok) xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int n = 0; n < DN_THIN_NMAX; ++n) yv[u][n] = (ok && n < N) ? Y[rr * N + n] : 0.f;
+                for (int n = 0; n < DN_THIN_NMAX; ++n) yv[u][n] = (ok && n0 + n < N) ? Y[rr * N + n0 + n] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -467,9 +481,9 @@ __global__ __launch_bounds__(256) void thin_tn_kernel(const float* X, int M, con
         }
         // fixed-order sum over the 8 row lanes, one quantity at a time through 4 KiB of LDS
 #pragma unroll
-        for (int q = 0; q <= DN_THIN_NMAX; ++q) {      // q < NMAX: P[.][q];  q == NMAX: sx
-            if (q < DN_THIN_NMAX && q >= N) continue;
-            if (q == DN_THIN_NMAX && !ws_sx) continue;
+        for (int q = 0; q <= DN_THIN_NMAX; ++q) {      // q < NMAX: P[.][n0 + q];  q == NMAX: sx
+            if (q < DN_THIN_NMAX && n0 + q >= N) continue;
+            if (q == DN_THIN_NMAX && (!ws_sx || n0 != 0)) continue;
             __syncthreads();
 #pragma unroll
             for (int e = 0; e < 4; ++e) red[rl][4 * c4 + e] = q < DN_THIN_NMAX ? acc[q][e] : sx[e];
@@ -479,7 +493,7 @@ __global__ __launch_bounds__(256) void thin_tn_kernel(const float* X, int M, con
 #pragma unroll
                 for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
                 const int mm = m0 + threadIdx.x;
-                if (q < DN_THIN_NMAX) wp[nm_major ? (long long)q * M + mm : (long long)mm * N + q] = t;
+                if (q < DN_THIN_NMAX) wp[nm_major ? (long long)(n0 + q) * M + mm : (long long)mm * N + n0 + q] = t;
                 else ws_sx[(long long)blockIdx.x * M + mm] = t;
             }
         }
@@ -489,11 +503,11 @@ __global__ __launch_bounds__(256) void thin_tn_kernel(const float* X, int M, con
 #pragma unroll
                 for (int n = 0; n < DN_THIN_NMAX; ++n) red[rl][n] = sy[n];
             __syncthreads();
-            if (threadIdx.x < N) {
+            if (threadIdx.x < DN_THIN_NMAX && n0 + (int)threadIdx.x < N) {
                 float t = 0.f;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
-                ws_sy[(long long)blockIdx.x * N + threadIdx.x] = t;
+                ws_sy[(long long)blockIdx.x * N + n0 + threadIdx.x] = t;
             }
         }
     }
@@ -503,7 +517,7 @@ __global__ __launch_bounds__(256) void thin_tn_kernel(const float* X, int M, con
 int dn_launch_thin_tn(const float* X, int M, const float* Y, int N, long long rows, int nm_major, int db_is_sx, float* dW, float* db,
                       float* ws_p, float* ws_s, int nblk, hipStream_t stream) {
     if (rows <= 0 || M <= 0 || N <= 0) return 0;
-    if (N > DN_THIN_NMAX || M % 4 != 0 || ((uintptr_t)X & 15) != 0 || nblk <= 0) return DN_ERR_BAD_MODE;
+    if (N > 4 * DN_THIN_NMAX || M % 4 != 0 || ((uintptr_t)X & 15) != 0 || nblk <= 0) return DN_ERR_BAD_MODE;
     dn_prof_begin(DN_K_SMALL, stream);
     DN_LAUNCH(thin_tn_kernel, dim3(nblk, 1, 1), dim3(256, 1, 1), 0, stream, X, M, Y, N, rows, nm_major,
               ws_p, (db && db_is_sx) ? ws_s : (float*)nullptr, (db && !db_is_sx) ? ws_s : (float*)nullptr);
