@@ -363,8 +363,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="cfg2/cfg3: replay a captured HIP graph of the step (diffusion_net.graphs) instead of enqueueing ~150 launches per step "
                                                          "(the headline step is replayed from a graph by default; see --eager)")
     ap.add_argument("--eager", action="store_true", help="headline: enqueue the ~190 launches of every step from the host instead of replaying the captured HIP graph")
-    ap.add_argument("--config", default="headline", choices=["headline", "cfg2", "cfg3", "cfg4"],
-                    help="headline: BASELINE metric workload (default, what the driver runs); cfg2/cfg3/cfg4: the other BASELINE.json configs, same JSON contract")
+    ap.add_argument("--config", default="headline", choices=["headline", "cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="headline: BASELINE metric workload (default, what the driver runs); cfg2/cfg3/cfg4: the other BASELINE.json configs, same JSON contract; "
+                         "cfg5: the headline step at the rna_mesh_segmentation shape (8 meshes x ~15k vertices per GPU, 260 classes at the vertices; works with --gpus N)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -403,12 +404,16 @@ def main():
             dist.barrier()
     lib = _hip.lib()
 
-    if args.config != "headline":
+    if args.config not in ("headline", "cfg5"):
         return run_other_config(args, device, lib, world, rank)
     C_in, C_out = 3, 8
+    at_faces = True
+    if args.config == "cfg5":                  # rna_mesh_segmentation.py:69-75: C_out = 260 classes, outputs_at = 'vertices', ~15k-vertex meshes
+        C_out, at_faces = 260, False
+        args.meshes, args.verts = 8, 15000
     torch.manual_seed(0)                       # identical replicas on every rank
-    model = diffusion_net.layers.DiffusionNet(C_in, C_out, C_width=args.cwidth, N_block=args.blocks, outputs_at="faces", dropout=True,
-                                              last_activation=lambda t: F.log_softmax(t, dim=-1))   # as human_segmentation_original.py:69-75
+    model = diffusion_net.layers.DiffusionNet(C_in, C_out, C_width=args.cwidth, N_block=args.blocks, outputs_at="faces" if at_faces else "vertices",
+                                              dropout=True, last_activation=lambda t: F.log_softmax(t, dim=-1))   # as human_segmentation_original.py:69-75
     model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=0))
     model.to(device).train()
     nsub = max(1, min(args.streams, args.meshes))
@@ -423,7 +428,9 @@ def main():
     for j in range(nsub):
         sub_sizes = sizes[j::nsub]
         _, mb_j, gather_j, x_j = build_batch(sub_sizes, args.keig, device, seed0=1000 * rank + 100 * j)
-        labels_j = torch.randint(0, C_out, (gather_j.n_out,), device=device)
+        if not at_faces:
+            gather_j = None
+        labels_j = torch.randint(0, C_out, (gather_j.n_out if at_faces else sum(sub_sizes),), device=device)
         subs.append((mb_j, gather_j, x_j, labels_j, sum(sub_sizes)))
     mb = subs[0][0]
     v_step = sum(sizes)
@@ -559,13 +566,13 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "arithmetic": "fp32 storage and accumulation; dense products on 3-term split-bf16 MFMA (fp32-level accuracy: rel-L2 1.6e-7 vs 2.0e-7 for the f32 MFMA chain, profiles/r01_exp_bf16x3.txt)",
             "config": {"workload": "train step (fwd+NLL+bwd+Adam%s) on a ragged batch of %d meshes x ~%d vertices per GPU, "
-                                   "DiffusionNet C_in=3 C_out=8 C_width=%d K=%d N_block=%d outputs_at=faces dropout=on"
-                                   % ("+RCCL all-reduce" if world > 1 else "", args.meshes, args.verts, Cw, K, args.blocks),
-                       "meshes_per_gpu": args.meshes, "verts_per_gpu_step": v_step, "parallelism": "dp%d" % world,
+                                   "DiffusionNet C_in=3 C_out=%d C_width=%d K=%d N_block=%d outputs_at=%s dropout=on"
+                                   % ("+RCCL all-reduce" if world > 1 else "", args.meshes, args.verts, C_out, Cw, K, args.blocks, "faces" if at_faces else "vertices"),
+                       "baseline_config": args.config, "meshes_per_gpu": args.meshes, "verts_per_gpu_step": v_step, "parallelism": "dp%d" % world,
                        "streams_per_gpu": nsub, "step_mode": step_mode},
             "roofline": roof, "kernel_families": fam, "diffusion_block": diff,
         }
-        if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only (the other ranks would sit idle behind it)
+        if not args.no_cpu_baseline and world == 1 and args.config == "headline":   # reported at N = 1 only (the other ranks would sit idle behind it)
             res["cpu_baseline"] = cpu_baseline(args, C_out, mesh_sizes(args.meshes, args.verts, 0))
             res["torch_rocm_baseline"] = torch_rocm_baseline(args, C_out, mesh_sizes(args.meshes, args.verts, 0), device)
         print(json.dumps(res))
