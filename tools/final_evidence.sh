@@ -9,6 +9,7 @@ for c in cfg2 cfg3; do
   timeout 200 python bench.py --config $c --graph --steps 40 --warmup 8 > gpurun_out/bench_${c}_graph.json 2>> gpurun_out/bench.err < /dev/null
 done
 timeout 200 python bench.py --config cfg4 --steps 10 --warmup 2 > gpurun_out/bench_cfg4.json 2>> gpurun_out/bench.err < /dev/null
+timeout 200 python bench.py --config cfg5 > gpurun_out/bench_cfg5.json 2>> gpurun_out/bench.err < /dev/null
 timeout 200 python tools/bench_dropin.py > gpurun_out/dropin.txt 2>> gpurun_out/bench.err < /dev/null
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_b && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o trace -- python "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$R/gpurun_out/prof_bench.json" 2> "$R/gpurun_out/prof.err" < /dev/null)
 f=$(find /tmp/prof_b -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" gpurun_out/bench_kernel_stats.csv
@@ -17,7 +18,7 @@ if [ -z "$NO_PMC" ]; then
   (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_m && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_m -o trace -- python "$R/tools/microbench.py" --reps 3 > /dev/null 2>&1 < /dev/null)
   f=$(find /tmp/prof_m -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" gpurun_out/microbench_kernel_stats.csv
 fi
-for j in bench bench_eager bench_cfg2 bench_cfg2_graph bench_cfg3 bench_cfg3_graph bench_cfg4; do
+for j in bench bench_eager bench_cfg2 bench_cfg2_graph bench_cfg3 bench_cfg3_graph bench_cfg4 bench_cfg5; do
   python - "$j" <<'PY'
 import json, sys
 try:
