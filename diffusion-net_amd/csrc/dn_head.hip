@@ -22,6 +22,8 @@ __device__ __forceinline__ float head_group_max(float v, int G) {
     return v;
 }
 
+// CPL = classes per lane (1, 2, 4 or 8): with a fixed CPL = 8 the eight-class head spent most of its time on seven dead class slots
+template <int CPL>
 __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a, int G) {
     __shared__ float red[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -32,11 +34,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a, int G) {
         const long long i = i0 + wave * rows_per_wave + gr;
         const bool live = i < a.n_out;                       // dead rows run along (the shuffles need every lane) on row 0
         const long long ii = live ? i : 0;
-        float z[DN_HEAD_CPL];
+        float z[CPL];
         int beg = 0, end = 1;
         if (a.rowptr) { beg = a.rowptr[ii]; end = a.rowptr[ii + 1]; }
 #pragma unroll
-        for (int k = 0; k < DN_HEAD_CPL; ++k) {
+        for (int k = 0; k < CPL; ++k) {
             const int c = gl + k * G;
             float s = 0.f;
             if (c < a.C) {
@@ -48,26 +50,26 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a, int G) {
         if (a.lsm) {
             float mx = -3.0e38f;
 #pragma unroll
-            for (int k = 0; k < DN_HEAD_CPL; ++k) if (gl + k * G < a.C) mx = z[k] > mx ? z[k] : mx;
+            for (int k = 0; k < CPL; ++k) if (gl + k * G < a.C) mx = z[k] > mx ? z[k] : mx;
             mx = head_group_max(mx, G);
             float se = 0.f;
 #pragma unroll
-            for (int k = 0; k < DN_HEAD_CPL; ++k) if (gl + k * G < a.C) se += expf(z[k] - mx);
+            for (int k = 0; k < CPL; ++k) if (gl + k * G < a.C) se += expf(z[k] - mx);
             se = head_group_sum(se, G);
             const float lse = mx + logf(se);
 #pragma unroll
-            for (int k = 0; k < DN_HEAD_CPL; ++k) z[k] -= lse;
+            for (int k = 0; k < CPL; ++k) z[k] -= lse;
         }
         if (a.logp && live) {
 #pragma unroll
-            for (int k = 0; k < DN_HEAD_CPL; ++k) if (gl + k * G < a.C) a.logp[i * a.C + gl + k * G] = z[k];
+            for (int k = 0; k < CPL; ++k) if (gl + k * G < a.C) a.logp[i * a.C + gl + k * G] = z[k];
         }
         if (a.labels) {
             const long long t = a.labels[ii];
             const bool valid = live && t >= 0 && t < a.C;
             float at = 0.f, all = 0.f;
 #pragma unroll
-            for (int k = 0; k < DN_HEAD_CPL; ++k) if (gl + k * G < a.C) { all += z[k]; if (gl + k * G == t) at += z[k]; }
+            for (int k = 0; k < CPL; ++k) if (gl + k * G < a.C) { all += z[k]; if (gl + k * G == t) at += z[k]; }
             at = head_group_sum(at, G);
             all = head_group_sum(all, G);
             if (valid && gl == 0) {
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(256) void head_finish_kernel(const float* partial, 
     if (threadIdx.x == 0) { loss[0] = red[0][0] / red[1][0]; count[0] = red[1][0]; }
 }
 
+template <int CPL>
 __global__ __launch_bounds__(256) void head_bwd_kernel(HeadArgs a, int G) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rows_per_wave = 64 / G, gl = lane % G, gr = lane / G;
@@ -119,18 +122,18 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadArgs a, int G) {
         // the lanes of a group walk the same outputs; groups of one wave may have different counts -> pad to the wave's maximum
         int n_it = end - beg;
         for (int m = 32; m >= G && m > 0; m >>= 1) { const int o = __shfl_xor(n_it, m, 64); n_it = o > n_it ? o : n_it; }
-        float acc[DN_HEAD_CPL];
+        float acc[CPL];
 #pragma unroll
-        for (int k = 0; k < DN_HEAD_CPL; ++k) acc[k] = 0.f;
+        for (int k = 0; k < CPL; ++k) acc[k] = 0.f;
         for (int it = 0; it < n_it; ++it) {
             const bool on = beg + it < end;
             const long long i = a.t_rowptr ? a.t_col[on ? beg + it : beg < end ? beg : 0] : vv;
             long long t = -1;
             if (a.labels) t = a.labels[i];
             const bool valid = t >= 0 && t < a.C;
-            float dlp[DN_HEAD_CPL], sum = 0.f;
+            float dlp[CPL], sum = 0.f;
 #pragma unroll
-            for (int k = 0; k < DN_HEAD_CPL; ++k) {
+            for (int k = 0; k < CPL; ++k) {
                 const int c = gl + k * G;
                 float d = 0.f;
                 if (c < a.C) {
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadArgs a, int G) {
             }
             if (a.lsm) sum = head_group_sum(sum, G);
 #pragma unroll
-            for (int k = 0; k < DN_HEAD_CPL; ++k) {
+            for (int k = 0; k < CPL; ++k) {
                 const int c = gl + k * G;
                 if (c < a.C && on) {
                     float dz = dlp[k];
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadArgs a, int G) {
         }
         if (live) {
 #pragma unroll
-            for (int k = 0; k < DN_HEAD_CPL; ++k) if (gl + k * G < a.C) a.d_x[v * a.C + gl + k * G] = acc[k] * a.inv_div;
+            for (int k = 0; k < CPL; ++k) if (gl + k * G < a.C) a.d_x[v * a.C + gl + k * G] = acc[k] * a.inv_div;
         }
     }
 }
@@ -167,7 +170,11 @@ int dn_launch_head_fwd(const HeadArgs& a, int nb, float* loss, float* count, hip
     int blocks = (int)(((long long)a.n_out + rpb - 1) / rpb);
     if (blocks > nb) blocks = nb;
     dn_prof_begin(DN_K_SMALL, stream);
-    DN_LAUNCH(head_fwd_kernel, dim3(blocks, 1, 1), dim3(256, 1, 1), 0, stream, a, G);
+    const int cpl = (a.C + G - 1) / G;
+    if (cpl <= 1) DN_LAUNCH(head_fwd_kernel<1>, dim3(blocks, 1, 1), dim3(256, 1, 1), 0, stream, a, G);
+    else if (cpl <= 2) DN_LAUNCH(head_fwd_kernel<2>, dim3(blocks, 1, 1), dim3(256, 1, 1), 0, stream, a, G);
+    else if (cpl <= 4) DN_LAUNCH(head_fwd_kernel<4>, dim3(blocks, 1, 1), dim3(256, 1, 1), 0, stream, a, G);
+    else DN_LAUNCH(head_fwd_kernel<DN_HEAD_CPL>, dim3(blocks, 1, 1), dim3(256, 1, 1), 0, stream, a, G);
     if (a.labels) DN_LAUNCH(head_finish_kernel, dim3(1, 1, 1), dim3(256, 1, 1), 0, stream, a.partial, blocks, loss, count);
     dn_prof_end(DN_K_SMALL, stream, 0.0, 4.0 * a.n_out * a.C * (a.logp ? 2.0 : 1.0));
     return (int)hipGetLastError();
@@ -180,7 +187,11 @@ int dn_launch_head_bwd(const HeadArgs& a, hipStream_t stream) {
     long long blocks = ((long long)a.n_src + rpb - 1) / rpb;
     if (blocks > 8192) blocks = 8192;
     dn_prof_begin(DN_K_SMALL, stream);
-    DN_LAUNCH(head_bwd_kernel, dim3((unsigned)blocks, 1, 1), dim3(256, 1, 1), 0, stream, a, G);
+    const int cpl = (a.C + G - 1) / G;
+    if (cpl <= 1) DN_LAUNCH(head_bwd_kernel<1>, dim3((unsigned)blocks, 1, 1), dim3(256, 1, 1), 0, stream, a, G);
+    else if (cpl <= 2) DN_LAUNCH(head_bwd_kernel<2>, dim3((unsigned)blocks, 1, 1), dim3(256, 1, 1), 0, stream, a, G);
+    else if (cpl <= 4) DN_LAUNCH(head_bwd_kernel<4>, dim3((unsigned)blocks, 1, 1), dim3(256, 1, 1), 0, stream, a, G);
+    else DN_LAUNCH(head_bwd_kernel<DN_HEAD_CPL>, dim3((unsigned)blocks, 1, 1), dim3(256, 1, 1), 0, stream, a, G);
     dn_prof_end(DN_K_SMALL, stream, 0.0, 4.0 * a.n_src * a.C * 3.0);
     return (int)hipGetLastError();
 }
