@@ -22,7 +22,8 @@
 #define DN_SP_CHUNK 8   // non-zeros gathered per branch-free step (a mesh vertex has ~7 gradient entries)
 #endif
 
-template <int VEC>
+// MODE is a compile-time copy of s.mode: with the mode tested at run time every unrolled gather step carried its own scalar branches
+template <int VEC, int MODE>
 __global__ __launch_bounds__(256) void spmm_kernel(SpArgs s, int tpr) {
 
     const int tid = threadIdx.x;
@@ -56,13 +57,13 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpArgs s, int tpr) {
                 const int jm = mine ? j0 + cg : end - 1;
                 const int colm = s.col[jm];
                 const float vam = mine ? (s.va ? s.va[jm] : 1.f) : 0.f;
-                const float vbm = (s.mode != DN_SP_ONE && mine) ? s.vb[jm] : 0.f;
+                const float vbm = (MODE != DN_SP_ONE && mine) ? s.vb[jm] : 0.f;
                 const int gbase = (tid & 63) - cg;
 #pragma unroll
                 for (int u = 0; u < DN_SP_CHUNK; ++u) {
                     src[u] = (long long)__shfl(colm, gbase + u, 64) * s.ldx + c;
                     wa[u] = __shfl(vam, gbase + u, 64);
-                    wb[u] = s.mode != DN_SP_ONE ? __shfl(vbm, gbase + u, 64) : 0.f;
+                    wb[u] = MODE != DN_SP_ONE ? __shfl(vbm, gbase + u, 64) : 0.f;
                 }
             } else {
 #pragma unroll
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpArgs s, int tpr) {
                     const int j = in ? j0 + u : end - 1;
                     src[u] = (long long)s.col[j] * s.ldx + c;
                     wa[u] = in ? (s.va ? s.va[j] : 1.f) : 0.f;
-                    wb[u] = (s.mode != DN_SP_ONE && in) ? s.vb[j] : 0.f;
+                    wb[u] = (MODE != DN_SP_ONE && in) ? s.vb[j] : 0.f;
                 }
             }
             float xv[DN_SP_CHUNK][VEC], yv[DN_SP_CHUNK][VEC];
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpArgs s, int tpr) {
                 } else {
                     xv[u][0] = s.x1[src[u]];
                 }
-                if (s.mode == DN_SP_BWD2) {
+                if (MODE == DN_SP_BWD2) {
                     if (VEC == 4) {
                         const float4 t = *reinterpret_cast<const float4*>(s.x2 + src[u]);
                         yv[u][0] = t.x; yv[u][1 % VEC] = t.y; yv[u][2 % VEC] = t.z; yv[u][3 % VEC] = t.w;
@@ -94,10 +95,10 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpArgs s, int tpr) {
             }
 #pragma unroll
             for (int u = 0; u < DN_SP_CHUNK; ++u) {
-                if (s.mode == DN_SP_FWD2) {
+                if (MODE == DN_SP_FWD2) {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) { a1[e] = fmaf(wa[u], xv[u][e], a1[e]); a2[e] = fmaf(wb[u], xv[u][e], a2[e]); }
-                } else if (s.mode == DN_SP_BWD2) {
+                } else if (MODE == DN_SP_BWD2) {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) a1[e] = fmaf(wb[u], yv[u][e], fmaf(wa[u], xv[u][e], a1[e]));
                 } else {
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpArgs s, int tpr) {
             }
         }
         const long long dst = (long long)row * s.ldo + c;
-        if (s.mode == DN_SP_ONE) {
+        if (MODE == DN_SP_ONE) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) a1[e] = a1[e] / s.div;
         }
@@ -117,11 +118,11 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpArgs s, int tpr) {
         }
         if (VEC == 4) {
             *reinterpret_cast<float4*>(s.o1 + dst) = make_float4(a1[0], a1[1 % VEC], a1[2 % VEC], a1[3 % VEC]);
-            if (s.mode == DN_SP_FWD2)
+            if (MODE == DN_SP_FWD2)
                 *reinterpret_cast<float4*>(s.o2 + dst) = make_float4(a2[0], a2[1 % VEC], a2[2 % VEC], a2[3 % VEC]);
         } else {
             s.o1[dst] = a1[0];
-            if (s.mode == DN_SP_FWD2) s.o2[dst] = a2[0];
+            if (MODE == DN_SP_FWD2) s.o2[dst] = a2[0];
         }
     }
 }
@@ -143,11 +144,13 @@ int dn_launch_spmm(const SpArgs& s, hipStream_t stream) {
     const int rpb = 256 / tpr;
     dim3 grid(DN_SP_XCD ? (((s.nrows + rpb - 1) / rpb) + 7) / 8 * 8 : (s.nrows + rpb - 1) / rpb, 1, 1);
     dn_prof_begin(DN_K_SPMM, stream);
+#define DN_SP_GO(V, M) DN_LAUNCH((spmm_kernel<V, M>), grid, dim3(256, 1, 1), 0, stream, s, tpr)
     if (vec) {
-        DN_LAUNCH(spmm_kernel<4>, grid, dim3(256, 1, 1), 0, stream, s, tpr);
+        if (s.mode == DN_SP_FWD2) DN_SP_GO(4, DN_SP_FWD2); else if (s.mode == DN_SP_BWD2) DN_SP_GO(4, DN_SP_BWD2); else DN_SP_GO(4, DN_SP_ONE);
     } else {
-        DN_LAUNCH(spmm_kernel<1>, grid, dim3(256, 1, 1), 0, stream, s, tpr);
+        if (s.mode == DN_SP_FWD2) DN_SP_GO(1, DN_SP_FWD2); else if (s.mode == DN_SP_BWD2) DN_SP_GO(1, DN_SP_BWD2); else DN_SP_GO(1, DN_SP_ONE);
     }
+#undef DN_SP_GO
     {
         const double nnz = (double)s.acct_nnz, nout = s.mode == DN_SP_FWD2 ? 2.0 : 1.0, nin = s.mode == DN_SP_BWD2 ? 2.0 : 1.0;
         dn_prof_end(DN_K_SPMM, stream, 2.0 * nnz * s.C * (s.mode == DN_SP_ONE ? 1.0 : 2.0),
