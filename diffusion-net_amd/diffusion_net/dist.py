@@ -60,6 +60,7 @@ class FlatParams:
                 self.buckets.append((lo, hi))
                 blk._cfg.grad_hook = (lambda k: (lambda: self._bucket_ready(k)))(bi)
         self._force_collectives = False   # tests: run the collective path at world size 1
+        self.suspend_overlap = False      # graphs.GraphedTrainStep(all_reduce="eager"): backward is being captured, send nothing from it
 
     # ------------------------------------------------------------------ overlap machinery
     def _active(self, group=None):
@@ -67,7 +68,7 @@ class FlatParams:
 
     def _bucket_ready(self, k):
         """Called by ops.BlockFn.backward once block k's gradients sit in the flat bucket (stream-ordered on the current stream)."""
-        if not self._active() or k in self._sent:
+        if self.suspend_overlap or not self._active() or k in self._sent:
             return
         lo, hi = self.buckets[k]
         self._sent.append(k)

@@ -12,8 +12,10 @@ What makes the step capturable:
   * the parameters live in ``dist.FlatParams`` (one buffer, gradients delivered by the ops straight into it), the optimizer is torch's
     Adam with ``capturable=True``;
   * inputs are static buffers owned by the object: ``step(x=..., labels=...)`` copies new values in before the replay.
-``all_reduce=True`` captures the bucketed RCCL gradient all-reduce of ``FlatParams`` with the step (data-parallel ranks each replay
-their own graph; the collectives inside keep them in lock step).
+Data-parallel runs: ``all_reduce="eager"`` replays forward + loss + backward from the graph and then issues ONE flat RCCL all-reduce
+and the optimizer update from the host (no collective is ever captured: the robust choice, and at 1.85 MB of gradients the lost
+overlap is ~20 us); ``all_reduce=True`` captures the bucketed all-reduce of ``FlatParams`` with the step (the per-block collectives
+fork from and join the captured stream; every rank replays its own graph, the collectives inside keep them in lock step).
 """
 from __future__ import annotations
 
@@ -36,7 +38,11 @@ class GraphedTrainStep:
         if warmup < 1:
             raise ValueError("at least one eager warm-up step is needed: it creates the optimizer state the captured update works on")
         self.model, self.flat, self.opt, self.mb, self.gather, self.smoothing = model, flat, opt, mb, gather, float(smoothing)
-        self.all_reduce = bool(all_reduce)
+        if all_reduce not in (False, True, "eager", "captured"):
+            raise ValueError("all_reduce must be False, True / 'captured', or 'eager'")
+        self.all_reduce = "captured" if all_reduce is True else all_reduce
+        if self.all_reduce == "eager":
+            flat.suspend_overlap = True            # backward only ever runs inside the graph: no collective may be launched from it
         self.x = x.detach().clone()
         self.labels = labels.detach().clone()
         # dropout: constant host part per block + one device word advanced by the graph
@@ -50,6 +56,7 @@ class GraphedTrainStep:
         with torch.cuda.stream(side):              # eager warm-up on a side stream (allocator, per-device kernel attributes)
             for _ in range(warmup):
                 self._body()
+                self._tail()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
@@ -64,14 +71,23 @@ class GraphedTrainStep:
         self.flat.zero_grad()
         preds, loss = self.model.forward_packed_loss(self.x, self.mb, self.gather, self.labels, self.smoothing)
         loss.backward()
-        if self.all_reduce:                        # RCCL collectives are stream work too: the per-block side-stream all-reduces fork
+        if self.all_reduce == "eager":             # the rest of the step (all-reduce, update) is issued from the host: _tail()
+            return loss, preds
+        if self.all_reduce == "captured":          # RCCL collectives are stream work too: the per-block side-stream all-reduces fork
             self.flat.all_reduce_mean()            # from and join the captured stream
         self.opt.step()
         return loss, preds
 
+    def _tail(self):
+        if self.all_reduce == "eager":
+            self.flat.all_reduce_mean()
+            self.opt.step()
+
     def release(self):
         for blk in self.model.blocks:
             blk._graph_seed = None
+        if self.all_reduce == "eager":
+            self.flat.suspend_overlap = False
 
     def step(self, x: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None):
         """One optimizer step.  Returns the (static) loss tensor of this replay; ``self.preds`` holds the log-probabilities."""
@@ -80,4 +96,5 @@ class GraphedTrainStep:
         if labels is not None:
             self.labels.copy_(labels, non_blocking=True)
         self.graph.replay()
+        self._tail()
         return self.loss
