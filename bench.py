@@ -386,13 +386,22 @@ def main():
         print(json.dumps({"rank": rank, "local": local, "world": world, "master": os.environ.get("MASTER_ADDR")}), flush=True)
         return
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU path)"
+    # TEST HOOK (tests/test_gpu_parity.py on the 1-GPU boxes): every rank on GPU 0, collectives over gloo -- exercises the N-rank logic
+    # (sharding, graph replay + host all-reduce, agreement flags, max-over-ranks timing) where N GPUs are not available; never a result
+    shared_gpu = os.environ.get("DN_BENCH_TEST_SHARED_GPU") == "1"
+    if shared_gpu:
+        local = 0
     assert torch.cuda.device_count() >= (local + 1), "rank %d has no GPU (visible devices: %d)" % (rank, torch.cuda.device_count())
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
-        assert dist.get_backend() == "nccl" and dist.get_world_size() == args.gpus
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
+            assert dist.get_backend() == "nccl"
+        assert dist.get_world_size() == args.gpus
 
     import diffusion_net
     from diffusion_net import _hip, synthetic
@@ -575,7 +584,8 @@ def main():
                                    "DiffusionNet C_in=3 C_out=%d C_width=%d K=%d N_block=%d outputs_at=%s dropout=on"
                                    % ("+RCCL all-reduce" if world > 1 else "", args.meshes, args.verts, C_out, Cw, K, args.blocks, "faces" if at_faces else "vertices"),
                        "baseline_config": args.config, "meshes_per_gpu": args.meshes, "verts_per_gpu_step": v_step, "parallelism": "dp%d" % world,
-                       "streams_per_gpu": nsub, "step_mode": step_mode},
+                       "streams_per_gpu": nsub, "step_mode": step_mode,
+                       **({"TEST_ONLY": "all ranks share GPU 0, gloo collectives (DN_BENCH_TEST_SHARED_GPU)"} if shared_gpu else {})},
             "roofline": roof, "kernel_families": fam, "diffusion_block": diff,
         }
         if not args.no_cpu_baseline and world == 1 and args.config == "headline":   # reported at N = 1 only (the other ranks would sit idle behind it)

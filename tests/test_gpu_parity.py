@@ -267,6 +267,27 @@ def test_graph_captures_the_rccl_gradient_all_reduce(dev):
         dist.destroy_process_group()
 
 
+def test_bench_two_ranks_on_one_gpu_over_gloo(dev):
+    """The N-rank logic of bench.py (self-launch, per-rank batches, graph replay of forward+backward followed by the host-issued
+    all-reduce and update, the capture-agreement flag, max-over-ranks timing, one JSON line from rank 0) with two ranks sharing this
+    box's one GPU and gloo as the transport (DN_BENCH_TEST_SHARED_GPU: a test hook, not a result) -- RCCL itself is covered by the
+    world-size-1 tests above, N real GPUs only exist on the driver's node."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DN_BENCH_TEST_SHARED_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--meshes", "4",
+                        "--verts", "3000", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["value"] > 0
+    assert "forward+backward" in d["config"]["step_mode"], d["config"]["step_mode"]     # graph replay, host-issued all-reduce
+
+
 def test_run_to_run_determinism_stress(dev):
     """Every op of the block, repeated on identical inputs at a multi-mesh 128-wide shape, must be bitwise identical every
     time (tools/determinism_stress.py; this is the test that exposes stale-register / packed-op hazards that stay far
