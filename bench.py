@@ -465,10 +465,16 @@ def main():
             torch.cuda.synchronize()
         except Exception as e:                 # never silently: the mode is reported in the bench line
             ok, why = 0, repr(e)[:200]
-        if world > 1:                          # all ranks replay, or none does
-            t = torch.tensor([ok], device=device, dtype=torch.int32)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            ok = int(t.item())
+        try:
+            if not ok:
+                torch.cuda.synchronize()       # (a capture that died half-way can leave the stream unusable: found out here, not later)
+            if world > 1:                      # all ranks replay, or none does
+                t = torch.tensor([ok], device=device, dtype=torch.int32)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                ok = int(t.item())
+        except Exception as e2:
+            raise RuntimeError("HIP-graph capture of the step failed (%s) and the device could not be used afterwards (%s): "
+                               "re-run with --eager" % (why, repr(e2)[:200]))
         if ok:
             opt, step_mode = opt_g, ("HIP-graph replay" if world == 1 else ("HIP-graph replay incl. the bucketed RCCL all-reduce" if args.graph_collectives
                                                                          else "HIP-graph replay of forward+backward, then one flat RCCL all-reduce and Adam from the host"))
