@@ -20,13 +20,26 @@ __global__ __launch_bounds__(256) void spec_bwd_kernel(float* dys, const float* 
     float dt = 0.f;
     if (c < C) {
         const float t = time[c];
-        for (int k = kl; k < K; k += 8) {
-            const long long i = m * KC + (long long)k * C + c;
-            const float d = dys[i];
-            const float lam = evals[m * K + k];
-            const float coef = expf(-lam * t);
-            dys[i] = coef * d;
-            dt -= lam * d * coef * xs[i];
+        for (int k0 = kl; k0 < K; k0 += 32) {     // four k per step with their loads in flight together (64 workgroups in all: latency-bound)
+            float d[4], lam[4], x[4];
+            long long i[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 8 * u;
+                const bool ok = k < K;
+                i[u] = m * KC + (long long)(ok ? k : kl) * C + c;
+                d[u] = dys[i[u]];
+                x[u] = xs[i[u]];
+                lam[u] = ok ? evals[m * K + k] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (k0 + 8 * u < K) {
+                    const float coef = expf(-lam[u] * t);
+                    dys[i[u]] = coef * d[u];
+                    dt -= lam[u] * d[u] * coef * x[u];     // same order as k ascending per lane: bitwise the same sum
+                }
+            }
         }
     }
     red[kl][cl] = dt;
