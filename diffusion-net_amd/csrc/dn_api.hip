@@ -628,6 +628,13 @@ int dn_coo_to_csr_i64(const int64_t* rows, int row_div, const int64_t* cols, con
                                 t_vx, t_vy, status, w, S(stream));
 }
 
+// 128-bit content checksum of a device buffer, ACCUMULATED into acc[0..1] (the caller zeroes them; several operands with different
+// salts share one accumulator).  nbytes must be a multiple of 4 and data 4-byte aligned (every operand of the path is fp32 / int32 / int64).
+int dn_checksum128(const void* data, size_t nbytes, uint64_t salt, uint64_t* acc, void* stream) {
+    if (!acc || (nbytes && !data) || nbytes % 4 != 0 || ((uintptr_t)data & 3) != 0 || ((uintptr_t)acc & 7) != 0) return DN_ERR_INVALID;
+    return dn_launch_checksum(data, (long long)(nbytes / 4), (unsigned long long)salt, (unsigned long long*)acc, S(stream));
+}
+
 // ------------------------------------------------------------------ output remaps
 int dn_csr_mean_f32(const int32_t* rowptr, const int32_t* col, int n_rows, const float* x, int C, float div, float* out,
                     void* stream) {

@@ -373,6 +373,7 @@ size_t dn_pack_ws_bytes(long long nnz, int n_cols);
 int dn_launch_coo_to_csr(const long long* rows, int row_div, const long long* cols, const float* vx, const float* vy, long long nnz, int n_rows,
                          int n_cols, int* rowptr, int* col32, int* t_rowptr, int* t_col, float* t_vx, float* t_vy, int* status, int* ws,
                          hipStream_t stream);
+int dn_launch_checksum(const void* data, long long nwords, unsigned long long salt, unsigned long long* acc, hipStream_t stream);
 // launchers (host), defined in the .hip files; all return hipError_t as int
 int dn_launch_rowgemm(const RgArgs& g, int ntiles, int nout, hipStream_t stream);
 int dn_launch_tngemm(const TnArgs& g, int nchunks, hipStream_t stream);

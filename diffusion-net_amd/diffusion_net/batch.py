@@ -220,24 +220,84 @@ class GatherPattern:
                                                                                   self.n_out, self.n_src)
 
 
+def _storage_bytes(tensors, seen):
+    """Bytes of the distinct storages behind ``tensors`` that are not in ``seen`` yet (views share their storage)."""
+    total = 0
+    for t in tensors:
+        if t is None:
+            continue
+        parts = (t._indices(), t._values()) if t.is_sparse else (t,)
+        for u in parts:
+            st = u.untyped_storage()
+            key = (u.device, st.data_ptr())
+            if key not in seen:
+                seen.add(key)
+                total += int(st.nbytes())
+    return total
+
+
+def _entry_tensors(value):
+    out = []
+    for obj in value:
+        if obj is None:
+            continue
+        for v in vars(obj).values():
+            if isinstance(v, torch.Tensor):
+                out.append(v)
+    return out
+
+
+def content_checksum(operands) -> bytes:
+    """128-bit checksum over EVERY byte of every operand (``dn_checksum128``, dn_pack.hip): one streaming kernel per buffer, all
+    accumulated on the device, then ONE 16-byte device-to-host copy -- the only host synchronisation of a content lookup."""
+    L = _hip.lib()
+    dev = next(t.device for t in operands if t is not None)
+    acc = torch.zeros(2, dtype=torch.int64, device=dev)
+    stream = None
+    for slot, t in enumerate(operands):
+        if t is None:
+            continue
+        parts = (t._indices(), t._values()) if t.is_sparse else (t,)
+        for k, u in enumerate(parts):
+            u = u.contiguous()
+            if u.element_size() % 4 != 0:                 # bool / uint8 / fp16 operands: widen (never the case for the reference's operands)
+                u = u.to(torch.int32 if not u.is_floating_point() else torch.float32)
+            if stream is None:
+                stream = _hip.stream_of(u)
+            _hip.check(L.dn_checksum128(u.data_ptr(), u.numel() * u.element_size(), 4 * slot + k + 1, acc.data_ptr(), stream), "dn_checksum128")
+    return acc.cpu().numpy().tobytes()
+
+
+class _CacheEntry:
+    __slots__ = ("value", "operands", "versions", "nbytes", "device", "kid", "kfp")
+
+
 class OperatorCache:
     """Device-resident operator cache behind the REFERENCE signature.  The experiment scripts hand the same meshes'
     operators to ``forward`` again and again -- and move them to the device anew every step
     (human_segmentation_original.py:111-120) -- so re-packing them per call (COO -> CSR, transpose, tile tables) made the
-    unmodified loop host-bound.  Two levels:
-      1. identity: (data_ptr, version, shape) of every operand.  Hits when the caller keeps its device tensors; no host sync.  The
-         entry holds references to the keyed tensors, so an address cannot be recycled under a live key.
-      2. content fingerprint: shapes, nnz, ALL eigenvalues and 16 mass entries (plus 32 entries of the faces/edges array), fetched with
-         one small device-to-host copy.  Hits when the caller re-uploads the same mesh.  Two different meshes with the same vertex
-         count and the same K eigenvalues to the last bit do not occur in practice; set ``operator_cache.fingerprint = False`` to
-         rely on identity only, ``operator_cache.enabled = False`` to pack on every call as round 1 did.
-    LRU over both levels, bounded by entries and by the bytes of eigenbasis they keep alive."""
+    unmodified loop host-bound.  Two levels, both EXACT:
+      1. identity: (device, dtype, data_ptr, version counter, shape) of every operand.  Hits when the caller keeps its device
+         tensors; no kernel, no host synchronisation.  The entry holds references to the keyed tensors, so an address cannot be
+         recycled under a live key, and an in-place edit bumps the version counter and misses.
+      2. content: shapes / dtypes / device plus a 128-bit checksum over every byte of every operand (mass, evals, evecs, the index
+         AND value arrays of gradX and gradY, faces / edges), computed on the device (``content_checksum``).  Hits when the caller
+         re-uploads the same mesh.  Costs one 16-byte device-to-host copy -- the one host synchronisation of this path, taken only
+         when identity missed, i.e. after the caller's own ten synchronous host-to-device uploads.  An entry found by content is
+         only served while the tensors it aliases still carry the version counters they had when it was built.
+         ``operator_cache.fingerprint = False`` relies on identity only; ``operator_cache.enabled = False`` packs on every call.
+    One LRU over both levels, bounded by entries and by the bytes of device memory the entries keep alive (every tensor of the packed
+    operators and every caller tensor pinned by the key), by default half of the device's memory; cleared and retried once if packing
+    runs out of memory."""
 
-    def __init__(self, max_entries=8192, max_bytes=64 << 30):   # a whole dataset stays resident (human seg: 399 meshes x ~5 MB of eigenbasis; HBM: 288 GB)
+    def __init__(self, max_entries=8192, max_bytes=None, mem_fraction=0.5):
         self.enabled, self.fingerprint = True, True
-        self.max_entries, self.max_bytes = max_entries, max_bytes
-        self._by_id = collections.OrderedDict()
-        self._by_fp = collections.OrderedDict()
+        self.max_entries, self.max_bytes, self.mem_fraction = max_entries, max_bytes, mem_fraction
+        self._by_id = {}
+        self._by_fp = {}
+        self._lru = collections.OrderedDict()        # id(entry) -> entry, least recently used first
+        self._bytes = collections.defaultdict(int)   # per device
+        self._budget = {}
         self.hits_id = self.hits_fp = self.misses = 0
 
     @staticmethod
@@ -246,57 +306,119 @@ class OperatorCache:
             return None
         if t.is_sparse:
             i, v = t._indices(), t._values()
-            return (i.data_ptr(), v.data_ptr(), v._version, tuple(t.shape), int(v.shape[0]))
-        return (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+            return ("coo", str(t.device), v.dtype, i.data_ptr(), i._version, v.data_ptr(), v._version, tuple(t.shape), int(v.shape[0]))
+        return (str(t.device), t.dtype, t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()))
+
+    @staticmethod
+    def _versions(operands):
+        out = []
+        for t in operands:
+            if t is None:
+                out.append(None)
+            elif t.is_sparse:
+                out.append((t._indices()._version, t._values()._version))
+            else:
+                out.append(t._version)
+        return tuple(out)
+
+    @staticmethod
+    def _shape_key(t):
+        if t is None:
+            return None
+        if t.is_sparse:
+            return ("coo", tuple(t.shape), t._values().dtype, int(t._values().shape[0]))
+        return (tuple(t.shape), t.dtype)
+
+    def budget(self, device):
+        if self.max_bytes is not None:
+            return self.max_bytes
+        key = str(device)
+        b = self._budget.get(key)
+        if b is None:
+            b = 64 << 30
+            if torch.device(device).type == "cuda":
+                try:
+                    b = int(self.mem_fraction * torch.cuda.mem_get_info(device)[1])
+                except Exception:      # noqa: BLE001
+                    pass
+            self._budget[key] = b
+        return b
+
+    def bytes_held(self, device=None):
+        return sum(self._bytes.values()) if device is None else self._bytes[str(device)]
+
+    def __len__(self):
+        return len(self._lru)
 
     def clear(self):
         self._by_id.clear()
         self._by_fp.clear()
+        self._lru.clear()
+        self._bytes.clear()
 
-    def _trim(self, d):
-        total = 0
-        for k in reversed(list(d.keys())):
-            total += d[k][2]
-            if total > self.max_bytes and len(d) > 1:
-                del d[k]
-        while len(d) > self.max_entries:
-            d.popitem(last=False)
+    def _drop(self, e):
+        self._lru.pop(id(e), None)
+        if e.kid is not None and self._by_id.get(e.kid) is e:
+            del self._by_id[e.kid]
+        if e.kfp is not None and self._by_fp.get(e.kfp) is e:
+            del self._by_fp[e.kfp]
+        self._bytes[e.device] -= e.nbytes
+
+    def _trim(self, device):
+        dev, budget = str(device), self.budget(device)
+        while len(self._lru) > max(1, self.max_entries):
+            self._drop(next(iter(self._lru.values())))
+        if self._bytes[dev] > budget:
+            newest = next(reversed(self._lru.values()))
+            for e in list(self._lru.values()):           # least recently used first; the entry just built always stays
+                if self._bytes[dev] <= budget or e is newest:
+                    break
+                if e.device == dev:
+                    self._drop(e)
 
     def lookup(self, mass, evals, evecs, gradX, gradY, index, tag, build, key_operands=None):
         """build() -> (MeshBatch, GatherPattern or None).  Tensors are the batched reference operands; ``tag`` the static part;
-        ``key_operands``: the tensors as the caller handed them over (``unsqueeze`` of a sparse tensor copies it), for the identity key."""
+        ``key_operands``: the tensors as the caller handed them over (``unsqueeze`` of a sparse tensor copies it), for both keys."""
         if not self.enabled:
             return build()
-        operands = key_operands if key_operands is not None else (mass, evals, evecs, gradX, gradY, index)
+        operands = tuple(key_operands) if key_operands is not None else (mass, evals, evecs, gradX, gradY, index)
         kid = (tag,) + tuple(self._ident(t) for t in operands)
-        hit = self._by_id.get(kid)
-        if hit is not None:
-            self._by_id.move_to_end(kid)
+        e = self._by_id.get(kid)
+        if e is not None:
+            self._lru.move_to_end(id(e))
             self.hits_id += 1
-            return hit[0]
+            return e.value
         kfp = None
-        if self.fingerprint and evals is not None and evals.numel() > 0:
-            m = mass.reshape(-1)
-            parts = [evals.reshape(-1).to(torch.float32), m[:8].to(torch.float32), m[-8:].to(torch.float32)]
-            if index is not None:
-                ix = index.reshape(-1)
-                parts += [ix[:16].to(torch.float32), ix[-16:].to(torch.float32)]
-            fp = torch.cat(parts).cpu().numpy().tobytes()          # the one host synchronisation of a level-2 lookup
-            nnz = int(gradX._values().shape[0]) if gradX is not None else -1
-            kfp = (tag, tuple(evecs.shape), nnz, tuple(index.shape) if index is not None else None, fp)
-            hit = self._by_fp.get(kfp)
-            if hit is not None:
-                self._by_fp.move_to_end(kfp)
-                self.hits_fp += 1
-                return hit[0]
+        device = next((t.device for t in operands if t is not None), None)
+        if self.fingerprint and device is not None and (device.type == "cuda" or _hip._allow_host_tensors):
+            kfp = (tag, str(device)) + tuple(self._shape_key(t) for t in operands) + (content_checksum(operands),)
+            e = self._by_fp.get(kfp)
+            if e is not None:
+                if self._versions(e.operands) == e.versions:
+                    self._lru.move_to_end(id(e))
+                    self.hits_fp += 1
+                    return e.value
+                self._drop(e)       # the tensors it aliases were edited in place since: its contents no longer match its key
         self.misses += 1
-        value = build()
-        nbytes = int(evecs.numel()) * 4
-        self._by_id[kid] = (value, operands, nbytes)
-        self._trim(self._by_id)
+        try:
+            value = build()
+        except torch.cuda.OutOfMemoryError:
+            self.clear()
+            torch.cuda.empty_cache()
+            value = build()
+        e = _CacheEntry()
+        e.value, e.operands, e.versions, e.kid, e.kfp = value, operands, self._versions(operands), kid, kfp
+        e.device = str(device)
+        e.nbytes = _storage_bytes(_entry_tensors(value) + [t for t in operands if t is not None], set())
+        old = self._by_id.get(kid)
+        if old is not None:
+            self._drop(old)
+        self._by_id[kid] = e
         if kfp is not None:
-            self._by_fp[kfp] = (value, None, nbytes)
-            self._trim(self._by_fp)
+            self._by_fp[kfp] = e
+        self._lru[id(e)] = e
+        self._bytes[e.device] += e.nbytes
+        self._trim(device)
         return value
 
 

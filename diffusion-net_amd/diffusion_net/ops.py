@@ -29,6 +29,14 @@ def _on_device(fn):
     return wrapped
 
 
+def _require(t: torch.Tensor, mb=None):
+    """Tensors on a ROCm device, and on the SAME device as the packed operators they are used with (an operator cache hit or a
+    caller-built MeshBatch from another GPU would otherwise be dereferenced on the wrong device)."""
+    _hip.require_device(t)
+    if mb is not None and mb.device is not None and torch.device(mb.device) != t.device:
+        raise RuntimeError("MeshBatch lives on %s but the features are on %s" % (mb.device, t.device))
+
+
 def _f32c(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         raise TypeError("diffusion_net HIP ops are fp32 (got %s)" % t.dtype)
@@ -68,7 +76,7 @@ class ToBasisFn(torch.autograd.Function):
     @staticmethod
     @_on_device
     def forward(ctx, x, mb):
-        _hip.require_device(x)
+        _require(x, mb)
         ctx.mb = mb
         return _to_basis_raw(mb, _f32c(x), True)
 
@@ -84,7 +92,7 @@ class FromBasisFn(torch.autograd.Function):
     @staticmethod
     @_on_device
     def forward(ctx, spec, mb):
-        _hip.require_device(spec)
+        _require(spec, mb)
         ctx.mb = mb
         return _from_basis_raw(mb, _f32c(spec))
 
@@ -101,7 +109,7 @@ class DiffusionFn(torch.autograd.Function):
     @staticmethod
     @_on_device
     def forward(ctx, x, time, mb):
-        _hip.require_device(x)
+        _require(x, mb)
         L = _hip.lib()
         x, time = _f32c(x), _f32c(time)
         Cc = x.shape[1]
@@ -138,7 +146,7 @@ class GradApplyFn(torch.autograd.Function):
     @staticmethod
     @_on_device
     def forward(ctx, x, mb):
-        _hip.require_device(x)
+        _require(x, mb)
         x = _f32c(x)
         gx, gy = torch.empty_like(x), torch.empty_like(x)
         _hip.check(_hip.lib().dn_grad_apply_fwd_f32(mb.ref(), x.data_ptr(), x.shape[1], gx.data_ptr(), gy.data_ptr(),
@@ -160,7 +168,7 @@ class GradFeatFn(torch.autograd.Function):
     @staticmethod
     @_on_device
     def forward(ctx, gx, gy, A_re, A_im, mb):
-        _hip.require_device(gx)
+        _require(gx, mb)
         gx, gy, A_re = _f32c(gx), _f32c(gy), _f32c(A_re)
         A_im = _f32c(A_im) if A_im is not None else None
         g, bre, bim = torch.empty_like(gx), torch.empty_like(gx), torch.empty_like(gx)
@@ -253,7 +261,7 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     @_on_device
     def forward(ctx, x, W, b, mb):
-        _hip.require_device(x)
+        _require(x, mb)
         ctx.sinks = _sinks([W, b])
         x, W, b = _f32c(x), _f32c(W), _f32c(b)
         out = torch.empty(x.shape[0], W.shape[0], dtype=torch.float32, device=x.device)
@@ -340,7 +348,7 @@ class BlockFn(torch.autograd.Function):
     @staticmethod
     @_on_device
     def forward(ctx, mb, cfg, masks, x, time, A_re, A_im, *wb):
-        _hip.require_device(x)
+        _require(x, mb)
         ctx.sinks = _sinks([time, A_re, A_im, *wb])
         L = _hip.lib()
         x, time = _f32c(x), _f32c(time)
@@ -433,7 +441,7 @@ class GatherMeanFn(torch.autograd.Function):
     @staticmethod
     @_on_device
     def forward(ctx, x, pat: GatherPattern):
-        _hip.require_device(x)
+        _require(x)
         x = _f32c(x)
         out = torch.empty(pat.n_out, x.shape[1], dtype=torch.float32, device=x.device)
         _hip.check(_hip.lib().dn_csr_mean_f32(pat.rowptr.data_ptr(), pat.col.data_ptr(), pat.n_out, x.data_ptr(), x.shape[1],
@@ -459,7 +467,7 @@ class MassMeanFn(torch.autograd.Function):
     @staticmethod
     @_on_device
     def forward(ctx, x, mb):
-        _hip.require_device(x)
+        _require(x, mb)
         x = _f32c(x)
         out = torch.empty(mb.n_mesh, x.shape[1], dtype=torch.float32, device=x.device)
         msum = torch.empty(mb.n_mesh, dtype=torch.float32, device=x.device)
@@ -493,7 +501,7 @@ class HeadFn(torch.autograd.Function):
     @staticmethod
     @_on_device
     def forward(ctx, x, pat, labels, log_softmax, smoothing, want_logp):
-        _hip.require_device(x)
+        _require(x)
         L = _hip.lib()
         x = _f32c(x)
         n_src, Cc = x.shape

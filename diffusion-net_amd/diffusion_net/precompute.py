@@ -14,13 +14,14 @@ Triangle meshes only: the point-cloud branch needs robust_laplacian's point-clou
 """
 from __future__ import annotations
 
-import hashlib
 import os
 
 import numpy as np
 import scipy.sparse as sp
 import scipy.sparse.linalg as sla
 import torch
+
+from .utils import hash_arrays  # noqa: F401  (the cache key; also reachable as precompute.hash_arrays)
 
 EPS = 1e-8            # geometry.py:309
 GRAD_REG = 1e-5       # geometry.py:239
@@ -174,14 +175,6 @@ def compute_operators(verts, faces, k_eig, normals=None):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dtype)
     return (t(frames), t(mass), _to_torch_sparse(L, device, dtype), t(evals), t(evecs),
             _to_torch_sparse(grad.real, device, dtype), _to_torch_sparse(grad.imag, device, dtype))
-
-
-def hash_arrays(arrs):
-    """sha1 over the raw bytes of the arrays, as the reference keys its operator cache (utils.py:71-76)."""
-    h = hashlib.sha1()
-    for a in arrs:
-        h.update(np.ascontiguousarray(a).view(np.uint8))
-    return h.hexdigest()
 
 
 def _sparse_to_csc(t):

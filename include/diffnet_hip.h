@@ -162,6 +162,12 @@ int dn_coo_to_csr_i64(const int64_t* rows, int row_div, const int64_t* cols, con
                       int n_cols, int32_t* rowptr, int32_t* col, int32_t* t_rowptr, int32_t* t_col, float* t_vx, float* t_vy,
                       int32_t* status, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- content checksum for the device-resident operator cache (the reference re-uploads the operators of a mesh every step,
+ *      human_segmentation_original.py:111-120, and caches them on disk by a hash of the mesh, geometry.py:476-494: the device-side analogue).
+ *      Adds a 128-bit, order-independent checksum of the nbytes at `data` (multiple of 4, 4-byte aligned) to acc[0..1] (device, zeroed by
+ *      the caller).  `salt` separates operands that share one accumulator.  EVERY byte of the operand enters the sum. */
+int dn_checksum128(const void* data, size_t nbytes, uint64_t salt, uint64_t* acc, void* stream);
+
 /* ---- output remaps (layers.py:379-397).
  *      csr_mean: out[i] = (sum_{j in row i} x[col[j]]) / div  -- faces (div=3) / edges (div=2) gather-mean, and with the
  *      transposed pattern its gradient.  mass_mean: out[m] = sum_v mass*x / sum_v mass per mesh (global_mean). */

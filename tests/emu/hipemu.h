@@ -167,6 +167,7 @@ static inline void __syncthreads() { dnemu::block_barrier(); }
 // single-threaded fibers: plain read-modify-write is atomic here
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline int atomicOr(int* p, int v) { int o = *p; *p = o | v; return o; }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 
 typedef float dnemu_f32x16 __attribute__((ext_vector_type(16)));
 static inline dnemu_f32x16 dnemu_mfma_f32_32x32x2f32(float a, float b, dnemu_f32x16 c) {

@@ -605,4 +605,65 @@ def run_operator_cache(device, V=300, K=16, C=32, seed=6):
     with torch.no_grad():
         o5 = call(a)
     assert torch.equal(o5, o4)
+    # the entry built from `a` aliases a's tensors, which no longer hold what its content key says: a fresh upload of the ORIGINAL mesh
+    # must not be served from it (it is dropped and the mesh packed again)
+    with torch.no_grad():
+        o6 = call(up())
+    assert torch.equal(o6, base)
+    # EVERY operand is part of the content key (the heuristic key ignored evecs, gradient values and most of mass, and served
+    # stale operators): a re-upload that differs in any one of them misses and gives the uncached result of the changed operators
+    def changed(which):
+        c = up()
+        if which == "evecs":
+            c["evecs"].mul_(0.5)
+        elif which == "gradX":
+            c["gradX"] = torch.sparse_coo_tensor(c["gradX"]._indices(), c["gradX"]._values() * 3.0, c["gradX"].shape).coalesce()
+        elif which == "gradY_one":
+            v = c["gradY"]._values().clone(); v[v.numel() // 2] += 0.25
+            c["gradY"] = torch.sparse_coo_tensor(c["gradY"]._indices(), v, c["gradY"].shape).coalesce()
+        elif which == "mass_one":
+            c["mass"][100] *= 1.01
+        elif which == "evecs_one":
+            c["evecs"][V // 2, K // 2] += 1e-3
+        elif which == "faces":
+            c["faces"] = c["faces"].roll(1, dims=1).contiguous()[torch.randperm(c["faces"].shape[0], generator=torch.Generator().manual_seed(3)).to(device)]
+        return c
+    for which in ("evecs", "gradX", "gradY_one", "mass_one", "evecs_one", "faces"):
+        c = changed(which)
+        m0, f0 = operator_cache.misses, operator_cache.hits_fp
+        with torch.no_grad():
+            got = call(c)
+            operator_cache.enabled = False
+            want = call(c)
+            operator_cache.enabled = True
+        assert operator_cache.misses == m0 + 1 and operator_cache.hits_fp == f0, which
+        assert torch.equal(got, want), which
+        if which not in ("faces", "mass_one"):
+            assert not torch.equal(got, base), which
+    # the same mesh in another dtype / on the identity path with a foreign device string never collides (device and dtype are in both keys)
+    assert len({operator_cache._ident(t) for t in (a["mass"], a["mass"].double())}) == 2
+    # steady state of a caller that keeps its device tensors: an identity hit issues no host synchronisation at all
+    a2 = up()
+    with torch.no_grad():
+        call(a2)
+        if torch.device(device).type == "cuda":
+            torch.cuda.synchronize()
+            torch.cuda.set_sync_debug_mode("error")
+            try:
+                o7 = call(a2)
+            finally:
+                torch.cuda.set_sync_debug_mode("default")
+        else:
+            o7 = call(a2)
+    assert torch.equal(o7, base)
+    # memory accounting covers every tensor an entry keeps alive, and the byte budget evicts least-recently-used entries
+    assert operator_cache.bytes_held() >= sum(int(t._values().numel() * 4 if t.is_sparse else t.numel() * t.element_size()) for t in (a2["evecs"], a2["gradX"]))
+    n_before, saved = len(operator_cache), operator_cache.max_bytes
+    operator_cache.max_bytes = 1
+    fresh = up()
+    fresh["evecs"].mul_(0.25)
+    with torch.no_grad():
+        call(fresh)
+    assert len(operator_cache) == 1 and n_before > 1, (len(operator_cache), n_before, dict(operator_cache._bytes), [e.device for e in operator_cache._lru.values()])
+    operator_cache.max_bytes = saved
     operator_cache.clear()
