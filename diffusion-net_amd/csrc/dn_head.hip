@@ -7,11 +7,13 @@
 //             driven by the transposed gather pattern, no intermediate [n_out, C] gradient tensor.
 // Every stage in brackets is optional, so the same two kernels are: F.nll_loss alone, the label-smoothing loss alone,
 // face-mean + log_softmax (what the unmodified scripts get), and the fully fused face-mean + log_softmax + loss.
-// Rows with a label outside [0, C) (e.g. ignore_index = -100) do not contribute and do not count (torch semantics).
+// Rows labelled ignore_index = -100 (torch's default) do not contribute and do not count.  Any other label outside [0, C) is an error in
+// torch (a device-side assert); here it turns the loss into NaN -- loud, and without a host synchronisation.
 // A row is handled by G = 2^k <= 64 lanes (G >= C for C <= 64), lane l owns classes l, l + G, ...
 #include "dn_common.h"
 
-#define DN_HEAD_CPL 8   // classes per lane: C <= 512
+#define DN_HEAD_CPL 32  // classes per lane: C <= 2048 (instantiated for 1, 2, 4, 8, 16, 32 classes per lane)
+#define DN_HEAD_IGNORE (-100LL)
 
 __device__ __forceinline__ float head_group_sum(float v, int G) {
     for (int m = G >> 1; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
@@ -77,6 +79,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a, int G) {
                 loss_sum -= (1.f - a.smoothing) * at + off * (all - at);
                 cnt += 1.f;
             }
+            if (live && !valid && t != DN_HEAD_IGNORE && gl == 0) loss_sum += __uint_as_float(0x7fc00000u);   // not a class, not ignore_index
         }
     }
     if (!a.labels) return;
@@ -174,6 +177,8 @@ int dn_launch_head_fwd(const HeadArgs& a, int nb, float* loss, float* count, hip
     if (cpl <= 1) DN_LAUNCH(head_fwd_kernel<1>, dim3(blocks, 1, 1), dim3(256, 1, 1), 0, stream, a, G);
     else if (cpl <= 2) DN_LAUNCH(head_fwd_kernel<2>, dim3(blocks, 1, 1), dim3(256, 1, 1), 0, stream, a, G);
     else if (cpl <= 4) DN_LAUNCH(head_fwd_kernel<4>, dim3(blocks, 1, 1), dim3(256, 1, 1), 0, stream, a, G);
+    else if (cpl <= 8) DN_LAUNCH(head_fwd_kernel<8>, dim3(blocks, 1, 1), dim3(256, 1, 1), 0, stream, a, G);
+    else if (cpl <= 16) DN_LAUNCH(head_fwd_kernel<16>, dim3(blocks, 1, 1), dim3(256, 1, 1), 0, stream, a, G);
     else DN_LAUNCH(head_fwd_kernel<DN_HEAD_CPL>, dim3(blocks, 1, 1), dim3(256, 1, 1), 0, stream, a, G);
     if (a.labels) DN_LAUNCH(head_finish_kernel, dim3(1, 1, 1), dim3(256, 1, 1), 0, stream, a.partial, blocks, loss, count);
     dn_prof_end(DN_K_SMALL, stream, 0.0, 4.0 * a.n_out * a.C * (a.logp ? 2.0 : 1.0));
@@ -191,6 +196,8 @@ int dn_launch_head_bwd(const HeadArgs& a, hipStream_t stream) {
     if (cpl <= 1) DN_LAUNCH(head_bwd_kernel<1>, dim3((unsigned)blocks, 1, 1), dim3(256, 1, 1), 0, stream, a, G);
     else if (cpl <= 2) DN_LAUNCH(head_bwd_kernel<2>, dim3((unsigned)blocks, 1, 1), dim3(256, 1, 1), 0, stream, a, G);
     else if (cpl <= 4) DN_LAUNCH(head_bwd_kernel<4>, dim3((unsigned)blocks, 1, 1), dim3(256, 1, 1), 0, stream, a, G);
+    else if (cpl <= 8) DN_LAUNCH(head_bwd_kernel<8>, dim3((unsigned)blocks, 1, 1), dim3(256, 1, 1), 0, stream, a, G);
+    else if (cpl <= 16) DN_LAUNCH(head_bwd_kernel<16>, dim3((unsigned)blocks, 1, 1), dim3(256, 1, 1), 0, stream, a, G);
     else DN_LAUNCH(head_bwd_kernel<DN_HEAD_CPL>, dim3((unsigned)blocks, 1, 1), dim3(256, 1, 1), 0, stream, a, G);
     dn_prof_end(DN_K_SMALL, stream, 0.0, 4.0 * a.n_src * a.C * 3.0);
     return (int)hipGetLastError();

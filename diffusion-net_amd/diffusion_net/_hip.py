@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 MAX_MLP = 8
+HEAD_MAX_CLASSES = 2048   # dn_head.hip: 64 lanes x DN_HEAD_CPL classes per row
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # DN_LIB_VARIANT=<tag> selects libdiffnet_hip_<tag>.so (same sources, other build flags) for A/B experiments
 _VARIANT = os.environ.get("DN_LIB_VARIANT", "")

@@ -46,7 +46,8 @@ class FlatParams:
         self.master.grad = self.grad
         # ---- per-block buckets: the contiguous flat range of every DiffusionNetBlock, in parameter order
         self.buckets: List[tuple] = []
-        self._pending, self._sent = [], []
+        self._pending, self._sent = {}, []
+        self._hold = 0                    # > 0 inside no_sync(): backward passes accumulate locally, nothing is sent
         self._side = None
         index_of = {id(p): i for i, p in enumerate(params)}
         blocks = getattr(module, "blocks", None) if overlap else None
@@ -59,6 +60,7 @@ class FlatParams:
                 lo, hi = offs[ids[0]], offs[ids[-1]] + (sizes[ids[-1]] + 3) // 4 * 4
                 self.buckets.append((lo, hi))
                 blk._cfg.grad_hook = (lambda k: (lambda: self._bucket_ready(k)))(bi)
+                blk._cfg.grad_pre_hook = (lambda k: (lambda: self._bucket_reopen(k)))(bi)
         self._force_collectives = False   # tests: run the collective path at world size 1
         self.suspend_overlap = False      # graphs.GraphedTrainStep(all_reduce="eager"): backward is being captured, send nothing from it
 
@@ -66,9 +68,41 @@ class FlatParams:
     def _active(self, group=None):
         return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or self._force_collectives)
 
+    def no_sync(self):
+        """Context manager for gradient accumulation: backward passes inside it only accumulate into the local bucket; the first
+        backward outside it (the last micro-batch) sends the per-block ranges.  Without it every backward of a step still gives
+        the right result (see ``_bucket_reopen``), at the price of one collective per block and backward."""
+        flat = self
+
+        class _Hold:
+            def __enter__(self_):
+                flat._hold += 1
+
+            def __exit__(self_, *exc):
+                flat._hold -= 1
+                return False
+        return _Hold()
+
+    def _bucket_reopen(self, k):
+        """Called by ops.BlockFn.backward BEFORE it writes block k's gradients.  If the block's range already went out in this step
+        (a second backward before all_reduce_mean(): gradient accumulation, a block used twice), the bucket holds the SUM over
+        ranks of the earlier contributions and its collective may still be in flight: wait for it, scale the range back by
+        1 / world (so that the next SUM over ranks restores it), and mark it unsent -- the new local gradients are then added to it
+        and it is sent again.  (without this the later contributions were never reduced and raced the collective.)"""
+        if k not in self._sent:
+            return
+        w = self._pending.pop(k, None)
+        if w is not None:
+            w.wait()
+        if self._side is not None and self.grad.is_cuda:
+            torch.cuda.current_stream(self.grad.device).wait_stream(self._side)
+        lo, hi = self.buckets[k]
+        self.grad[lo:hi].div_(dist.get_world_size())
+        self._sent.remove(k)
+
     def _bucket_ready(self, k):
         """Called by ops.BlockFn.backward once block k's gradients sit in the flat bucket (stream-ordered on the current stream)."""
-        if self.suspend_overlap or not self._active() or k in self._sent:
+        if self.suspend_overlap or self._hold or not self._active() or k in self._sent:
             return
         lo, hi = self.buckets[k]
         self._sent.append(k)
@@ -78,9 +112,9 @@ class FlatParams:
                 self._side = torch.cuda.Stream(self.grad.device)
             self._side.wait_stream(torch.cuda.current_stream(self.grad.device))   # the bucket's adds have been enqueued
             with torch.cuda.stream(self._side):
-                self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+                self._pending[k] = dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True)
         else:
-            self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+            self._pending[k] = dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True)
 
     def rebind(self):
         """Re-point parameters at the flat buffers (needed after code that re-binds ``p.data``,
@@ -96,7 +130,7 @@ class FlatParams:
 
     def zero_grad(self):
         self.grad.zero_()
-        self._sent, self._pending = [], []
+        self._sent, self._pending = [], {}
         if self.direct_sinks:     # a zeroed sink may be written by the gradient kernel itself (ops._grad_out): store == accumulate
             for p in self.params:
                 sink = getattr(p, "_dn_grad_sink", None)
@@ -119,11 +153,11 @@ class FlatParams:
             rest.append((cur, self.grad.numel()))
         for lo, hi in rest:
             dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=group)
-        for w in self._pending:
+        for w in self._pending.values():
             w.wait()          # orders the current stream behind the side-stream collectives
         if self._side is not None:
             torch.cuda.current_stream(self.grad.device).wait_stream(self._side)
-        self._pending, self._sent = [], []
+        self._pending, self._sent = {}, []
         self.grad.div_(world)
 
 

@@ -45,10 +45,14 @@ class GraphedTrainStep:
             flat.suspend_overlap = True            # backward only ever runs inside the graph: no collective may be launched from it
         self.x = x.detach().clone()
         self.labels = labels.detach().clone()
-        # dropout: constant host part per block + one device word advanced by the graph
+        # dropout: constant host part per block + one device word advanced by the graph.  The host part is drawn from torch's CPU
+        # generator (so torch.manual_seed governs the masks, as in the eager path, layers._dropout_masks) and mixed with the rank:
+        # replicas of a data-parallel job are seeded identically, their masks must not be
         self.seed = torch.zeros(1, dtype=torch.int64, device=dev)
+        base = int(torch.randint(1, 2 ** 62, (1,), dtype=torch.int64).item())
+        rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
         for bi, blk in enumerate(model.blocks):
-            blk._graph_seed = ((0x1234567 + 0x51ED27 * (bi + 1)) | 1, self.seed)
+            blk._graph_seed = (((base + 0x51ED27 * (bi + 1) + _GOLDEN * (rank + 1)) % (2 ** 62)) | 1, self.seed)
         step = _GOLDEN - (1 << 64)                 # the 64-bit increment as a signed value
         self._advance = lambda: self.seed.add_(step)
         side = torch.cuda.Stream(dev)

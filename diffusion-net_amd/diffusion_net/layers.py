@@ -18,7 +18,7 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _hip, ops
 from .batch import GatherPattern, MeshBatch, operator_cache
 
 _MIN_TIME = 1e-8
@@ -295,7 +295,7 @@ class DiffusionNet(nn.Module):
         """``forward_packed`` followed by the mean NLL (or label-smoothed log loss) against ``labels`` with the whole head -- remap,
         log_softmax, loss -- in one kernel each way.  Needs a log_softmax ``last_activation`` (as the segmentation scripts have) and
         outputs at vertices, edges or faces.  Returns (log-probabilities, loss)."""
-        if not self._activation_is_log_softmax() or self.outputs_at == "global_mean":
+        if not self._activation_is_log_softmax() or self.outputs_at == "global_mean" or self.C_out > _hip.HEAD_MAX_CLASSES:
             preds = self.forward_packed(x2d, mb, gather)
             from .utils import label_smoothing_log_loss, nll_loss
             return preds, (nll_loss(preds, labels) if smoothing == 0.0 else label_smoothing_log_loss(preds, labels, smoothing))
@@ -319,7 +319,7 @@ class DiffusionNet(nn.Module):
         ``gather`` built from global vertex ids) or [n_mesh, C_out] ('global_mean'); the last
         activation is applied as in ``forward``."""
         x = self._trunk(x2d, mb)
-        if self.outputs_at != "global_mean" and self._activation_is_log_softmax():
+        if self.outputs_at != "global_mean" and self.C_out <= _hip.HEAD_MAX_CLASSES and self._activation_is_log_softmax():
             # remap + log_softmax as one kernel (the scripts' per-face / per-vertex log-probabilities)
             return ops.HeadFn.apply(x, gather if self.outputs_at in ("edges", "faces") else None, None, True, 0.0, True)[0]
         if self.outputs_at in ("edges", "faces"):

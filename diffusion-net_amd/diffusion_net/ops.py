@@ -299,7 +299,8 @@ class BlockConfig:
     def __init__(self, C, widths, with_grad, with_rot):
         self.C, self.widths, self.with_grad, self.with_rot = int(C), [int(w) for w in widths], bool(with_grad), bool(with_rot)
         self.n_mlp = len(self.widths) - 1
-        self.grad_hook = None
+        self.grad_hook = None        # dist.FlatParams: called after the block's gradients were delivered
+        self.grad_pre_hook = None    # ... and before they are written
         if self.n_mlp > _hip.MAX_MLP:
             raise ValueError("MiniMLP deeper than %d layers is not supported by the HIP block" % _hip.MAX_MLP)
 
@@ -390,6 +391,9 @@ class BlockFn(torch.autograd.Function):
     def backward(ctx, d_out):
         L = _hip.lib()
         mb, cfg, masks = ctx.mb, ctx.cfg, ctx.masks
+        pre = getattr(cfg, "grad_pre_hook", None)
+        if pre is not None:
+            pre()
         sav = list(ctx.saved_tensors)
         x, time, xs, xd = sav[:4]
         pos = 4
@@ -505,6 +509,9 @@ class HeadFn(torch.autograd.Function):
         L = _hip.lib()
         x = _f32c(x)
         n_src, Cc = x.shape
+        if Cc > _hip.HEAD_MAX_CLASSES:
+            raise ValueError("the fused head handles up to %d classes (got %d); DiffusionNet.forward_packed composes the remap and the "
+                             "activation from separate ops above that" % (_hip.HEAD_MAX_CLASSES, Cc))
         n_out = pat.n_out if pat is not None else n_src
         if labels is not None:
             if labels.dtype != torch.int64:

@@ -19,11 +19,15 @@ def toNP(x):
 
 def nll_loss(log_probs, labels):
     """Drop-in for ``torch.nn.functional.nll_loss(log_probs, labels)`` (mean reduction, rows x classes) on the HIP path: one pass over
-    the log-probabilities forward, one backward (dn_head.hip).  Rows whose label lies outside [0, C) -- e.g. ``ignore_index=-100`` --
-    neither contribute nor count, as in torch; class weights and other reductions are not implemented (TypeError / use torch)."""
-    from . import ops
+    the log-probabilities forward, one backward (dn_head.hip).  Rows labelled -100 (torch's default ``ignore_index``) neither
+    contribute nor count; any other label outside [0, C) makes the loss NaN (torch raises a device-side assert there; a NaN is as loud
+    and needs no host synchronisation).  Class weights and other reductions are not implemented (use torch); more than 2048 classes
+    fall back to ``torch.nn.functional.nll_loss``."""
+    from . import _hip, ops
     if log_probs.dim() != 2:
         raise ValueError("nll_loss expects [rows, classes] log-probabilities")
+    if log_probs.shape[1] > _hip.HEAD_MAX_CLASSES:
+        return torch.nn.functional.nll_loss(log_probs, labels)
     return ops.HeadFn.apply(log_probs, None, labels, False, 0.0, False)[1]
 
 
@@ -33,7 +37,7 @@ def label_smoothing_log_loss(pred, labels, smoothing=0.0):
     proper one-hot only for the 1-D prediction of its single caller (classification_shrec11.py: one mesh, scalar label);
     that case is reproduced exactly, and 2-D predictions get the per-row one-hot the formula intends.  On a ROCm device the loss
     and its gradient are one HIP kernel each (the NLL kernel with a smoothed target); host tensors use the torch formula."""
-    if pred.is_cuda and pred.dtype == torch.float32 and pred.dim() in (1, 2):
+    if pred.is_cuda and pred.dtype == torch.float32 and pred.dim() in (1, 2) and pred.shape[-1] <= 2048:
         from . import ops
         p2 = pred.reshape(1, -1) if pred.dim() == 1 else pred
         lab = labels.reshape(-1).to(torch.int64)

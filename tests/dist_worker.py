@@ -47,3 +47,42 @@ def run(rank, world, port, emu_so, sizes, out_dir):
         opt.step()
     torch.save({"flat": flat.flat.clone(), "grad": first_grad, "mine": mine}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.destroy_process_group()
+
+
+def run_accumulate(rank, world, port, emu_so, sizes, out_dir):
+    """Two micro-batches per optimizer step on every rank (gradient accumulation), three ways: per-block overlap with both backwards
+    sending (``_bucket_reopen`` path), overlap with the first backward under ``no_sync()``, and ``overlap=False`` (one flat
+    all-reduce).  ADVICE r2: the first used to leave later contributions unreduced and raced the in-flight collective."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import diffusion_net
+    from diffusion_net import _hip, synthetic
+    from diffusion_net.dist import FlatParams
+    import parity_cases
+    _hip._use_library_for_tests(emu_so, True)
+    meshes, feats = parity_cases.make_ragged(sizes, 16, 3, seed=1)
+    mine = [i for i in range(len(sizes)) if i % world == rank]          # two meshes per rank = two micro-batches
+    grads = {}
+    for mode in ("overlap", "no_sync", "flat"):
+        torch.manual_seed(0)
+        model = diffusion_net.layers.DiffusionNet(3, 4, C_width=32, N_block=2, dropout=False)
+        model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=0))
+        flat = FlatParams(model, overlap=(mode != "flat"))
+        assert len(flat.buckets) == (0 if mode == "flat" else 2)
+        flat.zero_grad()
+        for j, i in enumerate(mine):
+            mb = parity_cases.pack([meshes[i]], "cpu")
+            last = j == len(mine) - 1
+            if mode == "no_sync" and not last:
+                with flat.no_sync():
+                    model.forward_packed(feats[i], mb).square().mean().backward()
+                assert not flat._sent
+            else:
+                model.forward_packed(feats[i], mb).square().mean().backward()
+        if mode != "flat":
+            assert sorted(flat._sent) == [0, 1]
+        flat.all_reduce_mean()
+        grads[mode] = flat.grad.clone()
+    torch.save(grads, os.path.join(out_dir, f"acc_rank{rank}.pt"))
+    dist.destroy_process_group()

@@ -12,7 +12,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def golden_names():
     """Whole-net golden cases (the geom_* fixtures of the host precompute are separate)."""
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                  if not os.path.basename(p).startswith(("geom_", "feat_", "refcache_")))
+                  if not os.path.basename(p).startswith(("geom_", "feat_", "refcache_", "utils_")))
 
 
 def load_golden(name, dtype=torch.float32, device="cpu"):

@@ -9,6 +9,7 @@ Tolerances (fp32, north_star: 1e-5 relative):
 """
 import os
 
+import pytest
 import torch
 
 import helpers
@@ -465,6 +466,51 @@ def run_head(device, V=700, C=8, seed=0, smoothing=0.0, outputs="faces"):
     rl = torch.nn.functional.nll_loss(b, labels)
     rl.backward()
     assert abs(float(l) - float(rl)) < 1e-5 * max(1.0, abs(float(rl))) and helpers.rel_l2(a.grad.cpu(), b.grad) < 1e-6
+
+
+def run_head_edge_cases(device, V=90):
+    """(a) wide heads -- more classes than the 512 the round-2 kernel covered run fused up to 2048 and through the composed
+    remap + activation above that, in the network and in utils.nll_loss; (b) a label that is neither a class nor ignore_index (-100)
+    is an error in torch: here the loss turns NaN instead of silently dropping the row."""
+    from diffusion_net import _hip, utils
+    g = torch.Generator().manual_seed(3)
+    for C in (600, 2048):                                     # fused kernels, 16 / 32 classes per lane
+        x = torch.randn(V, C, generator=g)
+        labels = torch.randint(0, C, (V,), generator=g)
+        labels[::5] = -100
+        a = x.clone().to(device).requires_grad_(True)
+        lp, loss = ops.HeadFn.apply(a, None, labels.to(device), True, 0.0, True)
+        (loss * 1.3 + (lp * 0.01).sum()).backward()
+        b = x.clone().requires_grad_(True)
+        rlp = torch.log_softmax(b, -1)
+        rl = torch.nn.functional.nll_loss(rlp, labels)
+        (rl * 1.3 + (rlp * 0.01).sum()).backward()
+        assert abs(float(loss) - float(rl)) < 1e-5 * abs(float(rl)) and helpers.rel_max(lp.detach().cpu(), rlp.detach()) < 1e-5
+        assert helpers.rel_l2(a.grad.cpu(), b.grad) < 1e-5
+    C = _hip.HEAD_MAX_CLASSES + 52                            # beyond the fused kernels: composed path, same results
+    torch.manual_seed(0)
+    model = diffusion_net.layers.DiffusionNet(3, C, C_width=32, N_block=1, outputs_at="vertices", dropout=False,
+                                              last_activation=lambda t: torch.nn.functional.log_softmax(t, dim=-1)).to(device)
+    meshes, feats = make_ragged((V,), 8, 3, seed=2)
+    mb = pack(meshes, device)
+    labels = torch.randint(0, C, (V,), generator=g)
+    preds, loss = model.forward_packed_loss(feats[0].to(device), mb, None, labels.to(device))
+    loss.backward()
+    assert preds.shape == (V, C) and abs(float(torch.logsumexp(preds.detach(), -1).abs().max())) < 1e-4
+    rl = torch.nn.functional.nll_loss(preds.detach().cpu(), labels)
+    assert abs(float(loss) - float(rl)) < 1e-5 * abs(float(rl))
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
+    with pytest.raises(ValueError):
+        ops.HeadFn.apply(torch.zeros(4, C, device=device), None, None, True, 0.0, True)
+    # labels: -100 is ignored, anything else outside [0, C) poisons the loss
+    lp = torch.log_softmax(torch.randn(50, 5, generator=g), -1)
+    lab = torch.randint(0, 5, (50,), generator=g)
+    lab[3] = -100
+    ok = utils.nll_loss(lp.to(device), lab.to(device))
+    assert abs(float(ok) - float(torch.nn.functional.nll_loss(lp, lab))) < 1e-6
+    for bad in (7, 5, -1):
+        lab2 = lab.clone(); lab2[10] = bad
+        assert torch.isnan(utils.nll_loss(lp.to(device), lab2.to(device))), bad
 
 
 def run_head_in_net(device, sizes=(300, 140), K=16, C=32, C_out=8, seed=5, outputs_at="faces"):

@@ -54,6 +54,24 @@ def test_two_rank_gloo_matches_single_process():
         assert float((results[1][0]["flat"] - results[2][0]["flat"]).abs().max()) < 1e-3
 
 
+def test_gradient_accumulation_with_overlap_two_ranks():
+    """Two backward passes per step and rank: the overlapped per-block all-reduce gives the same averaged gradient as the single flat
+    all-reduce, with or without ``no_sync()`` around the first micro-batch, and the ranks agree bit for bit."""
+    subprocess.run(["make", "-C", CSRC, "-j8", "emu"], check=True, capture_output=True)
+    import torch.multiprocessing as mp
+    import dist_worker
+    sizes = [96, 64, 80, 72]
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(dist_worker.run_accumulate, args=(2, _free_port(), EMU_SO, sizes, tmp), nprocs=2, join=True)
+        r0, r1 = (torch.load(os.path.join(tmp, f"acc_rank{r}.pt")) for r in range(2))
+    for mode in ("overlap", "no_sync", "flat"):
+        assert torch.equal(r0[mode], r1[mode]), mode                       # replicas see the same averaged gradient
+    ref = r0["flat"]
+    assert float(ref.norm()) > 0
+    assert torch.equal(r0["no_sync"], ref)                                 # same single collective per range, same summation order
+    assert float((r0["overlap"] - ref).norm() / ref.norm()) < 1e-6       # (S1/R + g2) summed over ranks: round-off only
+
+
 def test_bench_gpus_n_launches_n_ranks():
     """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the driver's command) must become its own launcher: two ranks
     under torch.distributed.run on 127.0.0.1, each seeing WORLD_SIZE == --gpus.  The DN_BENCH_LAUNCH_CHECK hook stops every rank

@@ -73,6 +73,7 @@ def test_fused_head_on_emulator(emu):
     parity_cases.run_head(emu, V=120, C=30, seed=2, smoothing=0.2, outputs="vertices")
     parity_cases.run_head_in_net(emu)
     parity_cases.run_head_in_net(emu, outputs_at="vertices", C_out=5)
+    parity_cases.run_head_edge_cases(emu, V=40)
 
 
 def test_real_mesh_pipeline_on_emulator(emu):

@@ -74,6 +74,7 @@ def test_fused_head(dev):
     parity_cases.run_head(dev, V=5000, C=260, seed=1, outputs="vertices")
     parity_cases.run_head(dev, V=3000, C=30, seed=2, smoothing=0.2, outputs="vertices")
     parity_cases.run_head(dev, V=4000, C=8, seed=3, smoothing=0.1)
+    parity_cases.run_head_edge_cases(dev, V=3000)
     parity_cases.run_head_in_net(dev, sizes=(3000, 1400), K=64, C=128)
     parity_cases.run_head_in_net(dev, sizes=(1500, 1100), K=64, C=128, C_out=260, outputs_at="vertices")
 

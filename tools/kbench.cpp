@@ -3,7 +3,7 @@
 //   hipcc -O2 -std=c++17 tools/kbench.cpp -o tools/kbench -ldl
 //   tools/kbench [--lib path.so] [--meshes 16] [--verts 10000] [--C 128] [--K 128] [--reps 20] [--ops a,b,..] [--check]
 // Ops: to_basis from_basis diffusion diffusion_bwd spmm gradfeat gradfeat_bwd linear linear_relu linear_bwd
-//      block_inf block_fwd block_bwd copy
+//      block_inf block_fwd block_bwd copy copyk (hand-written float4 copy / read / fill kernels on 2 GiB of rotating buffers)
 // Every op line: avg us (hipEvents around `reps` back-to-back calls), algorithmic GB/s and, with --check, the worst error of a
 // row sample against an fp64 host evaluation of the same formula (relative to the largest reference magnitude).
 #include <hip/hip_runtime.h>
@@ -21,6 +21,45 @@
 
 #define HC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %d (%s) at %s:%d\n", (int)e_, hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 #define DC(x) do { int e_ = (x); if (e_) { fprintf(stderr, "library error %d at %s:%d: %s\n", e_, __FILE__, __LINE__, #x); exit(3); } } while (0)
+
+// ---- hand-written HBM calibration kernels (hipMemcpy is a blit path, not the yard-stick): float4 grid-stride copy, plain and
+//      with nontemporal loads/stores, a read-only sum and a write-only fill; run on rotating buffers of > 1 GiB in total.
+typedef float kb_f4 __attribute__((ext_vector_type(4)));   // the nontemporal builtins take native vectors, not HIP's float4 struct
+__device__ __forceinline__ float4 kb_nt_load(const float4* p) { const kb_f4 v = __builtin_nontemporal_load(reinterpret_cast<const kb_f4*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void kb_nt_store(float4 v, float4* p) { __builtin_nontemporal_store(kb_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<kb_f4*>(p)); }
+template <bool NT>
+__global__ __launch_bounds__(256) void k_copy_f4(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        if (NT) { const float4 v = kb_nt_load(src + i); kb_nt_store(v, dst + i); }
+        else dst[i] = src[i];
+    }
+}
+// four independent float4 in flight per thread and iteration (a thread owns 4 consecutive 256-float4 stripes)
+template <bool NT>
+__global__ __launch_bounds__(256) void k_copy_f4x4(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
+    const long long stride = (long long)gridDim.x * 1024;
+    for (long long i = (long long)blockIdx.x * 1024 + threadIdx.x; i < n4; i += stride) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const long long j = i + 256 * u; if (j < n4) v[u] = NT ? kb_nt_load(src + j) : src[j]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const long long j = i + 256 * u; if (j < n4) { if (NT) kb_nt_store(v[u], dst + j); else dst[j] = v[u]; } }
+    }
+}
+__global__ __launch_bounds__(256) void k_read_f4(const float4* __restrict__ src, float* __restrict__ sink, long long n4) {
+    const long long stride = (long long)gridDim.x * 1024;
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 1024 + threadIdx.x; i < n4; i += stride) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const long long j = i + 256 * u; if (j < n4) { const float4 v = src[j]; s += (v.x + v.y) + (v.z + v.w); } }
+    }
+    if (s == 123.456f) sink[0] = s;
+}
+__global__ __launch_bounds__(256) void k_fill_f4(float4* __restrict__ dst, long long n4, float val) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) dst[i] = make_float4(val, val, val, val);
+}
 
 struct Lib {
     void* h;
@@ -152,6 +191,31 @@ int main(int argc, char** argv) {
 
     const double VC = (double)V * C * 4, VK = (double)V * K * 4;
     if (want("copy")) { timeit("copy", 2 * VC, 0, [&](int it) { HC(hipMemcpyAsync(o0r[it % NROT], xr[it % NROT], (size_t)V * C * 4, hipMemcpyDeviceToDevice, st)); }); endl_(); }
+    if (want("copyk")) {   // eight rotating 128 MiB source / destination pairs = 2 GiB touched per round trip
+        constexpr int NR8 = 8; const long long n4 = (128ll << 20) / 16; const double bytes = 2.0 * (128ll << 20);
+        float4 *cs[NR8], *cd[NR8];
+        for (int i = 0; i < NR8; ++i) { HC(hipMalloc(&cs[i], 128ll << 20)); HC(hipMalloc(&cd[i], 128ll << 20)); HC(hipMemset(cs[i], 0x3c, 128ll << 20)); HC(hipMemset(cd[i], 0, 128ll << 20)); }
+        timeit("copyk_memcpy", bytes, 0, [&](int it) { HC(hipMemcpyAsync(cd[it % NR8], cs[it % NR8], 128ll << 20, hipMemcpyDeviceToDevice, st)); }); endl_();
+        for (int nb : {1024, 2048, 4096, 8192, 32768}) {
+            char nm[64];
+            snprintf(nm, sizeof nm, "copyk_f4_g%d", nb);
+            timeit(nm, bytes, 0, [&](int it) { hipLaunchKernelGGL(k_copy_f4<false>, dim3(nb), dim3(256), 0, st, cs[it % NR8], cd[it % NR8], n4); }); endl_();
+            snprintf(nm, sizeof nm, "copyk_f4nt_g%d", nb);
+            timeit(nm, bytes, 0, [&](int it) { hipLaunchKernelGGL(k_copy_f4<true>, dim3(nb), dim3(256), 0, st, cs[it % NR8], cd[it % NR8], n4); }); endl_();
+            snprintf(nm, sizeof nm, "copyk_f4x4_g%d", nb);
+            timeit(nm, bytes, 0, [&](int it) { hipLaunchKernelGGL(k_copy_f4x4<false>, dim3(nb), dim3(256), 0, st, cs[it % NR8], cd[it % NR8], n4); }); endl_();
+            snprintf(nm, sizeof nm, "copyk_f4x4nt_g%d", nb);
+            timeit(nm, bytes, 0, [&](int it) { hipLaunchKernelGGL(k_copy_f4x4<true>, dim3(nb), dim3(256), 0, st, cs[it % NR8], cd[it % NR8], n4); }); endl_();
+        }
+        for (int nb : {2048, 8192}) {
+            char nm[64];
+            snprintf(nm, sizeof nm, "readk_f4x4_g%d", nb);
+            timeit(nm, bytes / 2, 0, [&](int it) { hipLaunchKernelGGL(k_read_f4, dim3(nb), dim3(256), 0, st, cs[it % NR8], (float*)cd[0], n4); }); endl_();
+            snprintf(nm, sizeof nm, "fillk_f4_g%d", nb);
+            timeit(nm, bytes / 2, 0, [&](int it) { hipLaunchKernelGGL(k_fill_f4, dim3(nb), dim3(256), 0, st, cd[it % NR8], n4, 1.0f); }); endl_();
+        }
+        for (int i = 0; i < NR8; ++i) { HC(hipFree(cs[i])); HC(hipFree(cd[i])); }
+    }
     if (want("to_basis")) {
         auto f = L.sym<int (*)(const dn_mesh_batch_t*, const float*, int, int, float*, void*, size_t, void*)>("dn_to_basis_f32");
         timeit("to_basis", VC + VK + V * 4.0, 2.0 * V * K * C, [&](int it) { DC(f(&mb, xr[it % NROT], C, 1, specout, ws, wsb, st)); });
