@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import collections
 import ctypes as C
+import weakref
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -269,7 +270,7 @@ def content_checksum(operands) -> bytes:
 
 
 class _CacheEntry:
-    __slots__ = ("value", "operands", "versions", "nbytes", "device", "kid", "kfp")
+    __slots__ = ("value", "operands", "versions", "nbytes", "device", "kid", "kfp", "aliases")
 
 
 class OperatorCache:
@@ -295,6 +296,7 @@ class OperatorCache:
         self.max_entries, self.max_bytes, self.mem_fraction = max_entries, max_bytes, mem_fraction
         self._by_id = {}
         self._by_fp = {}
+        self._alias = {}                             # identity key of a re-uploaded copy -> (entry, weak references to its tensors)
         self._lru = collections.OrderedDict()        # id(entry) -> entry, least recently used first
         self._bytes = collections.defaultdict(int)   # per device
         self._budget = {}
@@ -353,6 +355,7 @@ class OperatorCache:
     def clear(self):
         self._by_id.clear()
         self._by_fp.clear()
+        self._alias.clear()
         self._lru.clear()
         self._bytes.clear()
 
@@ -362,6 +365,9 @@ class OperatorCache:
             del self._by_id[e.kid]
         if e.kfp is not None and self._by_fp.get(e.kfp) is e:
             del self._by_fp[e.kfp]
+        for k in list(e.aliases):
+            self._alias.pop(k, None)
+        e.aliases.clear()
         self._bytes[e.device] -= e.nbytes
 
     def _trim(self, device):
@@ -376,6 +382,26 @@ class OperatorCache:
                 if e.device == dev:
                     self._drop(e)
 
+    def _remember_alias(self, kid, e, operands):
+        """A re-uploaded copy that was found by content: remember its IDENTITY as well, so that a caller who keeps these tensors gets the
+        synchronisation-free path from the second call on.  Only weak references are held (the scripts upload fresh copies every step:
+        pinning them would leak a mesh per step); the alias disappears with the first of its tensors -- a recycled address can
+        therefore never match a stale key -- and with its entry."""
+        if len(self._alias) > 4 * self.max_entries:
+            return
+        def gone(_ref, kid=kid, cache=weakref.ref(self)):
+            c = cache()
+            if c is not None:
+                hit = c._alias.pop(kid, None)
+                if hit is not None:
+                    hit[0].aliases.discard(kid)
+        try:
+            refs = [weakref.ref(t, gone) for t in operands if t is not None]
+        except TypeError:
+            return
+        self._alias[kid] = (e, refs)
+        e.aliases.add(kid)
+
     def lookup(self, mass, evals, evecs, gradX, gradY, index, tag, build, key_operands=None):
         """build() -> (MeshBatch, GatherPattern or None).  Tensors are the batched reference operands; ``tag`` the static part;
         ``key_operands``: the tensors as the caller handed them over (``unsqueeze`` of a sparse tensor copies it), for both keys."""
@@ -384,6 +410,9 @@ class OperatorCache:
         operands = tuple(key_operands) if key_operands is not None else (mass, evals, evecs, gradX, gradY, index)
         kid = (tag,) + tuple(self._ident(t) for t in operands)
         e = self._by_id.get(kid)
+        if e is None:
+            hit = self._alias.get(kid)
+            e = hit[0] if hit is not None and self._versions(hit[0].operands) == hit[0].versions else None
         if e is not None:
             self._lru.move_to_end(id(e))
             self.hits_id += 1
@@ -397,6 +426,7 @@ class OperatorCache:
                 if self._versions(e.operands) == e.versions:
                     self._lru.move_to_end(id(e))
                     self.hits_fp += 1
+                    self._remember_alias(kid, e, operands)
                     return e.value
                 self._drop(e)       # the tensors it aliases were edited in place since: its contents no longer match its key
         self.misses += 1
@@ -408,7 +438,7 @@ class OperatorCache:
             value = build()
         e = _CacheEntry()
         e.value, e.operands, e.versions, e.kid, e.kfp = value, operands, self._versions(operands), kid, kfp
-        e.device = str(device)
+        e.device, e.aliases = str(device), set()
         e.nbytes = _storage_bytes(_entry_tensors(value) + [t for t in operands if t is not None], set())
         old = self._by_id.get(kid)
         if old is not None:

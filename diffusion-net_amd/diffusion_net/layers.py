@@ -335,42 +335,48 @@ class DiffusionNet(nn.Module):
         if x_in.shape[-1] != self.C_in:
             raise ValueError("DiffusionNet was constructed with C_in={}, but x_in has last dim={}".format(
                 self.C_in, x_in.shape[-1]))
-        key_ops = (mass, evals, evecs, gradX, gradY, edges if self.outputs_at == "edges" else faces)   # identity key: as handed over
+        key_ops = (mass, evals, evecs, gradX, gradY, edges if self.outputs_at == "edges" else faces)   # identity / content keys: as handed over
         if x_in.dim() == 2:
             squeeze = True
-            x_in, mass = x_in.unsqueeze(0), mass.unsqueeze(0)
-            L = L.unsqueeze(0) if L is not None else None
-            evals = evals.unsqueeze(0) if evals is not None else None
-            evecs = evecs.unsqueeze(0) if evecs is not None else None
-            gradX = gradX.unsqueeze(0) if gradX is not None else None
-            gradY = gradY.unsqueeze(0) if gradY is not None else None
-            edges = edges.unsqueeze(0) if edges is not None else None
-            faces = faces.unsqueeze(0) if faces is not None else None
         elif x_in.dim() == 3:
             squeeze = False
         else:
             raise ValueError("x_in should be tensor with shape [N,C] or [B,N,C]")
 
-        if self.diffusion_method != "spectral":
-            return self._forward_unfused(x_in, mass, L, evals, evecs, gradX, gradY, edges, faces, squeeze)
+        def batched():
+            """The operands with the batch dimension of layers.py:346-358.  Evaluated only when something is packed: ``unsqueeze`` of a
+            sparse tensor copies it (and synchronises with the host on a ROCm device), and the steady state of a cached mesh needs none
+            of them."""
+            if not squeeze:
+                return mass, L, evals, evecs, gradX, gradY, edges, faces
+            u = lambda t: t.unsqueeze(0) if t is not None else None
+            return tuple(u(t) for t in (mass, L, evals, evecs, gradX, gradY, edges, faces))
 
+        if self.diffusion_method != "spectral":
+            mass_b, L_b, evals_b, evecs_b, gX_b, gY_b, edges_b, faces_b = batched()
+            return self._forward_unfused(x_in.unsqueeze(0) if squeeze else x_in, mass_b, L_b, evals_b, evecs_b, gX_b, gY_b, edges_b, faces_b, squeeze)
+
+        if squeeze:
+            x_in = x_in.unsqueeze(0)
         B, V, _ = x_in.shape
         use_grad = self.with_gradient_features
         idx = None
         if self.outputs_at in ("edges", "faces"):
             idx = edges if self.outputs_at == "edges" else faces
-            n_per_mesh = idx.shape[1]                                  # AttributeError on None, as the reference
+            n_per_mesh = idx.shape[-2]                                 # AttributeError on None, as the reference
 
         def pack():
-            mb_ = MeshBatch.from_reference_args(mass, evals, evecs, gradX if use_grad else None, gradY if use_grad else None)
+            mass_b, _, evals_b, evecs_b, gX_b, gY_b, edges_b, faces_b = batched()
+            mb_ = MeshBatch.from_reference_args(mass_b, evals_b, evecs_b, gX_b if use_grad else None, gY_b if use_grad else None)
             gather_ = None
             if idx is not None:
-                offs = (torch.arange(B, device=idx.device, dtype=idx.dtype) * V).view(B, 1, 1)
-                gather_ = GatherPattern((idx + offs).reshape(-1, idx.shape[-1]), B * V)
+                idx_b = edges_b if self.outputs_at == "edges" else faces_b
+                offs = (torch.arange(B, device=idx_b.device, dtype=idx_b.dtype) * V).view(B, 1, 1)
+                gather_ = GatherPattern((idx_b + offs).reshape(-1, idx_b.shape[-1]), B * V)
             return mb_, gather_
         # the packed operators of a mesh are built once and found again on later calls (batch.OperatorCache)
-        mb, gather = operator_cache.lookup(mass, evals, evecs, gradX if use_grad else None, gradY if use_grad else None, idx,
-                                           ("net", use_grad, self.outputs_at), pack, key_ops)
+        mb, gather = operator_cache.lookup(None, None, None, None, None, None, ("net", use_grad, self.outputs_at, squeeze), pack,
+                                           key_ops[:3] + ((gradX, gradY) if use_grad else (None, None)) + key_ops[5:])
         out = self.forward_packed(x_in.reshape(B * V, self.C_in), mb, gather)
         if self.outputs_at == "vertices":
             out = out.reshape(B, V, -1)

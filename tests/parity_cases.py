@@ -691,7 +691,11 @@ def run_operator_cache(device, V=300, K=16, C=32, seed=6):
     # steady state of a caller that keeps its device tensors: an identity hit issues no host synchronisation at all
     a2 = up()
     with torch.no_grad():
-        call(a2)
+        i0, f0, n0 = operator_cache.hits_id, operator_cache.hits_fp, len(operator_cache._alias)
+        call(a2)              # a re-upload found by content (one 16-byte read-back); its identity is remembered weakly ...
+        assert (operator_cache.hits_id, operator_cache.hits_fp) == (i0, f0 + 1) and len(operator_cache._alias) == n0 + 1
+        call(a2)              # ... so the caller who keeps these tensors is on the identity path from now on
+        assert (operator_cache.hits_id, operator_cache.hits_fp) == (i0 + 1, f0 + 1)
         if torch.device(device).type == "cuda":
             torch.cuda.synchronize()
             torch.cuda.set_sync_debug_mode("error")
@@ -702,6 +706,12 @@ def run_operator_cache(device, V=300, K=16, C=32, seed=6):
         else:
             o7 = call(a2)
     assert torch.equal(o7, base)
+    n_alias = len(operator_cache._alias)
+    keep_evecs = a2["mass"]
+    del a2["evecs"]          # the alias dies with the first of its tensors: no key can outlive the memory it names
+    import gc; gc.collect()
+    assert len(operator_cache._alias) == n_alias - 1 and keep_evecs is not None
+    a2 = up()
     # memory accounting covers every tensor an entry keeps alive, and the byte budget evicts least-recently-used entries
     assert operator_cache.bytes_held() >= sum(int(t._values().numel() * 4 if t.is_sparse else t.numel() * t.element_size()) for t in (a2["evecs"], a2["gradX"]))
     n_before, saved = len(operator_cache), operator_cache.max_bytes
