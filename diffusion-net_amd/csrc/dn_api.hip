@@ -4,6 +4,7 @@
 #include "dn_common.h"
 #include "../../include/diffnet_hip.h"
 #include <string.h>
+#include <stdlib.h>
 
 static_assert(sizeof(dn_tile_t) == sizeof(DnTile), "tile layout");
 #define DN_ERR_INVALID 1   /* hipErrorInvalidValue */
@@ -35,6 +36,8 @@ RgArgs rg_new(const dn_mesh_batch_t* mb) {
     g.acct_rows = mb->v_total;
     for (int o = 0; o < 2; ++o) for (int s = 0; s < 3; ++s) g.bsign[o][s] = 1.f;
     g.scale = 1.f;
+    static const int force_f16 = getenv("DN_FORCE_F16") ? atoi(getenv("DN_FORCE_F16")) : 0;   // experiment switch: split-fp16 engine, unit scales
+    g.f16 = force_f16;
     return g;
 }
 void rg_seg(RgArgs& g, const float* p, const float* q, int w, int ld) {

@@ -50,6 +50,15 @@ __device__ __forceinline__ f32x16 dn_mfma_bf16(uint4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dn_bf16x8, a), __builtin_bit_cast(dn_bf16x8, b), c, 0, 0, 0);
 #endif
 }
+// One 32x32x16 f16 MFMA step (fp32 accumulate); operand layout as the bf16 form.
+__device__ __forceinline__ f32x16 dn_mfma_f16(uint4 a, uint4 b, f32x16 c) {
+#ifdef DN_EMULATE
+    return dnemu_mfma_f32_32x32x16_f16(a, b, c);
+#else
+    typedef _Float16 dn_f16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dn_f16x8, a), __builtin_bit_cast(dn_f16x8, b), c, 0, 0, 0);
+#endif
+}
 // gfx950 LDS transpose read: lane l of a 16-lane group gets column l&15 of the 4x16 16-bit matrix whose row j is named by
 // the addresses of lanes 4j..4j+3 of the group (each an 8-byte chunk).  Turns k-major LDS tiles into MFMA operands.
 __device__ __forceinline__ uint2 dn_lds_tr16(const unsigned char* p) {
@@ -101,6 +110,39 @@ __device__ __forceinline__ void dn_split3_pair(float x, float y, unsigned& hi, u
 __device__ __forceinline__ void dn_split3_f4(float4 v, uint2& hi, uint2& mid, uint2& lo) {
     dn_split3_pair(v.x, v.y, hi.x, mid.x, lo.x);
     dn_split3_pair(v.z, v.w, hi.y, mid.y, lo.y);
+}
+// 2-term fp16 split, x * s = hi + lo up to 2^-22 relative, for |x * s| < 65504 (RNE; the residual is exact in fp32; s is a power of two
+// chosen from the operand's largest magnitude, so x * s is exact as well).  gfx950: v_cvt_pk_f16_f32 rounds and packs two values, the
+// residual is one v_fma_mix_f32 (fp16 operand read in place): 6 VALU instructions per pair against 11 for the 3-term bf16 split --
+// and three cross products (hi*lo, lo*hi, hi*hi) on v_mfma_f32_32x32x16_f16 instead of six, two LDS planes instead of three.
+// Elements below 2^-14 / s lose their low term to fp16's subnormal spacing: an absolute error of 2^-25 / s, i.e. 2^-40 of the operand's
+// largest magnitude -- far below fp32's own 2^-24 in every norm-wise measure (the tolerance of the parity tests is norm-wise).
+__device__ __forceinline__ void dn_split2_pair(float x, float y, float s, unsigned& hi, unsigned& lo) {
+    typedef float dn_f2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 dn_h2 __attribute__((ext_vector_type(2)));
+    const float xs = x * s, ys = y * s;
+    const dn_h2 h = __builtin_convertvector(dn_f2{xs, ys}, dn_h2);
+    hi = __builtin_bit_cast(unsigned, h);
+    const dn_f2 hb = __builtin_convertvector(h, dn_f2);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(dn_f2{xs - hb.x, ys - hb.y}, dn_h2));
+}
+// NP = 3: bf16 planes (hi, mid, lo), s ignored;  NP = 2: fp16 planes (hi, lo) of v * s
+template <int NP>
+__device__ __forceinline__ void dn_split_f4(float4 v, float s, uint2 (&pl)[NP]) {
+    if constexpr (NP == 3) dn_split3_f4(v, pl[0], pl[1], pl[2]);
+    else { dn_split2_pair(v.x, v.y, s, pl[0].x, pl[1].x); dn_split2_pair(v.z, v.w, s, pl[0].y, pl[1].y); }
+}
+template <int NP>
+__device__ __forceinline__ void dn_split_pair(float x, float y, float s, unsigned (&w)[NP]) {
+    if constexpr (NP == 3) dn_split3_pair(x, y, w[0], w[1], w[2]);
+    else dn_split2_pair(x, y, s, w[0], w[1]);
+}
+// power of two that puts `amax` into [2^14, 2^15) (1 for amax = 0; inf / nan operands propagate through the products on their own)
+__device__ __forceinline__ float dn_pow2_scale(float amax) {
+    const unsigned e = (__float_as_uint(amax) >> 23) & 0xffu;
+    int f = 127 + 14 + 127 - (int)e;
+    f = f > 254 ? 254 : (f < 1 ? 1 : f);
+    return e == 0 ? 1.f : __uint_as_float((unsigned)f << 23);
 }
 // LDS bf16 plane: R rows x 32 k, 64 bytes per row = four 16-byte slots, slot' = slot ^ ((row>>2)&3): a wave's ds_read_b128 of
 // one slot for 32 consecutive rows hits all sixteen 16-byte positions of the 256-byte bank row once per 16-lane group.
@@ -197,6 +239,12 @@ struct RgArgs {
     const unsigned long long* rng_seed_dev;   // optional device word added to rng_seed by the kernel (a captured graph advances it per replay)
     float scale;
     int acct_rows;         // rows covered by the launch (= v_total of the mesh batch)
+    // split-fp16 engine (f16 != 0): A (all segments) and B are scaled by powers of two derived from device words holding (an upper bound
+    // of) their largest magnitudes -- written by the kernels that produced them -- and the result is scaled back exactly.  o_amax: optional
+    // device word that receives max |o0| over the launch (atomic max on the bit pattern of a non-negative float; zeroed by the caller).
+    int f16;
+    const float* a_amax; const float* b_amax;
+    float* o_amax;
 };
 enum {
     DN_EPI_STORE = 0,        // o0 = acc (+bias)

@@ -278,21 +278,21 @@ __device__ __forceinline__ void rg_compute(const float* sA, const float* sB, int
 // The staging is written as two halves so that a kernel can put the MFMAs of the current slice between them: rg_split_x3
 // is pure VALU on the prefetched registers, rg_put_x3 only writes LDS (the compiler must keep LDS writes behind earlier LDS
 // reads of the other buffer -- it cannot prove they do not alias -- so the reads are issued first, see rg_frag_x3).
-template <int NOUT, int A_IT, int B_IT>
-struct X3Planes {
-    uint2 a[A_IT][3];
-    uint2 b[NOUT][B_IT][3];   // BCOLK: one 8-byte chunk per float4; PAIRK: dword e of column group h is (i = 2h + (e >> 1), .x/.y = e & 1)
+template <int NOUT, int A_IT, int B_IT, int NP = 3>
+struct X3Planes {             // NP planes: 3 = split-bf16 (hi, mid, lo), 2 = split-fp16 (hi, lo) of the pre-scaled operand
+    uint2 a[A_IT][NP];
+    uint2 b[NOUT][B_IT][NP];  // BCOLK: one 8-byte chunk per float4; PAIRK: dword e of column group h is (i = 2h + (e >> 1), .x/.y = e & 1)
 };
 
-template <int NOUT, bool BCOLK, bool HASQ, int A_IT, int B_IT, bool DO_A = true, bool DO_B = true>
-__device__ __forceinline__ void rg_split_x3(const RgRegs<NOUT, A_IT, B_IT>& R, X3Planes<NOUT, A_IT, B_IT>& P) {
+template <int NOUT, bool BCOLK, bool HASQ, int A_IT, int B_IT, bool DO_A = true, bool DO_B = true, int NP = 3>
+__device__ __forceinline__ void rg_split_x3(const RgRegs<NOUT, A_IT, B_IT>& R, X3Planes<NOUT, A_IT, B_IT, NP>& P, float sa = 1.f, float sb = 1.f) {
     if (DO_A) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             // no row mask here: a row past the unit's end (its address was clamped) only feeds its own, never stored, output row
             float4 v = R.a[i];
             if (HASQ) v = dn_f4_mul(v, R.q[i]);
-            dn_split3_f4(v, P.a[i][0], P.a[i][1], P.a[i][2]);
+            dn_split_f4<NP>(v, sa, P.a[i]);
         }
     }
     if (!DO_B) return;
@@ -304,7 +304,7 @@ __device__ __forceinline__ void rg_split_x3(const RgRegs<NOUT, A_IT, B_IT>& R, X
                 // the factor carries the sign of a two-output product; with one output it is the column mask only, and
                 // a column past N (clamped address) only feeds its own, never stored, output column
                 const float4 v = NOUT == 2 ? dn_f4_scale(R.b[o][i], R.bm[o][i]) : R.b[o][i];
-                dn_split3_f4(v, P.b[o][i][0], P.b[o][i][1], P.b[o][i][2]);
+                dn_split_f4<NP>(v, sb, P.b[o][i]);
             }
         } else {   // PAIRK: R.b[o][2h] = row 2p, R.b[o][2h+1] = row 2p+1 of column group q4(h) -> packed (k, k+1) dwords per column
             static_assert(BCOLK || B_IT % 2 == 0, "pair mapping needs two rows per thread and column group");
@@ -312,17 +312,23 @@ __device__ __forceinline__ void rg_split_x3(const RgRegs<NOUT, A_IT, B_IT>& R, X
             for (int h = 0; h < B_IT / 2; ++h) {
                 const float4 v0 = NOUT == 2 ? dn_f4_scale(R.b[o][2 * h], R.bm[o][2 * h]) : R.b[o][2 * h];
                 const float4 v1 = NOUT == 2 ? dn_f4_scale(R.b[o][2 * h + 1], R.bm[o][2 * h + 1]) : R.b[o][2 * h + 1];
-                dn_split3_pair(v0.x, v1.x, P.b[o][2 * h][0].x, P.b[o][2 * h][1].x, P.b[o][2 * h][2].x);
-                dn_split3_pair(v0.y, v1.y, P.b[o][2 * h][0].y, P.b[o][2 * h][1].y, P.b[o][2 * h][2].y);
-                dn_split3_pair(v0.z, v1.z, P.b[o][2 * h + 1][0].x, P.b[o][2 * h + 1][1].x, P.b[o][2 * h + 1][2].x);
-                dn_split3_pair(v0.w, v1.w, P.b[o][2 * h + 1][0].y, P.b[o][2 * h + 1][1].y, P.b[o][2 * h + 1][2].y);
+                unsigned wx[NP], wy[NP], wz[NP], ww[NP];
+                dn_split_pair<NP>(v0.x, v1.x, sb, wx);
+                dn_split_pair<NP>(v0.y, v1.y, sb, wy);
+                dn_split_pair<NP>(v0.z, v1.z, sb, wz);
+                dn_split_pair<NP>(v0.w, v1.w, sb, ww);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    P.b[o][2 * h][p].x = wx[p]; P.b[o][2 * h][p].y = wy[p];
+                    P.b[o][2 * h + 1][p].x = wz[p]; P.b[o][2 * h + 1][p].y = ww[p];
+                }
             }
         }
     }
 }
 
-template <int NTHR, int NOUT, bool BCOLK, int A_IT, int B_IT>
-__device__ __forceinline__ void rg_put_x3(unsigned char* sA, unsigned char* sB, int tid, const X3Planes<NOUT, A_IT, B_IT>& P) {
+template <int NTHR, int NOUT, bool BCOLK, int A_IT, int B_IT, int NP = 3>
+__device__ __forceinline__ void rg_put_x3(unsigned char* sA, unsigned char* sB, int tid, const X3Planes<NOUT, A_IT, B_IT, NP>& P) {
     constexpr int PL = DN_TM * 64;    // bytes per A plane (128 rows x 32 bf16)
     constexpr int PLB = 128 * 64;     // bytes per B plane (128 output columns); output o uses planes [3o, 3o+3)
 #pragma unroll
@@ -331,7 +337,7 @@ __device__ __forceinline__ void rg_put_x3(unsigned char* sA, unsigned char* sB, 
         const int row = idx >> 3, q = idx & 7;
         const int off = dn_plane_off(row, q >> 1) + (q & 1) * 8;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(sA + p * PL + off) = P.a[i][p];
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(sA + p * PL + off) = P.a[i][p];
     }
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
@@ -343,7 +349,7 @@ __device__ __forceinline__ void rg_put_x3(unsigned char* sA, unsigned char* sB, 
                 const int nrow = idx >> 3, q = idx & 7;
                 const int off = dn_plane_off(nrow, q >> 1) + (q & 1) * 8;
 #pragma unroll
-                for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(sBo + p * PLB + off) = P.b[o][i][p];
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(sBo + p * PLB + off) = P.b[o][i][p];
             }
         } else {
             const int pr = tid & 15;
@@ -354,7 +360,7 @@ __device__ __forceinline__ void rg_put_x3(unsigned char* sA, unsigned char* sB, 
                 for (int e = 0; e < 4; ++e) {
                     const int off = dn_plane_off(4 * q4 + e, pr >> 2) + (pr & 3) * 4;
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) {
+                    for (int p = 0; p < NP; ++p) {
                         const uint2 w = P.b[o][2 * h + (e >> 1)][p];
                         *reinterpret_cast<unsigned*>(sBo + p * PLB + off) = (e & 1) ? w.y : w.x;
                     }
@@ -372,18 +378,18 @@ __device__ __forceinline__ void rg_store_x3(unsigned char* sA, unsigned char* sB
 }
 
 // MFMA operands of one 32-wide slice (two k16 steps; lane group lg owns k = 16 s + 8 lg .. +7), read in one burst
-template <int MT, int NT, int NOUT>
+template <int MT, int NT, int NOUT, int NP = 3>
 struct X3Frags {
-    uint4 a[2][3][MT];
-    uint4 b[2][NOUT][3][NT];
+    uint4 a[2][NP][MT];
+    uint4 b[2][NOUT][NP][NT];
 };
 
-template <int MT, int NT, int NOUT>
+template <int MT, int NT, int NOUT, int NP = 3>
 __device__ __forceinline__ void rg_frag_x3(const unsigned char* sA, const unsigned char* sB, int arow0, int bcol0, int li, int lg,
-                                           int s, X3Frags<MT, NT, NOUT>& F) {
+                                           int s, X3Frags<MT, NT, NOUT, NP>& F) {
     constexpr int PL = DN_TM * 64, PLB = 128 * 64;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < NP; ++p) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
             F.a[s][p][mt] = *reinterpret_cast<const uint4*>(sA + p * PL + dn_plane_off(arow0 + mt * 32 + li, 2 * s + lg));

@@ -261,6 +261,27 @@ __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_pers
 #define DN_WS_PTHR (64 * DN_WS_PW)
 #define DN_WS_NP (128 * 128 / 4 / DN_WS_PTHR)   // float4 pieces per piece thread and unit
 
+#if defined(DN_WS_TRACE) && !defined(DN_EMULATE)   // development build only (make EXTRA=-DDN_WS_TRACE=<block>): s_memtime stamps of one workgroup's
+__device__ unsigned long long dn_ws_trace_buf[12 * 256];   // waves (12 x 256 stamps), read by tools/kbench --trace
+extern "C" int dn_debug_rd_trace_read(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dn_ws_trace_buf), (size_t)(n < 12 * 256 ? n : 12 * 256) * sizeof(unsigned long long));
+}
+#define WS_TR_DECL int trn = 0
+#define WS_TR()                                                                                                         \
+    do {                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        if (blockIdx.x == (DN_WS_TRACE) && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && trn < 256)                     \
+            dn_ws_trace_buf[(threadIdx.x >> 6) * 256 + trn] = __builtin_amdgcn_s_memtime();                            \
+        ++trn;                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    } while (0)
+#define WS_TR_WAITV() __builtin_amdgcn_s_waitcnt(0x0F70)   /* vmcnt(0), other counters untouched */
+#else
+#define WS_TR_DECL
+#define WS_TR() do {} while (0)
+#define WS_TR_WAITV() do {} while (0)
+#endif
+
 struct WsAux {
     float4 a0;
     uint32_t mk;
@@ -271,7 +292,7 @@ struct WsAux {
 };
 
 // issue the auxiliary loads of one deferred piece (nothing here is used before the next slice iteration)
-template <int MODE, bool FLAG>
+template <int MODE, bool FLAG, bool XMASK = false>
 __device__ __forceinline__ void ws_aux_load(const RgArgs& g, unsigned long long seed, int piece, int lt, int row0, int nrows, int n0, WsAux& A) {
     const bool live = piece < DN_WS_NP;
     const int idx = lt + (live ? piece : 0) * DN_WS_PTHR;
@@ -286,31 +307,39 @@ __device__ __forceinline__ void ws_aux_load(const RgArgs& g, unsigned long long 
     constexpr bool need_r0 = MODE == DN_EPI_BIAS_RESID || MODE == DN_EPI_MUL_DFAC || MODE == DN_EPI_ADD ||
                              MODE == DN_EPI_DTANH || MODE == DN_EPI_MASS_ADD;
     if (need_r0) A.a0 = *reinterpret_cast<const float4*>(g.r0 + roff);
-    if (MODE == DN_EPI_BIAS_RELU && FLAG) {   // explicit mask or drawn bits (see pt_piece_load)
-        const uint32_t ld = *reinterpret_cast<const uint32_t*>(g.mask ? g.mask + roff : reinterpret_cast<const uint8_t*>(g.bias));
-        A.mk = g.mask ? ld : dn_keep_bytes(dn_keep_bits(seed, grow, ccol >> 2, (g.N + 3) >> 2));
+    // drawn bits or (XMASK, compile time: the parity tests' explicit uint8 masks) a 4-byte mask load.  The round-2 form "mask ? load :
+    // hash" compiled to a branch per piece with s_waitcnt vmcnt(0) at every join -- three full drains of the memory pipeline per slice.
+    if (MODE == DN_EPI_BIAS_RELU && FLAG) {
+        if constexpr (XMASK) A.mk = *reinterpret_cast<const uint32_t*>(g.mask + roff);
+        else A.mk = dn_keep_bytes(dn_keep_bits(seed, grow, ccol >> 2, (g.N + 3) >> 2));
     }
     if (MODE == DN_EPI_MASS_ADD) A.rs = g.rowv[grow];
 }
 
 template <int MODE, bool FLAG>
-__device__ __forceinline__ void ws_piece_out(const RgArgs& g, const float* sE, const float4& bias, const WsAux& A) {
+__device__ __forceinline__ void ws_piece_out(const RgArgs& g, const float4& v, const float4& bias, const WsAux& A, float so = 1.f) {
     PtPiece P;
-    P.v = *reinterpret_cast<const float4*>(&sE[A.lds]);
+    P.v = v;
+    if (so != 1.f) P.v = dn_f4_scale(P.v, so);     // split-fp16 engine: exact power-of-two rescale of the product
     P.a0 = A.a0; P.bias = bias; P.mk = A.mk; P.rs = A.rs; P.off = A.off; P.ok = A.ok;
     pt_piece_store<MODE, FLAG>(g, P);
 }
 
-// six cross products of one k16 step, product-major: consecutive MFMAs go to different accumulators
-__device__ __forceinline__ void ws_mma(const X3Frags<2, 2, 1>& F, int s, f32x16 (&acc)[1][2][2]) {
-    constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};   // mid*mid, hi*lo, lo*hi, hi*mid, mid*hi, hi*hi
+// the cross products of one k16 step, product-major: consecutive MFMAs go to different accumulators.
+// NP = 3 (split-bf16): mid*mid, hi*lo, lo*hi, hi*mid, mid*hi, hi*hi;  NP = 2 (split-fp16): hi*lo, lo*hi, hi*hi -- smallest terms first
+template <int NP>
+__device__ __forceinline__ void ws_mma(const X3Frags<2, 2, 1, NP>& F, int s, f32x16 (&acc)[1][2][2]) {
+    constexpr int NPROD = NP == 3 ? 6 : 3;
+    constexpr int PA[6] = {NP == 3 ? 1 : 0, NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, 0, 1, 0};
+    constexpr int PB[6] = {1, NP == 3 ? 2 : 0, 0, 1, 0, 0};
 #pragma unroll
-    for (int p = 0; p < 6; ++p)
+    for (int p = 0; p < NPROD; ++p)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                acc[0][mt][nt] = dn_mfma_bf16(F.a[s][PA[p]][mt], F.b[s][0][PB[p]][nt], acc[0][mt][nt]);
+                if constexpr (NP == 3) acc[0][mt][nt] = dn_mfma_bf16(F.a[s][PA[p]][mt], F.b[s][0][PB[p]][nt], acc[0][mt][nt]);
+                else acc[0][mt][nt] = dn_mfma_f16(F.a[s][PA[p]][mt], F.b[s][0][PB[p]][nt], acc[0][mt][nt]);
             }
 }
 
@@ -349,7 +378,7 @@ __device__ __forceinline__ void ws_load(const float* ap, int ald, const float* b
 // BC ("B cached"): products with ONE 128-wide segment (4 slices) and the same B for every unit (nn.Linear weights): every loader
 // thread stages the same B elements of slice s for every unit, so it splits them once, before the loop, and keeps the 4 x 12
 // plane dwords in registers -- the per-slice B work shrinks from 2 loads + 44 VALU + 6 LDS writes to the 6 LDS writes.
-template <int MODE, bool BCOLK, bool FLAG, int PPI, bool BC>
+template <int MODE, bool BCOLK, bool FLAG, int PPI, bool BC, int NP, bool XMASK>
 __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2 : 3) void rowgemm_ws_kernel(RgArgs g, int ntiles) {
     const unsigned long long seed = (MODE == DN_EPI_BIAS_RELU && FLAG) ? rg_seed(g) : 0ull;
 
@@ -391,15 +420,18 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][mt][nt][r] = 0.f;
         int cs = 0;
+        WS_TR_DECL;
         __syncthreads();   // slice 0 staged
         for (int j = 0; j < T; ++j) {
             const unsigned char* cA = reinterpret_cast<const unsigned char*>(smem + (j & 1) * SBUF);
             const unsigned char* cB = cA + SA * 4;
-            X3Frags<2, 2, 1> F;
-            rg_frag_x3<2, 2, 1>(cA, cB, wr * 64, wc * 64, li, lg, 0, F);
-            rg_frag_x3<2, 2, 1>(cA, cB, wr * 64, wc * 64, li, lg, 1, F);
-            ws_mma(F, 0, acc);
-            ws_mma(F, 1, acc);
+            X3Frags<2, 2, 1, NP> F;
+            WS_TR();   // m0: iteration start
+            rg_frag_x3<2, 2, 1, NP>(cA, cB, wr * 64, wc * 64, li, lg, 0, F);
+            rg_frag_x3<2, 2, 1, NP>(cA, cB, wr * 64, wc * 64, li, lg, 1, F);
+            ws_mma<NP>(F, 0, acc);
+            ws_mma<NP>(F, 1, acc);
+            WS_TR();   // m1: reads + MFMAs issued
             if (++cs == nsl) {   // unit complete: park it (fragment layout -> row-major) for the loader waves to stream out
                 cs = 0;
 #pragma unroll
@@ -412,6 +444,7 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
                             acc[0][mt][nt][r] = 0.f;
                         }
             }
+            WS_TR();   // m2: before the barrier
             __syncthreads();
         }
         return;
@@ -420,6 +453,13 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     // ---------------------------------------------------- loader waves ----------------------------------------------------
     DN_SETPRIO(DN_WS_LOADER_PRIO);
     const int lt = lw * 64 + lane;
+    // split-fp16: operand scales (powers of two from the producers' amax words) and the exact inverse of their product
+    float sa = 1.f, sb = 1.f, so = 1.f;
+    if constexpr (NP == 2) {
+        if (g.a_amax) sa = dn_pow2_scale(*g.a_amax);
+        if (g.b_amax) sb = dn_pow2_scale(*g.b_amax);
+        so = (1.f / sa) * (1.f / sb);
+    }
     float4 bias = dn_f4_zero();
     {
         const int col = n0 + 4 * (lt & 31);
@@ -433,18 +473,27 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     const float* sb0 = g.b[0][0]; const float* sb1 = g.b[0][1]; const float* sb2 = g.b[0][2];
     const int nseg = g.nseg, ldb = g.ldb, Ncols = g.N;
     const long long bms = g.b_mesh_stride;
+    // Tile descriptors are fetched per lane (every lane the same address) through a pointer the compiler cannot prove uniform: for a
+    // uniform address it emits a vector load + v_readfirstlane, i.e. an s_waitcnt vmcnt(0) right behind the load -- a full drain of
+    // the memory pipeline (slice prefetch included) in every iteration (seen in the ISA of round 2's kernel).  As per-lane values
+    // they are waited for where they are used: one iteration later.  (An explicit s_load through inline asm is not an option: the
+    // compiler copies the destination registers at the loop back-edge before the load has returned -- tried, wrong results.)
+    const DnTile* tl = g.tiles;
+#ifndef DN_EMULATE
+    { int vz_; asm volatile("v_mov_b32 %0, 0" : "=v"(vz_)); tl += vz_; }
+#endif
     // load cursor; the next unit's tile descriptor is fetched one unit ahead
     int lu = blockIdx.x, lseg = 0, lkoff = 0;
-    DnTile ltile = g.tiles[lu];
-    DnTile ltile_next = g.tiles[lu + G < ntiles ? lu + G : lu];
+    DnTile ltile = tl[lu];
+    DnTile ltile_next = tl[lu + G < ntiles ? lu + G : lu];
     // mirror of the compute cursor (which unit is parked when) and the parked unit being streamed out
     int cu = blockIdx.x, cs = 0;
     DnTile ctile = ltile, ctile_next = ltile_next;
     int p_row0 = ctile.row0, p_nrows = 0, p_next = DN_WS_NP;   // p_next >= NP: nothing pending
-    const bool piece_wave = lt < DN_WS_PTHR;
+    const bool piece_wave = (DN_WS_PW == DN_WS_LW) ? true : lt < DN_WS_PTHR;
     WsAux AX[PPI];
 #pragma unroll
-    for (int k = 0; k < PPI; ++k) ws_aux_load<MODE, FLAG>(g, seed, DN_WS_NP, lt, p_row0, p_nrows, n0, AX[k]);   // dead pieces
+    for (int k = 0; k < PPI; ++k) ws_aux_load<MODE, FLAG, XMASK>(g, seed, DN_WS_NP, lt, p_row0, p_nrows, n0, AX[k]);   // dead pieces
 
 // one step of the load cursor without control flow or memory access on the path; past the last slice it stays put
 #define WS_ADVANCE(commit)                                                                                              \
@@ -462,7 +511,7 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
         lkoff = ok_ ? nk_ : lkoff; lseg = ok_ ? ns_ : lseg; lu = ok_ ? nu_ : lu;                                        \
         ltile.row0 = sw_ ? ltile_next.row0 : ltile.row0; ltile.nrows = sw_ ? ltile_next.nrows : ltile.nrows;            \
         ltile.mesh = sw_ ? ltile_next.mesh : ltile.mesh;                                                                \
-        ltile_next = g.tiles[lu + G < ntiles ? lu + G : lu];   /* consumed at the next unit switch at the earliest */    \
+        ltile_next = tl[lu + G < ntiles ? lu + G : lu];   /* consumed at the next unit switch at the earliest */         \
     } while (0)
 #define WS_LOAD(RS)                                                                                                     \
     ws_load<BCOLK, A_IT, B_IT, true, !BC>(lseg == 0 ? sp0 : (lseg == 1 ? sp1 : sp2), lseg == 0 ? sl0 : (lseg == 1 ? sl1 : sl2), \
@@ -470,25 +519,35 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
                                ltile.row0, ltile.nrows, n0, lkoff, lt, RS)
 #define WS_STAGE(buf, RS, SIDX)                                                                                         \
     do {                                                                                                                \
-        X3Planes<NOUT, A_IT, B_IT> PLN;                                                                                 \
-        rg_split_x3<NOUT, BCOLK, HASQ, A_IT, B_IT, true, !BC>(RS, PLN);                                                 \
+        X3Planes<NOUT, A_IT, B_IT, NP> PLN;                                                                             \
+        rg_split_x3<NOUT, BCOLK, HASQ, A_IT, B_IT, true, !BC, NP>(RS, PLN, sa, sb);                                     \
         if constexpr (BC) {                                                                                             \
             _Pragma("unroll") for (int i_ = 0; i_ < B_IT; ++i_)                                                         \
-                _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_) PLN.b[0][i_][p_] = Bc[SIDX][i_][p_];                   \
+                _Pragma("unroll") for (int p_ = 0; p_ < NP; ++p_) PLN.b[0][i_][p_] = Bc[SIDX][i_][p_];                  \
         }                                                                                                               \
-        rg_put_x3<LTHR, NOUT, BCOLK, A_IT, B_IT>(reinterpret_cast<unsigned char*>(buf),                                 \
+        rg_put_x3<LTHR, NOUT, BCOLK, A_IT, B_IT, NP>(reinterpret_cast<unsigned char*>(buf),                             \
                                                  reinterpret_cast<unsigned char*>((buf) + SA), lt, PLN);                \
     } while (0)
 
 // Order inside an iteration: stage -> deferred pieces (their operands were requested an iteration ago) -> operands of the
 // next iteration's pieces -> slice prefetch.  (Measured: a second register set / fetching two slices ahead, and requesting
 // the piece operands before the prefetch, were both slower -- 60/48/135 us vs 53/51/127 us for the NN, C->C, 3C->C products.)
-#define WS_ITER(j, RS, SIDX)                                                                                            \
+#define WS_SPLIT(RS, SIDX, PLN)                                                                                         \
     do {                                                                                                                \
-        float* nxt = smem + (((j) & 1) ^ 1) * SBUF;                                                                     \
-        WS_STAGE(nxt, RS, SIDX);       /* slice j+1 (the last iteration stages a stale copy nobody reads) */            \
+        rg_split_x3<NOUT, BCOLK, HASQ, A_IT, B_IT, true, !BC, NP>(RS, PLN, sa, sb);                                     \
+        if constexpr (BC) {                                                                                             \
+            _Pragma("unroll") for (int i_ = 0; i_ < B_IT; ++i_)                                                         \
+                _Pragma("unroll") for (int p_ = 0; p_ < NP; ++p_) PLN.b[0][i_][p_] = Bc[SIDX][i_][p_];                  \
+        }                                                                                                               \
+    } while (0)
+#define WS_PUT(buf, PLN)                                                                                                \
+    rg_put_x3<LTHR, NOUT, BCOLK, A_IT, B_IT, NP>(reinterpret_cast<unsigned char*>(buf), reinterpret_cast<unsigned char*>((buf) + SA), lt, PLN)
+#define WS_PIECES()                                                                                                     \
+    do {                                                                                                                \
         if (piece_wave) {              /* wave-uniform: only the first DN_WS_PW loader waves stream the parked unit out */ \
-            _Pragma("unroll") for (int k = 0; k < PPI; ++k) ws_piece_out<MODE, FLAG>(g, sE, bias, AX[k]);               \
+            float4 pv_[PPI];           /* all LDS reads of the parked unit first, then the maths and the stores */       \
+            _Pragma("unroll") for (int k = 0; k < PPI; ++k) pv_[k] = *reinterpret_cast<const float4*>(&sE[AX[k].lds]);  \
+            _Pragma("unroll") for (int k = 0; k < PPI; ++k) ws_piece_out<MODE, FLAG>(g, pv_[k], bias, AX[k], so);       \
             p_next = (p_next + PPI < DN_WS_NP) ? p_next + PPI : DN_WS_NP;                                               \
             {   /* the MFMA waves park unit cu at the end of the iteration that multiplies its last slice */            \
                 const bool park = ++cs == nsl;                                                                          \
@@ -498,28 +557,71 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
                 cu = park ? cu + G : cu;                                                                                \
                 ctile.row0 = park ? ctile_next.row0 : ctile.row0; ctile.nrows = park ? ctile_next.nrows : ctile.nrows;  \
                 const int cn = cu + G < ntiles ? cu + G : ntiles - 1;                                                   \
-                ctile_next = g.tiles[cn];   /* consumed at the next park at the earliest */                             \
+                ctile_next = tl[cn];   /* consumed at the next park at the earliest */                                  \
             }                                                                                                           \
             _Pragma("unroll") for (int k = 0; k < PPI; ++k)                                                             \
-                ws_aux_load<MODE, FLAG>(g, seed, p_next + k, lt, p_row0, p_nrows, n0, AX[k]);                                 \
+                ws_aux_load<MODE, FLAG, XMASK>(g, seed, p_next + k, lt, p_row0, p_nrows, n0, AX[k]);                                 \
         }                                                                                                               \
-        WS_ADVANCE((j) + 1 + 1 < T);                                                                          \
-        WS_LOAD(RS);                   /* slice j+1+DEPTH */                                                            \
-        __syncthreads();                                                                                                \
     } while (0)
 
-    uint2 Bc[BC ? 4 : 1][B_IT][3];
+#ifndef DN_WS_EARLY
+#define DN_WS_EARLY 1
+#endif
+// Order inside an iteration (DN_WS_EARLY, round 3): wait for slice j+1 -> split it into plane registers -> the registers it came in are
+// free: request slice j+2 NOW -> LDS writes of slice j+1 -> deferred pieces -> operands of the next pieces -> barrier.  The s_memtime
+// timeline of the round-2 order (request at the end of the iteration, profiles/r03_ws_trace_*.txt) showed 1300-2100 of a loader's
+// ~4600-5200 cycles per slice spent waiting for that request: it had only the barrier to fly in; now it has most of an iteration.
+// DN_WS_EARLY=0 keeps the round-2 order: stage -> pieces -> piece operands -> request.
+#if DN_WS_EARLY
+#define WS_ITER(j, RS, SIDX)                                                                                            \
+    do {                                                                                                                \
+        float* nxt = smem + (((j) & 1) ^ 1) * SBUF;                                                                     \
+        X3Planes<NOUT, A_IT, B_IT, NP> PLN;                                                                             \
+        WS_TR();                       /* l0: iteration start */                                                        \
+        WS_TR_WAITV(); WS_TR();        /* l1: the prefetched slice has arrived (explicit wait in the trace build only) */ \
+        WS_SPLIT(RS, SIDX, PLN);       /* slice j+1 (the last iteration stages a stale copy nobody reads) */            \
+        WS_TR();                       /* l2: split */                                                                  \
+        WS_ADVANCE((j) + 1 + 1 < T);                                                                                    \
+        WS_LOAD(RS);                   /* slice j+2 */                                                                  \
+        WS_TR();                       /* l3: prefetch issued */                                                        \
+        WS_PUT(nxt, PLN);                                                                                               \
+        WS_TR();                       /* l4: LDS writes issued */                                                      \
+        WS_PIECES();                                                                                                    \
+        WS_TR();                       /* l5: pieces out + next pieces' operands requested */                           \
+        __syncthreads();                                                                                                \
+    } while (0)
+#else
+#define WS_ITER(j, RS, SIDX)                                                                                            \
+    do {                                                                                                                \
+        float* nxt = smem + (((j) & 1) ^ 1) * SBUF;                                                                     \
+        X3Planes<NOUT, A_IT, B_IT, NP> PLN;                                                                             \
+        WS_TR();                       /* l0: iteration start */                                                        \
+        WS_TR_WAITV(); WS_TR();        /* l1: the prefetched slice has arrived (trace build only) */                    \
+        WS_SPLIT(RS, SIDX, PLN);       /* slice j+1 (the last iteration stages a stale copy nobody reads) */            \
+        WS_PUT(nxt, PLN);                                                                                               \
+        WS_TR();                       /* l2: staged */                                                                 \
+        WS_PIECES();                                                                                                    \
+        WS_TR();                       /* l3: pieces out + next pieces' operands requested */                           \
+        WS_ADVANCE((j) + 1 + 1 < T);                                                                                    \
+        WS_LOAD(RS);                   /* slice j+2 */                                                                  \
+        WS_TR();                       /* l4: prefetch issued */                                                        \
+        __syncthreads();                                                                                                \
+    } while (0)
+#endif
+
+    WS_TR_DECL;
+    uint2 Bc[BC ? 4 : 1][B_IT][NP];
     if constexpr (BC) {   // split the whole B strip of this workgroup once (4 slices of the one segment)
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             RgRegs<NOUT, A_IT, B_IT> Rb;
             ws_load<BCOLK, A_IT, B_IT, false, true>(sp0, sl0, sb0, ldb, Ncols, 0, 0, n0, DN_KB * s4, lt, Rb);
-            X3Planes<NOUT, A_IT, B_IT> Pb;
-            rg_split_x3<NOUT, BCOLK, HASQ, A_IT, B_IT, false, true>(Rb, Pb);
+            X3Planes<NOUT, A_IT, B_IT, NP> Pb;
+            rg_split_x3<NOUT, BCOLK, HASQ, A_IT, B_IT, false, true, NP>(Rb, Pb, sa, sb);
 #pragma unroll
             for (int i = 0; i < B_IT; ++i)
 #pragma unroll
-                for (int p3 = 0; p3 < 3; ++p3) Bc[s4][i][p3] = Pb.b[0][i][p3];
+                for (int p3 = 0; p3 < NP; ++p3) Bc[s4][i][p3] = Pb.b[0][i][p3];
         }
     }
     WS_LOAD(R0);
@@ -538,6 +640,9 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
         for (int j = 0; j < T; ++j) WS_ITER(j, R0, 0);
     }
 #undef WS_ITER
+#undef WS_PIECES
+#undef WS_PUT
+#undef WS_SPLIT
 #undef WS_STAGE
 #undef WS_LOAD
 #undef WS_ADVANCE
@@ -545,22 +650,30 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     if (!piece_wave) return;
     for (; p_next < DN_WS_NP; ++p_next) {
         WsAux A1;
-        ws_aux_load<MODE, FLAG>(g, seed, p_next, lt, p_row0, p_nrows, n0, A1);
-        ws_piece_out<MODE, FLAG>(g, sE, bias, A1);
+        ws_aux_load<MODE, FLAG, XMASK>(g, seed, p_next, lt, p_row0, p_nrows, n0, A1);
+        ws_piece_out<MODE, FLAG>(g, *reinterpret_cast<const float4*>(&sE[A1.lds]), bias, A1, so);
     }
 }
 
-template <int MODE, bool BCOLK, bool FLAG, int PPI, bool BC>
-static int ws_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
+template <int MODE, bool BCOLK, bool FLAG, int PPI, bool BC, int NP, bool XMASK>
+static int ws_launch_x(const RgArgs& g, int ntiles, hipStream_t stream) {
     const size_t smem = (size_t)(2 * (DN_TM * 64 * 3 + 128 * 64 * 3) + 128 * 128 * 4);   // 160 KiB
 #ifndef DN_EMULATE
     static unsigned long long lds_opt_in = 0;   // per-device bitmap
-    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&rowgemm_ws_kernel<MODE, BCOLK, FLAG, PPI, BC>), smem, &lds_opt_in); if (oe_) return oe_; }
+    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&rowgemm_ws_kernel<MODE, BCOLK, FLAG, PPI, BC, NP, XMASK>), smem, &lds_opt_in); if (oe_) return oe_; }
 #endif
     int gx = dn_num_cus();
     if (gx > ntiles) gx = ntiles;
-    DN_LAUNCH((rowgemm_ws_kernel<MODE, BCOLK, FLAG, PPI, BC>), dim3(gx, (g.N + 127) / 128, 1), dim3(256 + DN_WS_LTHR, 1, 1), smem, stream, g, ntiles);
+    DN_LAUNCH((rowgemm_ws_kernel<MODE, BCOLK, FLAG, PPI, BC, NP, XMASK>), dim3(gx, (g.N + 127) / 128, 1), dim3(256 + DN_WS_LTHR, 1, 1), smem, stream, g, ntiles);
     return (int)hipGetLastError();
+}
+
+template <int MODE, bool BCOLK, bool FLAG, int PPI, bool BC, int NP = 3>
+static int ws_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
+    if constexpr (MODE == DN_EPI_BIAS_RELU && FLAG) {
+        if (g.mask) return ws_launch_x<MODE, BCOLK, FLAG, PPI, BC, NP, true>(g, ntiles, stream);
+    }
+    return ws_launch_x<MODE, BCOLK, FLAG, PPI, BC, NP, false>(g, ntiles, stream);
 }
 
 template <int MODE, bool BCOLK, bool FLAG>
@@ -570,6 +683,12 @@ static int pt_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
         int nsl = 0;
         for (int s = 0; s < g.nseg; ++s) nsl += g.a[s].w / DN_KB;
         // PPI = ceil(NP / (nsl - 1)) for the two slice counts that matter (K = 128: 4 slices, K = 384: 12)
+        if (g.f16) {   // split-fp16 engine (the caller supplies the operand magnitudes)
+            if (nsl >= 9) return ws_launch<MODE, BCOLK, FLAG, (DN_WS_NP + 7) / 8, false, 2>(g, ntiles, stream);
+            if (DN_WS_BCACHE && nsl == 4 && g.nseg == 1 && g.b_mesh_stride == 0)
+                return ws_launch<MODE, BCOLK, FLAG, (DN_WS_NP + 2) / 3, true, 2>(g, ntiles, stream);
+            if (nsl >= 4) return ws_launch<MODE, BCOLK, FLAG, (DN_WS_NP + 2) / 3, false, 2>(g, ntiles, stream);
+        }
         if (nsl >= 9) return ws_launch<MODE, BCOLK, FLAG, (DN_WS_NP + 7) / 8, false>(g, ntiles, stream);
         if (DN_WS_BCACHE && nsl == 4 && g.nseg == 1 && g.b_mesh_stride == 0)
             return ws_launch<MODE, BCOLK, FLAG, (DN_WS_NP + 2) / 3, true>(g, ntiles, stream);

@@ -213,6 +213,30 @@ static inline dnemu_f32x16 dnemu_mfma_f32_32x32x16_bf16(uint4 a, uint4 b, dnemu_
     }
     return d;
 }
+// v_mfma_f32_32x32x16_f16: same layout, fp16 operands
+static inline dnemu_f32x16 dnemu_mfma_f32_32x32x16_f16(uint4 a, uint4 b, dnemu_f32x16 c) {
+    dnemu::WaveState& w = dnemu::cur_wave();
+    int l = dnemu::cur_lane();
+    unsigned slot = w.gen & 1;
+    const unsigned aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+    for (int j = 0; j < 8; ++j) {
+        w.ha[slot][l][j] = (unsigned short)((aw[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+        w.hb[slot][l][j] = (unsigned short)((bw[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+    }
+    dnemu::wave_barrier();
+    auto h2f = [](unsigned short u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; };
+    dnemu_f32x16 d;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        int col = l & 31;
+        float v = c[r];
+        for (int g = 0; g < 2; ++g)
+            for (int j = 0; j < 8; ++j)
+                v = fmaf(h2f(w.ha[slot][row + 32 * g][j]), h2f(w.hb[slot][col + 32 * g][j]), v);
+        d[r] = v;
+    }
+    return d;
+}
 // v_mfma_f32_16x16x32_bf16: lane l supplies A[i=l&15][k=8*(l>>4)+j] and B[k=8*(l>>4)+j][col=l&15], j = 0..7;
 // accumulator register r of lane l is D[4*(l>>4)+r][l&15] (cdna_hip_programming.md section 3).
 typedef float dnemu_f32x4 __attribute__((ext_vector_type(4)));

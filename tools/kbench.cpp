@@ -338,6 +338,30 @@ int main(int argc, char** argv) {
         DC(blk_f(&mb, &bp, x, o0, &sv, ws, wsb, st));
         timeit("block_bwd", 40 * VC, 0, [&](int it) { DC(f(&mb, &bp, x, &sv, yr[it % NROT], &gr, ws, wsb, st)); }); endl_();
     }
+    if (trace) {   // libraries built with EXTRA=-DDN_WS_TRACE=<block>: stamps of the wave-specialised row GEMM (MFMA wave 0: 3 per slice, loader wave 4: 5)
+        auto rd = (int (*)(unsigned long long*, int))dlsym(L.h, "dn_debug_rd_trace_read");
+        if (rd) {
+            for (const char* which : {"linear", "from_basis"}) {
+                if (std::string(which) == "linear") DC(lin(&mb, x, C, W, b, C, 1, nullptr, o0, st));
+                else DC((L.sym<int (*)(const dn_mesh_batch_t*, const float*, int, int, float*, void*)>("dn_from_basis_f32"))(&mb, spec, C, 0, o0, st));
+                HC(hipStreamSynchronize(st));
+                std::vector<unsigned long long> tb(12 * 256); rd(tb.data(), 12 * 256);
+                printf("== trace %s\n", which);
+                auto dump = [&](int w, int per, const char* names) {
+                    printf(" wave %d (%s), deltas per iteration:\n", w, names);
+                    const unsigned long long* t = &tb[(size_t)w * 256];
+                    for (int it = 0; it < 20 && (it + 1) * per < 256; ++it) {
+                        printf("  it %2d:", it);
+                        for (int k = 0; k < per; ++k) printf(" %6llu", t[it * per + k + 1] - t[it * per + k]);
+                        printf("   | iter %6llu\n", t[(it + 1) * per] - t[it * per]);
+                    }
+                };
+                dump(0, 3, "MFMA: reads+mma issue | park | barrier");
+                const int per = getenv("WS_TR_PER") ? atoi(getenv("WS_TR_PER")) : 6;   // 6: DN_WS_EARLY=1 (wait|split|request|LDS put|pieces|barrier); 5: =0 (wait|stage|pieces|request|barrier)
+                dump(4, per, per == 6 ? "loader: vm wait | split | advance+request | LDS writes | pieces | barrier" : "loader: vm wait | split+LDS writes | pieces | advance+request | barrier");
+            }
+        }
+    }
     HC(hipStreamSynchronize(st));
     return 0;
 }
