@@ -211,6 +211,39 @@ __device__ __forceinline__ int dn_colk_off(int row, int slot) { return row * 32 
 #define DN_TM 128      // rows per workgroup tile
 #define DN_KB 32       // contraction slice staged per step
 
+// Magnitude bound of an operand of the split-fp16 engine: max(c, *p[0], *p[1], *p[2]) * (*mul), null pointers skipped.  The words are
+// written by the kernels that produced the tensors (atomic max over |value|); `mul` covers elementwise products (a*b <= max|a| max|b|).
+struct DnAmax {
+    const float* p[3];
+    const float* mul;
+    float c;
+};
+__device__ __forceinline__ float dn_amax_eval(const DnAmax& a) {
+    float m = a.c;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) if (a.p[i]) { const float v = *a.p[i]; m = v > m ? v : m; }
+    if (a.mul) m *= *a.mul;
+    return m;
+}
+// atomic max of a non-negative float through its bit pattern (monotonic for x >= 0; NaN never raises the word: it propagates through the
+// data itself); one atomic per wave
+__device__ __forceinline__ void dn_amax_commit(float* word, float m) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { const float o = __shfl_xor(m, d, 64); m = o > m ? o : m; }
+    // the word only grows: after the first few waves nearly every wave sees a value that already covers its own and skips the atomic
+    // (tens of thousands of atomics on one address would serialise in its L2 channel)
+    if ((threadIdx.x & 63) == 0 && m > *reinterpret_cast<volatile float*>(word)) atomicMax(reinterpret_cast<unsigned*>(word), __float_as_uint(m));
+}
+// per-lane form for kernels whose lanes do not all reach the end together: skip the atomic unless this lane would raise the word
+__device__ __forceinline__ void dn_amax_commit_lane(float* word, float m) {
+    if (m > *reinterpret_cast<volatile float*>(word)) atomicMax(reinterpret_cast<unsigned*>(word), __float_as_uint(m));
+}
+__device__ __forceinline__ float dn_f4_amax(float m, const float4& v) {
+    const float a = fabsf(v.x) > fabsf(v.y) ? fabsf(v.x) : fabsf(v.y), b = fabsf(v.z) > fabsf(v.w) ? fabsf(v.z) : fabsf(v.w);
+    const float c = a > b ? a : b;
+    return c > m ? c : m;
+}
+
 struct RgSeg {           // one column segment of the (virtually concatenated) A operand
     const float* p;      // [rows, ld] row-major
     const float* q;      // optional elementwise factor, same shape/ld (A = p*q), else null
@@ -243,7 +276,7 @@ struct RgArgs {
     // of) their largest magnitudes -- written by the kernels that produced them -- and the result is scaled back exactly.  o_amax: optional
     // device word that receives max |o0| over the launch (atomic max on the bit pattern of a non-negative float; zeroed by the caller).
     int f16;
-    const float* a_amax; const float* b_amax;
+    DnAmax a_amax, b_amax;
     float* o_amax;
 };
 enum {
@@ -278,6 +311,8 @@ struct TnArgs {
     int group;                  // consecutive chunks accumulated by one workgroup (1 for per-mesh outputs)
     int nchunks;                // filled by the launcher
     int acct_rows;              // host-side accounting only
+    int f16;                    // split-fp16 engine (aligned split path only); operand magnitude bounds as in RgArgs
+    DnAmax a_amax, b_amax;
 };
 // Allow more than 64 KiB of dynamic LDS for one kernel instantiation, once per DEVICE (function attributes are per device;
 // `done` is the instantiation's own 64-bit device bitmap).  Not thread-safe beyond "setting it twice is harmless".
@@ -343,6 +378,7 @@ struct SpArgs {
     int nrows, C, ldx, ldo, mode;
     float div;         // DN_SP_ONE: result divided by this (exact mean of n gathered rows)
     long long acct_nnz; // host-side accounting only
+    float* o_amax;     // optional device word: max |o1|, |o2| over the launch (split-fp16 consumers), zeroed by the caller
 };
 enum { DN_SP_FWD2 = 0, DN_SP_BWD2 = 1, DN_SP_ONE = 2 };
 
@@ -350,9 +386,20 @@ enum { DN_SP_FWD2 = 0, DN_SP_BWD2 = 1, DN_SP_ONE = 2 };
 // small reductions / pointwise kernels (dn_pointwise.hip)
 // ---------------------------------------------------------------------------------------
 int dn_launch_spec_fwd(const float* partial, const int* mesh_chunk_off, const float* evals, const float* time,
-                       float* xs, float* ys, int n_mesh, int K, int C, hipStream_t stream);
+                       float* xs, float* ys, int n_mesh, int K, int C, hipStream_t stream, float* ys_amax = nullptr);
 int dn_launch_spec_bwd(float* dys_inplace, const float* evals, const float* time, const float* xs, float* dt_part,
-                       int n_mesh, int K, int C, hipStream_t stream);
+                       int n_mesh, int K, int C, hipStream_t stream, float* dys_amax = nullptr);
+// max |x| of up to DN_AMAX_MAX_JOBS buffers in one launch (job j -> *dst[j], accumulated by atomic max: the caller zeroes the words);
+// two buffers may share a word (e.g. A_re and A_im)
+#define DN_AMAX_MAX_JOBS 12
+struct AmaxJobs { const float* src[DN_AMAX_MAX_JOBS]; long long n[DN_AMAX_MAX_JOBS]; float* dst[DN_AMAX_MAX_JOBS]; int count;
+    void push(const float* s, long long len, float* d) { if (s && d && len > 0 && count < DN_AMAX_MAX_JOBS) { src[count] = s; n[count] = len; dst[count] = d; ++count; } } };
+int dn_launch_amax(const AmaxJobs& jobs, hipStream_t stream);
+// one-launch start of a block call: stored maxima of small tensors (jobs with the same destination must be adjacent), zeroing of up to
+// four word ranges, one word copy
+struct AmaxInit { AmaxJobs jobs; int same[DN_AMAX_MAX_JOBS]; float* zero[4]; int zero_n[4]; int nzero; const float* copy_src; float* copy_dst;
+    void zero_range(float* p, int n) { if (p && n > 0 && nzero < 4) { zero[nzero] = p; zero_n[nzero] = n; ++nzero; } } };
+int dn_launch_amax_init(const AmaxInit& a, hipStream_t stream);
 int dn_launch_reduce(const float* partial, float* out, int n, long long stride, long long len, hipStream_t stream);
 // out[s][i] = sum_{ch in [seg_off[s], seg_off[s+1])} partial[ch][i]  (seg_off == nullptr: one segment [0,n))
 int dn_launch_seg_reduce(const float* partial, const int* seg_off, int nseg, int n, float* out, long long len, hipStream_t stream);
@@ -380,8 +427,11 @@ struct DaArgs {
     float* partial;                 // [gridDim.x][2][128][128]
     long long V;
     int rows_per_wg;                // multiple of 16
+    int f16;                        // split-fp16 engine: A = dd * g bounded by a_amax (product of the two words), B = g by b_amax
+    DnAmax a_amax, b_amax;
 };
-int dn_launch_tn_da(const float* dd, const float* gx, const float* gy, long long V, float* partial, int nwg, hipStream_t stream);
+int dn_launch_tn_da(const float* dd, const float* gx, const float* gy, long long V, float* partial, int nwg, hipStream_t stream,
+                    const float* dd_amax = nullptr, const float* g_amax = nullptr);
 int dn_launch_mass_mean_fwd(const DnTile* meshrows, const float* mass, const float* x, float* out, float* msum,
                             int n_mesh, int C, hipStream_t stream);
 int dn_launch_mass_mean_bwd(const DnTile* tiles, int ntiles, const float* mass, const float* msum, const float* dout,

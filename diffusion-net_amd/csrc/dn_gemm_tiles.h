@@ -87,6 +87,12 @@ __device__ __forceinline__ void rg_epilogue_tile(const RgArgs& g, unsigned long 
 #pragma unroll
     for (int r = 0; r < 16; ++r)
         if (ok[r]) g.o0[io[r]] = res0[r];
+    if (g.o_amax) {   // the split-fp16 consumers of o0 need its largest magnitude
+        float m = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float a = fabsf(res0[r]); m = (ok[r] && a > m) ? a : m; }
+        dn_amax_commit(g.o_amax, m);
+    }
     if (MODE == DN_EPI_GRADFEAT_BWD) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -370,11 +376,12 @@ __device__ __forceinline__ void rg_put_x3(unsigned char* sA, unsigned char* sB, 
     }
 }
 
-template <int NTHR, int NOUT, bool BCOLK, bool HASQ, int A_IT, int B_IT>
-__device__ __forceinline__ void rg_store_x3(unsigned char* sA, unsigned char* sB, int tid, const RgRegs<NOUT, A_IT, B_IT>& R) {
-    X3Planes<NOUT, A_IT, B_IT> P;
-    rg_split_x3<NOUT, BCOLK, HASQ, A_IT, B_IT>(R, P);
-    rg_put_x3<NTHR, NOUT, BCOLK, A_IT, B_IT>(sA, sB, tid, P);
+template <int NTHR, int NOUT, bool BCOLK, bool HASQ, int A_IT, int B_IT, int NP = 3>
+__device__ __forceinline__ void rg_store_x3(unsigned char* sA, unsigned char* sB, int tid, const RgRegs<NOUT, A_IT, B_IT>& R,
+                                            float sa = 1.f, float sb = 1.f) {
+    X3Planes<NOUT, A_IT, B_IT, NP> P;
+    rg_split_x3<NOUT, BCOLK, HASQ, A_IT, B_IT, true, true, NP>(R, P, sa, sb);
+    rg_put_x3<NTHR, NOUT, BCOLK, A_IT, B_IT, NP>(sA, sB, tid, P);
 }
 
 // MFMA operands of one 32-wide slice (two k16 steps; lane group lg owns k = 16 s + 8 lg .. +7), read in one burst
@@ -401,32 +408,36 @@ __device__ __forceinline__ void rg_frag_x3(const unsigned char* sA, const unsign
     }
 }
 
-// The six cross products of one k16 step, smallest terms first.  Product-major issue order: consecutive MFMAs go to
-// DIFFERENT accumulators (an MFMA on the accumulator of the previous one waits out its full latency), while every
-// accumulator still receives its six products in the same order -- bitwise the same sums as an accumulator-major loop.
-template <int MT, int NT, int NOUT>
-__device__ __forceinline__ void rg_mma_x3(const X3Frags<MT, NT, NOUT>& F, int s, f32x16 (&acc)[NOUT][MT][NT]) {
-    constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};   // mid*mid, hi*lo, lo*hi, hi*mid, mid*hi, hi*hi
+// The cross products of one k16 step, smallest terms first (NP = 3, split-bf16: mid*mid, hi*lo, lo*hi, hi*mid, mid*hi, hi*hi; NP = 2,
+// split-fp16: hi*lo, lo*hi, hi*hi).  Product-major issue order: consecutive MFMAs go to DIFFERENT accumulators (an MFMA on the
+// accumulator of the previous one waits out its full latency), while every accumulator still receives its products in the same
+// order -- bitwise the same sums as an accumulator-major loop.
+template <int MT, int NT, int NOUT, int NP = 3>
+__device__ __forceinline__ void rg_mma_x3(const X3Frags<MT, NT, NOUT, NP>& F, int s, f32x16 (&acc)[NOUT][MT][NT]) {
+    constexpr int NPROD = NP == 3 ? 6 : 3;
+    constexpr int PA[6] = {NP == 3 ? 1 : 0, NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, 0, 1, 0};
+    constexpr int PB[6] = {1, NP == 3 ? 2 : 0, 0, 1, 0, 0};
 #pragma unroll
-    for (int p = 0; p < 6; ++p)
+    for (int p = 0; p < NPROD; ++p)
 #pragma unroll
         for (int o = 0; o < NOUT; ++o)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    acc[o][mt][nt] = dn_mfma_bf16(F.a[s][PA[p]][mt], F.b[s][o][PB[p]][nt], acc[o][mt][nt]);
+                    if constexpr (NP == 3) acc[o][mt][nt] = dn_mfma_bf16(F.a[s][PA[p]][mt], F.b[s][o][PB[p]][nt], acc[o][mt][nt]);
+                    else acc[o][mt][nt] = dn_mfma_f16(F.a[s][PA[p]][mt], F.b[s][o][PB[p]][nt], acc[o][mt][nt]);
                 }
 }
 
-template <int MT, int NT, int NOUT>
+template <int MT, int NT, int NOUT, int NP = 3>
 __device__ __forceinline__ void rg_compute_x3(const unsigned char* sA, const unsigned char* sB, int arow0, int bcol0, int li,
                                               int lg, f32x16 (&acc)[NOUT][MT][NT]) {
-    X3Frags<MT, NT, NOUT> F;
+    X3Frags<MT, NT, NOUT, NP> F;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        rg_frag_x3<MT, NT, NOUT>(sA, sB, arow0, bcol0, li, lg, s, F);
-        rg_mma_x3<MT, NT, NOUT>(F, s, acc);
+        rg_frag_x3<MT, NT, NOUT, NP>(sA, sB, arow0, bcol0, li, lg, s, F);
+        rg_mma_x3<MT, NT, NOUT, NP>(F, s, acc);
     }
 }
 
@@ -442,7 +453,7 @@ struct PtPiece {
 
 // phase 2 (after the MFMAs): epilogue maths + one coalesced float4 store
 template <int MODE, bool FLAG>
-__device__ __forceinline__ void pt_piece_store(const RgArgs& g, const PtPiece& P) {
+__device__ __forceinline__ float4 pt_piece_store(const RgArgs& g, const PtPiece& P) {
     constexpr bool need_bias = (MODE == DN_EPI_STORE && FLAG) || MODE == DN_EPI_BIAS_RELU || MODE == DN_EPI_BIAS_RESID;
     float x[4] = {P.v.x, P.v.y, P.v.z, P.v.w};
     if (need_bias) { x[0] += P.bias.x; x[1] += P.bias.y; x[2] += P.bias.z; x[3] += P.bias.w; }
@@ -462,6 +473,8 @@ __device__ __forceinline__ void pt_piece_store(const RgArgs& g, const PtPiece& P
         else if (MODE == DN_EPI_MASS_ADD) y[e] = r[e] + P.rs * x[e];
         else y[e] = x[e];
     }
-    if (P.ok) *reinterpret_cast<float4*>(g.o0 + P.off) = make_float4(y[0], y[1], y[2], y[3]);
+    const float4 yv = make_float4(y[0], y[1], y[2], y[3]);
+    if (P.ok) *reinterpret_cast<float4*>(g.o0 + P.off) = yv;
+    return P.ok ? yv : dn_f4_zero();     // what was stored (zeros for a dead piece): the caller may track max |o0|
 }
 

@@ -11,13 +11,13 @@
 // dys: [n_mesh,K,C] = evecs^T d_xd (already reduced over chunks).  In place: dys <- exp(-lambda t) * dys (the
 // spectrum handed to from_basis), and d_t partial per (mesh, channel).  block = 32 channels x 8 k-lanes.
 __global__ __launch_bounds__(256) void spec_bwd_kernel(float* dys, const float* evals, const float* time, const float* xs,
-                                                       float* dt_part, int K, int C) {
+                                                       float* dt_part, int K, int C, float* dys_amax) {
     __shared__ float red[8][32];
     const int m = blockIdx.y;
     const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     const long long KC = (long long)K * C;
-    float dt = 0.f;
+    float dt = 0.f, amax = 0.f;
     if (c < C) {
         const float t = time[c];
         for (int k0 = kl; k0 < K; k0 += 32) {     // four k per step with their loads in flight together (64 workgroups in all: latency-bound)
@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void spec_bwd_kernel(float* dys, const float* 
                 if (k0 + 8 * u < K) {
                     const float coef = expf(-lam[u] * t);
                     dys[i[u]] = coef * d[u];
+                    amax = fabsf(coef * d[u]) > amax ? fabsf(coef * d[u]) : amax;
                     dt -= lam[u] * d[u] * coef * x[u];     // same order as k ascending per lane: bitwise the same sum
                 }
             }
@@ -50,14 +51,15 @@ __global__ __launch_bounds__(256) void spec_bwd_kernel(float* dys, const float* 
         for (int j = 0; j < 8; ++j) s += red[j][cl];
         dt_part[m * C + c] = s;
     }
+    if (dys_amax) dn_amax_commit(dys_amax, amax);    // the scaled spectrum feeds the split-fp16 from_basis product
 }
 
 int dn_launch_spec_bwd(float* dys, const float* evals, const float* time, const float* xs, float* dt_part, int n_mesh, int K,
-                       int C, hipStream_t stream) {
+                       int C, hipStream_t stream, float* dys_amax) {
     if (n_mesh <= 0 || K <= 0 || C <= 0) return 0;
     dim3 grid((C + 31) / 32, n_mesh, 1);
     dn_prof_begin(DN_K_SMALL, stream);
-    DN_LAUNCH(spec_bwd_kernel, grid, dim3(256, 1, 1), 0, stream, dys, evals, time, xs, dt_part, K, C);
+    DN_LAUNCH(spec_bwd_kernel, grid, dim3(256, 1, 1), 0, stream, dys, evals, time, xs, dt_part, K, C, dys_amax);
     dn_prof_end(DN_K_SMALL, stream, 0.0, 0.0);
     return (int)hipGetLastError();
 }
@@ -67,10 +69,11 @@ int dn_launch_spec_bwd(float* dys, const float* evals, const float* time, const 
 // the 8 lane sums are then combined in order through LDS -> bitwise reproducible, bandwidth-bound.
 struct SegStore {   // plain epilogue: out[s][i + e] = sum
     float* out; long long len;
-    __device__ __forceinline__ void operator()(int s, long long i, int e, float t) const { out[(long long)s * len + i + e] = t; }
+    __device__ __forceinline__ float operator()(int s, long long i, int e, float t) const { out[(long long)s * len + i + e] = t; return t; }
 };
+// returns max |epilogue value| over what this thread wrote (0 for the threads that write nothing)
 template <int VEC, class EPI>
-__device__ __forceinline__ void seg_reduce_body(const float* partial, int s, int beg, int end, long long len, const EPI& epi) {
+__device__ __forceinline__ float seg_reduce_body(const float* partial, int s, int beg, int end, long long len, const EPI& epi) {
     __shared__ float red[8][32 * VEC];
     const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
     const long long i = ((long long)blockIdx.x * 32 + cl) * VEC;
@@ -109,15 +112,18 @@ __device__ __forceinline__ void seg_reduce_body(const float* partial, int s, int
 #pragma unroll
     for (int e = 0; e < VEC; ++e) red[kl][cl * VEC + e] = a[e];
     __syncthreads();
+    float om = 0.f;
     if (kl == 0 && i < len) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             float t = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) t += red[j][cl * VEC + e];
-            epi(s, i, e, t);
+            const float w = fabsf(epi(s, i, e, t));
+            om = w > om ? w : om;
         }
     }
+    return om;
 }
 
 template <int VEC>
@@ -131,27 +137,32 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const float* partial, c
 // epilogue: xs[m] = sum, ys[m][k][c] = exp(-lambda_mk t_c) * sum  (layers.py:62-64).  Either output may be null.
 struct SpecEpi {
     const float* evals; const float* time; float* xs; float* ys; int K, C;
-    __device__ __forceinline__ void operator()(int m, long long i, int e, float t) const {
+    float* ys_amax;   // optional: max |ys| (the scaled spectrum is the B operand of the split-fp16 from_basis product)
+    __device__ __forceinline__ float operator()(int m, long long i, int e, float t) const {
         const long long o = (long long)m * K * C + i + e;
         if (xs) xs[o] = t;
+        float y = 0.f;
         if (ys) {
             const int k = (int)((i + e) / C), c = (int)((i + e) % C);
-            ys[o] = time ? expf(-evals[m * K + k] * time[c]) * t : t;
+            y = time ? expf(-evals[m * K + k] * time[c]) * t : t;
+            ys[o] = y;
         }
+        return y;
     }
 };
 template <int VEC>
 __global__ __launch_bounds__(256) void spec_fwd_kernel(const float* partial, const int* mco, SpecEpi epi) {
     const int m = blockIdx.y;
-    seg_reduce_body<VEC>(partial, m, mco[m], mco[m + 1], (long long)epi.K * epi.C, epi);
+    const float om = seg_reduce_body<VEC>(partial, m, mco[m], mco[m + 1], (long long)epi.K * epi.C, epi);
+    if (epi.ys_amax) dn_amax_commit(epi.ys_amax, om);
 }
 
 int dn_launch_spec_fwd(const float* partial, const int* mesh_chunk_off, const float* evals, const float* time,
-                       float* xs, float* ys, int n_mesh, int K, int C, hipStream_t stream) {
+                       float* xs, float* ys, int n_mesh, int K, int C, hipStream_t stream, float* ys_amax) {
     if (n_mesh <= 0 || K <= 0 || C <= 0) return 0;
     const long long len = (long long)K * C;
     const bool vec = (len % 4 == 0) && ((uintptr_t)partial % 16 == 0);
-    const SpecEpi epi{evals, time, xs, ys, K, C};
+    const SpecEpi epi{evals, time, xs, ys, K, C, ys_amax};
     dn_prof_begin(DN_K_SMALL, stream);
     if (vec) {
         DN_LAUNCH(spec_fwd_kernel<4>, dim3((unsigned)((len / 4 + 31) / 32), n_mesh, 1), dim3(256, 1, 1), 0, stream, partial, mesh_chunk_off, epi);
@@ -203,9 +214,10 @@ int dn_launch_reduce_pair(const float* pa, float* oa, long long la, const float*
 // whole-range sum of [n][2 * half] partials whose two halves go to different arrays (dA_re | dA_im, dn_tn_da.hip)
 struct SegSplitStore {
     float* o0; float* o1; long long half;
-    __device__ __forceinline__ void operator()(int, long long i, int e, float t) const {
+    __device__ __forceinline__ float operator()(int, long long i, int e, float t) const {
         const long long j = i + e;
         if (j < half) o0[j] = t; else o1[j - half] = t;
+        return t;
     }
 };
 __global__ __launch_bounds__(256) void seg_reduce_split_kernel(const float* partial, int n, float* o0, float* o1, long long half) {
@@ -331,6 +343,78 @@ __global__ __launch_bounds__(256) void dtanh_kernel(const float* dg, const float
         const float t = g[i];
         out[i] = dg[i] * (1.f - t * t);
     }
+}
+
+// max |x| of several buffers in one launch (operand magnitudes for the split-fp16 engine): blockIdx.y = job, grid-stride over the buffer,
+// one atomic max per wave.  Streams float4 where the buffer allows it.
+__global__ __launch_bounds__(256) void amax_kernel(AmaxJobs jobs) {
+    const int j = blockIdx.y;
+    const float* x = jobs.src[j];
+    const long long n = jobs.n[j];
+    float m = 0.f;
+    const long long stride = (long long)gridDim.x * 256;
+    if ((((uintptr_t)x) & 15) == 0) {
+        const long long n4 = n / 4;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) m = dn_f4_amax(m, *reinterpret_cast<const float4*>(x + 4 * i));
+        for (long long i = 4 * n4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = fabsf(x[i]) > m ? fabsf(x[i]) : m;
+    } else {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = fabsf(x[i]) > m ? fabsf(x[i]) : m;
+    }
+    dn_amax_commit(jobs.dst[j], m);
+}
+// Start-of-call bookkeeping of the split-fp16 engine in ONE launch: job j < count: max |src[j]| by a single workgroup (weights: a few
+// 10k elements), max-combined in LDS and STORED (jobs sharing a destination are merged by the host into consecutive jobs of one
+// workgroup chain -- see `same`); the last workgroup zeroes the words the later kernels of the call accumulate into and forwards one
+// word.  Replaces three memsets, a copy and the atomic amax launch (4 x ~6 us of blit kernels per block call).
+__global__ __launch_bounds__(256) void amax_init_kernel(AmaxInit a) {
+    __shared__ float red[256];
+    const int j = blockIdx.x;
+    if (j == a.jobs.count) {
+        for (int r = 0; r < a.nzero; ++r)
+            for (int i = threadIdx.x; i < a.zero_n[r]; i += 256) a.zero[r][i] = 0.f;
+        if (threadIdx.x == 0 && a.copy_src && a.copy_dst) *a.copy_dst = *a.copy_src;
+        return;
+    }
+    if (a.same[j]) return;                      // merged into the previous job's workgroup
+    float m = 0.f;
+    for (int jj = j; jj < a.jobs.count && (jj == j || a.same[jj]); ++jj) {
+        const float* x = a.jobs.src[jj];
+        const long long n = a.jobs.n[jj];
+        if ((((uintptr_t)x) & 15) == 0) {
+            const long long n4 = n / 4;
+            for (long long i = threadIdx.x; i < n4; i += 256) m = dn_f4_amax(m, *reinterpret_cast<const float4*>(x + 4 * i));
+            for (long long i = 4 * n4 + threadIdx.x; i < n; i += 256) m = fabsf(x[i]) > m ? fabsf(x[i]) : m;
+        } else {
+            for (long long i = threadIdx.x; i < n; i += 256) m = fabsf(x[i]) > m ? fabsf(x[i]) : m;
+        }
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) red[threadIdx.x] = red[threadIdx.x + d] > red[threadIdx.x] ? red[threadIdx.x + d] : red[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *a.jobs.dst[j] = red[0];
+}
+int dn_launch_amax_init(const AmaxInit& a_in, hipStream_t stream) {
+    AmaxInit a = a_in;
+    for (int j = 0; j < a.jobs.count; ++j) a.same[j] = (j > 0 && a.jobs.dst[j] == a.jobs.dst[j - 1]) ? 1 : 0;
+    dn_prof_begin(DN_K_SMALL, stream);
+    DN_LAUNCH(amax_init_kernel, dim3(a.jobs.count + 1, 1, 1), dim3(256, 1, 1), 0, stream, a);
+    dn_prof_end(DN_K_SMALL, stream, 0.0, 0.0);
+    return (int)hipGetLastError();
+}
+
+int dn_launch_amax(const AmaxJobs& jobs, hipStream_t stream) {
+    if (jobs.count <= 0) return 0;
+    long long nmax = 0;
+    for (int j = 0; j < jobs.count; ++j) nmax = jobs.n[j] > nmax ? jobs.n[j] : nmax;
+    long long nb = (nmax / 4 + 256 * 8 - 1) / (256 * 8);
+    nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
+    dn_prof_begin(DN_K_SMALL, stream);
+    DN_LAUNCH(amax_kernel, dim3((unsigned)nb, jobs.count, 1), dim3(256, 1, 1), 0, stream, jobs);
+    dn_prof_end(DN_K_SMALL, stream, 0.0, 0.0);
+    return (int)hipGetLastError();
 }
 
 int dn_launch_dtanh(const float* dg, const float* g, float* out, long long n, hipStream_t stream) {

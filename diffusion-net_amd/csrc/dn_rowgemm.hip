@@ -14,13 +14,13 @@ bool dn_rowgemm_try_persistent(const RgArgs& g, int ntiles, int nout, hipStream_
 #endif
 #define RG_STORE(buf)                                                                                                          \
     do {                                                                                                                       \
-        if constexpr (X3) rg_store_x3<NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>(reinterpret_cast<unsigned char*>(buf),               \
-                                                                          reinterpret_cast<unsigned char*>((buf) + SA), tid, R); \
+        if constexpr (X3) rg_store_x3<NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT, NP>(reinterpret_cast<unsigned char*>(buf),           \
+                                                                          reinterpret_cast<unsigned char*>((buf) + SA), tid, R, sa, sb); \
         else rg_store<TN, NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT>((buf), (buf) + SA, tid, R);                                      \
     } while (0)
 #define RG_COMPUTE(buf)                                                                                                        \
     do {                                                                                                                       \
-        if constexpr (X3) rg_compute_x3<MT, NT, NOUT>(reinterpret_cast<const unsigned char*>(buf),                             \
+        if constexpr (X3) rg_compute_x3<MT, NT, NOUT, NP>(reinterpret_cast<const unsigned char*>(buf),                         \
                                                       reinterpret_cast<const unsigned char*>((buf) + SA), wr * MT * 32,        \
                                                       wc * NT * 32, li, ls, acc);                                              \
         else rg_compute<TN, MT, NT, NOUT, BCOLK>((buf), (buf) + SA, wr * MT * 32, wc * NT * 32, li, ls, acc);                  \
@@ -32,10 +32,17 @@ bool dn_rowgemm_try_persistent(const RgArgs& g, int ntiles, int nout, hipStream_
 #define DN_RG2_EARLY_EPI(MODE) 1   // epilogue operands fetched under the last two slices (measured: fwd 201 -> 186 us, bwd pair 360 -> 348 us; 0: after them)
 #endif
 constexpr bool rg_is_x3(int TN, int NTHR, int NOUT, bool ALIGNED) { return DN_RG_X3 && ALIGNED && NOUT == 2 && TN == 128 && NTHR == 512; }
-template <int TN, int WR, int WC, int NOUT, int MODE, bool ALIGNED, bool BCOLK>
+// NP: planes of the split engine on the two-output path (3 = split-bf16; 2 = split-fp16 with the operand scales of RgArgs.a_amax / b_amax)
+template <int TN, int WR, int WC, int NOUT, int MODE, bool ALIGNED, bool BCOLK, int NP = 3>
 __global__ __launch_bounds__(WR* WC * 64) DN_MIN_WAVES_PER_EU(1)
 void rowgemm_kernel(RgArgs g) {
     const unsigned long long seed = (MODE == DN_EPI_BIAS_RELU) ? rg_seed(g) : 0ull;
+    float sa = 1.f, sb = 1.f, so = 1.f;
+    if constexpr (NP == 2) {
+        sa = dn_pow2_scale(dn_amax_eval(g.a_amax));
+        sb = dn_pow2_scale(dn_amax_eval(g.b_amax));
+        so = (1.f / sa) * (1.f / sb);
+    }
 
     constexpr int NTHR = WR * WC * 64;
     constexpr int MT = DN_TM / (32 * WR);
@@ -147,6 +154,16 @@ void rowgemm_kernel(RgArgs g) {
     if (!DN_RG2_EARLY_EPI(MODE)) epi_fetch();
 
     // ---------------- epilogue ----------------
+    if constexpr (NP == 2) {   // split-fp16: exact power-of-two rescale of the products
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[o][mt][nt][r] *= so;
+    }
     if constexpr (VEPI) {
         // The slice buffers are dead now, so both 128 x 128 accumulator tiles are parked in them (2 x 64 KiB of the 144 KiB) and the
         // epilogue runs on float4 pieces with coalesced 16-byte loads (issued above) and stores -- 8 pieces x (2-3 loads + 2-3
@@ -217,7 +234,7 @@ void rowgemm_kernel(RgArgs g) {
 #undef RG_STORE
 #undef RG_COMPUTE
 
-template <int TN, int WR, int WC, int NOUT, int MODE, bool ALIGNED, bool BCOLK>
+template <int TN, int WR, int WC, int NOUT, int MODE, bool ALIGNED, bool BCOLK, int NP = 3>
 static int rg_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
     const int ncol = (g.N + TN - 1) / TN;
     constexpr bool X3 = DN_RG_X3 && ALIGNED && NOUT == 2 && TN == 128 && WR * WC == 8;
@@ -225,9 +242,9 @@ static int rg_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
                            : (size_t)2 * (DN_TM * DN_KB + NOUT * DN_KB * TN) * sizeof(float);
 #ifndef DN_EMULATE
     static unsigned long long lds_opt_in = 0;   // per-device bitmap
-    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&rowgemm_kernel<TN, WR, WC, NOUT, MODE, ALIGNED, BCOLK>), smem, &lds_opt_in); if (oe_) return oe_; }
+    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&rowgemm_kernel<TN, WR, WC, NOUT, MODE, ALIGNED, BCOLK, NP>), smem, &lds_opt_in); if (oe_) return oe_; }
 #endif
-    DN_LAUNCH((rowgemm_kernel<TN, WR, WC, NOUT, MODE, ALIGNED, BCOLK>), dim3(ntiles, ncol, 1), dim3(WR * WC * 64, 1, 1), smem,
+    DN_LAUNCH((rowgemm_kernel<TN, WR, WC, NOUT, MODE, ALIGNED, BCOLK, NP>), dim3(ntiles, ncol, 1), dim3(WR * WC * 64, 1, 1), smem,
               stream, g);
     return (int)hipGetLastError();
 }
@@ -239,6 +256,7 @@ static int rg_dispatch_width(const RgArgs& g, int ntiles, hipStream_t stream) {
     if (!g.aligned) return rg_launch<128, 2, WC128, NOUT, MODE, false, BCOLK>(g, ntiles, stream);
     if (g.N <= 32) return rg_launch<32, 4, 1, NOUT, MODE, true, BCOLK>(g, ntiles, stream);
     if (g.N <= 64) return rg_launch<64, 2, 2, NOUT, MODE, true, BCOLK>(g, ntiles, stream);
+    if (NOUT == 2 && g.f16) return rg_launch<128, 2, WC128, NOUT, MODE, true, BCOLK, NOUT == 2 ? 2 : 3>(g, ntiles, stream);
     return rg_launch<128, 2, WC128, NOUT, MODE, true, BCOLK>(g, ntiles, stream);
 }
 int dn_launch_rowgemm(const RgArgs& g, int ntiles, int nout, hipStream_t stream) {

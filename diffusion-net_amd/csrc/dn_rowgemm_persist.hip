@@ -116,6 +116,7 @@ __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_pers
     // before it is written to LDS, so DEPTH x 16 KiB of reads per CU are in flight (one slice ahead covers only ~1 us of HBM
     // latency once the split-bf16 MFMAs made an iteration that short).
     RgRegs<NOUT, A_IT, B_IT> R0;
+    float om = 0.f;   // running max |o0| of this thread's pieces (committed to g.o_amax at the end)
     // load cursor (runs ahead of the compute cursor, across unit boundaries)
     int lu = blockIdx.x, lseg = 0, lkoff = 0;
     DnTile ltile = unit_tile(lu);
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_pers
             rg_mma_x3<MT, NT, NOUT>(F, 1, acc);                                                                         \
             rg_put_x3<NTHR, NOUT, BCOLK, A_IT, B_IT>(reinterpret_cast<unsigned char*>(nxt),                             \
                                                      reinterpret_cast<unsigned char*>(nxt + SA), tid, PLN);             \
-            _Pragma("unroll") for (int k = 0; k < PPI; ++k) pt_piece_store<MODE, FLAG>(g, P[k]);                        \
+            _Pragma("unroll") for (int k = 0; k < PPI; ++k) om = dn_f4_amax(om, pt_piece_store<MODE, FLAG>(g, P[k]));   \
             p_next = (p_next + PPI < DN_PT_NP) ? p_next + PPI : DN_PT_NP;                                               \
         } else {                                                                                                        \
             if ((j) + 1 < T) PT_STORE(nxt, RS);                                                                         \
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_pers
             }                                                                                                           \
             rg_compute<TN, MT, NT, NOUT, BCOLK>(cur, cur + SA, wr * MT * 32, wc * NT * 32, li, ls, acc);                \
             if (pending) {                                                                                              \
-                _Pragma("unroll") for (int k = 0; k < PPI; ++k) pt_piece_store<MODE, FLAG>(g, P[k]);                    \
+                _Pragma("unroll") for (int k = 0; k < PPI; ++k) om = dn_f4_amax(om, pt_piece_store<MODE, FLAG>(g, P[k])); \
                 p_next += PPI;                                                                                          \
             }                                                                                                           \
         }                                                                                                               \
@@ -226,8 +227,9 @@ __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_pers
     for (; p_next < DN_PT_NP; ++p_next) {
         PtPiece P1;
         pt_piece_load<MODE, FLAG>(g, seed, sE, p_next, tid, p_row0, p_nrows, n0, P1);
-        pt_piece_store<MODE, FLAG>(g, P1);
+        om = dn_f4_amax(om, pt_piece_store<MODE, FLAG>(g, P1));
     }
+    if (g.o_amax) dn_amax_commit(g.o_amax, om);
 }
 
 #ifndef DN_PT_X3
@@ -317,12 +319,12 @@ __device__ __forceinline__ void ws_aux_load(const RgArgs& g, unsigned long long 
 }
 
 template <int MODE, bool FLAG>
-__device__ __forceinline__ void ws_piece_out(const RgArgs& g, const float4& v, const float4& bias, const WsAux& A, float so = 1.f) {
+__device__ __forceinline__ void ws_piece_out(const RgArgs& g, const float4& v, const float4& bias, const WsAux& A, float so, float& om) {
     PtPiece P;
     P.v = v;
     if (so != 1.f) P.v = dn_f4_scale(P.v, so);     // split-fp16 engine: exact power-of-two rescale of the product
     P.a0 = A.a0; P.bias = bias; P.mk = A.mk; P.rs = A.rs; P.off = A.off; P.ok = A.ok;
-    pt_piece_store<MODE, FLAG>(g, P);
+    om = dn_f4_amax(om, pt_piece_store<MODE, FLAG>(g, P));
 }
 
 // the cross products of one k16 step, product-major: consecutive MFMAs go to different accumulators.
@@ -454,10 +456,10 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     DN_SETPRIO(DN_WS_LOADER_PRIO);
     const int lt = lw * 64 + lane;
     // split-fp16: operand scales (powers of two from the producers' amax words) and the exact inverse of their product
-    float sa = 1.f, sb = 1.f, so = 1.f;
+    float sa = 1.f, sb = 1.f, so = 1.f, om = 0.f;   // om: running max |o0| of this thread's pieces
     if constexpr (NP == 2) {
-        if (g.a_amax) sa = dn_pow2_scale(*g.a_amax);
-        if (g.b_amax) sb = dn_pow2_scale(*g.b_amax);
+        sa = dn_pow2_scale(dn_amax_eval(g.a_amax));
+        sb = dn_pow2_scale(dn_amax_eval(g.b_amax));
         so = (1.f / sa) * (1.f / sb);
     }
     float4 bias = dn_f4_zero();
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
         if (piece_wave) {              /* wave-uniform: only the first DN_WS_PW loader waves stream the parked unit out */ \
             float4 pv_[PPI];           /* all LDS reads of the parked unit first, then the maths and the stores */       \
             _Pragma("unroll") for (int k = 0; k < PPI; ++k) pv_[k] = *reinterpret_cast<const float4*>(&sE[AX[k].lds]);  \
-            _Pragma("unroll") for (int k = 0; k < PPI; ++k) ws_piece_out<MODE, FLAG>(g, pv_[k], bias, AX[k], so);       \
+            _Pragma("unroll") for (int k = 0; k < PPI; ++k) ws_piece_out<MODE, FLAG>(g, pv_[k], bias, AX[k], so, om);       \
             p_next = (p_next + PPI < DN_WS_NP) ? p_next + PPI : DN_WS_NP;                                               \
             {   /* the MFMA waves park unit cu at the end of the iteration that multiplies its last slice */            \
                 const bool park = ++cs == nsl;                                                                          \
@@ -651,8 +653,9 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     for (; p_next < DN_WS_NP; ++p_next) {
         WsAux A1;
         ws_aux_load<MODE, FLAG, XMASK>(g, seed, p_next, lt, p_row0, p_nrows, n0, A1);
-        ws_piece_out<MODE, FLAG>(g, *reinterpret_cast<const float4*>(&sE[A1.lds]), bias, A1, so);
+        ws_piece_out<MODE, FLAG>(g, *reinterpret_cast<const float4*>(&sE[A1.lds]), bias, A1, so, om);
     }
+    if (g.o_amax) dn_amax_commit(g.o_amax, om);
 }
 
 template <int MODE, bool BCOLK, bool FLAG, int PPI, bool BC, int NP, bool XMASK>

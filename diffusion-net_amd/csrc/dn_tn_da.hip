@@ -15,6 +15,7 @@
 // half-wave touch 4 rows x 64 B = all 64 banks once); one barrier per step, the staging of step s+1 shares the iteration with the
 // MFMAs of step s.  Register prefetch ring of two steps (the loads of step s+3 are issued while s is multiplied).
 #include "dn_common.h"
+#include <string.h>
 
 #define DN_DA_THREADS 512
 #define DN_DA_KS 16                              // rows per step (one MFMA k-step)
@@ -38,23 +39,25 @@ __device__ __forceinline__ void da_load(const DaArgs& g, long long r_beg, long l
     R.gy = *reinterpret_cast<const float4*>(g.gy + off);
 }
 
-__device__ __forceinline__ void da_put(unsigned char* planes, int off, float4 v) {
-    uint2 h, m, l;
-    dn_split3_f4(v, h, m, l);
-    *reinterpret_cast<uint2*>(planes + off) = h;
-    *reinterpret_cast<uint2*>(planes + DN_DA_PLANE + off) = m;
-    *reinterpret_cast<uint2*>(planes + 2 * DN_DA_PLANE + off) = l;
+// NP planes: 3 = split-bf16 (hi, mid, lo); 2 = split-fp16 (hi, lo) of v * s
+template <int NP>
+__device__ __forceinline__ void da_put(unsigned char* planes, int off, float4 v, float s) {
+    uint2 pl[NP];
+    dn_split_f4<NP>(v, s, pl);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(planes + p * DN_DA_PLANE + off) = pl[p];
 }
 
 // one 16-row step -> the A planes ([dd*gx | dd*gy]) and the B planes ([gx | gy]) of a step buffer
-__device__ __forceinline__ void da_store(unsigned char* buf, int kr, int q, const DaRegs& R) {
+template <int NP>
+__device__ __forceinline__ void da_store(unsigned char* buf, int kr, int q, const DaRegs& R, float sa, float sb) {
     const float4 bx = dn_f4_scale(R.gx, R.live), by = dn_f4_scale(R.gy, R.live);
     const float4 ax = dn_f4_mul(R.dd, bx), ay = dn_f4_mul(R.dd, by);
     const int off = kr * DN_DA_ROWB + q * 8;
-    da_put(buf, off, ax);
-    da_put(buf, off + 256, ay);
-    da_put(buf + 3 * DN_DA_PLANE, off, bx);
-    da_put(buf + 3 * DN_DA_PLANE, off + 256, by);
+    da_put<NP>(buf, off, ax, sa);
+    da_put<NP>(buf, off + 256, ay, sa);
+    da_put<NP>(buf + 3 * DN_DA_PLANE, off, bx, sb);
+    da_put<NP>(buf + 3 * DN_DA_PLANE, off + 256, by, sb);
 }
 
 __device__ __forceinline__ uint4 da_frag(const unsigned char* p) {   // 8 consecutive k of one column: two transpose reads of 4 rows
@@ -62,31 +65,45 @@ __device__ __forceinline__ uint4 da_frag(const unsigned char* p) {   // 8 consec
     return make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
 
+template <int NP>
 __device__ __forceinline__ void da_compute(const unsigned char* buf, int wr, int wc, int lane, f32x16 (&acc)[4][2]) {
     const int g = lane >> 4, c = lane & 15;
     const int lane_off = (8 * (g >> 1) + (c >> 2)) * DN_DA_ROWB + (16 * (g & 1) + 4 * (c & 3)) * 2;
     const unsigned char* sA = buf + lane_off + wr * 256;                       // this wave's 128 operand-A columns
     const unsigned char* sB = buf + 3 * DN_DA_PLANE + lane_off + wc * 128;     // its 64 operand-B columns
-    uint4 b[3][2];
+    uint4 b[NP][2];
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) b[p][nt] = da_frag(sB + p * DN_DA_PLANE + nt * 64);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-        uint4 a[3];
+        uint4 a[NP];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) a[p] = da_frag(sA + p * DN_DA_PLANE + mt * 64);
-        // same per-accumulator order of the six products as the generic kernel: mid*mid, hi*lo, lo*hi, hi*mid, mid*hi, hi*hi
-        constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+        for (int p = 0; p < NP; ++p) a[p] = da_frag(sA + p * DN_DA_PLANE + mt * 64);
+        // same per-accumulator order of the products as the generic kernel (NP = 3: mid*mid, hi*lo, lo*hi, hi*mid, mid*hi, hi*hi;
+        // NP = 2, split-fp16: hi*lo, lo*hi, hi*hi)
+        constexpr int NPROD = NP == 3 ? 6 : 3;
+        constexpr int PA[6] = {NP == 3 ? 1 : 0, NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, 0, 1, 0};
+        constexpr int PB[6] = {1, NP == 3 ? 2 : 0, 0, 1, 0, 0};
 #pragma unroll
-        for (int p = 0; p < 6; ++p)
+        for (int p = 0; p < NPROD; ++p)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = dn_mfma_bf16(a[PA[p]], b[PB[p]][nt], acc[mt][nt]);
+            for (int nt = 0; nt < 2; ++nt) {
+                if constexpr (NP == 3) acc[mt][nt] = dn_mfma_bf16(a[PA[p]], b[PB[p]][nt], acc[mt][nt]);
+                else acc[mt][nt] = dn_mfma_f16(a[PA[p]], b[PB[p]][nt], acc[mt][nt]);
+            }
     }
 }
 
+template <int NP>
 __global__ __launch_bounds__(DN_DA_THREADS) DN_WAVES_PER_EU(2) void tngemm_da_kernel(DaArgs g) {
+    float sa = 1.f, sb = 1.f, so = 1.f;
+    if constexpr (NP == 2) {   // split-fp16: A = dd * g (bound: the product of the two magnitudes), B = g
+        sa = dn_pow2_scale(dn_amax_eval(g.a_amax));
+        sb = dn_pow2_scale(dn_amax_eval(g.b_amax));
+        so = (1.f / sa) * (1.f / sb);
+    }
     DN_DYN_SMEM(smem_raw);
     unsigned char* smem = reinterpret_cast<unsigned char*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -109,19 +126,19 @@ __global__ __launch_bounds__(DN_DA_THREADS) DN_WAVES_PER_EU(2) void tngemm_da_ke
         DaRegs R0, R1;
         da_load(g, r_beg, r_end, 0, kr, q, R0);
         da_load(g, r_beg, r_end, 1, kr, q, R1);           // past-the-end steps load a valid row and stage zeros
-        da_store(smem, kr, q, R0);
+        da_store<NP>(smem, kr, q, R0, sa, sb);
         da_load(g, r_beg, r_end, 2, kr, q, R0);
         __syncthreads();
         // steps in pairs so that the ring set is a compile-time choice: buffer s&1 holds step s; R1 carries odd steps, R0 even ones
         for (int s = 0; s < nsteps; s += 2) {
-            da_store(smem + DN_DA_BUF, kr, q, R1);                        // step s+1
+            da_store<NP>(smem + DN_DA_BUF, kr, q, R1, sa, sb);            // step s+1
             da_load(g, r_beg, r_end, s + 3, kr, q, R1);
-            da_compute(smem, wr, wc, lane, acc);                          // step s
+            da_compute<NP>(smem, wr, wc, lane, acc);                      // step s
             __syncthreads();
             if (s + 1 < nsteps) {
-                da_store(smem, kr, q, R0);                                // step s+2
+                da_store<NP>(smem, kr, q, R0, sa, sb);                    // step s+2
                 da_load(g, r_beg, r_end, s + 4, kr, q, R0);
-                da_compute(smem + DN_DA_BUF, wr, wc, lane, acc);          // step s+1
+                da_compute<NP>(smem + DN_DA_BUF, wr, wc, lane, acc);      // step s+1
                 __syncthreads();
             }
         }
@@ -153,24 +170,32 @@ __global__ __launch_bounds__(DN_DA_THREADS) DN_WAVES_PER_EU(2) void tngemm_da_ke
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int o = mt * 32 + dn_acc_row(r, lane), c = wc * 64 + nt * 32 + li;
-                    out[o * 128 + c] = acc[mt][nt][r] + sgn * theirs[((mt * 2 + nt) * 16 + r) * 64 + lane];
+                    const float v = acc[mt][nt][r] + sgn * theirs[((mt * 2 + nt) * 16 + r) * 64 + lane];
+                    out[o * 128 + c] = NP == 2 ? v * so : v;
                 }
     }
 }
 
 // partial: [nwg][2][128][128] floats (dA_re part, dA_im part of every workgroup's row range)
-int dn_launch_tn_da(const float* dd, const float* gx, const float* gy, long long V, float* partial, int nwg, hipStream_t stream) {
+int dn_launch_tn_da(const float* dd, const float* gx, const float* gy, long long V, float* partial, int nwg, hipStream_t stream,
+                    const float* dd_amax, const float* g_amax) {
     if (V <= 0 || nwg <= 0) return DN_ERR_BAD_MODE;
     DaArgs g;
+    memset(&g, 0, sizeof(g));
     g.dd = dd; g.gx = gx; g.gy = gy; g.partial = partial; g.V = V;
+    g.f16 = (dd_amax && g_amax) ? 1 : 0;
+    g.a_amax.p[0] = dd_amax; g.a_amax.mul = g_amax; g.b_amax.p[0] = g_amax;
     const long long per = (V + nwg - 1) / nwg;
     g.rows_per_wg = (int)((per + DN_DA_KS - 1) / DN_DA_KS * DN_DA_KS);
 #ifndef DN_EMULATE
     static unsigned long long lds_opt_in = 0;   // per-device bitmap
-    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&tngemm_da_kernel), DN_DA_LDS, &lds_opt_in); if (oe_) return oe_; }
+    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&tngemm_da_kernel<3>), DN_DA_LDS, &lds_opt_in); if (oe_) return oe_; }
+    static unsigned long long lds_opt_in2 = 0;
+    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&tngemm_da_kernel<2>), DN_DA_LDS, &lds_opt_in2); if (oe_) return oe_; }
 #endif
     dn_prof_begin(DN_K_TNGEMM, stream);
-    DN_LAUNCH(tngemm_da_kernel, dim3(nwg, 1, 1), dim3(DN_DA_THREADS, 1, 1), DN_DA_LDS, stream, g);
+    if (g.f16) DN_LAUNCH(tngemm_da_kernel<2>, dim3(nwg, 1, 1), dim3(DN_DA_THREADS, 1, 1), DN_DA_LDS, stream, g);
+    else DN_LAUNCH(tngemm_da_kernel<3>, dim3(nwg, 1, 1), dim3(DN_DA_THREADS, 1, 1), DN_DA_LDS, stream, g);
     // four 128 x 128 products over V rows; three arrays read once, the partials written
     dn_prof_end(DN_K_TNGEMM, stream, 8.0 * (double)V * 128.0 * 128.0, 4.0 * (3.0 * (double)V * 128.0 + 2.0 * nwg * 128.0 * 128.0));
     return (int)hipGetLastError();

@@ -32,16 +32,17 @@ __device__ __forceinline__ void tx_load(const TnArgs& g, const DnTile& ch, int s
     }
 }
 
-__device__ __forceinline__ void tx_put(unsigned char* planes, int off, float4 v) {
-    uint2 h, m, l;
-    dn_split3_f4(v, h, m, l);
-    *reinterpret_cast<uint2*>(planes + off) = h;
-    *reinterpret_cast<uint2*>(planes + DN_TX_PLANE + off) = m;
-    *reinterpret_cast<uint2*>(planes + 2 * DN_TX_PLANE + off) = l;
+template <int NP = 3>
+__device__ __forceinline__ void tx_put(unsigned char* planes, int off, float4 v, float s = 1.f) {
+    uint2 pl[NP];
+    dn_split_f4<NP>(v, s, pl);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(planes + p * DN_TX_PLANE + off) = pl[p];
 }
 
-template <int FLAVOR>
-__device__ __forceinline__ void tx_store(unsigned char* sA, unsigned char* sB, int kr0, int q, const TxRegs& R, float4& csum) {
+template <int FLAVOR, int NP = 3>
+__device__ __forceinline__ void tx_store(unsigned char* sA, unsigned char* sB, int kr0, int q, const TxRegs& R, float4& csum,
+                                         float sa = 1.f, float sb = 1.f) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         float4 va = dn_f4_scale(R.a[i], R.ma[i]);
@@ -49,8 +50,8 @@ __device__ __forceinline__ void tx_store(unsigned char* sA, unsigned char* sB, i
         if (FLAVOR == DN_TN_QA) va = dn_f4_mul(va, R.qa[i]);
         if (FLAVOR == DN_TN_COLSUM) { csum.x += va.x; csum.y += va.y; csum.z += va.z; csum.w += va.w; }
         const int off = (kr0 + 16 * i) * DN_TX_ROWB + q * 8;
-        tx_put(sA, off, va);
-        tx_put(sB, off, vb);
+        tx_put<NP>(sA, off, va, sa);
+        tx_put<NP>(sB, off, vb, sb);
     }
 }
 
@@ -60,6 +61,7 @@ __device__ __forceinline__ uint4 tx_frag(const unsigned char* p) {
     return make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
 
+template <int NP = 3>
 __device__ __forceinline__ void tx_compute(const unsigned char* sA, const unsigned char* sB, int wr, int wc, int lane,
                                            f32x16 (&acc)[2]) {
     // lane -> chunk it names inside its 16-lane group: row (c/4) of the 4-row block, columns 4*(c%4)..+3 of the 16-column half
@@ -67,20 +69,26 @@ __device__ __forceinline__ void tx_compute(const unsigned char* sA, const unsign
     const int lane_off = (8 * (g >> 1) + (c >> 2)) * DN_TX_ROWB + (16 * (g & 1) + 4 * (c & 3)) * 2;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {   // two k16 steps per 32-row step
-        uint4 a[3][2], b[3];
+        uint4 a[NP][2], b[NP];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const int base = p * DN_TX_PLANE + s * 16 * DN_TX_ROWB + lane_off;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) a[p][mt] = tx_frag(sA + base + (wr * 64 + mt * 32) * 2);
             b[p] = tx_frag(sB + base + (wc * 32) * 2);
         }
         // product-major: consecutive MFMAs alternate between the two accumulators (same per-accumulator order, same sums)
-        constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};   // mid*mid, hi*lo, lo*hi, hi*mid, mid*hi, hi*hi
+        // NP = 3: mid*mid, hi*lo, lo*hi, hi*mid, mid*hi, hi*hi;  NP = 2 (split-fp16): hi*lo, lo*hi, hi*hi
+        constexpr int NPROD = NP == 3 ? 6 : 3;
+        constexpr int PA[6] = {NP == 3 ? 1 : 0, NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, 0, 1, 0};
+        constexpr int PB[6] = {1, NP == 3 ? 2 : 0, 0, 1, 0, 0};
 #pragma unroll
-        for (int p = 0; p < 6; ++p)
+        for (int p = 0; p < NPROD; ++p)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) acc[mt] = dn_mfma_bf16(a[PA[p]][mt], b[PB[p]], acc[mt]);
+            for (int mt = 0; mt < 2; ++mt) {
+                if constexpr (NP == 3) acc[mt] = dn_mfma_bf16(a[PA[p]][mt], b[PB[p]], acc[mt]);
+                else acc[mt] = dn_mfma_f16(a[PA[p]][mt], b[PB[p]], acc[mt]);
+            }
     }
 }
 

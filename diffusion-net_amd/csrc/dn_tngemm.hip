@@ -225,8 +225,14 @@ static int tn_launch(const TnArgs& g, dim3 grid, hipStream_t stream) {
 // =======================================================================================
 // (staging / fragment / MFMA helpers of this kernel: dn_tn_tiles.h, shared with the fused diffusion kernel)
 // single 60 KiB step buffer, two workgroups per CU (measured 60.1 vs 62.2 us against a double-buffered one-workgroup form)
-template <int FLAVOR>
+template <int FLAVOR, int NP>
 __global__ __launch_bounds__(DN_TX_THREADS, 4) void tngemm_x3_kernel(TnArgs g) {
+    float sa = 1.f, sb = 1.f, so = 1.f;
+    if constexpr (NP == 2) {   // split-fp16: operand scales from the producers' amax words, exact inverse on the way out
+        sa = dn_pow2_scale(dn_amax_eval(g.a_amax));
+        sb = dn_pow2_scale(dn_amax_eval(g.b_amax));
+        so = (1.f / sa) * (1.f / sb);
+    }
 
     constexpr int SBUF = 6 * DN_TX_PLANE;   // bytes of one (A,B) step buffer (3 planes each); two buffers in LDS
     DN_DYN_SMEM(smem_raw);
@@ -273,14 +279,14 @@ __global__ __launch_bounds__(DN_TX_THREADS, 4) void tngemm_x3_kernel(TnArgs g) {
         // single 60 KiB step buffer, two barriers per step: two workgroups (16 waves) share a CU and cover each other's
         // staging phases and HBM latency
         tx_load<FLAVOR>(g, ch, 0, kr0, a_ok, b_ok, ap, aq, ald, bp, bld, R);
-        tx_store<FLAVOR>(smem, smem + 3 * DN_TX_PLANE, kr0, q, R, csum);
+        tx_store<FLAVOR, NP>(smem, smem + 3 * DN_TX_PLANE, kr0, q, R, csum, sa, sb);
         __syncthreads();
         for (int st = 0; st < nsteps; ++st) {
             if (st + 1 < nsteps) tx_load<FLAVOR>(g, ch, st + 1, kr0, a_ok, b_ok, ap, aq, ald, bp, bld, R);
-            tx_compute(smem, smem + 3 * DN_TX_PLANE, wr, wc, lane, acc);
+            tx_compute<NP>(smem, smem + 3 * DN_TX_PLANE, wr, wc, lane, acc);
             __syncthreads();
             if (st + 1 < nsteps) {
-                tx_store<FLAVOR>(smem, smem + 3 * DN_TX_PLANE, kr0, q, R, csum);
+                tx_store<FLAVOR, NP>(smem, smem + 3 * DN_TX_PLANE, kr0, q, R, csum, sa, sb);
                 __syncthreads();
             }
         }
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(DN_TX_THREADS, 4) void tngemm_x3_kernel(TnArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wr * 2 + i) * 32 + dn_acc_row(r, lane);
-                if (m < g.M && n < g.N) out[(long long)m * g.N + n] = acc[i][r];
+                if (m < g.M && n < g.N) out[(long long)m * g.N + n] = NP == 2 ? acc[i][r] * so : acc[i][r];
             }
     }
     if (do_colsum) {   // uniform per block: 16 row lanes x 32 column groups -> [16][128] floats in LDS
@@ -309,15 +315,19 @@ __global__ __launch_bounds__(DN_TX_THREADS, 4) void tngemm_x3_kernel(TnArgs g) {
     }
 }
 
-template <int FLAVOR>
-static int tx_launch(const TnArgs& g, dim3 grid, hipStream_t stream) {
-    const size_t smem = (size_t)6 * DN_TX_PLANE;   // 60 KiB
+template <int FLAVOR, int NP>
+static int tx_launch_np(const TnArgs& g, dim3 grid, hipStream_t stream) {
+    const size_t smem = (size_t)6 * DN_TX_PLANE;   // 60 KiB (the split-fp16 form uses four of the six planes)
 #ifndef DN_EMULATE
     static unsigned long long lds_opt_in = 0;   // per-device bitmap
-    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&tngemm_x3_kernel<FLAVOR>), smem, &lds_opt_in); if (oe_) return oe_; }
+    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&tngemm_x3_kernel<FLAVOR, NP>), smem, &lds_opt_in); if (oe_) return oe_; }
 #endif
-    DN_LAUNCH((tngemm_x3_kernel<FLAVOR>), grid, dim3(DN_TX_THREADS, 1, 1), smem, stream, g);
+    DN_LAUNCH((tngemm_x3_kernel<FLAVOR, NP>), grid, dim3(DN_TX_THREADS, 1, 1), smem, stream, g);
     return (int)hipGetLastError();
+}
+template <int FLAVOR>
+static int tx_launch(const TnArgs& g, dim3 grid, hipStream_t stream) {
+    return g.f16 ? tx_launch_np<FLAVOR, 2>(g, grid, stream) : tx_launch_np<FLAVOR, 3>(g, grid, stream);
 }
 
 #ifndef DN_TN_X3

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 MAX_MLP = 8
+BLOCK_AMAX_WORDS = 16       # include/diffnet_hip.h: DN_BLOCK_AMAX_WORDS
 HEAD_MAX_CLASSES = 2048   # dn_head.hip: 64 lanes x DN_HEAD_CPL classes per row
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # DN_LIB_VARIANT=<tag> selects libdiffnet_hip_<tag>.so (same sources, other build flags) for A/B experiments
@@ -32,6 +33,7 @@ class MeshBatchStruct(C.Structure):
         ("mass", _vp), ("evals", _vp), ("evecs", _vp),
         ("g_rowptr", _vp), ("g_col", _vp), ("g_vx", _vp), ("g_vy", _vp),
         ("gt_rowptr", _vp), ("gt_col", _vp), ("gt_vx", _vp), ("gt_vy", _vp),
+        ("evecs_amax", _vp), ("mass_amax", _vp),
     ]
 
 
@@ -41,20 +43,21 @@ class BlockParamsStruct(C.Structure):
         ("widths", C.c_int32 * (MAX_MLP + 1)),
         ("time", _vp), ("A_re", _vp), ("A_im", _vp),
         ("W", _vp * MAX_MLP), ("b", _vp * MAX_MLP), ("mask", _vp * MAX_MLP), ("drop_seed", C.c_uint64), ("drop_seed_dev", _vp),
+        ("x_amax", _vp), ("out_amax", _vp),
     ]
 
 
 class BlockSavedStruct(C.Structure):
     _fields_ = [
         ("xs", _vp), ("xd", _vp), ("gx", _vp), ("gy", _vp), ("g", _vp), ("bre", _vp), ("bim", _vp),
-        ("h", _vp * MAX_MLP),
+        ("h", _vp * MAX_MLP), ("amax", _vp),
     ]
 
 
 class BlockGradsStruct(C.Structure):
     _fields_ = [
         ("d_x", _vp), ("d_time", _vp), ("dA_re", _vp), ("dA_im", _vp),
-        ("dW", _vp * MAX_MLP), ("db", _vp * MAX_MLP),
+        ("dW", _vp * MAX_MLP), ("db", _vp * MAX_MLP), ("d_out_amax", _vp), ("d_x_amax", _vp),
     ]
 
 

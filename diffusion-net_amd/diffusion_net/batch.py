@@ -96,6 +96,7 @@ class MeshBatch:
         self.g_rowptr = self.g_col = self.g_vx = self.g_vy = None
         self.gt_rowptr = self.gt_col = self.gt_vx = self.gt_vy = None
         self.tiles = self.chunks = self.mesh_chunk_off = self.mesh_rows = None
+        self.amax = None          # [2] device floats: max |evecs|, max |mass| (operand magnitudes of the split-fp16 engine, dn_api.hip)
         self._struct = None
 
     # ------------------------------------------------------------------ constructors
@@ -165,6 +166,10 @@ class MeshBatch:
         for name in ("tiles", "chunks", "mesh_chunk_off", "mesh_rows", "mass", "evals", "evecs",
                      "g_rowptr", "g_col", "g_vx", "g_vy", "gt_rowptr", "gt_col", "gt_vx", "gt_vy"):
             setattr(s, name, _hip.ptr(getattr(self, name)))
+        if self.evecs is not None and self.evecs.numel() > 0 and self.mass is not None:
+            # once per packed batch (two small reductions, no host synchronisation)
+            self.amax = torch.stack([self.evecs.detach().abs().amax(), self.mass.detach().abs().amax()]).to(torch.float32).contiguous()
+            s.evecs_amax, s.mass_amax = self.amax.data_ptr(), self.amax.data_ptr() + 4
         self._struct = s
 
     # ------------------------------------------------------------------ accessors

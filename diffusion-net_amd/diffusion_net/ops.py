@@ -305,8 +305,9 @@ class BlockConfig:
             raise ValueError("MiniMLP deeper than %d layers is not supported by the HIP block" % _hip.MAX_MLP)
 
 
-def _params_struct(cfg: BlockConfig, time, A_re, A_im, Ws, bs, masks):
+def _params_struct(cfg: BlockConfig, time, A_re, A_im, Ws, bs, masks, x_amax=None, out_amax=None):
     p = _hip.BlockParamsStruct()
+    p.x_amax, p.out_amax = _hip.ptr(x_amax), _hip.ptr(out_amax)
     p.C, p.n_mlp, p.with_grad, p.with_rot = cfg.C, cfg.n_mlp, int(cfg.with_grad), int(cfg.with_rot)
     for i, w in enumerate(cfg.widths):
         p.widths[i] = w
@@ -343,6 +344,23 @@ def keep_mask_reference(seed: int, layer: int, n_rows: int, width: int):
     return torch.from_numpy(np.ascontiguousarray(keep))
 
 
+def _tag_amax(t, word):
+    """Attach the device word holding max |t| to the tensor object (a plain attribute: it lives and dies with that object, so it can
+    never describe other data).  Autograd hands the same object on when a gradient has a single consumer; otherwise the tag is simply
+    absent and the consumer measures the tensor itself."""
+    try:
+        t._dn_amax = (word, t.data_ptr(), t._version)
+    except Exception:      # noqa: BLE001
+        pass
+
+
+def _amax_of(t):
+    tag = getattr(t, "_dn_amax", None)
+    if tag is None or tag[1] != t.data_ptr() or tag[2] != t._version or tag[0].device != t.device:
+        return None
+    return tag[0]
+
+
 class BlockFn(torch.autograd.Function):
     """forward(x, time, A_re, A_im, *W_and_b) with non-tensor (mb, cfg, masks) first."""
 
@@ -359,7 +377,12 @@ class BlockFn(torch.autograd.Function):
         bs = [_f32c(b) for b in wb[1::2]]
         dev, V, Cc = x.device, x.shape[0], cfg.C
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
-        p = _params_struct(cfg, time, A_re, A_im, Ws, bs, masks)
+        # magnitude words of the split-fp16 engine (dn_api.hip): the input's travels with the tensor from the block that produced it,
+        # this block's output gets one for the next block; a tensor without one is measured by the library (one extra pass)
+        x_amax = _amax_of(x)
+        words = new(_hip.BLOCK_AMAX_WORDS + 1)          # [saved-activation words | max |out|]
+        out_amax = words[_hip.BLOCK_AMAX_WORDS:]
+        p = _params_struct(cfg, time, A_re, A_im, Ws, bs, masks, x_amax, out_amax)
         out = new(V, Cc)
         need_grad = any(ctx.needs_input_grad)
         if need_grad:
@@ -372,6 +395,7 @@ class BlockFn(torch.autograd.Function):
                 sv.gx, sv.gy, sv.g, sv.bre, sv.bim = (t.data_ptr() for t in feats)
             for i, h in enumerate(hs):
                 sv.h[i] = h.data_ptr()
+            sv.amax = words.data_ptr()
             sv_ref = C.byref(sv)
         else:
             sv_ref = None
@@ -382,8 +406,9 @@ class BlockFn(torch.autograd.Function):
             ctx.mb, ctx.cfg, ctx.masks = mb, cfg, masks
             ctx.n_feat, ctx.n_h = len(feats), len(hs)
             ctx.has = (A_re is not None, A_im is not None)
-            ctx.save_for_backward(x, time, xs, xd, *feats, *hs, *Ws, *bs,
+            ctx.save_for_backward(x, time, xs, xd, words, *feats, *hs, *Ws, *bs,
                                   *([A_re] if A_re is not None else []), *([A_im] if A_im is not None else []))
+        _tag_amax(out, out_amax)      # the next block reads it off its input
         return out
 
     @staticmethod
@@ -395,8 +420,8 @@ class BlockFn(torch.autograd.Function):
         if pre is not None:
             pre()
         sav = list(ctx.saved_tensors)
-        x, time, xs, xd = sav[:4]
-        pos = 4
+        x, time, xs, xd, words = sav[:5]
+        pos = 5
         feats = sav[pos:pos + ctx.n_feat]; pos += ctx.n_feat
         hs = sav[pos:pos + ctx.n_h]; pos += ctx.n_h
         Ws = sav[pos:pos + cfg.n_mlp]; pos += cfg.n_mlp
@@ -414,6 +439,7 @@ class BlockFn(torch.autograd.Function):
             sv.gx, sv.gy, sv.g, sv.bre, sv.bim = (t.data_ptr() for t in feats)
         for i, h in enumerate(hs):
             sv.h[i] = h.data_ptr()
+        sv.amax = words.data_ptr()
         gr = _hip.BlockGradsStruct()
         sk = ctx.sinks                # order: time, A_re, A_im, W0, b0, W1, b1, ...
         d_x, d_time = torch.empty_like(x), _grad_out(sk[0], time)
@@ -421,6 +447,8 @@ class BlockFn(torch.autograd.Function):
         dWs = [_grad_out(sk[3 + 2 * i], w) for i, w in enumerate(Ws)]
         dbs = [_grad_out(sk[4 + 2 * i], b) for i, b in enumerate(bs)]
         gr.d_x, gr.d_time, gr.dA_re, gr.dA_im = d_x.data_ptr(), d_time.data_ptr(), _hip.ptr(dA_re), _hip.ptr(dA_im)
+        dx_amax = torch.empty(1, dtype=torch.float32, device=d_x.device)
+        gr.d_out_amax, gr.d_x_amax = _hip.ptr(_amax_of(d_out)), dx_amax.data_ptr()
         for i in range(cfg.n_mlp):
             gr.dW[i], gr.db[i] = dWs[i].data_ptr(), dbs[i].data_ptr()
         ws, n = _ws(mb, L.dn_block_bwd_workspace_bytes(mb.ref(), C.byref(p)))
@@ -433,6 +461,7 @@ class BlockFn(torch.autograd.Function):
         hook = getattr(cfg, "grad_hook", None)
         if hook is not None:          # dist.FlatParams: this block's gradient range may go out now
             hook()
+        _tag_amax(d_x, dx_amax)       # the block before this one finds it on the gradient it receives
         return (None, None, None, d_x, d_time, dA_re, dA_im, *wb)
 
 

@@ -50,6 +50,10 @@ typedef struct dn_mesh_batch {
     const float* evecs;              /* [v_total, k_eig]     mass-orthonormal eigenbasis             */
     const int32_t* g_rowptr;  const int32_t* g_col;  const float* g_vx;  const float* g_vy;   /* CSR of gradX/gradY  */
     const int32_t* gt_rowptr; const int32_t* gt_col; const float* gt_vx; const float* gt_vy;  /* CSR of transposes   */
+    /* Optional (round 3): one device float each holding max |evecs| and max |mass| (any upper bound within ~2^10 is as good) -- the
+     * operand magnitudes the split-fp16 matrix engine of the fused block scales by.  NULL: the block calls measure them themselves
+     * (one extra pass over the eigenbasis per call). */
+    const float* evecs_amax; const float* mass_amax;
 } dn_mesh_batch_t;
 
 /* Weights of one DiffusionNetBlock (layers.py:167-198), nn.Linear layout: W[out][in]. */
@@ -68,6 +72,10 @@ typedef struct dn_block_params {
                                               exactly where it was kept and active).  0 = no dropout where mask[i] == NULL. */
     const uint64_t* drop_seed_dev;         /* optional DEVICE word added to drop_seed inside the kernels: a captured HIP graph of the training
                                               step advances it with a graph node, so that every replay draws new masks without host work */
+    /* Optional (round 3), magnitudes for the split-fp16 engine: x_amax = device float holding max |x| of the block input (the previous
+     * block's out_amax); NULL: measured by the call (one extra pass over x).  out_amax: device float that receives max |out| (zeroed by
+     * the call), or NULL. */
+    const float* x_amax; float* out_amax;
 } dn_block_params_t;
 
 /* Activations the forward saves for the backward (caller-allocated). */
@@ -77,7 +85,10 @@ typedef struct dn_block_saved {
     float* gx; float* gy;              /* [v_total, C]        spatial gradients   (with_grad)   */
     float* g; float* bre; float* bim;  /* [v_total, C]        tanh features, rotated gradients  */
     float* h[DN_MAX_MLP_LAYERS];       /* h[i], i < n_mlp-1: [v_total, widths[i+1]] post-ReLU(+dropout) */
+    float* amax;                       /* optional [DN_BLOCK_AMAX_WORDS] device floats: magnitudes of the saved activations (written by the
+                                          forward, read by the backward).  NULL: both calls use the split-bf16 engine throughout. */
 } dn_block_saved_t;
+#define DN_BLOCK_AMAX_WORDS 16
 
 typedef struct dn_block_grads {
     float* d_x;                        /* [v_total, C] */
@@ -85,6 +96,8 @@ typedef struct dn_block_grads {
     float* dA_re; float* dA_im;        /* [C,C] (with_rot=0: dA_re holds dA) */
     float* dW[DN_MAX_MLP_LAYERS];
     float* db[DN_MAX_MLP_LAYERS];
+    const float* d_out_amax;           /* optional: device float with max |d_out| (the next block's d_x_amax); NULL: measured by the call */
+    float* d_x_amax;                   /* optional: device float that receives max |d_x| */
 } dn_block_grads_t;
 
 int dn_version(void);

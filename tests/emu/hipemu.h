@@ -45,6 +45,8 @@ typedef int hipError_t;
 enum { hipSuccess = 0 };
 static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+enum { hipMemcpyDeviceToDevice = 3 };
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
 
 #define __global__
 #define __device__
@@ -167,6 +169,7 @@ static inline void __syncthreads() { dnemu::block_barrier(); }
 // single-threaded fibers: plain read-modify-write is atomic here
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline int atomicOr(int* p, int v) { int o = *p; *p = o | v; return o; }
+static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 
 typedef float dnemu_f32x16 __attribute__((ext_vector_type(16)));

@@ -68,6 +68,11 @@ def run_golden(name, device):
         e_new, e_ref = helpers.rel_max(out.detach().cpu().double(), o64), helpers.rel_max(expect["out"].double(), o64)
         assert e_new < max(FWD_TOL, 2 * e_ref), (name, "forward vs fp64", e_new, e_ref)
         assert err < 4e-5, (name, "forward vs fp32 reference", err)
+        worst = max(((helpers.rel_l2(v.double(), g64[k]) / max(helpers.rel_l2(expect["grads"][k].double(), g64[k]), 1e-12), k) for k, v in got.items()))
+        if os.environ.get("DN_PARITY_VERBOSE"):
+            print("[%s] forward vs fp64: new %.3e, reference %.3e; worst gradient ratio new/reference vs fp64: %.2f (%s)" % (name, e_new, e_ref, worst[0], worst[1]))
+            for k, v in got.items():
+                print("   %-50s new %.3e  ref %.3e" % (k, helpers.rel_l2(v.double(), g64[k]), helpers.rel_l2(expect["grads"][k].double(), g64[k])))
         for k, v in got.items():
             gn, gr = helpers.rel_l2(v.double(), g64[k]), helpers.rel_l2(expect["grads"][k].double(), g64[k])
             assert gn < max(GRAD_TOL, 2 * gr), (name, k, gn, gr)

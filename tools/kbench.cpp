@@ -129,6 +129,13 @@ int main(int argc, char** argv) {
     mb.mass = dev(mass); mb.evals = dev(evals); mb.evecs = dev(evecs);
     mb.g_rowptr = dev(rowptr); mb.g_col = dev(col); mb.g_vx = dev(vx); mb.g_vy = dev(vy);
     mb.gt_rowptr = dev(t_rowptr); mb.gt_col = dev(t_col); mb.gt_vx = dev(t_vx); mb.gt_vy = dev(t_vy);
+    {   // operand magnitudes for the split-fp16 engine, as diffusion_net.batch.MeshBatch provides them
+        float am[2] = {0.f, 0.f};
+        for (float v : evecs) am[0] = std::max(am[0], fabsf(v));
+        for (float v : mass) am[1] = std::max(am[1], fabsf(v));
+        const float* d = dev(std::vector<float>{am[0], am[1]});
+        if (!getenv("KB_NO_AMAX")) { mb.evecs_amax = d; mb.mass_amax = d + 1; }
+    }
 
     auto randv = [&](size_t n, float sc) { std::vector<float> v(n); for (auto& x : v) x = sc * Nrm(rng); return v; };
     std::vector<float> hx = randv((size_t)V * C, 1.f), hy = randv((size_t)V * C, 1.f), hW = randv((size_t)C * C, 1.f / sqrtf((float)C)),
@@ -144,13 +151,24 @@ int main(int argc, char** argv) {
     float *o0 = o0r[0], *o1 = o1r[0], *o2 = devz((size_t)V * C), *o3 = devz((size_t)V * C), *o4 = devz((size_t)V * C);
     float *specout = devz((size_t)n_mesh * K * C), *dW = devz((size_t)3 * C * C), *db = devz(C), *dW2 = devz((size_t)C * C), *dt = devz(C);
 
+    const float* kb_dout_amax = nullptr; float* kb_dx_amax = nullptr;
     dn_block_params_t bp; memset(&bp, 0, sizeof(bp));
     bp.C = C; bp.n_mlp = 3; bp.with_grad = 1; bp.with_rot = 1; bp.widths[0] = 3 * C; bp.widths[1] = bp.widths[2] = bp.widths[3] = C;
     bp.time = tm; bp.A_re = W; bp.A_im = W2; bp.W[0] = W3; bp.W[1] = W; bp.W[2] = W2; bp.b[0] = bp.b[1] = bp.b[2] = b; bp.drop_seed = 0x1234567ull;
     dn_block_saved_t sv; memset(&sv, 0, sizeof(sv));
     sv.xs = devz((size_t)n_mesh * K * C); sv.xd = devz((size_t)V * C); sv.gx = devz((size_t)V * C); sv.gy = devz((size_t)V * C); sv.g = devz((size_t)V * C);
     sv.bre = devz((size_t)V * C); sv.bim = devz((size_t)V * C); sv.h[0] = devz((size_t)V * C); sv.h[1] = devz((size_t)V * C);
+    sv.amax = devz(DN_BLOCK_AMAX_WORDS);
+    {   // block input / incoming gradient magnitudes (x = hx, d_out = hy), as the previous / next block would hand them over
+        float ax = 0.f, ay = 0.f;
+        for (float v : hx) ax = std::max(ax, fabsf(v));
+        for (float v : hy) ay = std::max(ay, fabsf(v));
+        float* d = dev(std::vector<float>{ax, ay, 0.f, 0.f});
+        if (!getenv("KB_NO_AMAX")) { bp.x_amax = d; bp.out_amax = d + 2; }
+        kb_dout_amax = getenv("KB_NO_AMAX") ? nullptr : d + 1; kb_dx_amax = d + 3;
+    }
     dn_block_grads_t gr; memset(&gr, 0, sizeof(gr));
+    gr.d_out_amax = kb_dout_amax; gr.d_x_amax = kb_dx_amax;
     gr.d_x = o4; gr.d_time = dt; gr.dA_re = devz((size_t)C * C); gr.dA_im = devz((size_t)C * C);
     gr.dW[0] = dW; gr.dW[1] = devz((size_t)C * C); gr.dW[2] = devz((size_t)C * C); gr.db[0] = db; gr.db[1] = devz(C); gr.db[2] = devz(C);
 
@@ -332,11 +350,24 @@ int main(int argc, char** argv) {
     }
     auto blk_f = L.sym<int (*)(const dn_mesh_batch_t*, const dn_block_params_t*, const float*, float*, const dn_block_saved_t*, void*, size_t, void*)>("dn_block_fwd_f32");
     if (want("block_inf")) { dn_block_params_t p2 = bp; p2.drop_seed = 0; timeit("block_inf", 12 * VC, 0, [&](int it) { DC(blk_f(&mb, &p2, xr[it % NROT], o0r[it % NROT], nullptr, ws, wsb, st)); }); endl_(); }
-    if (want("block_fwd")) { timeit("block_fwd", 20 * VC, 0, [&](int it) { DC(blk_f(&mb, &bp, xr[it % NROT], o0r[it % NROT], &sv, ws, wsb, st)); }); endl_(); }
+    if (want("block_fwd")) {
+        timeit("block_fwd", 20 * VC, 0, [&](int it) { DC(blk_f(&mb, &bp, xr[it % NROT], o0r[it % NROT], &sv, ws, wsb, st)); });
+        if (check) {   // fingerprint of the output (compare runs with DN_F16=0 / 1 / masks): mean |out| and three entries
+            auto got = host(o0r[0], (size_t)V * C); double ma = 0; for (float v : got) ma += fabs(v);
+            printf("  mean|out| %.9e  out[0] %.7e out[V/2] %.7e out[-1] %.7e", ma / got.size(), got[0], got[(size_t)(V / 2) * C + 5], got.back());
+        }
+        endl_();
+    }
     if (want("block_bwd")) {
         auto f = L.sym<int (*)(const dn_mesh_batch_t*, const dn_block_params_t*, const float*, const dn_block_saved_t*, const float*, const dn_block_grads_t*, void*, size_t, void*)>("dn_block_bwd_f32");
         DC(blk_f(&mb, &bp, x, o0, &sv, ws, wsb, st));
-        timeit("block_bwd", 40 * VC, 0, [&](int it) { DC(f(&mb, &bp, x, &sv, yr[it % NROT], &gr, ws, wsb, st)); }); endl_();
+        timeit("block_bwd", 40 * VC, 0, [&](int it) { DC(f(&mb, &bp, x, &sv, yr[it % NROT], &gr, ws, wsb, st)); });
+        if (check) {
+            auto got = host(o4, (size_t)V * C); double ma = 0; for (float v : got) ma += fabs(v);
+            auto gw = host(dW, (size_t)3 * C * C); double mw = 0; for (float v : gw) mw += fabs(v);
+            printf("  mean|d_x| %.9e  d_x[V/2] %.7e  mean|dW0| %.9e", ma / got.size(), got[(size_t)(V / 2) * C + 5], mw / gw.size());
+        }
+        endl_();
     }
     if (trace) {   // libraries built with EXTRA=-DDN_WS_TRACE=<block>: stamps of the wave-specialised row GEMM (MFMA wave 0: 3 per slice, loader wave 4: 5)
         auto rd = (int (*)(unsigned long long*, int))dlsym(L.h, "dn_debug_rd_trace_read");
