@@ -102,9 +102,10 @@ int from_basis(const dn_mesh_batch_t* mb, const float* spec, int C, float* out, 
     rg_finish(g, 1);
     return dn_launch_rowgemm(g, mb->n_tiles, 1, st);
 }
-int grad_apply_fwd(const dn_mesh_batch_t* mb, const float* x, int C, float* gx, float* gy, hipStream_t st, float* o_amax = nullptr) {
+int grad_apply_fwd(const dn_mesh_batch_t* mb, const float* x, int C, float* gx, float* gy, hipStream_t st, float* o_amax = nullptr,
+                   const float* x_amax = nullptr) {
     SpArgs s; memset(&s, 0, sizeof(s));
-    s.o_amax = o_amax;
+    s.o_amax = o_amax; s.in_amax = x_amax; s.op_norm = x_amax ? mb->grad_norm : nullptr;   // the bound ||G||_inf max|x| when both are known
     s.rowptr = mb->g_rowptr; s.col = mb->g_col; s.va = mb->g_vx; s.vb = mb->g_vy;
     s.x1 = x; s.o1 = gx; s.o2 = gy; s.nrows = mb->v_total; s.C = C; s.ldx = C; s.ldo = C; s.mode = DN_SP_FWD2; s.div = 1.f; s.acct_nnz = mb->g_nnz;
     return dn_launch_spmm(s, st);
@@ -487,13 +488,15 @@ static bool block_f16_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p) 
 }
 static size_t amax_ws(void) { return pad256(AW_COUNT + DN_BLOCK_AMAX_WORDS + 2); }
 // Product classes of the block; DN_F16_MASK=<bits> (diagnostic) selects which of them run on the split-fp16 engine.
-// Default: all but the FORWARD back-projection x_diffuse = evecs * spectrum.  Its output is what the sparse gradient operators
+// Default: the row products (gradient features, MLP, input gradients, backward back-projection).  Not the split-V projections
+// evecs^T x (their lock-step kernel gains nothing: 55 -> 54.6 us, and leaving them out spares the transposed gather a magnitude
+// pass that cost it +60 %), and not the FORWARD back-projection x_diffuse = evecs * spectrum: its output is what the sparse gradient operators
 // difference (gx = G_X x_diffuse, row sums ~0), which amplifies its rounding noise, and its B operand -- a spectrum whose entries
 // decay over many orders of magnitude with the eigenvalue -- is the one tensor a single power-of-two scale serves badly.  Measured on
 // the trained-checkpoint golden (error against fp64, fp32 reference = 8.4e-5 on the worst tensor): every class on fp16 3.2e-4, every
 // class but this one 6e-5 ... 1.0e-4 -- the level of the split-bf16 engine and of the reference itself.
 enum { F16_TOB = 1, F16_FROMB = 2, F16_GF = 4, F16_MLP = 8, F16_LBI = 16, F16_GFB = 32, F16_TOB_B = 64, F16_FROMB_B = 128 };
-static int f16_mask(void) { static const int m = getenv("DN_F16_MASK") ? atoi(getenv("DN_F16_MASK")) : (0xffff & ~F16_FROMB); return m; }
+static int f16_mask(void) { static const int m = getenv("DN_F16_MASK") ? atoi(getenv("DN_F16_MASK")) : (F16_GF | F16_MLP | F16_LBI | F16_GFB | F16_FROMB_B); return m; }
 static F16 f16_if(int bit, const F16& f) { if (f16_mask() & bit) return f; F16 r; r.o = f.o; return r; }   // (the magnitude of the output is still recorded)
 
 size_t dn_block_fwd_workspace_bytes(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int with_saved) {
@@ -565,11 +568,12 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
         if (f16) { f = f16_of(ev_amax, x_amax); f.b.mul = ms_amax; }
         DN_CHECK(to_basis_partials(mb, x, C, true, partial, st, f16_if(F16_TOB, f)));
     }
-    DN_CHECK(dn_launch_spec_fwd(partial, mb->mesh_chunk_off, mb->evals, p->time, xs, ys, mb->n_mesh, K, C, st, f16 ? aw + AW_YS : nullptr));
+    DN_CHECK(dn_launch_spec_fwd(partial, mb->mesh_chunk_off, mb->evals, p->time, xs, ys, mb->n_mesh, K, C, st,
+                                (f16 && (f16_mask() & F16_FROMB)) ? aw + AW_YS : nullptr));   // only the split-fp16 back-projection needs max |ys|
     DN_CHECK(from_basis(mb, ys, C, xd, nullptr, false, st, f16 ? f16_if(F16_FROMB, f16_of(ev_amax, aw + AW_YS, sw + SW_XD)) : F16()));
     // gradient features (layers.py:213-226)
     if (p->with_grad) {
-        DN_CHECK(grad_apply_fwd(mb, xd, C, gx, gy, st, f16 ? sw + SW_G : nullptr));
+        DN_CHECK(grad_apply_fwd(mb, xd, C, gx, gy, st, f16 ? sw + SW_G : nullptr, f16 ? sw + SW_XD : nullptr));
         DN_CHECK(gradfeat_fwd(mb, gx, gy, p->A_re, p->with_rot ? p->A_im : nullptr, C, gf, bre, bim, st,
                               f16 ? f16_if(F16_GF, f16_of(sw + SW_G, aw + AW_WA)) : F16()));
     }
@@ -705,7 +709,7 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
         F16 fg;
         if (f16) { fg = f16_of(D(0), aw + AW_WA); fg.a.mul = sw + SW_G; }     // A = d_dots * (gx | gy)
         DN_CHECK(gradfeat_bwd_inputs(mb, d_dots, sv->gx, sv->gy, sv->bre, sv->bim, p->A_re, A_im, C, d_gx, d_gy, st, f16_if(F16_GFB, fg)));
-        DN_CHECK(grad_apply_bwd(mb, d_gx, d_gy, d_xd, C, d_xd, st, f16 ? aw + AW_MISC : nullptr));   // d_xd += gradX^T d_gx + gradY^T d_gy (in place)
+        DN_CHECK(grad_apply_bwd(mb, d_gx, d_gy, d_xd, C, d_xd, st, (f16 && (f16_mask() & F16_TOB_B)) ? aw + AW_MISC : nullptr));   // d_xd += gradX^T d_gx + gradY^T d_gy (in place)
     }
     DN_CHECK(dn_launch_multi_reduce(jobs, st));
     // ---- diffusion backward

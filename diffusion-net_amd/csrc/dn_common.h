@@ -227,12 +227,16 @@ __device__ __forceinline__ float dn_amax_eval(const DnAmax& a) {
 }
 // atomic max of a non-negative float through its bit pattern (monotonic for x >= 0; NaN never raises the word: it propagates through the
 // data itself); one atomic per wave
+// CHECK: read the word first and skip the atomic unless this wave would raise it -- for kernels with tens of thousands of short waves,
+// whose atomics on one address would serialise in its L2 channel.  Without it the atomic is posted (no return value, the wave does not
+// wait): right for long-lived waves (a few thousand commits per launch).
+template <bool CHECK = false>
 __device__ __forceinline__ void dn_amax_commit(float* word, float m) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { const float o = __shfl_xor(m, d, 64); m = o > m ? o : m; }
-    // the word only grows: after the first few waves nearly every wave sees a value that already covers its own and skips the atomic
-    // (tens of thousands of atomics on one address would serialise in its L2 channel)
-    if ((threadIdx.x & 63) == 0 && m > *reinterpret_cast<volatile float*>(word)) atomicMax(reinterpret_cast<unsigned*>(word), __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) {
+        if (!CHECK || m > *reinterpret_cast<volatile float*>(word)) atomicMax(reinterpret_cast<unsigned*>(word), __float_as_uint(m));
+    }
 }
 // per-lane form for kernels whose lanes do not all reach the end together: skip the atomic unless this lane would raise the word
 __device__ __forceinline__ void dn_amax_commit_lane(float* word, float m) {
@@ -378,7 +382,8 @@ struct SpArgs {
     int nrows, C, ldx, ldo, mode;
     float div;         // DN_SP_ONE: result divided by this (exact mean of n gathered rows)
     long long acct_nnz; // host-side accounting only
-    float* o_amax;     // optional device word: max |o1|, |o2| over the launch (split-fp16 consumers), zeroed by the caller
+    float* o_amax;     // optional device word: (a bound of) max |o1|, |o2| over the launch for split-fp16 consumers.  With op_norm and
+    const float* op_norm; const float* in_amax;   // in_amax it is STORED as *in_amax * *op_norm (||G||_inf max|x|); else measured (zeroed by the caller)
 };
 enum { DN_SP_FWD2 = 0, DN_SP_BWD2 = 1, DN_SP_ONE = 2 };
 

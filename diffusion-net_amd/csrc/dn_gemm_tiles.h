@@ -91,7 +91,7 @@ __device__ __forceinline__ void rg_epilogue_tile(const RgArgs& g, unsigned long 
         float m = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { const float a = fabsf(res0[r]); m = (ok[r] && a > m) ? a : m; }
-        dn_amax_commit(g.o_amax, m);
+        dn_amax_commit<true>(g.o_amax, m);
     }
     if (MODE == DN_EPI_GRADFEAT_BWD) {
 #pragma unroll

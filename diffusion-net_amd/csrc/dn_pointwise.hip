@@ -154,7 +154,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void spec_fwd_kernel(const float* partial, const int* mco, SpecEpi epi) {
     const int m = blockIdx.y;
     const float om = seg_reduce_body<VEC>(partial, m, mco[m], mco[m + 1], (long long)epi.K * epi.C, epi);
-    if (epi.ys_amax) dn_amax_commit(epi.ys_amax, om);
+    if (epi.ys_amax) dn_amax_commit<true>(epi.ys_amax, om);
 }
 
 int dn_launch_spec_fwd(const float* partial, const int* mesh_chunk_off, const float* evals, const float* time,
@@ -360,19 +360,19 @@ __global__ __launch_bounds__(256) void amax_kernel(AmaxJobs jobs) {
     } else {
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = fabsf(x[i]) > m ? fabsf(x[i]) : m;
     }
-    dn_amax_commit(jobs.dst[j], m);
+    dn_amax_commit<true>(jobs.dst[j], m);
 }
 // Start-of-call bookkeeping of the split-fp16 engine in ONE launch: job j < count: max |src[j]| by a single workgroup (weights: a few
 // 10k elements), max-combined in LDS and STORED (jobs sharing a destination are merged by the host into consecutive jobs of one
 // workgroup chain -- see `same`); the last workgroup zeroes the words the later kernels of the call accumulate into and forwards one
 // word.  Replaces three memsets, a copy and the atomic amax launch (4 x ~6 us of blit kernels per block call).
-__global__ __launch_bounds__(256) void amax_init_kernel(AmaxInit a) {
-    __shared__ float red[256];
-    const int j = blockIdx.x;
+__global__ __launch_bounds__(1024) void amax_init_kernel(AmaxInit a) {
+    __shared__ float red[1024];
+    const int j = blockIdx.x, tid = threadIdx.x;
     if (j == a.jobs.count) {
         for (int r = 0; r < a.nzero; ++r)
-            for (int i = threadIdx.x; i < a.zero_n[r]; i += 256) a.zero[r][i] = 0.f;
-        if (threadIdx.x == 0 && a.copy_src && a.copy_dst) *a.copy_dst = *a.copy_src;
+            for (int i = tid; i < a.zero_n[r]; i += 1024) a.zero[r][i] = 0.f;
+        if (tid == 0 && a.copy_src && a.copy_dst) *a.copy_dst = *a.copy_src;
         return;
     }
     if (a.same[j]) return;                      // merged into the previous job's workgroup
@@ -382,25 +382,31 @@ __global__ __launch_bounds__(256) void amax_init_kernel(AmaxInit a) {
         const long long n = a.jobs.n[jj];
         if ((((uintptr_t)x) & 15) == 0) {
             const long long n4 = n / 4;
-            for (long long i = threadIdx.x; i < n4; i += 256) m = dn_f4_amax(m, *reinterpret_cast<const float4*>(x + 4 * i));
-            for (long long i = 4 * n4 + threadIdx.x; i < n; i += 256) m = fabsf(x[i]) > m ? fabsf(x[i]) : m;
+            for (long long i = tid; i < n4; i += 4096) {     // four float4 in flight per thread (one workgroup: latency, not bandwidth)
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const long long k = i + 1024 * u; v[u] = *reinterpret_cast<const float4*>(x + 4 * (k < n4 ? k : i)); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) m = dn_f4_amax(m, v[u]);
+            }
+            for (long long i = 4 * n4 + tid; i < n; i += 1024) m = fabsf(x[i]) > m ? fabsf(x[i]) : m;
         } else {
-            for (long long i = threadIdx.x; i < n; i += 256) m = fabsf(x[i]) > m ? fabsf(x[i]) : m;
+            for (long long i = tid; i < n; i += 1024) m = fabsf(x[i]) > m ? fabsf(x[i]) : m;
         }
     }
-    red[threadIdx.x] = m;
+    red[tid] = m;
     __syncthreads();
-    for (int d = 128; d > 0; d >>= 1) {
-        if ((int)threadIdx.x < d) red[threadIdx.x] = red[threadIdx.x + d] > red[threadIdx.x] ? red[threadIdx.x + d] : red[threadIdx.x];
+    for (int d = 512; d > 0; d >>= 1) {
+        if (tid < d) red[tid] = red[tid + d] > red[tid] ? red[tid + d] : red[tid];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *a.jobs.dst[j] = red[0];
+    if (tid == 0) *a.jobs.dst[j] = red[0];
 }
 int dn_launch_amax_init(const AmaxInit& a_in, hipStream_t stream) {
     AmaxInit a = a_in;
     for (int j = 0; j < a.jobs.count; ++j) a.same[j] = (j > 0 && a.jobs.dst[j] == a.jobs.dst[j - 1]) ? 1 : 0;
     dn_prof_begin(DN_K_SMALL, stream);
-    DN_LAUNCH(amax_init_kernel, dim3(a.jobs.count + 1, 1, 1), dim3(256, 1, 1), 0, stream, a);
+    DN_LAUNCH(amax_init_kernel, dim3(a.jobs.count + 1, 1, 1), dim3(1024, 1, 1), 0, stream, a);
     dn_prof_end(DN_K_SMALL, stream, 0.0, 0.0);
     return (int)hipGetLastError();
 }

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_pers
         pt_piece_load<MODE, FLAG>(g, seed, sE, p_next, tid, p_row0, p_nrows, n0, P1);
         om = dn_f4_amax(om, pt_piece_store<MODE, FLAG>(g, P1));
     }
-    if (g.o_amax) dn_amax_commit(g.o_amax, om);
+    if (g.o_amax) dn_amax_commit<true>(g.o_amax, om);
 }
 
 #ifndef DN_PT_X3
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
         ws_aux_load<MODE, FLAG, XMASK>(g, seed, p_next, lt, p_row0, p_nrows, n0, A1);
         ws_piece_out<MODE, FLAG>(g, *reinterpret_cast<const float4*>(&sE[A1.lds]), bias, A1, so, om);
     }
-    if (g.o_amax) dn_amax_commit(g.o_amax, om);
+    if (g.o_amax) dn_amax_commit<true>(g.o_amax, om);
 }
 
 template <int MODE, bool BCOLK, bool FLAG, int PPI, bool BC, int NP, bool XMASK>

@@ -23,28 +23,31 @@
 #endif
 
 // MODE is a compile-time copy of s.mode: with the mode tested at run time every unrolled gather step carried its own scalar branches
-template <int VEC, int MODE>
-__global__ __launch_bounds__(256) void spmm_kernel(SpArgs s, int tpr, int nvb) {
+// AMAX: track max |output| and commit it to s.o_amax (measured: +25 % on the forward gather -- the waves are short-lived and every
+// commit is a round trip to L2; the fused block therefore uses the analytic bound max|G x| <= ||G||_inf max|x| instead, stored by one
+// thread: s.op_norm / s.in_amax).  The plain instantiation is the round-2 kernel unchanged (a grid-stride form of it was 50 % slower
+// on the transposed gather).
+template <int VEC, int MODE, bool AMAX>
+__global__ __launch_bounds__(256) void spmm_kernel(SpArgs s, int tpr) {
+    if (!AMAX && s.o_amax && blockIdx.x == 0 && threadIdx.x == 0) *s.o_amax = *s.in_amax * *s.op_norm;
 
     const int tid = threadIdx.x;
     const int rl = tid / tpr, cg = tid % tpr;
     const int rows_per_block = 256 / tpr;
+#if DN_SP_XCD   // every XCD walks a contiguous range of row blocks: the ~7 neighbour rows a row gathers mostly live in its L2
+    const int per_xcd = (gridDim.x + 7) >> 3;
+    const int rb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int row = rb * rows_per_block + rl;
+#else
+    const int row = blockIdx.x * rows_per_block + rl;
+#endif
     // cooperative index loads need every lane of the row's group alive in one wave (the row test below is uniform per group)
     // (and every lane of the group must run every column pass: C a multiple of the group's span)
     const bool coop = DN_SP_COOP && tpr >= DN_SP_CHUNK && tpr <= 64 && s.C % (tpr * VEC) == 0;
-    float om = 0.f;   // max |output| of this lane over all its rows (committed to s.o_amax once: the outputs feed split-fp16 products)
-    // A workgroup walks virtual row blocks vb = blockIdx.x, + gridDim.x, ... (nvb of them; the launcher caps the grid only when an
-    // amax word is requested: one commit per wave of a long-lived workgroup instead of one per two rows)
-    for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
-#if DN_SP_XCD   // every XCD walks a contiguous range of row blocks: the ~7 neighbour rows a row gathers mostly live in its L2
-    const int per_xcd = (nvb + 7) >> 3;
-    const int rb = (vb & 7) * per_xcd + (vb >> 3);
-    const int row = rb * rows_per_block + rl;
-#else
-    const int row = vb * rows_per_block + rl;
-#endif
-    if (row >= s.nrows) continue;
-    const int beg = s.rowptr[row], end = s.rowptr[row + 1];
+    if (!AMAX && row >= s.nrows) return;
+    const bool live = row < s.nrows;      // AMAX: every lane stays for the wave-wide reduction at the end; dead rows gather nothing
+    const int beg = live ? s.rowptr[row] : 0, end = live ? s.rowptr[row + 1] : 0;
+    float om = 0.f;
     for (int c = cg * VEC; c < s.C; c += tpr * VEC) {
         float a1[VEC], a2[VEC];
 #pragma unroll
@@ -111,6 +114,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpArgs s, int tpr, int nvb) {
                 }
             }
         }
+        if (AMAX && !live) continue;
         const long long dst = (long long)row * s.ldo + c;
         if (MODE == DN_SP_ONE) {
 #pragma unroll
@@ -120,10 +124,12 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpArgs s, int tpr, int nvb) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) a1[e] += s.add[dst + e];
         }
+        if (AMAX) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            om = fabsf(a1[e]) > om ? fabsf(a1[e]) : om;
-            if (MODE == DN_SP_FWD2) om = fabsf(a2[e]) > om ? fabsf(a2[e]) : om;
+            for (int e = 0; e < VEC; ++e) {
+                om = fabsf(a1[e]) > om ? fabsf(a1[e]) : om;
+                if (MODE == DN_SP_FWD2) om = fabsf(a2[e]) > om ? fabsf(a2[e]) : om;
+            }
         }
         if (VEC == 4) {
             *reinterpret_cast<float4*>(s.o1 + dst) = make_float4(a1[0], a1[1 % VEC], a1[2 % VEC], a1[3 % VEC]);
@@ -134,10 +140,8 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpArgs s, int tpr, int nvb) {
             if (MODE == DN_SP_FWD2) s.o2[dst] = a2[0];
         }
     }
-    }   // virtual row blocks
-    if (s.o_amax) dn_amax_commit(s.o_amax, om);
+    if (AMAX) dn_amax_commit<true>(s.o_amax, om);
 }
-
 
 static int pow2_at_least(int v) {
     int p = 1;
@@ -154,12 +158,11 @@ int dn_launch_spmm(const SpArgs& s, hipStream_t stream) {
     int tpr = pow2_at_least(vec ? (s.C + 3) / 4 : s.C);
     if (tpr > 256) tpr = 256;
     const int rpb = 256 / tpr;
-    const int nvb = DN_SP_XCD ? (((s.nrows + rpb - 1) / rpb) + 7) / 8 * 8 : (s.nrows + rpb - 1) / rpb;
-    int nblk = nvb;
-    if (s.o_amax) { const int cap = 8 * dn_num_cus(); nblk = nvb < cap ? nvb : cap; }   // multiple of 8 either way (XCD round-robin)
-    dim3 grid(nblk, 1, 1);
+    dim3 grid(DN_SP_XCD ? (((s.nrows + rpb - 1) / rpb) + 7) / 8 * 8 : (s.nrows + rpb - 1) / rpb, 1, 1);
     dn_prof_begin(DN_K_SPMM, stream);
-#define DN_SP_GO(V, M) DN_LAUNCH((spmm_kernel<V, M>), grid, dim3(256, 1, 1), 0, stream, s, tpr, nvb)
+    const bool amax = s.o_amax && !(s.op_norm && s.in_amax);
+#define DN_SP_GO(V, M) do { if (amax) DN_LAUNCH((spmm_kernel<V, M, true>), grid, dim3(256, 1, 1), 0, stream, s, tpr); \
+                            else DN_LAUNCH((spmm_kernel<V, M, false>), grid, dim3(256, 1, 1), 0, stream, s, tpr); } while (0)
     if (vec) {
         if (s.mode == DN_SP_FWD2) DN_SP_GO(4, DN_SP_FWD2); else if (s.mode == DN_SP_BWD2) DN_SP_GO(4, DN_SP_BWD2); else DN_SP_GO(4, DN_SP_ONE);
     } else {

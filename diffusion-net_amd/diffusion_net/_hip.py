@@ -33,7 +33,7 @@ class MeshBatchStruct(C.Structure):
         ("mass", _vp), ("evals", _vp), ("evecs", _vp),
         ("g_rowptr", _vp), ("g_col", _vp), ("g_vx", _vp), ("g_vy", _vp),
         ("gt_rowptr", _vp), ("gt_col", _vp), ("gt_vx", _vp), ("gt_vy", _vp),
-        ("evecs_amax", _vp), ("mass_amax", _vp),
+        ("evecs_amax", _vp), ("mass_amax", _vp), ("grad_norm", _vp),
     ]
 
 

@@ -96,7 +96,7 @@ class MeshBatch:
         self.g_rowptr = self.g_col = self.g_vx = self.g_vy = None
         self.gt_rowptr = self.gt_col = self.gt_vx = self.gt_vy = None
         self.tiles = self.chunks = self.mesh_chunk_off = self.mesh_rows = None
-        self.amax = None          # [2] device floats: max |evecs|, max |mass| (operand magnitudes of the split-fp16 engine, dn_api.hip)
+        self.amax = None          # [3] device floats: max |evecs|, max |mass|, ||[gradX; gradY]||_inf (magnitudes for the split-fp16 engine, dn_api.hip)
         self._struct = None
 
     # ------------------------------------------------------------------ constructors
@@ -168,8 +168,20 @@ class MeshBatch:
             setattr(s, name, _hip.ptr(getattr(self, name)))
         if self.evecs is not None and self.evecs.numel() > 0 and self.mass is not None:
             # once per packed batch (two small reductions, no host synchronisation)
-            self.amax = torch.stack([self.evecs.detach().abs().amax(), self.mass.detach().abs().amax()]).to(torch.float32).contiguous()
+            words = [self.evecs.detach().abs().amax(), self.mass.detach().abs().amax()]
+            if self.g_rowptr is not None and self.g_vx is not None and self.g_vx.numel() > 0:
+                # infinity norm of the stacked gradient operators: max |gradX x|, |gradY x| <= it * max |x|
+                rows = torch.repeat_interleave(torch.arange(vt, device=self.device), (self.g_rowptr[1:] - self.g_rowptr[:-1]).long())
+                rs = torch.zeros(2, vt, dtype=torch.float32, device=self.device)
+                rs[0].index_add_(0, rows, self.g_vx.abs())
+                rs[1].index_add_(0, rows, self.g_vy.abs())
+                words.append(rs.amax())
+            else:
+                words.append(torch.zeros((), dtype=torch.float32, device=self.device))
+            self.amax = torch.stack(words).to(torch.float32).contiguous()
             s.evecs_amax, s.mass_amax = self.amax.data_ptr(), self.amax.data_ptr() + 4
+            if self.g_rowptr is not None:
+                s.grad_norm = self.amax.data_ptr() + 8
         self._struct = s
 
     # ------------------------------------------------------------------ accessors

@@ -54,6 +54,10 @@ typedef struct dn_mesh_batch {
      * operand magnitudes the split-fp16 matrix engine of the fused block scales by.  NULL: the block calls measure them themselves
      * (one extra pass over the eigenbasis per call). */
     const float* evecs_amax; const float* mass_amax;
+    /* Optional: one device float holding the infinity norm of the stacked gradient operators, max_i sum_j max(|gradX_ij|, |gradY_ij|)
+     * summed as sum_j |gradX_ij| resp. sum_j |gradY_ij| (the larger of the two row sums): max |gradX x|, |gradY x| <= it * max |x| is
+     * the magnitude bound the split-fp16 gradient-feature products scale by (about 3x the true maximum on a mesh).  NULL: measured. */
+    const float* grad_norm;
 } dn_mesh_batch_t;
 
 /* Weights of one DiffusionNetBlock (layers.py:167-198), nn.Linear layout: W[out][in]. */

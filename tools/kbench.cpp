@@ -133,8 +133,10 @@ int main(int argc, char** argv) {
         float am[2] = {0.f, 0.f};
         for (float v : evecs) am[0] = std::max(am[0], fabsf(v));
         for (float v : mass) am[1] = std::max(am[1], fabsf(v));
-        const float* d = dev(std::vector<float>{am[0], am[1]});
-        if (!getenv("KB_NO_AMAX")) { mb.evecs_amax = d; mb.mass_amax = d + 1; }
+        float gn = 0.f;
+        for (long long r = 0; r < V; ++r) { float sx = 0, sy = 0; for (int j = rowptr[r]; j < rowptr[r + 1]; ++j) { sx += fabsf(vx[j]); sy += fabsf(vy[j]); } gn = std::max(gn, std::max(sx, sy)); }
+        const float* d = dev(std::vector<float>{am[0], am[1], gn});
+        if (!getenv("KB_NO_AMAX")) { mb.evecs_amax = d; mb.mass_amax = d + 1; mb.grad_norm = d + 2; }
     }
 
     auto randv = [&](size_t n, float sc) { std::vector<float> v(n); for (auto& x : v) x = sc * Nrm(rng); return v; };
