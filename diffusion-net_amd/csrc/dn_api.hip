@@ -475,7 +475,9 @@ int dn_linear_bwd_f32(const dn_mesh_batch_t* mb, const float* d_out, const float
 // through dn_block_params_t / dn_block_grads_t, and are measured by the call when the caller passes none.
 // Eligible: aligned operands and widths the split kernels take (C, K and every MLP width multiples of 32 and >= 128); anything else
 // -- and DN_F16=0 in the environment -- runs the split-bf16 / exact-f32 engines exactly as before.
-enum { AW_IN = 0, AW_YS, AW_WA, AW_MISC, AW_W0, AW_D0 = AW_W0 + DN_MAX_MLP_LAYERS, AW_COUNT = AW_D0 + DN_MAX_MLP_LAYERS + 1 };   // call-local words
+enum { AW_IN = 0, AW_YS, AW_MISC, AW_WA, AW_W0, AW_D0 = AW_W0 + DN_MAX_MLP_LAYERS, AW_COUNT = AW_D0 + DN_MAX_MLP_LAYERS + 1 };   // call-local words:
+// [0, AW_WA) and [AW_D0, ..) are accumulated into (zeroed by the start-of-call launch), [AW_WA, AW_D0) are STORED by that same launch -- the two
+// sets must not overlap: the zeroing workgroup runs concurrently with the storing ones (it once wiped the weight magnitude in 1 call of 2000)
 enum { SW_X = 0, SW_XD, SW_G, SW_H0 };                                                                                          // saved words
 static_assert(SW_H0 + DN_MAX_MLP_LAYERS <= DN_BLOCK_AMAX_WORDS, "saved amax words");
 static bool block_f16_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p) {
@@ -541,7 +543,7 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
         AmaxInit in; memset(&in, 0, sizeof(in));
         if (p->with_grad) { in.jobs.push(p->A_re, (long long)C * C, aw + AW_WA); if (p->with_rot) in.jobs.push(p->A_im, (long long)C * C, aw + AW_WA); }
         for (int j = 0; j < p->n_mlp && in.jobs.count < DN_AMAX_MAX_JOBS; ++j) in.jobs.push(p->W[j], (long long)p->widths[j] * p->widths[j + 1], aw + AW_W0 + j);
-        in.zero_range(aw, AW_W0);                                                  // AW_IN, AW_YS, (AW_WA is stored), AW_MISC
+        in.zero_range(aw, AW_WA);                                                  // AW_IN, AW_YS, AW_MISC
         in.zero_range(aw + AW_D0, DN_MAX_MLP_LAYERS + 1 + DN_BLOCK_AMAX_WORDS + 2);
         if (sv) in.zero_range(sw, DN_BLOCK_AMAX_WORDS);
         in.zero_range(p->out_amax, 1);
@@ -650,7 +652,7 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
         AmaxInit in; memset(&in, 0, sizeof(in));
         if (p->with_grad) { in.jobs.push(p->A_re, (long long)C * C, aw + AW_WA); if (p->with_rot) in.jobs.push(p->A_im, (long long)C * C, aw + AW_WA); }
         for (int j = 0; j < p->n_mlp && in.jobs.count < DN_AMAX_MAX_JOBS; ++j) in.jobs.push(p->W[j], (long long)p->widths[j] * p->widths[j + 1], aw + AW_W0 + j);
-        in.zero_range(aw, AW_W0);
+        in.zero_range(aw, AW_WA);
         in.zero_range(aw + AW_D0, DN_MAX_MLP_LAYERS + 1 + DN_BLOCK_AMAX_WORDS + 2);
         in.zero_range(gr->d_x_amax, 1);
         DN_CHECK(dn_launch_amax_init(in, st));

@@ -218,11 +218,20 @@ struct DnAmax {
     const float* mul;
     float c;
 };
+// The words are read with device-scope atomic loads (they are written by atomics of the kernels launched before; belt and braces --
+// the one run-to-run flip seen during bring-up was a host-side bug: a word zeroed concurrently with the store that set it).
+__device__ __forceinline__ float dn_amax_word(const float* p) {
+#ifdef DN_EMULATE
+    return *p;
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
 __device__ __forceinline__ float dn_amax_eval(const DnAmax& a) {
     float m = a.c;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) if (a.p[i]) { const float v = *a.p[i]; m = v > m ? v : m; }
-    if (a.mul) m *= *a.mul;
+    for (int i = 0; i < 3; ++i) if (a.p[i]) { const float v = dn_amax_word(a.p[i]); m = v > m ? v : m; }
+    if (a.mul) m *= dn_amax_word(a.mul);
     return m;
 }
 // atomic max of a non-negative float through its bit pattern (monotonic for x >= 0; NaN never raises the word: it propagates through the

@@ -12,6 +12,10 @@ bool dn_rowgemm_try_persistent(const RgArgs& g, int ntiles, int nout, hipStream_
 #ifndef DN_RG_X3
 #define DN_RG_X3 1   // -DDN_RG_X3=0: exact-f32 MFMA in the two-output kernels
 #endif
+#if defined(DN_DEBUG_SCALES) && !defined(DN_EMULATE)   // development build: the operand scales every workgroup of the two-output split-fp16 kernel read
+__device__ float dn_dbg_scales[2 * 8192];
+extern "C" int dn_debug_scales_read(float* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dn_dbg_scales), (size_t)(n < 2 * 8192 ? n : 2 * 8192) * sizeof(float)); }
+#endif
 #define RG_STORE(buf)                                                                                                          \
     do {                                                                                                                       \
         if constexpr (X3) rg_store_x3<NTHR, NOUT, BCOLK, HASQ, A_IT, B_IT, NP>(reinterpret_cast<unsigned char*>(buf),           \
@@ -42,6 +46,9 @@ void rowgemm_kernel(RgArgs g) {
         sa = dn_pow2_scale(dn_amax_eval(g.a_amax));
         sb = dn_pow2_scale(dn_amax_eval(g.b_amax));
         so = (1.f / sa) * (1.f / sb);
+#if defined(DN_DEBUG_SCALES) && !defined(DN_EMULATE)
+        if (threadIdx.x == 0 && blockIdx.x < 8192 && blockIdx.y == 0) { dn_dbg_scales[2 * blockIdx.x] = sa; dn_dbg_scales[2 * blockIdx.x + 1] = sb; }
+#endif
     }
 
     constexpr int NTHR = WR * WC * 64;

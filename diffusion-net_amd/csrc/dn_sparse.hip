@@ -29,7 +29,8 @@
 // on the transposed gather).
 template <int VEC, int MODE, bool AMAX>
 __global__ __launch_bounds__(256) void spmm_kernel(SpArgs s, int tpr) {
-    if (!AMAX && s.o_amax && blockIdx.x == 0 && threadIdx.x == 0) *s.o_amax = *s.in_amax * *s.op_norm;
+    if (!AMAX && s.o_amax && blockIdx.x == 0 && threadIdx.x == 0)     // (atomic: the word is read with device-scope atomic loads)
+        atomicMax(reinterpret_cast<unsigned*>(s.o_amax), __float_as_uint(dn_amax_word(s.in_amax) * dn_amax_word(s.op_norm)));
 
     const int tid = threadIdx.x;
     const int rl = tid / tpr, cg = tid % tpr;
