@@ -105,20 +105,27 @@ def gradient_features(gx, gy, A_re=None, A_im=None, A=None):
 # --------------------------------------------------------------------------
 # MiniMLP (layers.py:137-164)
 # --------------------------------------------------------------------------
-def mini_mlp(h, weights, biases, keep_masks=None):
+def mini_mlp(h, weights, biases, keep_masks=None, act_pattern=None, capture=None):
     """Linear stack with ReLU between layers and dropout(p=.5) in front of every
     layer but the first (layers.py:143-147); nothing after the last (layers.py:160).
 
     keep_masks: None (eval / dropout off) or a list with one {0,1} mask per
     layer i>0, shaped like that layer's input; kept values are scaled by 2 as
-    nn.Dropout(p=.5) does."""
+    nn.Dropout(p=.5) does.
+    Test diagnostics (no reference counterpart): ``capture`` -- a list that receives the pre-activations of every hidden layer;
+    ``act_pattern`` -- one boolean tensor per hidden layer: the ReLU is replaced by "pass where True, zero where False", i.e. the
+    network is evaluated with a GIVEN activation pattern (a ReLU net is piecewise linear: its gradient is only defined per pattern,
+    and a unit whose pre-activation lies within rounding distance of zero may land on either side in any finite-precision
+    evaluation, including the reference's own)."""
     n = len(weights)
     for i in range(n):
         if keep_masks is not None and i > 0:
             h = h * keep_masks[i - 1] * 2.0
         h = h @ weights[i].T + biases[i]
         if i + 1 < n:
-            h = torch.relu(h)
+            if capture is not None:
+                capture.append(h.detach())
+            h = torch.relu(h) if act_pattern is None else h * act_pattern[i].to(h.dtype)
     return h
 
 
@@ -144,7 +151,7 @@ def count_blocks(params):
 # --------------------------------------------------------------------------
 # DiffusionNetBlock (layers.py:200-241)
 # --------------------------------------------------------------------------
-def block_forward(params, prefix, x, mass, evals, evecs, gradX, gradY, keep_masks=None):
+def block_forward(params, prefix, x, mass, evals, evecs, gradX, gradY, keep_masks=None, act_pattern=None, capture=None):
     time = clamp_time(params[f"{prefix}.diffusion.diffusion_time"])
     xd = spectral_diffusion(x, mass, evals, evecs, time)                  # layers.py:210
     feats = [x, xd]
@@ -159,7 +166,7 @@ def block_forward(params, prefix, x, mass, evals, evecs, gradX, gradY, keep_mask
         feats.append(gradient_features(gx, gy, A=params[f"{prefix}.gradient_features.A.weight"]))
     h0 = torch.cat(feats, dim=-1)                                         # layers.py:229/232
     ws, bs = mlp_params(params, prefix)
-    return mini_mlp(h0, ws, bs, keep_masks) + x                           # layers.py:236-239
+    return mini_mlp(h0, ws, bs, keep_masks, act_pattern, capture) + x     # layers.py:236-239
 
 
 # --------------------------------------------------------------------------
@@ -179,7 +186,7 @@ def remap_outputs(x, outputs_at, mass=None, edges=None, faces=None):
 
 
 def net_forward(params, x_in, mass, evals, evecs, gradX=None, gradY=None, edges=None, faces=None,
-                outputs_at="vertices", last_activation=None, keep_masks=None):
+                outputs_at="vertices", last_activation=None, keep_masks=None, act_patterns=None, capture=None):
     """Whole-net forward.  ``params``: dict of tensors keyed like the reference's
     state_dict.  Inputs unbatched ([V,..]) or batched ([B,V,..]) as layers.py:346-363;
     gradX/gradY torch sparse COO ([V,V] / [B,V,V]) or a list of [V,V] sparse.
@@ -204,7 +211,11 @@ def net_forward(params, x_in, mass, evals, evecs, gradX=None, gradY=None, edges=
     x = x_in @ params["first_lin.weight"].T + params["first_lin.bias"]      # layers.py:366
     for i in range(count_blocks(params)):                                    # layers.py:369-370
         km = keep_masks[i] if keep_masks is not None else None
-        x = block_forward(params, f"block_{i}", x, mass, evals, evecs, gradX, gradY, km)
+        cap = [] if capture is not None else None
+        x = block_forward(params, f"block_{i}", x, mass, evals, evecs, gradX, gradY, km,
+                          act_patterns[i] if act_patterns is not None else None, cap)
+        if capture is not None:
+            capture.append(cap)
     x = x @ params["last_lin.weight"].T + params["last_lin.bias"]           # layers.py:373
     out = remap_outputs(x, outputs_at, mass=mass, edges=edges, faces=faces)
     if last_activation is not None:                                          # layers.py:400-401
@@ -213,14 +224,14 @@ def net_forward(params, x_in, mass, evals, evecs, gradX=None, gradY=None, edges=
 
 
 def net_forward_backward(params, inputs, outputs_at="vertices", last_activation=None,
-                         keep_masks=None, loss_weights=None):
+                         keep_masks=None, loss_weights=None, act_patterns=None, capture=None):
     """Forward + autograd backward of ``sum(out * loss_weights)``; returns
     (out, grads-dict incl. 'x_in').  Parameters are re-leafed so callers keep theirs."""
     leaf = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
     x_in = inputs["x_in"].detach().clone().requires_grad_(True)
     kw = {k: v for k, v in inputs.items() if k != "x_in"}
     out = net_forward(leaf, x_in, outputs_at=outputs_at, last_activation=last_activation,
-                      keep_masks=keep_masks, **kw)
+                      keep_masks=keep_masks, act_patterns=act_patterns, capture=capture, **kw)
     w = loss_weights if loss_weights is not None else torch.ones_like(out)
     (out * w).sum().backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}

@@ -128,7 +128,26 @@ def run_ragged_net(device, sizes=(130, 257, 64), K=24, C=32, C_in=3, C_out=5, N_
             rows.append(m["faces"] + offs)
             offs += v
         gather = GatherPattern(torch.cat(rows, 0).to(device), sum(sizes))
-    out = model.forward_packed(x, mb, gather)
+    saved_h = None
+    if fp64_bracket and masks is None:
+        # keep the post-ReLU activations the HIP forward saved for its backward (one list per block): the activation pattern its
+        # gradients belong to (see the flip-aware criterion below)
+        keep_out = {}
+        orig_fp = diffusion_net.layers.DiffusionNetBlock.forward_packed
+        def _fp(self, x2d, mb_):
+            o = orig_fp(self, x2d, mb_)
+            keep_out[id(self)] = o
+            return o
+        diffusion_net.layers.DiffusionNetBlock.forward_packed = _fp
+    try:
+        out = model.forward_packed(x, mb, gather)
+    finally:
+        if fp64_bracket and masks is None:
+            diffusion_net.layers.DiffusionNetBlock.forward_packed = orig_fp
+    if fp64_bracket and masks is None:
+        n_h = len(model.blocks[0].mlp.linears()) - 1
+        n_feat = 5 if model.blocks[0].with_gradient_features else 0
+        saved_h = [[t.cpu() for t in keep_out[id(blk)].grad_fn.saved_tensors[5 + n_feat:5 + n_feat + n_h]] for blk in model.blocks]
     wgen = torch.Generator().manual_seed(seed + 1)
     w = torch.randn(out.shape, generator=wgen)
     (out * w.to(device)).sum().backward()
@@ -179,10 +198,58 @@ def run_ragged_net(device, sizes=(130, 257, 64), K=24, C=32, C_in=3, C_out=5, N_
     # fp64 oracle and allowed twice the distance the fp32 oracle itself keeps from it.
     out64, ref64 = oracle_pass(torch.float64)
     e_new, e_ref = helpers.rel_max(out.detach().cpu().double(), out64), helpers.rel_max(ref_out.double(), out64)
+    # the measured margins go to the log, so that the bracket claim can be audited
+    rows = sorted(((helpers.rel_l2(gk.double(), ref64[k]), helpers.rel_l2(ref_grads[k].double(), ref64[k]), k) for k, gk in got.items()), reverse=True)
+    print("[fp64 bracket] sizes=%s K=%d C=%d blocks=%d outputs_at=%s: forward rel-max vs fp64: new %.3e, fp32 oracle %.3e (vs fp32 oracle: %.3e); "
+          "gradients rel-L2 vs fp64, largest: %s" % (tuple(sizes), K, C, N_block, outputs_at, e_new, e_ref, e_out,
+                                                     "; ".join("%s new %.2e ref %.2e" % (k, a, b) for a, b, k in rows[:4])))
     assert e_new < max(FWD_TOL, 2 * e_ref), ("out vs fp64", e_new, e_ref)
-    for k, gk in got.items():
-        e_new, e_ref = helpers.rel_l2(gk.double(), ref64[k]), helpers.rel_l2(ref_grads[k].double(), ref64[k])
-        assert e_new < max(GRAD_TOL, 2 * e_ref), (k, e_new, e_ref)
+    bad = [(a, b, k) for a, b, k in rows if not a < max(GRAD_TOL, 2 * b)]
+    if bad:
+        # A ReLU net is piecewise linear: its gradient is defined per ACTIVATION PATTERN, and a unit whose pre-activation lies within
+        # rounding distance of zero lands on either side in any finite-precision evaluation.  With random loss weights one flipped
+        # (vertex, unit) pair moves a parameter gradient by ~1/sqrt(#terms) = 1e-3 relative -- the fp32 oracle does it to itself (4e-3
+        # from fp64 on the two-mesh case of the headline test); on the one-mesh case round 3's engine flipped ONE unit whose exact
+        # pre-activation is 1.5e-8 of the layer's scale (tools/flip_probe.py).  Criterion for the tensors that miss the simple bracket:
+        #   (1) the pattern of the HIP forward differs from the exact (fp64) one only at units whose exact pre-activation is within
+        #       2^-20 of the layer's largest, and at fewer than one unit in 10^5;
+        #   (2) against the EXACT gradient of the network evaluated with the HIP forward's own pattern the simple bracket holds.
+        assert masks is None and saved_h is not None
+        got_rows, grads_p, n_flip, n_units, worst = 0, None, 0, 0, 0.0
+        off_out = 0
+        for m, f in zip(meshes, feats):
+            n_out = {"vertices": f.shape[0], "faces": m["faces"].shape[0], "global_mean": 1}[outputs_at]
+            wi = w[off_out:off_out + n_out]
+            off_out += n_out
+            c64 = lambda t: t.double() if t.is_floating_point() else t
+            pattern = [[h[got_rows:got_rows + f.shape[0]] > 0 for h in blk] for blk in saved_h]
+            cap = []
+            _, gg = orc.net_forward_backward({k: c64(v) for k, v in params.items()},
+                                             dict(x_in=c64(f), mass=c64(m["mass"]), evals=c64(m["evals"]), evecs=c64(m["evecs"]),
+                                                  gradX=c64(m["gradX"]), gradY=c64(m["gradY"]), faces=m["faces"]),
+                                             outputs_at=outputs_at, loss_weights=c64(wi[0] if outputs_at == "global_mean" else wi),
+                                             act_patterns=pattern, capture=cap)
+            for pb, cb in zip(pattern, cap):
+                for pat, z in zip(pb, cb):
+                    z = z.reshape(pat.shape)
+                    flips = pat != (z > 0)
+                    n_flip += int(flips.sum()); n_units += pat.numel()
+                    if bool(flips.any()):
+                        worst = max(worst, float(z[flips].abs().max() / z.abs().max()))
+            got_rows += f.shape[0]
+            if grads_p is None:
+                grads_p = {k: v.clone() for k, v in gg.items() if k != "x_in"}
+            else:
+                for k, v in gg.items():
+                    if k != "x_in":
+                        grads_p[k] += v
+        print("[fp64 bracket] activation pattern of the HIP forward vs exact: %d of %d hidden units differ, largest exact |pre-activation| among "
+              "them %.2e of its layer's maximum" % (n_flip, n_units, worst))
+        assert n_flip <= max(1, n_units // 100000) and worst < 2.0 ** -20, (n_flip, n_units, worst)
+        for a, b, k in bad:
+            a2 = helpers.rel_l2(got[k].double(), grads_p[k])
+            print("[fp64 bracket] %s: vs exact gradient %.2e (fp32 oracle %.2e); vs exact gradient at the forward's own activation pattern %.2e" % (k, a, b, a2))
+            assert k != "x_in" and a2 < max(GRAD_TOL, 2 * b), (k, a, b, a2)
 
 
 # ------------------------------------------------------------------------------------------
