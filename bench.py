@@ -29,7 +29,7 @@ import torch.nn.functional as F
 PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: exact-f32 MFMA = f32 vector peak
 PEAK_HBM_GBPS = 8000.0            # HBM3E spec (6.29 TB/s measured copy ceiling)
 PEAK_MFMA_BF16_TFLOPS = 2500.0    # dense bf16 MFMA (no sparsity)
-TRAFFIC_JSON = "r02_traffic.json"  # PMC FETCH/WRITE passes of the same command (tools/pmc_run.sh + tools/traffic_summary.py)
+TRAFFIC_JSON = "r03_traffic.json"  # PMC FETCH/WRITE passes of the same kernels (tools/pmc_run.sh + tools/traffic_summary.py), committed under profiles/
 
 
 def mesh_sizes(n_meshes, v_mean, rank):
@@ -216,7 +216,9 @@ def kernel_family_report(lib):
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_JSON)))
         roof["traffic"] = tr[dom["kernel"]]["hbm_bytes_per_launch"]
-        roof["traffic_note"] = "PMC (2*FETCH_SIZE+WRITE_SIZE)*1024 B per launch; algorithmic bytes per launch = %.4g" % dom["bytes_per_launch"]
+        roof["traffic_source"] = ("NOT measured in this run: read from profiles/%s -- separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; "
+                                  "(2*FETCH_SIZE+WRITE_SIZE)*1024 B per launch, gfx950 read correction) over tools/microbench.py at this batch shape; "
+                                  "algorithmic bytes per launch = %.4g" % (TRAFFIC_JSON, dom["bytes_per_launch"]))
     except Exception:
         pass
     roof.update({"kernel": dom["kernel"], "avg_launch_us": dom["avg_us"], "launches": dom["launches"],
@@ -341,6 +343,7 @@ def run_other_config(args, device, lib, world, rank):
     assert torch.isfinite(loss).item()
     fam, roof = ([], None) if args.graph else kernel_family_report(lib)   # a replayed graph bypasses the library's host-side event brackets
     print(json.dumps({
+        "engine": _engine_note(),
         "metric": "vertices/sec %s, C_width=%d K=%d" % ("fwd" if cfg == "cfg4" else "fwd+bwd", Cw, K),
         "value": verts / elapsed, "unit": "vertices/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -348,18 +351,51 @@ def run_other_config(args, device, lib, world, rank):
         "roofline": roof, "kernel_families": fam}))
 
 
+def _engine_note():
+    return ("split-bf16 MFMA only (DN_F16=0)" if os.environ.get("DN_F16") == "0" else
+            "row products (gradient features, MLP, input gradients, backward back-projection) on 2-term split-fp16 MFMA with producer-side "
+            "power-of-two scales; projections, forward back-projection and all parameter-gradient sums on 3-term split-bf16 MFMA")
+
+
+def other_configs_brief(args):
+    """Short runs of the other BASELINE.json configs, each in its own process (its own model, graphs and allocator state), summarised for the
+    headline line's `configs` object.  cfg5 here is the single-GPU shard shape; its multi-GPU form is `--gpus N --config cfg5`."""
+    import subprocess
+    out = {}
+    runs = (("cfg2", ["--config", "cfg2", "--steps", "40", "--warmup", "8"]),
+            ("cfg2_graph", ["--config", "cfg2", "--graph", "--steps", "40", "--warmup", "8"]),
+            ("cfg3", ["--config", "cfg3", "--graph", "--steps", "20", "--warmup", "3"]),
+            ("cfg4", ["--config", "cfg4", "--steps", "5", "--warmup", "1"]),
+            ("cfg5", ["--config", "cfg5", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-other-configs"]))
+    for name, extra in runs:
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra, capture_output=True, text=True, timeout=300)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[name] = {"error": (r.stderr or r.stdout)[-300:]}
+                continue
+            d = json.loads(line[-1])
+            out[name] = {"value": d["value"], "unit": d["unit"], "metric": d["metric"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                         "workload": d["config"]["workload"], "wall_s": round(time.perf_counter() - t0, 1)}
+        except Exception as e:      # noqa: BLE001
+            out[name] = {"error": repr(e)[:300]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--meshes", type=int, default=16, help="meshes per GPU per step")
-    ap.add_argument("--verts", type=int, default=10000, help="mean vertices per mesh")
+    ap.add_argument("--meshes", type=int, default=None, help="meshes per GPU per step (default 16; cfg5: 8)")
+    ap.add_argument("--verts", type=int, default=None, help="mean vertices per mesh (default 10000; cfg5: 15000)")
     ap.add_argument("--cwidth", type=int, default=128)
     ap.add_argument("--keig", type=int, default=128)
     ap.add_argument("--blocks", type=int, default=4)
     ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch into this many sub-batches run on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="headline at 1 GPU: do not append the short runs of cfg2..cfg5 (`configs` object)")
     ap.add_argument("--graph", action="store_true", help="cfg2/cfg3: replay a captured HIP graph of the step (diffusion_net.graphs) instead of enqueueing ~150 launches per step "
                                                          "(the headline step is replayed from a graph by default; see --eager)")
     ap.add_argument("--graph-collectives", action="store_true", help="N > 1: capture the bucketed RCCL all-reduce inside the step graph instead of issuing one flat all-reduce from the host after the replay")
@@ -420,7 +456,8 @@ def main():
     at_faces = True
     if args.config == "cfg5":                  # rna_mesh_segmentation.py:69-75: C_out = 260 classes, outputs_at = 'vertices', ~15k-vertex meshes
         C_out, at_faces = 260, False
-        args.meshes, args.verts = 8, 15000
+        args.meshes, args.verts = args.meshes or 8, args.verts or 15000
+    args.meshes, args.verts = args.meshes or 16, args.verts or 10000
     torch.manual_seed(0)                       # identical replicas on every rank
     model = diffusion_net.layers.DiffusionNet(C_in, C_out, C_width=args.cwidth, N_block=args.blocks, outputs_at="faces" if at_faces else "vertices",
                                               dropout=True, last_activation=lambda t: F.log_softmax(t, dim=-1))   # as human_segmentation_original.py:69-75
@@ -434,6 +471,20 @@ def main():
         opt = torch.optim.Adam([flat.master], lr=1e-3)
 
     sizes = mesh_sizes(args.meshes, args.verts, rank)
+    shard_note = None
+    if args.config == "cfg5":
+        # ONE ragged dataset for the whole job (the rna_mesh_segmentation shape: ~15k-vertex meshes, here 0.6..1.4 x --verts), split over the ranks
+        # with the package's greedy longest-processing-time sharding (diffusion_net.dist.shard_by_cost; cost = vertices): the designed
+        # multi-GPU path end to end.  Ranks hold different mesh counts; the imbalance is reported next to the rate.
+        from diffusion_net.dist import shard_by_cost
+        g = torch.Generator().manual_seed(4321)
+        all_sizes = [int(args.verts * (0.6 + 0.8 * torch.rand(1, generator=g).item())) for _ in range(args.meshes * world)]
+        mine = shard_by_cost(all_sizes, world)[rank]
+        sizes = [all_sizes[i] for i in mine]
+        per_rank = [sum(all_sizes[i] for i in part) for part in shard_by_cost(all_sizes, world)]
+        shard_note = {"dataset_meshes": len(all_sizes), "dataset_vertices": sum(all_sizes), "meshes_per_rank": [len(p_) for p_ in shard_by_cost(all_sizes, world)],
+                      "vertices_per_rank": per_rank, "load_imbalance_max_over_mean": max(per_rank) / (sum(per_rank) / len(per_rank))}
+        args.meshes = len(sizes)
     subs = []
     for j in range(nsub):
         sub_sizes = sizes[j::nsub]
@@ -539,41 +590,64 @@ def main():
         v_all = float(v_step)
     assert torch.isfinite(loss).item()
 
+    eager_ms = None
     if gs is not None:      # the library's per-launch event brackets are host-side: time the same launches in a short eager pass
         lib.dn_prof_reset()
         lib.dn_prof_enable(1)
+        te = time.perf_counter()
         for _ in range(min(args.steps, 5)):
             gs._body()
             gs._tail()
         fence()
+        eager_ms = 1e3 * (time.perf_counter() - te) / min(args.steps, 5)
         lib.dn_prof_enable(0)
     fam, roof = kernel_family_report(lib)
     if roof is not None:
+        fam_ms = sum(f["ms_total"] for f in fam) / (min(args.steps, 5) if gs is not None else args.steps)
         roof["timing"] = ("HIP events around every launch of %d eager steps run right after the timed graph replays (the event brackets are "
                           "host-side; a replayed graph bypasses them); profiles/ holds the rocprofv3 kernel trace of the replays themselves"
                           % min(args.steps, 5)) if gs is not None else "HIP events around every launch of the timed steps"
+        # the brackets inflate: event records sit between the launches and the eager pass has host gaps the replay does not
+        roof["families_ms_per_step"] = fam_ms
+        roof["bracket_inflation_vs_timed_step"] = fam_ms / (1e3 * elapsed / args.steps)
+        if eager_ms is not None:
+            roof["eager_pass_ms_per_step"] = eager_ms
 
     # ---- diffusion block (to_basis + exp(-lambda t) + from_basis) on the same batch: HBM GB/s of BASELINE.json
     from diffusion_net import ops
     Cw, K = args.cwidth, args.keig
     v_sub0 = subs[0][4]
     sizes = sizes[0::nsub]
-    xb = torch.randn(v_sub0, Cw, device=device)
     tt = torch.full((Cw,), 0.05, device=device)
-    with torch.no_grad():
-        for _ in range(3):
-            ops.DiffusionFn.apply(xb, tt, mb)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        reps = 20
-        for _ in range(reps):
-            ops.DiffusionFn.apply(xb, tt, mb)
-        e1.record()
-        torch.cuda.synchronize()
-    t_diff = e0.elapsed_time(e1) * 1e-3 / reps
     bytes_diff = sum(4.0 * (v * (2 * Cw + 2 * K + 1) + 2 * K * Cw + K + Cw) for v in sizes)
     flops_diff = sum(4.0 * v * K * Cw for v in sizes)
+
+    def time_diffusion(n_rot):
+        # n_rot input buffers touched in turn (the eigenbasis itself is one 81 MB array: it is re-read from HBM only when the inputs and
+        # outputs streaming past it evict it from the 256 MiB Infinity Cache, as in the network)
+        xs_ = [torch.randn(v_sub0, Cw, device=device) for _ in range(n_rot)]
+        with torch.no_grad():
+            for i in range(3):
+                ops.DiffusionFn.apply(xs_[i % n_rot], tt, mb)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            reps = 24
+            keep = []
+            for i in range(reps):
+                keep.append(ops.DiffusionFn.apply(xs_[i % n_rot], tt, mb))
+                if len(keep) > n_rot:
+                    keep.pop(0)
+            e1.record()
+            torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+    t_diff = time_diffusion(8)        # 8 inputs + 8 live outputs x 81 MB = 1.3 GB in rotation: HBM
+    t_diff_cached = time_diffusion(1)
     diff = {"ms": t_diff * 1e3, "gbps": bytes_diff / t_diff / 1e9, "frac_hbm_8TBs": bytes_diff / t_diff / 1e9 / PEAK_HBM_GBPS,
+            "frac_of_measured_copy_6p3TBs": bytes_diff / t_diff / 1e9 / 6300.0,
+            "buffers": "8 rotating input / output sets (1.3 GB): operands come from HBM as inside the network; one re-used set (Infinity-Cache assisted): "
+                       "%.3f ms = %.3f of 8 TB/s" % (t_diff_cached * 1e3, bytes_diff / t_diff_cached / 1e9 / PEAK_HBM_GBPS),
+            "copy_calibration": "hand-written float4 nontemporal copy on 2 GiB of rotating buffers: 6.2-6.36 TB/s = 0.79 of 8 TB/s; hipMemcpy D2D 5.3 TB/s "
+                                "(tools/kbench --ops copyk, profiles/r03_copy_calibration.txt)",
             "tflops": flops_diff / t_diff / 1e12, "frac_mfma_f32": flops_diff / t_diff / 1e12 / PEAK_MFMA_F32_TFLOPS,
             "frac_mfma_bf16x3": flops_diff / t_diff / 1e12 / (PEAK_MFMA_BF16_TFLOPS / 6.0),
             "note": "arithmetic intensity KC/(2(K+C)) = %.0f flop/B; ridge 19.7 (f32 MFMA) / 52 (split-bf16 MFMA, used) -> HBM-bound" % (K * Cw / (2.0 * (K + Cw)))}
@@ -585,18 +659,24 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "arithmetic": "fp32 storage and accumulation; dense products on 3-term split-bf16 MFMA (fp32-level accuracy: rel-L2 1.6e-7 vs 2.0e-7 for the f32 MFMA chain, profiles/r01_exp_bf16x3.txt)",
+            "arithmetic": "fp32 storage, accumulation and epilogues; dense products on split MFMA with fp32-level accuracy: " + _engine_note() +
+                          " (forward of the 4-block net vs fp64: 3.3e-7 rel-max against 1.4e-7 for the fp32 CPU evaluation, tolerance 1e-5; every gradient "
+                          "within 1e-6 rel-L2 of the exact gradient at the forward's activation pattern: profiles/r03_gpu_tests.log)",
             "config": {"workload": "train step (fwd+NLL+bwd+Adam%s) on a ragged batch of %d meshes x ~%d vertices per GPU, "
                                    "DiffusionNet C_in=3 C_out=%d C_width=%d K=%d N_block=%d outputs_at=%s dropout=on"
                                    % ("+RCCL all-reduce" if world > 1 else "", args.meshes, args.verts, C_out, Cw, K, args.blocks, "faces" if at_faces else "vertices"),
                        "baseline_config": args.config, "meshes_per_gpu": args.meshes, "verts_per_gpu_step": v_step, "parallelism": "dp%d" % world,
-                       "streams_per_gpu": nsub, "step_mode": step_mode,
+                       "streams_per_gpu": nsub, "step_mode": step_mode, **({"sharding": shard_note} if shard_note else {}),
                        **({"TEST_ONLY": "all ranks share GPU 0, gloo collectives (DN_BENCH_TEST_SHARED_GPU)"} if shared_gpu else {})},
             "roofline": roof, "kernel_families": fam, "diffusion_block": diff,
         }
         if not args.no_cpu_baseline and world == 1 and args.config == "headline":   # reported at N = 1 only (the other ranks would sit idle behind it)
             res["cpu_baseline"] = cpu_baseline(args, C_out, mesh_sizes(args.meshes, args.verts, 0))
             res["torch_rocm_baseline"] = torch_rocm_baseline(args, C_out, mesh_sizes(args.meshes, args.verts, 0), device)
+        if world == 1 and args.config == "headline" and not args.no_other_configs:
+            del gs, model, flat, subs, mb            # hand the GPU's memory back before the other configs' processes start
+            torch.cuda.empty_cache()
+            res["configs"] = other_configs_brief(args)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

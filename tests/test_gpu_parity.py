@@ -287,6 +287,14 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(dev):
     d = lines[0]
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["value"] > 0
     assert "forward+backward" in d["config"]["step_mode"], d["config"]["step_mode"]     # graph replay, host-issued all-reduce
+    # cfg5: ONE ragged dataset split over the ranks by cost (diffusion_net.dist.shard_by_cost), imbalance reported
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "cfg5", "--steps", "2", "--warmup", "1", "--meshes", "3",
+                        "--verts", "3000", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")][0]
+    sh = d["config"]["sharding"]
+    assert d["n_gpus"] == 2 and sh["dataset_meshes"] == 6 and sum(sh["meshes_per_rank"]) == 6 and sum(sh["vertices_per_rank"]) == sh["dataset_vertices"]
+    assert 1.0 <= sh["load_imbalance_max_over_mean"] < 1.25 and d["value"] > 0
 
 
 def test_run_to_run_determinism_stress(dev):
