@@ -21,6 +21,21 @@ from . import _hip
 
 _table_cache = {}
 
+# integer handles of the packed objects, for the torch.library ops (torchlib.py): custom operators take tensors and plain numbers only
+_handles = weakref.WeakValueDictionary()
+_next_handle = [1]
+
+
+def register_handle(obj) -> int:
+    k = _next_handle[0]
+    _next_handle[0] += 1
+    _handles[k] = obj
+    return k
+
+
+def handle_object(k: int):
+    return _handles[int(k)] if k else None
+
 
 def default_chunk_rows(v_total: int) -> int:
     """Rows per split-V chunk: aim for >= ~512 chunks, 128 <= rows <= 1024, multiple of 32."""
@@ -96,6 +111,7 @@ class MeshBatch:
         self.g_rowptr = self.g_col = self.g_vx = self.g_vy = None
         self.gt_rowptr = self.gt_col = self.gt_vx = self.gt_vy = None
         self.tiles = self.chunks = self.mesh_chunk_off = self.mesh_rows = None
+        self.handle = register_handle(self)
         self.amax = None          # [3] device floats: max |evecs|, max |mass|, ||[gradX; gradY]||_inf (magnitudes for the split-fp16 engine, dn_api.hip)
         self._struct = None
 
@@ -233,6 +249,7 @@ class GatherPattern:
     def __init__(self, index: torch.Tensor, n_src_rows: int):
         # index: [n_out, n_per] int64, global row ids into the [n_src_rows, C] source
         n_out, n_per = index.shape
+        self.handle = register_handle(self)
         self.n_out, self.n_per, self.n_src = int(n_out), int(n_per), int(n_src_rows)
         self.rowptr, self.col, _, _, self.t_rowptr, self.t_col, _, _ = coo_to_csr(None, n_per, index.reshape(-1), None, None,
                                                                                   self.n_out, self.n_src)

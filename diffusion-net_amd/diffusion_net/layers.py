@@ -24,6 +24,15 @@ from .batch import GatherPattern, MeshBatch, operator_cache
 _MIN_TIME = 1e-8
 
 
+def _compiling():
+    """True while torch.compile / torch.export is tracing: the ops then go through their torch.library registrations (torchlib.py),
+    which a compiler keeps as opaque graph nodes; eager execution calls the autograd Functions of ops.py directly."""
+    if torch.compiler.is_compiling():
+        from . import torchlib  # noqa: F401  (registers torch.ops.diffusion_net.*)
+        return True
+    return False
+
+
 def _linear_init_(weight: torch.Tensor, bias: Optional[torch.Tensor]):
     """Same distribution as ``nn.Linear.reset_parameters`` (U(+-1/sqrt(fan_in)))."""
     nn.init.kaiming_uniform_(weight, a=math.sqrt(5))
@@ -44,6 +53,8 @@ class _RowLinear(nn.Module):
 
     def apply_rows(self, x2d, mb):
         b = self.bias if self.bias is not None else torch.zeros(self.out_features, device=x2d.device)
+        if _compiling():
+            return torch.ops.diffusion_net.linear(x2d, self.weight, b, mb.handle)
         return ops.LinearFn.apply(x2d, self.weight, b, mb)
 
     def forward(self, x):
@@ -77,6 +88,10 @@ class LearnedTimeDiffusion(nn.Module):
         # optimizer sees the clamped value); done in place so flat parameter buckets keep their storage
         # (.data: the clamp is idempotent between optimizer steps and must not invalidate tensors another
         # in-flight forward saved for its backward)
+        if torch.compiler.is_compiling():
+            with torch.no_grad():
+                self.diffusion_time.clamp_(min=_MIN_TIME)
+            return
         self.diffusion_time.data.clamp_(min=_MIN_TIME)
 
     def forward(self, x, L, mass, evals, evecs):
@@ -179,6 +194,8 @@ class DiffusionNetBlock(nn.Module):
         if not (self.training and self.dropout):
             return None
         if self.mask_provider is None:
+            if torch.compiler.is_compiling():   # a traceable draw: constant host part + a device word from torch's device generator
+                return (0x5DEECE66D | 1, torch.randint(1, 2 ** 62, (1,), dtype=torch.int64, device=device))
             gs = getattr(self, "_graph_seed", None)
             if gs is not None:           # graphs.GraphedTrainStep: (constant host part, device word advanced by the graph itself)
                 return gs
@@ -212,6 +229,12 @@ class DiffusionNetBlock(nn.Module):
         for lin in self.mlp.linears():
             wb += [lin.weight, lin.bias]
         masks = self._dropout_masks(x2d.shape[0], x2d.device)
+        if _compiling():
+            if isinstance(masks, list):
+                raise NotImplementedError("explicit dropout masks (a test hook) are not available under torch.compile")
+            seed, seed_dev = (masks if isinstance(masks, tuple) else (masks or 0, None))
+            return torch.ops.diffusion_net.block(x2d, self.diffusion.diffusion_time, A_re, A_im, wb, mb.handle, self._cfg.handle, seed, seed_dev,
+                                                 mb.n_mesh, mb.k_eig)[0]
         return ops.BlockFn.apply(mb, self._cfg, masks, x2d, self.diffusion.diffusion_time, A_re, A_im, *wb)
 
     def forward(self, x_in, mass, L, evals, evecs, gradX, gradY):
@@ -319,13 +342,17 @@ class DiffusionNet(nn.Module):
         ``gather`` built from global vertex ids) or [n_mesh, C_out] ('global_mean'); the last
         activation is applied as in ``forward``."""
         x = self._trunk(x2d, mb)
+        comp = _compiling()
         if self.outputs_at != "global_mean" and self.C_out <= _hip.HEAD_MAX_CLASSES and self._activation_is_log_softmax():
             # remap + log_softmax as one kernel (the scripts' per-face / per-vertex log-probabilities)
-            return ops.HeadFn.apply(x, gather if self.outputs_at in ("edges", "faces") else None, None, True, 0.0, True)[0]
+            pat = gather if self.outputs_at in ("edges", "faces") else None
+            if comp:
+                return torch.ops.diffusion_net.head(x, pat.handle if pat is not None else 0, None, True, 0.0, pat.n_out if pat is not None else x.shape[0])[0]
+            return ops.HeadFn.apply(x, pat, None, True, 0.0, True)[0]
         if self.outputs_at in ("edges", "faces"):
-            x = ops.GatherMeanFn.apply(x, gather)
+            x = torch.ops.diffusion_net.gather_mean(x, gather.handle, gather.n_out) if comp else ops.GatherMeanFn.apply(x, gather)
         elif self.outputs_at == "global_mean":
-            x = ops.MassMeanFn.apply(x, mb)
+            x = torch.ops.diffusion_net.mass_mean(x, mb.handle, mb.n_mesh)[0] if comp else ops.MassMeanFn.apply(x, mb)
         if self.last_activation is not None:
             x = self.last_activation(x)
         return x

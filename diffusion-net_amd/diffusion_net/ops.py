@@ -13,7 +13,7 @@ from typing import List, Optional
 import torch
 
 from . import _hip
-from .batch import GatherPattern, MeshBatch
+from .batch import GatherPattern, MeshBatch, register_handle
 
 
 def _on_device(fn):
@@ -300,6 +300,7 @@ class BlockConfig:
     def __init__(self, C, widths, with_grad, with_rot):
         self.C, self.widths, self.with_grad, self.with_rot = int(C), [int(w) for w in widths], bool(with_grad), bool(with_rot)
         self.n_mlp = len(self.widths) - 1
+        self.handle = register_handle(self)
         self.grad_hook = None        # dist.FlatParams: called after the block's gradients were delivered
         self.grad_pre_hook = None    # ... and before they are written
         if self.n_mlp > _hip.MAX_MLP:

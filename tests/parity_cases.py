@@ -585,6 +585,46 @@ def run_head_edge_cases(device, V=90):
         assert torch.isnan(utils.nll_loss(lp.to(device), lab2.to(device))), bad
 
 
+def run_compile(device, sizes=(300, 140), K=16, C=32, seed=8):
+    """torch.compile of the packed forward: every op of the path is a registered torch.library operator with a fake
+    kernel and an autograd formula, so the whole network traces into ONE graph (fullgraph=True: any graph break is an error) with the
+    ops as opaque nodes; forward and all gradients equal the eager path bit for bit (the same kernels run underneath)."""
+    import torch._dynamo
+    lsm = lambda t: torch.nn.functional.log_softmax(t, dim=-1)
+    for outputs_at, act, train in (("faces", lsm, False), ("global_mean", None, False), ("vertices", lsm, True)):
+        torch.manual_seed(seed)
+        model = diffusion_net.layers.DiffusionNet(3, 6, C_width=C, N_block=2, outputs_at=outputs_at, dropout=train, last_activation=act).to(device)
+        model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=seed))
+        model.train(train)
+        meshes, feats = make_ragged(sizes, K, 3, seed)
+        mb = pack(meshes, device)
+        gather = None
+        if outputs_at == "faces":
+            offs, rows = 0, []
+            for m, v in zip(meshes, sizes):
+                rows.append(m["faces"] + offs)
+                offs += v
+            gather = GatherPattern(torch.cat(rows, 0).to(device), sum(sizes))
+        x0 = torch.cat(feats, 0).to(device)
+        torch._dynamo.reset()
+        compiled = torch.compile(lambda t: model.forward_packed(t, mb, gather), backend="aot_eager", fullgraph=True)
+        res = []
+        for fn in ((lambda t: model.forward_packed(t, mb, gather)), compiled):
+            model.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            out = fn(x)
+            if train:        # masks are drawn per call: only shapes / finiteness are comparable
+                assert out.shape[0] == sum(sizes) and bool(torch.isfinite(out).all())
+                out.square().sum().backward()
+                assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
+                continue
+            out.square().sum().backward()
+            res.append([out.detach().cpu(), x.grad.cpu()] + [p.grad.cpu() for p in model.parameters()])
+        if not train:
+            for a, b in zip(*res):
+                assert torch.equal(a, b)
+
+
 def run_head_in_net(device, sizes=(300, 140), K=16, C=32, C_out=8, seed=5, outputs_at="faces"):
     """DiffusionNet.forward_packed_loss (remap + log_softmax + NLL in one kernel each way) against the unfused sequence
     forward_packed -> F.nll_loss on the same network: same log-probabilities, same loss, same parameter gradients."""

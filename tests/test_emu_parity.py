@@ -76,6 +76,11 @@ def test_fused_head_on_emulator(emu):
     parity_cases.run_head_edge_cases(emu, V=40)
 
 
+def test_torch_compile_packed_forward_on_emulator(emu):
+    import parity_cases
+    parity_cases.run_compile(emu)
+
+
 def test_real_mesh_pipeline_on_emulator(emu):
     import parity_cases
     parity_cases.run_real_mesh_pipeline(emu)

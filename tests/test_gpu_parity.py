@@ -59,6 +59,9 @@ def test_rna_like_wide_head(dev):
     """BASELINE configs[4] shape: C_out = 260 per-vertex classes, C_width = 128 (last_lin N = 260, its backward K = 260)."""
     import parity_cases
     parity_cases.run_ragged_net(dev, sizes=(1500, 1100), K=128, C=128, C_out=260, N_block=1)
+    # at the config's depth and mesh size (rna_mesh_segmentation.py:69-75: 4 blocks, meshes of ~15k vertices; here one 11k + one 10k mesh),
+    # forward and every gradient against the fp64 bracket (VERDICT r2: cfg5's 260-wide head had only been checked at 1 block x 2.6k vertices)
+    parity_cases.run_ragged_net(dev, sizes=(11000, 10100), K=128, C=128, C_out=260, N_block=4, seed=5, fp64_bracket=True, fwd_tol=2e-5)
 
 
 def test_nll_loss(dev):
@@ -77,6 +80,14 @@ def test_fused_head(dev):
     parity_cases.run_head_edge_cases(dev, V=3000)
     parity_cases.run_head_in_net(dev, sizes=(3000, 1400), K=64, C=128)
     parity_cases.run_head_in_net(dev, sizes=(1500, 1100), K=64, C=128, C_out=260, outputs_at="vertices")
+
+
+def test_torch_compile_packed_forward(dev):
+    """The ops as torch.library custom operators (diffusion_net/torchlib.py): torch.compile(fullgraph=True) of the packed forward, forward
+    and gradients bitwise equal to eager, at a small shape and at the split-fp16 engine's width."""
+    import parity_cases
+    parity_cases.run_compile(dev)
+    parity_cases.run_compile(dev, sizes=(3000, 1400), K=128, C=128, seed=9)
 
 
 def test_real_mesh_pipeline(dev):
