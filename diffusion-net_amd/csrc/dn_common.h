@@ -359,8 +359,11 @@ static inline int dn_num_cus() {
 // number of partial results a tngemm launch over `nchunks` chunks with grouping `group` writes
 static inline int dn_tn_npartial(int nchunks, int group) { return (nchunks + (group < 1 ? 1 : group) - 1) / (group < 1 ? 1 : group); }
 // grouping for sums over ALL rows (weight gradients): about two workgroups per CU
+#ifndef DN_TN_WS
+#define DN_TN_WS 1   // wave-specialised split-V kernel (dn_tngemm_ws.hip): one workgroup per CU
+#endif
 #ifndef DN_TN_TARGET_PARTIALS
-#define DN_TN_TARGET_PARTIALS 512
+#define DN_TN_TARGET_PARTIALS (DN_TN_WS ? 256 : 512)   // about one (wave-specialised) or two (lock-step) workgroups per CU
 #endif
 static inline int dn_tn_global_group(int nchunks) { int g = (nchunks + DN_TN_TARGET_PARTIALS - 1) / DN_TN_TARGET_PARTIALS; return g < 1 ? 1 : g; }
 // the same for an M x N result of several 128 x 128 output tiles: every (partial, tile) pair is a workgroup, so the partial count --

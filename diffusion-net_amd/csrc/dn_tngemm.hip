@@ -334,6 +334,8 @@ static int tx_launch(const TnArgs& g, dim3 grid, hipStream_t stream) {
 #define DN_TN_X3 1   // -DDN_TN_X3=0: exact-f32 MFMA in the split-V kernels
 #endif
 
+bool dn_tngemm_try_ws(const TnArgs& g, int flavor, dim3 grid, hipStream_t stream, int* err);   // dn_tngemm_ws.hip
+
 // returns the number of partials written (= gridDim.x) through *npartial
 int dn_launch_tngemm(const TnArgs& g_in, int nchunks, hipStream_t stream) {
     if (nchunks <= 0 || g_in.M <= 0 || g_in.N <= 0) return 0;
@@ -351,7 +353,9 @@ int dn_launch_tngemm(const TnArgs& g_in, int nchunks, hipStream_t stream) {
     const double rows = g.acct_rows;
     dn_prof_begin(DN_K_TNGEMM, stream);
     int err;
-    if (g.aligned && DN_TN_X3) {
+    if (g.aligned && DN_TN_X3 && dn_tngemm_try_ws(g, flavor, grid, stream, &err)) {
+        // wave-specialised split kernel (dn_tngemm_ws.hip)
+    } else if (g.aligned && DN_TN_X3) {
         switch (flavor) {
             case DN_TN_QA: err = tx_launch<DN_TN_QA>(g, grid, stream); break;
             case DN_TN_COLSUM: err = tx_launch<DN_TN_COLSUM>(g, grid, stream); break;
