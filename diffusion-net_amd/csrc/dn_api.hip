@@ -333,6 +333,7 @@ const char* dn_prof_kind_name(int kind) {
 
 int dn_version(void) { return 100; }
 int dn_tile_rows(void) { return DN_TM; }
+int dn_tn_target_chunks(void) { return (DN_TN_WS ? 1 : 2) * dn_num_cus(); }
 
 // ------------------------------------------------------------------ to_basis / from_basis
 size_t dn_to_basis_workspace_bytes(const dn_mesh_batch_t* mb, int C) {

@@ -371,10 +371,11 @@ static inline int dn_tn_global_group(int nchunks) { int g = (nchunks + DN_TN_TAR
 // more partials than dn_tn_global_group(nchunks) gives, which is what the workspace is sized for)
 static inline int dn_tn_global_group_mn(int nchunks, int M, int N) {
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    const int g0 = dn_tn_global_group(nchunks);
+    if (DN_TN_WS) return g0;   // one workgroup per CU: (partials x tiles) workgroups are whole rounds when the chunk table has dn_tn_target_chunks() entries
     int target = DN_TN_TARGET_PARTIALS / (tiles < 1 ? 1 : tiles);
     if (target < 128) target = 128;
     int g = (nchunks + target - 1) / target;
-    const int g0 = dn_tn_global_group(nchunks);
     return g < g0 ? g0 : g;
 }
 

@@ -66,6 +66,7 @@ _SIGNATURES = {
     # name: (restype, argtypes)
     "dn_version": (C.c_int, []),
     "dn_tile_rows": (C.c_int, []),
+    "dn_tn_target_chunks": (C.c_int, []),
     "dn_prof_enable": (C.c_int, [C.c_int]),
     "dn_prof_reset": (C.c_int, []),
     "dn_prof_read": (C.c_int, [C.c_int, _P(C.c_double)]),

@@ -38,21 +38,46 @@ def handle_object(k: int):
 
 
 def default_chunk_rows(v_total: int) -> int:
-    """Rows per split-V chunk: aim for >= ~512 chunks, 128 <= rows <= 1024, multiple of 32."""
+    """Rows per split-V chunk when a fixed size is asked for: aim for >= ~512 chunks, 128 <= rows <= 1024, multiple of 32."""
     rows = 32 * max(1, -(-v_total // (512 * 32)))
     return int(min(1024, max(128, rows)))
 
 
-def build_tables(sizes: Sequence[int], chunk_rows: int, tile_rows: int):
-    """Host-side tile / chunk tables for meshes of the given vertex counts."""
+def balanced_chunk_rows(sizes: Sequence[int], target: int, min_rows: int = 128) -> List[int]:
+    """Rows per chunk FOR EVERY MESH such that the batch has (at most, and if the meshes allow exactly) ``target`` chunks of nearly equal
+    size: the split-V kernels run one workgroup per chunk (per-mesh sums) on ``target`` = one workgroup slot per CU, so 514 chunks on
+    256 slots is three rounds of which the last holds two workgroups (+50 % on that launch), 256 chunks is one round.  Chunk counts
+    are dealt to the meshes in proportion to their vertex counts (largest remainders first)."""
+    n, vt = len(sizes), sum(sizes)
+    if n == 0 or vt == 0:
+        return [min_rows] * n
+    caps = [max(1, v // min_rows) for v in sizes]
+    quotas = [target * v / vt for v in sizes]
+    counts = [min(cap, max(1, int(q))) for q, cap in zip(quotas, caps)]
+    rem = target - sum(counts)
+    order = sorted(range(n), key=lambda i: -(quotas[i] - int(quotas[i])))
+    progressed = True
+    while rem > 0 and progressed:
+        progressed = False
+        for j in order:
+            if rem > 0 and counts[j] < caps[j]:
+                counts[j] += 1
+                rem -= 1
+                progressed = True
+    return [32 * max(1, -(-v // (c * 32))) for v, c in zip(sizes, counts)]
+
+
+def build_tables(sizes: Sequence[int], chunk_rows, tile_rows: int):
+    """Host-side tile / chunk tables for meshes of the given vertex counts.  chunk_rows: one int, or one per mesh."""
+    per_mesh = list(chunk_rows) if isinstance(chunk_rows, (list, tuple)) else [int(chunk_rows)] * len(sizes)
     tiles, chunks, mco, mrows = [], [], [0], []
     row0 = 0
     for m, v in enumerate(sizes):
         mrows.append((row0, v, m, 0))
         for r in range(0, v, tile_rows):
             tiles.append((row0 + r, min(tile_rows, v - r), m, 0))
-        for i, r in enumerate(range(0, v, chunk_rows)):
-            chunks.append((row0 + r, min(chunk_rows, v - r), m, i))
+        for i, r in enumerate(range(0, v, per_mesh[m])):
+            chunks.append((row0 + r, min(per_mesh[m], v - r), m, i))
         mco.append(len(chunks))
         row0 += v
     as_t = lambda rows: np.array(rows, dtype=np.int32).reshape(-1, 4)
@@ -61,7 +86,7 @@ def build_tables(sizes: Sequence[int], chunk_rows: int, tile_rows: int):
 
 def _tables_on(device, sizes, chunk_rows):
     tile_rows = _hip.lib().dn_tile_rows()
-    key = (str(device), tuple(sizes), chunk_rows, tile_rows)
+    key = (str(device), tuple(sizes), tuple(chunk_rows) if isinstance(chunk_rows, (list, tuple)) else chunk_rows, tile_rows)
     hit = _table_cache.get(key)
     if hit is None:
         if len(_table_cache) > 256:
@@ -173,7 +198,9 @@ class MeshBatch:
         vt = sum(self.sizes)
         if vt >= 2 ** 31 - 1:
             raise ValueError("more than 2^31 vertices in one batch")
-        self.chunk_rows = int(chunk_rows or default_chunk_rows(vt))
+        # default: as many chunks as the split-V kernels have workgroup slots, nearly equal in size (balanced_chunk_rows); an explicit
+        # chunk_rows (tests) gives fixed-size chunks
+        self.chunk_rows = int(chunk_rows) if chunk_rows else balanced_chunk_rows(self.sizes, _hip.lib().dn_tn_target_chunks())
         self.tiles, self.chunks, self.mesh_chunk_off, self.mesh_rows = _tables_on(self.device, self.sizes, self.chunk_rows)
         s = _hip.MeshBatchStruct()
         s.n_mesh, s.v_total, s.k_eig = len(self.sizes), vt, self.k_eig

@@ -106,6 +106,8 @@ typedef struct dn_block_grads {
 
 int dn_version(void);
 int dn_tile_rows(void);      /* rows per entry of dn_mesh_batch_t.tiles (128) */
+int dn_tn_target_chunks(void);  /* how many entries dn_mesh_batch_t.chunks should have on the current device for the split-V products to fill it in
+                                   whole rounds: one workgroup slot per CU (wave-specialised kernel).  Any chunk list is CORRECT; this one is fastest. */
 
 /* ---- opt-in per-kernel timing for benchmarks (no reference counterpart; the one piece of mutable global
  *      state, off by default): every launch is bracketed by hipEvents on its stream and summed per kernel

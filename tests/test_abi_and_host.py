@@ -37,14 +37,31 @@ def test_library_exports_every_declared_symbol(product_lib):
     assert product_lib.dn_version() >= 100 and product_lib.dn_tile_rows() == 128
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
+    """The ctypes mirrors of the C structs against the header itself: a C program built from include/diffnet_hip.h prints sizeof and every
+    field offset, which must equal what the Python binding uses."""
+    import subprocess
     from diffusion_net import _hip
-    P = ctypes.sizeof(ctypes.c_void_p)
-    assert ctypes.sizeof(_hip.MeshBatchStruct) == 6 * 4 + 15 * P
-    assert ctypes.sizeof(_hip.BlockParamsStruct) == (4 + 9) * 4 + 4 + (3 + 3 * 8) * P + 8 + P   # 4 B padding before the pointers, uint64 drop_seed, then the device seed pointer
-    assert ctypes.sizeof(_hip.BlockSavedStruct) == (7 + 8) * P
-    assert ctypes.sizeof(_hip.BlockGradsStruct) == (4 + 16) * P
-    assert _hip.TILE_DTYPE.itemsize == 16
+    pairs = (("dn_mesh_batch_t", _hip.MeshBatchStruct), ("dn_block_params_t", _hip.BlockParamsStruct),
+             ("dn_block_saved_t", _hip.BlockSavedStruct), ("dn_block_grads_t", _hip.BlockGradsStruct))
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "diffnet_hip.h"', 'int main(void) {']
+    for cname, st in pairs:
+        lines.append('printf("%s.sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in st._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines.append('printf("dn_tile_t.sizeof %zu\\n", sizeof(dn_tile_t)); printf("DN_MAX_MLP_LAYERS %d\\n", DN_MAX_MLP_LAYERS); '
+                 'printf("DN_BLOCK_AMAX_WORDS %d\\n", DN_BLOCK_AMAX_WORDS); return 0; }')
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True, capture_output=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, st in pairs:
+        assert int(got[cname + ".sizeof"]) == ctypes.sizeof(st), cname
+        for fname, _ in st._fields_:
+            assert int(got["%s.%s" % (cname, fname)]) == getattr(st, fname).offset, (cname, fname)
+    assert int(got["dn_tile_t.sizeof"]) == _hip.TILE_DTYPE.itemsize == 16
+    assert int(got["DN_MAX_MLP_LAYERS"]) == _hip.MAX_MLP and int(got["DN_BLOCK_AMAX_WORDS"]) == _hip.BLOCK_AMAX_WORDS
 
 
 def test_product_path_refuses_cpu_tensors(product_lib):
@@ -93,6 +110,15 @@ def test_tile_and_chunk_tables():
         assert mrows[m, 0] <= r0 and r0 + n <= mrows[m, 0] + mrows[m, 1]
     assert default_chunk_rows(10_000) == 128 and default_chunk_rows(160_000) % 32 == 0
     assert default_chunk_rows(10 ** 7) == 1024
+    # balanced tables: as many chunks as workgroup slots (when the meshes allow), nearly equal sizes, every mesh covered without gaps
+    from diffusion_net.batch import balanced_chunk_rows
+    sizes = [9057, 9803, 9519, 10988, 10001, 9333, 10750, 9100, 10640, 9999, 9001, 10900, 9777, 10321, 9650, 10400]
+    per = balanced_chunk_rows(sizes, 256)
+    t2, c2, mco2, _ = build_tables(sizes, per, tile_rows=128)
+    assert 250 <= c2.shape[0] <= 256 and all(r % 32 == 0 for r in per)
+    assert int(c2[:, 1].sum()) == sum(sizes) and int(c2[:, 1].max()) <= 1.25 * sum(sizes) / 256 + 32
+    assert all(int(c2[i, 0]) + int(c2[i, 1]) == int(c2[i + 1, 0]) for i in range(c2.shape[0] - 1))
+    assert balanced_chunk_rows([100, 40], 256) == [128, 64] and balanced_chunk_rows([300] * 400, 256) == [320] * 400   # tiny meshes / more meshes than slots
 
 
 def test_synthetic_operators_are_consistent():

@@ -99,11 +99,24 @@ int main(int argc, char** argv) {
     std::vector<int> sizes(n_mesh);
     for (auto& s : sizes) s = (int)(verts * (0.9 + 0.2 * U(rng)));
     long long V = 0; for (int s : sizes) V += s;
-    if (!chunk_rows) { chunk_rows = 32 * std::max<long long>(1, (V + 512 * 32 - 1) / (512 * 32)); chunk_rows = std::min(1024, std::max(128, chunk_rows)); }
+    // chunk table: --chunk R gives fixed R-row chunks; default: as diffusion_net.batch.balanced_chunk_rows -- dn_tn_target_chunks() chunks of nearly equal size
+    std::vector<int> per_mesh(n_mesh, chunk_rows);
+    if (!chunk_rows) {
+        auto tgt = (int (*)())dlsym(L.h, "dn_tn_target_chunks");
+        const int target = tgt ? tgt() : 512;
+        std::vector<int> cnt(n_mesh), cap(n_mesh); std::vector<double> quota(n_mesh); int sum = 0;
+        for (int m = 0; m < n_mesh; ++m) { quota[m] = (double)target * sizes[m] / V; cap[m] = std::max(1, sizes[m] / 128); cnt[m] = std::min(cap[m], std::max(1, (int)quota[m])); sum += cnt[m]; }
+        std::vector<int> order(n_mesh); for (int m = 0; m < n_mesh; ++m) order[m] = m;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return quota[a] - (int)quota[a] > quota[b] - (int)quota[b]; });
+        bool prog = true; int rem = target - sum;
+        while (rem > 0 && prog) { prog = false; for (int j : order) if (rem > 0 && cnt[j] < cap[j]) { ++cnt[j]; --rem; prog = true; } }
+        for (int m = 0; m < n_mesh; ++m) per_mesh[m] = 32 * std::max(1, (sizes[m] + cnt[m] * 32 - 1) / (cnt[m] * 32));
+        chunk_rows = per_mesh[0];
+    }
     std::vector<dn_tile_t> tiles, chunks, mrows; std::vector<int> mco{0};
     { int row0 = 0; for (int m = 0; m < n_mesh; ++m) { int v = sizes[m]; mrows.push_back({row0, v, m, 0});
         for (int r = 0; r < v; r += tile_rows) tiles.push_back({row0 + r, std::min(tile_rows, v - r), m, 0});
-        int i = 0; for (int r = 0; r < v; r += chunk_rows) chunks.push_back({row0 + r, std::min(chunk_rows, v - r), m, i++});
+        int i = 0; for (int r = 0; r < v; r += per_mesh[m]) chunks.push_back({row0 + r, std::min(per_mesh[m], v - r), m, i++});
         mco.push_back((int)chunks.size()); row0 += v; } }
     std::vector<float> mass(V), evals((size_t)n_mesh * K), evecs((size_t)V * K);
     for (auto& m : mass) m = (0.5f + U(rng)) * 12.566f / verts;
