@@ -360,8 +360,9 @@ static inline int dn_num_cus() {
 static inline int dn_tn_npartial(int nchunks, int group) { return (nchunks + (group < 1 ? 1 : group) - 1) / (group < 1 ? 1 : group); }
 // grouping for sums over ALL rows (weight gradients): about two workgroups per CU
 #ifndef DN_TN_WS
-#define DN_TN_WS 1   // wave-specialised split-V kernel (dn_tngemm_ws.hip): one workgroup per CU
-#endif
+#define DN_TN_WS 0   // 1: wave-specialised split-V kernel (dn_tngemm_ws.hip), one workgroup per CU.  Measured (round 3): 45 vs 48.5 us for the
+#endif               // projection alone (tools/kbench), but inside the training step the weight-gradient launches got SLOWER (avg 65 vs 56 us; the
+                     // three-tile dW0 139 vs 115 us: 768 one-per-CU workgroups against 512 two-per-CU ones) -- the lock-step kernel stays the default
 #ifndef DN_TN_TARGET_PARTIALS
 #define DN_TN_TARGET_PARTIALS (DN_TN_WS ? 256 : 512)   // about one (wave-specialised) or two (lock-step) workgroups per CU
 #endif

@@ -15,9 +15,6 @@
 // the lock-step kernel whenever the grouping is the same.
 #include "dn_tn_tiles.h"
 
-#ifndef DN_TN_WS
-#define DN_TN_WS 1
-#endif
 #define DN_TW_LTHR 512                       // loader threads (8 waves)
 #define DN_TW_THREADS (256 + DN_TW_LTHR)
 #define DN_TW_BUF (6 * DN_TX_PLANE)          // bytes of one step buffer: A planes then B planes (3 planes each; split-fp16 uses 2 + 2)
