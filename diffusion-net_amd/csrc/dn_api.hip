@@ -423,16 +423,31 @@ static size_t linear_partial_elems(const dn_mesh_batch_t* mb, int C_in, int C_ou
 size_t dn_linear_workspace_bytes(const dn_mesh_batch_t* mb, int C_in, int C_out) {
     return pad256(linear_partial_elems(mb, C_in, C_out)) + pad256((size_t)mb->n_chunks * C_out) + 512;
 }
-int dn_linear_fwd_f32(const dn_mesh_batch_t* mb, const float* x, int C_in, const float* W, const float* b, int C_out,
-                      int relu, const uint8_t* mask, float* out, void* stream) {
+// max |t| of a tensor nobody tracked while producing it: one measuring pass, accumulated into *word
+static int measure_amax(const float* t, long long n, float* word, hipStream_t st) {
+    AmaxJobs jobs; jobs.count = 0;
+    jobs.push(t, n, word);
+    return dn_launch_amax(jobs, st);
+}
+int dn_linear_fwd_amax_f32(const dn_mesh_batch_t* mb, const float* x, int C_in, const float* W, const float* b, int C_out,
+                           int relu, const uint8_t* mask, float* out, float* out_amax, void* stream) {
     if (C_in <= 16 && C_out <= 1024 && !relu && !mask)   // thin contraction (first_lin: xyz / hks features): bandwidth-bound VALU kernel
-        return dn_launch_smallk_rows(x, C_in, W, 0, b, C_out, out, mb->v_total, S(stream));
+        return dn_launch_smallk_rows(x, C_in, W, 0, b, C_out, out, mb->v_total, S(stream), out_amax);
     const float* xs[1] = {x};
     const int ws_[1] = {C_in};
-    return linear_fwd(mb, xs, ws_, 1, W, C_in, b, C_out, relu ? DN_EPI_BIAS_RELU : DN_EPI_STORE, mask, nullptr, out, S(stream));
+    DN_CHECK(linear_fwd(mb, xs, ws_, 1, W, C_in, b, C_out, relu ? DN_EPI_BIAS_RELU : DN_EPI_STORE, mask, nullptr, out, S(stream)));
+    return out_amax ? measure_amax(out, (long long)mb->v_total * C_out, out_amax, S(stream)) : 0;
+}
+int dn_linear_fwd_f32(const dn_mesh_batch_t* mb, const float* x, int C_in, const float* W, const float* b, int C_out,
+                      int relu, const uint8_t* mask, float* out, void* stream) {
+    return dn_linear_fwd_amax_f32(mb, x, C_in, W, b, C_out, relu, mask, out, nullptr, stream);
 }
 int dn_linear_bwd_f32(const dn_mesh_batch_t* mb, const float* d_out, const float* x, const float* W, int C_in, int C_out,
                       float* d_x, float* dW, float* db, void* ws, size_t ws_bytes, void* stream) {
+    return dn_linear_bwd_amax_f32(mb, d_out, x, W, C_in, C_out, d_x, dW, db, nullptr, ws, ws_bytes, stream);
+}
+int dn_linear_bwd_amax_f32(const dn_mesh_batch_t* mb, const float* d_out, const float* x, const float* W, int C_in, int C_out,
+                           float* d_x, float* dW, float* db, float* d_x_amax, void* ws, size_t ws_bytes, void* stream) {
     Bump b(ws, ws_bytes);
     float* partial = b.f(linear_partial_elems(mb, C_in, C_out));
     float* colsum = b.f((size_t)mb->n_chunks * C_out);
@@ -462,8 +477,12 @@ int dn_linear_bwd_f32(const dn_mesh_batch_t* mb, const float* d_out, const float
         DN_CHECK(linear_bwd_weights(mb, d_out, C_out, ins, ws_, 1, dW, db, partial, colsum, S(stream)));
     }
     if (d_x) {
-        if (C_out <= 16 && C_in <= 1024) DN_CHECK(dn_launch_smallk_rows(d_out, C_out, W, 1, nullptr, C_in, d_x, mb->v_total, S(stream)));
-        else DN_CHECK(linear_bwd_input(mb, d_out, C_out, W, C_in, 0, C_in, DN_EPI_STORE, nullptr, 1.f, d_x, S(stream)));
+        if (C_out <= 16 && C_in <= 1024) {
+            DN_CHECK(dn_launch_smallk_rows(d_out, C_out, W, 1, nullptr, C_in, d_x, mb->v_total, S(stream), d_x_amax));
+        } else {
+            DN_CHECK(linear_bwd_input(mb, d_out, C_out, W, C_in, 0, C_in, DN_EPI_STORE, nullptr, 1.f, d_x, S(stream)));
+            if (d_x_amax) DN_CHECK(measure_amax(d_x, (long long)mb->v_total * C_in, d_x_amax, S(stream)));
+        }
     }
     return 0;
 }

@@ -458,7 +458,7 @@ int dn_launch_mass_mean_bwd(const DnTile* tiles, int ntiles, const float* mass, 
 int dn_launch_spmm(const SpArgs& s, hipStream_t stream);
 // out[r, n] = (bias ? bias[n] : 0) + sum_{k<K} x[r,k] * (w_kn ? W[k*N+n] : W[n*K+k]),  K <= 32  (VALU, bandwidth-bound)
 int dn_launch_smallk_rows(const float* x, int K, const float* W, int w_kn, const float* bias, int N, float* out,
-                          long long rows, hipStream_t stream);
+                          long long rows, hipStream_t stream, float* o_amax = nullptr);
 // partial-free small-N vertex contraction: out[m, n] = sum_r A[r,m] * B[r,n], N <= 16, via per-block partials in ws
 int dn_launch_smalln_tn(const float* A, int M, const float* B, int N, long long rows, float* out, float* ws, int nblk,
                         hipStream_t stream);

@@ -436,14 +436,14 @@ int dn_launch_dtanh(const float* dg, const float* g, float* out, long long n, hi
 // reads the K inputs (wave-broadcast) and writes one float4.  Bandwidth-bound on the output stream.
 template <int KMAX>
 __global__ __launch_bounds__(256) void smallk_rows_kernel(const float* x, int K, const float* W, int w_kn, const float* bias,
-                                                          int N, float* out, long long rows) {
+                                                          int N, float* out, long long rows, float* o_amax) {
     constexpr int UR = KMAX <= 8 ? 4 : 2;       // independent row passes in flight per thread
     const int n4 = (N + 3) / 4;                 // column groups per row
     const int cg = threadIdx.x % n4, rl = threadIdx.x / n4;
     const int rows_per_pass = 256 / n4;         // rows a block covers per pass (threads beyond rows_per_pass*n4 idle)
-    if (rl >= rows_per_pass) return;
+    const bool idle = rl >= rows_per_pass;      // (stays for the wave-wide reduction of the magnitude word)
     const int n = cg * 4;
-    float w[4][KMAX], b4[4];
+    float w[4][KMAX], b4[4], om = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         b4[e] = (bias && n + e < N) ? bias[n + e] : 0.f;
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void smallk_rows_kernel(const float* x, int K,
     const bool vec = (N % 4 == 0) && (((uintptr_t)out & 15) == 0);
     const bool kvec = (K == KMAX) && (((uintptr_t)x & 15) == 0);
     const long long stride = (long long)gridDim.x * rows_per_pass;
-    for (long long r0 = (long long)blockIdx.x * rows_per_pass + rl; r0 < rows; r0 += UR * stride) {
+    for (long long r0 = (long long)blockIdx.x * rows_per_pass + rl; r0 < rows && !idle; r0 += UR * stride) {
         float xv[UR][KMAX];
 #pragma unroll
         for (int u = 0; u < UR; ++u) {           // all input loads of the UR passes first (clamped row, no branch)
@@ -479,6 +479,8 @@ __global__ __launch_bounds__(256) void smallk_rows_kernel(const float* x, int K,
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[e] = fmaf(xv[u][k], w[e][k], acc[e]);   // w is 0 for k >= K
             if (r < rows) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) om = (n + e < N && fabsf(acc[e]) > om) ? fabsf(acc[e]) : om;
                 if (vec) {
                     *reinterpret_cast<float4*>(out + r * N + n) = make_float4(acc[0], acc[1], acc[2], acc[3]);
                 } else {
@@ -489,10 +491,13 @@ __global__ __launch_bounds__(256) void smallk_rows_kernel(const float* x, int K,
             }
         }
     }
+    // max |out| for the split-fp16 engine of the consumer (first_lin -> block 0, last_lin's input gradient -> last block): the threads are
+    // long-lived (grid-stride), so this is one read of the word per wave at the very end and an atomic only from the few that raise it
+    if (o_amax) dn_amax_commit<true>(o_amax, om);
 }
 
 int dn_launch_smallk_rows(const float* x, int K, const float* W, int w_kn, const float* bias, int N, float* out,
-                          long long rows, hipStream_t stream) {
+                          long long rows, hipStream_t stream, float* o_amax) {
     if (rows <= 0 || N <= 0) return 0;
     if (K > 16 || N > 1024) return DN_ERR_BAD_MODE;
     const int n4 = (N + 3) / 4;
@@ -501,11 +506,11 @@ int dn_launch_smallk_rows(const float* x, int K, const float* W, int w_kn, const
     if (nb > 4096) nb = 4096;
     dn_prof_begin(DN_K_SMALL, stream);
     if (K <= 4) {
-        DN_LAUNCH(smallk_rows_kernel<4>, dim3((unsigned)nb, 1, 1), dim3(256, 1, 1), 0, stream, x, K, W, w_kn, bias, N, out, rows);
+        DN_LAUNCH(smallk_rows_kernel<4>, dim3((unsigned)nb, 1, 1), dim3(256, 1, 1), 0, stream, x, K, W, w_kn, bias, N, out, rows, o_amax);
     } else if (K <= 8) {
-        DN_LAUNCH(smallk_rows_kernel<8>, dim3((unsigned)nb, 1, 1), dim3(256, 1, 1), 0, stream, x, K, W, w_kn, bias, N, out, rows);
+        DN_LAUNCH(smallk_rows_kernel<8>, dim3((unsigned)nb, 1, 1), dim3(256, 1, 1), 0, stream, x, K, W, w_kn, bias, N, out, rows, o_amax);
     } else {
-        DN_LAUNCH(smallk_rows_kernel<16>, dim3((unsigned)nb, 1, 1), dim3(256, 1, 1), 0, stream, x, K, W, w_kn, bias, N, out, rows);
+        DN_LAUNCH(smallk_rows_kernel<16>, dim3((unsigned)nb, 1, 1), dim3(256, 1, 1), 0, stream, x, K, W, w_kn, bias, N, out, rows, o_amax);
     }
     dn_prof_end(DN_K_SMALL, stream, 2.0 * rows * K * N, 4.0 * rows * (K + N));
     return (int)hipGetLastError();

@@ -18,7 +18,7 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
-from . import _hip, ops
+from . import _hip, autograph, ops
 from .batch import GatherPattern, MeshBatch, operator_cache
 
 _MIN_TIME = 1e-8
@@ -404,7 +404,10 @@ class DiffusionNet(nn.Module):
         # the packed operators of a mesh are built once and found again on later calls (batch.OperatorCache)
         mb, gather = operator_cache.lookup(None, None, None, None, None, None, ("net", use_grad, self.outputs_at, squeeze), pack,
                                            key_ops[:3] + ((gradX, gradY) if use_grad else (None, None)) + key_ops[5:])
-        out = self.forward_packed(x_in.reshape(B * V, self.C_in), mb, gather)
+        x2d = x_in.reshape(B * V, self.C_in)
+        out = autograph.run(self, x2d, mb, gather)     # replay of a captured graph once this mesh has been seen a few times
+        if out is None:
+            out = self.forward_packed(x2d, mb, gather)
         if self.outputs_at == "vertices":
             out = out.reshape(B, V, -1)
         elif self.outputs_at in ("edges", "faces"):

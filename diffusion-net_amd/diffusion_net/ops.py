@@ -266,10 +266,14 @@ class LinearFn(torch.autograd.Function):
         ctx.sinks = _sinks([W, b])
         x, W, b = _f32c(x), _f32c(W), _f32c(b)
         out = torch.empty(x.shape[0], W.shape[0], dtype=torch.float32, device=x.device)
-        _hip.check(_hip.lib().dn_linear_fwd_f32(mb.ref(), x.data_ptr(), W.shape[1], W.data_ptr(), b.data_ptr(), W.shape[0],
-                                                0, None, out.data_ptr(), _hip.stream_of(x)), "dn_linear_fwd_f32")
+        # first_lin (thin input -> block width): its kernel leaves max |out| in a device word for block 0's split-fp16 engine for free
+        word = torch.zeros(1, dtype=torch.float32, device=x.device) if (W.shape[1] <= 16 and W.shape[0] >= 128 and _amax_tags_on()) else None
+        _hip.check(_hip.lib().dn_linear_fwd_amax_f32(mb.ref(), x.data_ptr(), W.shape[1], W.data_ptr(), b.data_ptr(), W.shape[0],
+                                                     0, None, out.data_ptr(), _hip.ptr(word), _hip.stream_of(x)), "dn_linear_fwd_amax_f32")
         ctx.mb = mb
         ctx.save_for_backward(x, W)
+        if word is not None:
+            _tag_amax(out, word)
         return out
 
     @staticmethod
@@ -284,10 +288,14 @@ class LinearFn(torch.autograd.Function):
         dW = _grad_out(ctx.sinks[0], W)
         db = _grad_out(ctx.sinks[1], W.new_empty(C_out))
         ws, n = _ws(mb, L.dn_linear_workspace_bytes(mb.ref(), C_in, C_out))
-        _hip.check(L.dn_linear_bwd_f32(mb.ref(), d_out.data_ptr(), x.data_ptr(), W.data_ptr(), C_in, C_out, _hip.ptr(d_x),
-                                       dW.data_ptr(), db.data_ptr(), ws.data_ptr(), n, _hip.stream_of(d_out)),
-                   "dn_linear_bwd_f32")
+        # last_lin (block width -> a few classes): the input gradient's magnitude for the last block's backward, likewise for free
+        word = torch.zeros(1, dtype=torch.float32, device=x.device) if (d_x is not None and C_out <= 16 and C_in >= 128 and _amax_tags_on()) else None
+        _hip.check(L.dn_linear_bwd_amax_f32(mb.ref(), d_out.data_ptr(), x.data_ptr(), W.data_ptr(), C_in, C_out, _hip.ptr(d_x),
+                                            dW.data_ptr(), db.data_ptr(), _hip.ptr(word), ws.data_ptr(), n, _hip.stream_of(d_out)),
+                   "dn_linear_bwd_amax_f32")
         dW, db = _deliver(ctx.sinks, [dW, db])
+        if word is not None:
+            _tag_amax(d_x, word)
         return d_x, dW, db, None
 
 
@@ -356,8 +364,12 @@ def _tag_amax(t, word):
         pass
 
 
+def _amax_tags_on():
+    return not os.environ.get("DN_NO_AMAX_TAGS")      # diagnostic: every block measures its input itself
+
+
 def _amax_of(t):
-    if os.environ.get("DN_NO_AMAX_TAGS"):      # diagnostic: every block measures its input itself
+    if not _amax_tags_on():
         return None
     tag = getattr(t, "_dn_amax", None)
     if tag is None or tag[1] != t.data_ptr() or tag[2] != t._version or tag[0].device != t.device:

@@ -158,6 +158,14 @@ int dn_linear_fwd_f32(const dn_mesh_batch_t* mb, const float* x, int C_in, const
                       int relu, const uint8_t* mask, float* out, void* stream);
 int dn_linear_bwd_f32(const dn_mesh_batch_t* mb, const float* d_out, const float* x, const float* W, int C_in, int C_out,
                       float* d_x, float* dW, float* db, void* ws, size_t ws_bytes, void* stream);
+/* The same two products, additionally leaving max |out| (max |d_x|) in a device word for the split-fp16 engine of the block that
+ * consumes the result (dn_block_params_t.x_amax / dn_block_grads_t.d_out_amax): first_lin feeds block 0, last_lin's input gradient feeds
+ * the last block's backward.  The word is ACCUMULATED into (atomic max): the caller zeroes it.  NULL = not tracked (the plain forms).
+ * Thin products (C_in <= 16 forward, C_out <= 16 backward) track inside their kernel; others take one measuring pass. */
+int dn_linear_fwd_amax_f32(const dn_mesh_batch_t* mb, const float* x, int C_in, const float* W, const float* b, int C_out,
+                           int relu, const uint8_t* mask, float* out, float* out_amax, void* stream);
+int dn_linear_bwd_amax_f32(const dn_mesh_batch_t* mb, const float* d_out, const float* x, const float* W, int C_in, int C_out,
+                           float* d_x, float* dW, float* db, float* d_x_amax, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- DiffusionNetBlock.forward (layers.py:200-241) and its backward, fused orchestration.
  *      saved = NULL runs inference (intermediates live in ws). */

@@ -835,3 +835,142 @@ def run_operator_cache(device, V=300, K=16, C=32, seed=6):
     assert len(operator_cache) == 1 and n_before > 1, (len(operator_cache), n_before, dict(operator_cache._bytes), [e.device for e in operator_cache._lru.values()])
     operator_cache.max_bytes = saved
     operator_cache.clear()
+
+
+def run_autograph(device, V=120, K=8, C=32, seed=12):
+    """Automatic graph replay behind the reference-signature forward (diffusion_net.autograph): the reference's train loop gives bitwise the
+    losses and parameters of the eager path; gradient accumulation, a second forward before the first backward (must go eager), a dropped
+    result, re-allocated parameters and a stale backward behave as documented.  On a ROCm device the graphs are HIP graphs; on the CPU
+    emulator tier the capture backend re-executes the recorded closures (same buffer plumbing, gate and autograd wiring)."""
+    from diffusion_net import autograph
+    from diffusion_net.batch import operator_cache
+    lsm = lambda t: torch.nn.functional.log_softmax(t, dim=-1)
+    m = synthetic.make_mesh_operators(V, K, seed=seed)
+    m2 = synthetic.make_mesh_operators(V + 37, K, seed=seed + 1)
+    up = lambda mm: {k: mm[k].to(device) for k in ("verts", "mass", "evals", "evecs", "gradX", "gradY", "faces")}
+    a, b = up(m), up(m2)
+    lab = {id(a): torch.randint(0, 4, (m["faces"].shape[0],), generator=torch.Generator().manual_seed(1)).to(device),
+           id(b): torch.randint(0, 4, (m2["faces"].shape[0],), generator=torch.Generator().manual_seed(2)).to(device)}
+    call = lambda model, d: model(d["verts"], d["mass"], L=None, evals=d["evals"], evecs=d["evecs"], gradX=d["gradX"], gradY=d["gradY"], faces=d["faces"])
+
+    def fresh(dropout=False):
+        torch.manual_seed(seed)
+        model = diffusion_net.layers.DiffusionNet(3, 4, C_width=C, N_block=2, outputs_at="faces", dropout=dropout, last_activation=lsm).to(device)
+        model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=0))
+        return model.train()
+
+    def loop(model, steps):
+        opt = torch.optim.SGD(model.parameters(), lr=0.05)
+        losses = []
+        for i in range(steps):
+            d = a if i % 2 == 0 else b                     # two meshes, alternating
+            opt.zero_grad()
+            loss = torch.nn.functional.nll_loss(call(model, d), lab[id(d)])
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach().clone())
+        return torch.stack(losses), [p.detach().clone() for p in model.parameters()]
+
+    saved = (autograph.enabled, autograph.backend, autograph.warm_calls)
+    if torch.device(device).type != "cuda":
+        autograph.backend, autograph.warm_calls = autograph.RerunBackend, 1      # (the emulator is slow: capture at the second sighting)
+    n_steps = 2 * (autograph.warm_calls + 2)                                     # four replayed steps (the capturing call replays too)
+    try:
+        operator_cache.clear()
+        autograph.enabled = False
+        l0, p0 = loop(fresh(), n_steps)
+        operator_cache.clear()
+        autograph.enabled = True
+        for k in autograph.stats:
+            autograph.stats[k] = 0
+        model = fresh()
+        l1, p1 = loop(model, n_steps)
+        st = dict(autograph.stats)
+        assert st["captures"] == 2 and st["failed"] == 0 and st["replays_fwd"] == 4 and st["replays_bwd"] == 4, st
+        assert torch.equal(l0, l1), (l0, l1)
+        for u, v in zip(p0, p1):
+            assert torch.equal(u, v)
+
+        # gradient accumulation over two replays without zero_grad == the same in eager mode
+        def two_backwards(model):
+            for p in model.parameters():
+                p.grad = None
+            for _ in range(2):
+                torch.nn.functional.nll_loss(call(model, a), lab[id(a)]).backward()
+            return [p.grad.clone() for p in model.parameters()]
+        r0 = autograph.stats["replays_bwd"]
+        g_graph = two_backwards(model)
+        assert autograph.stats["replays_bwd"] == r0 + 2
+        autograph.enabled = False
+        g_eager = two_backwards(model)
+        autograph.enabled = True
+        for u, v in zip(g_graph, g_eager):
+            assert torch.equal(u, v)
+
+        # a second forward while the first still waits for its backward takes the eager path; both backwards are right
+        for p in model.parameters():
+            p.grad = None
+        e0 = autograph.stats["eager_pending"]
+        o1 = call(model, a)
+        o2 = call(model, b)
+        assert autograph.stats["eager_pending"] == e0 + 1
+        (torch.nn.functional.nll_loss(o1, lab[id(a)]) + torch.nn.functional.nll_loss(o2, lab[id(b)])).backward()
+        g_mixed = [p.grad.clone() for p in model.parameters()]
+        autograph.enabled = False
+        for p in model.parameters():
+            p.grad = None
+        (torch.nn.functional.nll_loss(call(model, a), lab[id(a)]) + torch.nn.functional.nll_loss(call(model, b), lab[id(b)])).backward()
+        autograph.enabled = True
+        for u, v in zip(g_mixed, [p.grad for p in model.parameters()]):
+            assert helpers.rel_l2(u, v) < 1e-6          # (the sum's backward visits the two branches in another order: same values per branch)
+
+        # a result that is dropped without a backward releases the gate
+        o1 = call(model, a)
+        del o1
+        r0 = autograph.stats["replays_fwd"]
+        o1 = call(model, a)
+        assert autograph.stats["replays_fwd"] == r0 + 1
+        # a backward whose activations were overwritten by a later replay raises instead of returning wrong gradients
+        o1.sum().backward(retain_graph=True)
+        o2 = call(model, a)
+        o2.sum().backward()
+        with pytest.raises(RuntimeError, match="overwritten"):
+            o1.sum().backward()
+
+        # no-grad / eval replays equal the eager evaluation bit for bit
+        model.eval()
+        with torch.no_grad():
+            outs = [call(model, a) for _ in range(autograph.warm_calls + 2)]
+            autograph.enabled = False
+            ref = call(model, a)
+            autograph.enabled = True
+        for o in outs:
+            assert torch.equal(o, ref)
+        model.train()
+
+        # re-allocated parameters invalidate the graph (its kernels hold the old addresses): eager again, then a new capture
+        c0 = autograph.stats["captures"]
+        w = model.first_lin.weight
+        w.data = w.data.clone()
+        with torch.no_grad():
+            w.mul_(1.5)
+        got = [call(model, a).detach().clone() for _ in range(autograph.warm_calls + 2)]
+        for p in model.parameters():
+            p.grad = None
+        autograph.enabled = False
+        want = call(model, a).detach()
+        autograph.enabled = True
+        for o in got:
+            assert torch.equal(o, want)
+        assert autograph.stats["captures"] == c0 + 1
+
+        # dropout: every replay draws fresh masks
+        operator_cache.clear()
+        model = fresh(dropout=True)
+        outs = [call(model, a).detach().clone() for _ in range(autograph.warm_calls + 3)]
+        assert autograph.stats["captures"] == c0 + 2
+        assert all(torch.isfinite(o).all() for o in outs)
+        assert not torch.equal(outs[-1], outs[-2]) and not torch.equal(outs[-2], outs[-3])
+    finally:
+        autograph.enabled, autograph.backend, autograph.warm_calls = saved
+        operator_cache.clear()

@@ -118,3 +118,9 @@ def test_device_packing_and_operator_cache_on_emulator(emu):
     import parity_cases
     parity_cases.run_packing(emu)
     parity_cases.run_operator_cache(emu)
+
+
+def test_autograph_on_emulator(emu):
+    """diffusion_net.autograph with the closure-rerun capture backend (tests the static buffers, the pending gate, the autograd wiring)"""
+    import parity_cases
+    parity_cases.run_autograph(emu)

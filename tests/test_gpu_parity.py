@@ -103,6 +103,14 @@ def test_device_packing_and_operator_cache(dev):
     parity_cases.run_operator_cache(dev, V=7000, K=128, C=128)
 
 
+def test_autograph_reference_loop(dev):
+    """Automatic HIP-graph replay behind the reference-signature forward (diffusion_net/autograph.py): the reference's own train loop gives
+    bitwise the losses and parameters of the eager path; accumulation, interleaved forwards, dropped results, re-allocated parameters."""
+    import parity_cases
+    parity_cases.run_autograph(dev, V=300, K=16, C=32)
+    parity_cases.run_autograph(dev, V=7000, K=128, C=128, seed=3)
+
+
 def test_mismatched_patterns(dev):
     import parity_cases
     parity_cases.run_mismatched_patterns(dev)
