@@ -197,6 +197,8 @@ def kernel_family_report(lib):
                         "avg_us": 1e3 * ms / n, "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
                         "gbps": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
                         "flops_per_launch": fl / n, "bytes_per_launch": by / n})
+    if not fam:          # nothing went through the library's brackets (the timed region replayed graphs)
+        return [], None
     dom = max(fam, key=lambda f: f["ms_total"])
     # Binding roof of a family = the lower of the two roofs at its arithmetic intensity.  The GEMM families run on
     # split-bf16 MFMA (6 bf16 MFMAs per fp32 product: effective fp32 peak = 2.5 PF / 6); the sparse family is HBM-bound.
@@ -341,7 +343,9 @@ def run_other_config(args, device, lib, world, rank):
     elapsed = time.perf_counter() - t0
     lib.dn_prof_enable(0)
     assert torch.isfinite(loss).item()
-    fam, roof = ([], None) if args.graph else kernel_family_report(lib)   # a replayed graph bypasses the library's host-side event brackets
+    # a replayed graph bypasses the library's host-side event brackets (cfg2: the automatic capture of diffusion_net.autograph replays too)
+    graphed = args.graph or (cfg == "cfg2" and diffusion_net.autograph.enabled and diffusion_net.autograph.stats["replays_fwd"] > 0)
+    fam, roof = ([], None) if graphed else kernel_family_report(lib)
     print(json.dumps({
         "engine": _engine_note(),
         "metric": "vertices/sec %s, C_width=%d K=%d" % ("fwd" if cfg == "cfg4" else "fwd+bwd", Cw, K),

@@ -70,7 +70,27 @@ class _Gate:
 
 
 _gate = _Gate()
+
+
+class _Pool:
+    """The memory pool the graphs of one device share.  A pool dies with its last graph (the allocator drops it when its use count
+    reaches zero) and its handle must not be used again after that: ``users`` tracks the live owners, and a new handle is drawn when
+    none is left."""
+
+    def __init__(self):
+        self.handle = torch.cuda.graph_pool_handle()
+        self.users = weakref.WeakSet()
+
+
 _pools = {}
+
+
+def _pool_for(device, owner):
+    p = _pools.get(device)
+    if p is None or len(p.users) == 0:
+        p = _pools[device] = _Pool()
+    p.users.add(owner)
+    return p
 
 
 class _HipGraphs:
@@ -78,7 +98,8 @@ class _HipGraphs:
 
     @staticmethod
     def usable(x):
-        return x.is_cuda and not torch.cuda.is_current_stream_capturing()
+        # (a capture synchronises with the device: not inside a region where the caller has asked torch to flag synchronisations)
+        return x.is_cuda and not torch.cuda.is_current_stream_capturing() and torch.cuda.get_sync_debug_mode() == 0
 
     @staticmethod
     def warm(fn, device):
@@ -91,13 +112,14 @@ class _HipGraphs:
     reruns = False
 
     @staticmethod
-    def capture(fn, device, adopt=None):
-        pool = _pools.get(device)
-        if pool is None:
-            pool = _pools[device] = torch.cuda.graph_pool_handle()
+    def new_pool(device, owner):
+        return _pool_for(device, owner)
+
+    @staticmethod
+    def capture(fn, device, pool, adopt=None):
         g = torch.cuda.CUDAGraph()
         # thread-local capture mode: a data-loader or watchdog thread may call into HIP while this thread captures
-        with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+        with torch.cuda.graph(g, pool=pool.handle, capture_error_mode="thread_local"):
             res = fn()
         return g.replay, res
 
@@ -116,7 +138,11 @@ class RerunBackend:
         fn()
 
     @staticmethod
-    def capture(fn, device, adopt=None):
+    def new_pool(device, owner):
+        return None
+
+    @staticmethod
+    def capture(fn, device, pool, adopt=None):
         res = fn()
         return (lambda: adopt(fn())), res
 
@@ -151,6 +177,7 @@ class GraphedForward:
         self.sig = self._signature(model)
         self.static_x = x.detach().clone()
         self.generation = 0
+        pool = backend.new_pool(self.device, self)
         drop = model.training and any(blk.dropout for blk in model.blocks)
         self.seed = torch.zeros(1, dtype=torch.int64, device=x.device) if drop else None
         if drop:
@@ -179,7 +206,7 @@ class GraphedForward:
             def adopt_fwd(new):            # (RerunBackend only)
                 self.static_out.copy_(new.detach())
                 self._live_out = new
-            self.fwd_replay, self._live_out = backend.capture(fwd, self.device, adopt_fwd)
+            self.fwd_replay, self._live_out = backend.capture(fwd, self.device, pool, adopt_fwd)
             self.static_out = self._live_out.detach()
             self.static_gout = self.flat = None
             self.slices = []
@@ -194,7 +221,7 @@ class GraphedForward:
                 def adopt_bwd(new):        # (RerunBackend only)
                     if self.flat is not None:
                         self.flat.copy_(new[1])
-                self.bwd_replay, (gs, self.flat) = backend.capture(bwd, self.device, adopt_bwd)
+                self.bwd_replay, (gs, self.flat) = backend.capture(bwd, self.device, pool, adopt_bwd)
                 off = 0
                 for g in gs:
                     if g is None:

@@ -871,6 +871,9 @@ def run_autograph(device, V=120, K=8, C=32, seed=12):
             losses.append(loss.detach().clone())
         return torch.stack(losses), [p.detach().clone() for p in model.parameters()]
 
+    def say(msg):
+        if os.environ.get("DN_PARITY_VERBOSE"):
+            print("[autograph V=%d] %s %s" % (V, msg, dict(autograph.stats)), flush=True)
     saved = (autograph.enabled, autograph.backend, autograph.warm_calls)
     if torch.device(device).type != "cuda":
         autograph.backend, autograph.warm_calls = autograph.RerunBackend, 1      # (the emulator is slow: capture at the second sighting)
@@ -891,6 +894,7 @@ def run_autograph(device, V=120, K=8, C=32, seed=12):
         for u, v in zip(p0, p1):
             assert torch.equal(u, v)
 
+        say("reference loop: bitwise equal to eager")
         # gradient accumulation over two replays without zero_grad == the same in eager mode
         def two_backwards(model):
             for p in model.parameters():
@@ -907,6 +911,7 @@ def run_autograph(device, V=120, K=8, C=32, seed=12):
         for u, v in zip(g_graph, g_eager):
             assert torch.equal(u, v)
 
+        say("accumulation ok")
         # a second forward while the first still waits for its backward takes the eager path; both backwards are right
         for p in model.parameters():
             p.grad = None
@@ -924,6 +929,7 @@ def run_autograph(device, V=120, K=8, C=32, seed=12):
         for u, v in zip(g_mixed, [p.grad for p in model.parameters()]):
             assert helpers.rel_l2(u, v) < 1e-6          # (the sum's backward visits the two branches in another order: same values per branch)
 
+        say("interleaved forwards ok")
         # a result that is dropped without a backward releases the gate
         o1 = call(model, a)
         del o1
@@ -937,6 +943,7 @@ def run_autograph(device, V=120, K=8, C=32, seed=12):
         with pytest.raises(RuntimeError, match="overwritten"):
             o1.sum().backward()
 
+        say("dropped result + stale backward ok")
         # no-grad / eval replays equal the eager evaluation bit for bit
         model.eval()
         with torch.no_grad():
@@ -948,6 +955,7 @@ def run_autograph(device, V=120, K=8, C=32, seed=12):
             assert torch.equal(o, ref)
         model.train()
 
+        say("eval replays ok")
         # re-allocated parameters invalidate the graph (its kernels hold the old addresses): eager again, then a new capture
         c0 = autograph.stats["captures"]
         w = model.first_lin.weight
@@ -964,6 +972,7 @@ def run_autograph(device, V=120, K=8, C=32, seed=12):
             assert torch.equal(o, want)
         assert autograph.stats["captures"] == c0 + 1
 
+        say("re-allocated parameters ok")
         # dropout: every replay draws fresh masks
         operator_cache.clear()
         model = fresh(dropout=True)
@@ -971,6 +980,7 @@ def run_autograph(device, V=120, K=8, C=32, seed=12):
         assert autograph.stats["captures"] == c0 + 2
         assert all(torch.isfinite(o).all() for o in outs)
         assert not torch.equal(outs[-1], outs[-2]) and not torch.equal(outs[-2], outs[-3])
+        say("dropout replays ok")
     finally:
         autograph.enabled, autograph.backend, autograph.warm_calls = saved
         operator_cache.clear()
