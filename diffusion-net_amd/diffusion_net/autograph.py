@@ -27,6 +27,7 @@ Rules that keep this exact:
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import warnings
 import weakref
@@ -172,9 +173,33 @@ class GraphedForward:
     def __init__(self, model, x, mb, gather, grad):
         self.model = weakref.ref(model)
         self.device, self.grad = x.device, grad
-        self.params = [p for p in model.parameters() if p.requires_grad] if grad else []
-        self.all_params = list(model.parameters())
+        # The captured forward runs on ALIASES of the parameters (fresh leaves on the same storage), swapped into the modules for the
+        # duration of a capture.  Reason: a parameter's gradient-accumulator node remembers the stream that was current when it was
+        # created, and it lives as long as ANY autograd graph references it -- e.g. the caller's previous `loss`, built on the default
+        # stream.  A captured backward that flows into such a node makes the engine synchronise the capture stream with that other
+        # stream (event record + wait with a temporary event): the other stream joins the capture, the event is destroyed, and
+        # hipStreamEndCapture dereferences it (observed: segmentation fault in hip::Stream::EndCapture).  Fresh leaves get fresh
+        # accumulator nodes on the capture stream, and the graphs hold no reference into the caller's autograd state.
+        slots, alias = [], {}
+        for mod in model.modules():
+            for name, p in mod._parameters.items():
+                if p is not None:
+                    if id(p) not in alias:
+                        alias[id(p)] = p.detach().requires_grad_(p.requires_grad)
+                    slots.append((mod, name, p, alias[id(p)]))
+        self.real_params = [p for p in model.parameters() if p.requires_grad] if grad else []
+        self.params = [alias[id(p)] for p in self.real_params]
         self.sig = self._signature(model)
+
+        @contextlib.contextmanager
+        def swapped():
+            try:
+                for mod, name, _, a in slots:
+                    mod._parameters[name] = a
+                yield
+            finally:
+                for mod, name, p, _ in slots:
+                    mod._parameters[name] = p
         self.static_x = x.detach().clone()
         self.generation = 0
         pool = backend.new_pool(self.device, self)
@@ -189,7 +214,7 @@ class GraphedForward:
         def fwd():
             if drop:
                 self.seed.add_(step)
-            with torch.set_grad_enabled(grad):
+            with swapped(), torch.set_grad_enabled(grad):
                 return model.forward_packed(self.static_x, mb, gather)
 
         def fwd_bwd():
@@ -249,7 +274,7 @@ class GraphedForward:
             self.fwd_replay()
             stats["replays_fwd"] += 1
             return self.static_out.clone()
-        return _Replay.apply(self, x, *self.params)
+        return _Replay.apply(self, x, *self.real_params)
 
 
 class _Replay(torch.autograd.Function):
