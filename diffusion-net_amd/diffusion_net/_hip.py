@@ -166,6 +166,12 @@ def workspace(device, nbytes):
     """Grow-only scratch buffer per (device, current stream): reuse is stream-ordered, and concurrent streams
     (two half-batches in flight) never share scratch."""
     dev = torch.device(device)
+    if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        # A graph owns its scratch: the buffer comes from the capture's memory pool and goes back to it when the caller drops it (later
+        # allocations of the same capture may reuse it -- stream order makes that safe, as for every temporary under capture).  A cached
+        # buffer must not be handed to a capture: it may live in the pool of graphs that are gone (unmapped with them: seen as a GPU
+        # memory fault in a replay), and growing it mid-capture would free memory the nodes already captured still use.
+        return torch.empty(int(nbytes) + 4096, dtype=torch.uint8, device=dev)
     sid = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
     key = (str(dev), sid)
     buf = _workspaces.get(key)

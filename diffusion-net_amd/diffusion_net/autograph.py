@@ -102,9 +102,13 @@ class _HipGraphs:
         # (a capture synchronises with the device: not inside a region where the caller has asked torch to flag synchronisations)
         return x.is_cuda and not torch.cuda.is_current_stream_capturing() and torch.cuda.get_sync_debug_mode() == 0
 
+    _side = {}       # one warm-up stream per device (the library keeps a scratch buffer per stream it has run on)
+
     @staticmethod
     def warm(fn, device):
-        side = torch.cuda.Stream(device)
+        side = _HipGraphs._side.get(device)
+        if side is None:
+            side = _HipGraphs._side[device] = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
             fn()
