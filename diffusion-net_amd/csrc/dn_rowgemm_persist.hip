@@ -247,6 +247,11 @@ __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_pers
 #ifndef DN_PT_WS
 #define DN_PT_WS 1
 #endif
+// DN_WS_KO (development, timing only -- results are wrong): knock out one phase of the loader / MFMA loops to see what bounds the period:
+// 1 = no deferred pieces (nothing is stored), 2 = no LDS writes, 4 = no slice requests after the prologue, 8 = no MFMAs, 16 = no LDS fragment reads
+#ifndef DN_WS_KO
+#define DN_WS_KO 0
+#endif
 #ifndef DN_WS_LW
 #define DN_WS_LW 8                            // loader waves per workgroup (4 or 8); measured: 4 loader waves made the loaders the pole
 #endif
@@ -408,8 +413,17 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
 
     // Roles.  Default: waves 0-3 (one per SIMD) multiply, waves 4-11 load.  DN_WS_SPLIT_SIMD=1 instead puts the four MFMA
     // waves on two SIMDs (a workgroup's waves are dealt to the SIMDs cyclically) and leaves the other two to the loaders.
+#ifndef DN_WS_SPLIT_SIMD
+#define DN_WS_SPLIT_SIMD 0
+#endif
+#if DN_WS_SPLIT_SIMD   // MFMA waves 0,1,4,5 (SIMDs 0 and 1, two each), loaders 2,3,6,7 (SIMDs 2, 3) and 8..11 (one per SIMD)
+    const bool is_mfma = wave < 8 && (wave & 3) < 2;
+    const int mw = (wave & 1) + 2 * (wave >> 2);
+    const int lw = wave >= 8 ? wave - 4 : (wave & 1) + 2 * (wave >> 2);
+#else
     const bool is_mfma = wave < 4;
     const int mw = wave, lw = wave - 4;
+#endif
     if (is_mfma) {
         // ------------------------------------------------ MFMA waves ------------------------------------------------
         const int wr = mw >> 1, wc = mw & 1;
@@ -424,15 +438,24 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
         int cs = 0;
         WS_TR_DECL;
         __syncthreads();   // slice 0 staged
+#if DN_WS_KO & 16
+        X3Frags<2, 2, 1, NP> F;
+#endif
         for (int j = 0; j < T; ++j) {
             const unsigned char* cA = reinterpret_cast<const unsigned char*>(smem + (j & 1) * SBUF);
             const unsigned char* cB = cA + SA * 4;
+#if !(DN_WS_KO & 16)
             X3Frags<2, 2, 1, NP> F;
+#endif
             WS_TR();   // m0: iteration start
-            rg_frag_x3<2, 2, 1, NP>(cA, cB, wr * 64, wc * 64, li, lg, 0, F);
-            rg_frag_x3<2, 2, 1, NP>(cA, cB, wr * 64, wc * 64, li, lg, 1, F);
-            ws_mma<NP>(F, 0, acc);
-            ws_mma<NP>(F, 1, acc);
+            if ((DN_WS_KO & 16) == 0 || j == 0) {
+                rg_frag_x3<2, 2, 1, NP>(cA, cB, wr * 64, wc * 64, li, lg, 0, F);
+                rg_frag_x3<2, 2, 1, NP>(cA, cB, wr * 64, wc * 64, li, lg, 1, F);
+            }
+            if (!(DN_WS_KO & 8)) {
+                ws_mma<NP>(F, 0, acc);
+                ws_mma<NP>(F, 1, acc);
+            }
             WS_TR();   // m1: reads + MFMAs issued
             if (++cs == nsl) {   // unit complete: park it (fragment layout -> row-major) for the loader waves to stream out
                 cs = 0;
@@ -569,11 +592,22 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
 #ifndef DN_WS_EARLY
 #define DN_WS_EARLY 1
 #endif
+// DN_WS_DEPTH = 2: two register sets, slice s travels in set s & 1 and is requested two iterations before it is split (three slices of
+// reads per loader lane in flight instead of two).  The 16 KiB A slice per workgroup and ~1.5 slices in flight are 6 MB of HBM reads in
+// flight on 256 CUs -- at ~2 us loaded latency that is the 3.2 TB/s the kernel runs at.
+#ifndef DN_WS_DEPTH
+#define DN_WS_DEPTH 1
+#endif
 // Order inside an iteration (DN_WS_EARLY, round 3): wait for slice j+1 -> split it into plane registers -> the registers it came in are
 // free: request slice j+2 NOW -> LDS writes of slice j+1 -> deferred pieces -> operands of the next pieces -> barrier.  The s_memtime
 // timeline of the round-2 order (request at the end of the iteration, profiles/r03_ws_trace_*.txt) showed 1300-2100 of a loader's
 // ~4600-5200 cycles per slice spent waiting for that request: it had only the barrier to fly in; now it has most of an iteration.
 // DN_WS_EARLY=0 keeps the round-2 order: stage -> pieces -> piece operands -> request.
+// DN_WS_ORDER 1: pieces before the slice request (with DN_WS_DEPTH = 2 the request is two iterations ahead anyway, and vmcnt retires in
+// order: piece operands requested AFTER a slice force that slice to have arrived when they are consumed)
+#ifndef DN_WS_ORDER
+#define DN_WS_ORDER 0
+#endif
 #if DN_WS_EARLY
 #define WS_ITER(j, RS, SIDX)                                                                                            \
     do {                                                                                                                \
@@ -583,12 +617,13 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
         WS_TR_WAITV(); WS_TR();        /* l1: the prefetched slice has arrived (explicit wait in the trace build only) */ \
         WS_SPLIT(RS, SIDX, PLN);       /* slice j+1 (the last iteration stages a stale copy nobody reads) */            \
         WS_TR();                       /* l2: split */                                                                  \
-        WS_ADVANCE((j) + 1 + 1 < T);                                                                                    \
-        WS_LOAD(RS);                   /* slice j+2 */                                                                  \
+        if (DN_WS_ORDER == 1 && !(DN_WS_KO & 1)) WS_PIECES();                                                           \
+        WS_ADVANCE((j) + 1 + DN_WS_DEPTH < T);                                                                          \
+        if (!(DN_WS_KO & 4)) WS_LOAD(RS);   /* slice j+1+DEPTH */                                                       \
         WS_TR();                       /* l3: prefetch issued */                                                        \
-        WS_PUT(nxt, PLN);                                                                                               \
+        if (!(DN_WS_KO & 2)) WS_PUT(nxt, PLN);                                                                          \
         WS_TR();                       /* l4: LDS writes issued */                                                      \
-        WS_PIECES();                                                                                                    \
+        if (DN_WS_ORDER == 0 && !(DN_WS_KO & 1)) WS_PIECES();                                                           \
         WS_TR();                       /* l5: pieces out + next pieces' operands requested */                           \
         __syncthreads();                                                                                                \
     } while (0)
@@ -604,8 +639,8 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
         WS_TR();                       /* l2: staged */                                                                 \
         WS_PIECES();                                                                                                    \
         WS_TR();                       /* l3: pieces out + next pieces' operands requested */                           \
-        WS_ADVANCE((j) + 1 + 1 < T);                                                                                    \
-        WS_LOAD(RS);                   /* slice j+2 */                                                                  \
+        WS_ADVANCE((j) + 1 + DN_WS_DEPTH < T);                                                                          \
+        WS_LOAD(RS);                   /* slice j+1+DEPTH */                                                            \
         WS_TR();                       /* l4: prefetch issued */                                                        \
         __syncthreads();                                                                                                \
     } while (0)
@@ -629,6 +664,28 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     WS_LOAD(R0);
     WS_STAGE(smem, R0, 0);
     WS_ADVANCE(T > 1);
+#if DN_WS_DEPTH == 2
+    RgRegs<NOUT, A_IT, B_IT> R1;
+    WS_LOAD(R1);                       // slice 1
+    WS_ADVANCE(T > 2);
+    WS_LOAD(R0);                       // slice 2
+    __syncthreads();                   // slice 0 staged
+    if constexpr (BC) {                // T is a multiple of 4: iteration j stages slice (j + 1) % 4 of its unit (it travels in set (j + 1) & 1)
+        for (int j = 0; j < T; j += 4) {
+            WS_ITER(j, R1, 1);
+            WS_ITER(j + 1, R0, 2);
+            WS_ITER(j + 2, R1, 3);
+            WS_ITER(j + 3, R0, 0);
+        }
+    } else {
+        int j = 0;
+        for (; j + 1 < T; j += 2) {
+            WS_ITER(j, R1, 0);
+            WS_ITER(j + 1, R0, 0);
+        }
+        if (j < T) WS_ITER(j, R1, 0);
+    }
+#else
     WS_LOAD(R0);                       // slice 1
     __syncthreads();                   // slice 0 staged
     if constexpr (BC) {                // T is a multiple of 4: iteration j stages slice (j + 1) % 4 of its unit
@@ -641,6 +698,7 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     } else {
         for (int j = 0; j < T; ++j) WS_ITER(j, R0, 0);
     }
+#endif
 #undef WS_ITER
 #undef WS_PIECES
 #undef WS_PUT
