@@ -3,7 +3,9 @@
 # rocprofv3 kernel stats of the default bench, PMC traffic passes, kbench tables.  Everything lands in gpurun_out/.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"; mkdir -p gpurun_out
-NO_MICRO=1 NO_PROF=1 BENCH_STEPS=1 bash tests/run_gpu_suite.sh > gpurun_out/suite.log 2>&1
+# the driver's form first: the whole GPU tier in ONE process
+timeout 900 python -m pytest tests/ -x -q -m gpu > gpurun_out/gpu_tests_one_process.log 2>&1 < /dev/null; tail -3 gpurun_out/gpu_tests_one_process.log
+if [ -z "$NO_GROUPS" ]; then NO_MICRO=1 NO_PROF=1 BENCH_STEPS=1 bash tests/run_gpu_suite.sh > gpurun_out/suite.log 2>&1; fi
 timeout 600 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err < /dev/null
 timeout 200 python bench.py --eager --no-cpu-baseline --no-other-configs > gpurun_out/bench_eager.json 2>> gpurun_out/bench.err < /dev/null
 DN_F16=0 timeout 200 python bench.py --no-cpu-baseline --no-other-configs > gpurun_out/bench_bf16x3_only.json 2>> gpurun_out/bench.err < /dev/null
