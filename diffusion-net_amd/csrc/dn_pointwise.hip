@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void smallk_rows_kernel(const float* x, int K,
                 for (int e = 0; e < 4; ++e) acc[e] = fmaf(xv[u][k], w[e][k], acc[e]);   // w is 0 for k >= K
             if (r < rows) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) om = (n + e < N && fabsf(acc[e]) > om) ? fabsf(acc[e]) : om;
+                for (int e = 0; e < 4; ++e) om = fmaxf(om, fabsf(acc[e]));   // one v_max_f32 with |.| each (a column past N has zero weights and bias: acc = 0)
                 if (vec) {
                     *reinterpret_cast<float4*>(out + r * N + n) = make_float4(acc[0], acc[1], acc[2], acc[3]);
                 } else {

@@ -23,6 +23,7 @@ Rules that keep this exact:
   * anything unusual -- features that require grad, module hooks inside the model, test hooks, gradient sinks of ``dist.FlatParams``,
     an enclosing capture or compiler trace, a failed capture -- means the eager path, permanently for that (model, mesh, mode) after a
     failed capture (one warning).
+Only batches in the launch-bound regime are captured (``max_work``: vertices x C_width <= 4 M, i.e. up to 32k vertices at C_width 128).
 ``diffusion_net.autograph.enabled = False`` (or DN_AUTOGRAPH=0 in the environment) switches it off.
 """
 from __future__ import annotations
@@ -36,6 +37,8 @@ import torch
 
 enabled = os.environ.get("DN_AUTOGRAPH", "1") != "0"
 warm_calls = 2          # eager sightings of a (model, mesh, mode) before it is captured
+max_work = 1 << 22      # capture only where launches are the bottleneck: vertices x C_width up to this (32k vertices at C_width = 128).  Above
+                        # it the device is the bottleneck, a replay buys nothing, and the graph would pin the batch's activations in the pool
 stats = {"captures": 0, "replays_fwd": 0, "replays_bwd": 0, "eager_pending": 0, "failed": 0}
 
 _GOLDEN = 0x9E3779B97F4A7C15
@@ -319,7 +322,7 @@ def run(model, x2d, mb, gather):
     """The packed forward through a captured graph, or None when this call has to take the eager path."""
     if not enabled or x2d.requires_grad or not backend.usable(x2d) or torch.compiler.is_compiling():
         return None
-    if torch.is_autocast_enabled() or torch.is_anomaly_enabled() or not _blocks_plain(model):
+    if torch.is_autocast_enabled() or torch.is_anomaly_enabled() or not _blocks_plain(model) or x2d.shape[0] * model.C_width > max_work:
         return None
     grad = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
     table = mb.__dict__.setdefault("_autograph", {})
