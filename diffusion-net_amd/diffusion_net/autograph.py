@@ -326,9 +326,12 @@ def run(model, x2d, mb, gather):
         return None
     grad = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
     table = mb.__dict__.setdefault("_autograph", {})
-    key = (id(model), model.training, grad, tuple(x2d.shape), x2d.dtype, id(gather))
+    key = (id(model), model.training, grad, tuple(x2d.shape), x2d.dtype, id(gather), model.outputs_at, id(model.last_activation))
     rec = table.get(key)
     if rec is None:
+        for k, r in list(table.items()):      # graphs of models that no longer exist (they pin the old parameters' storage through their aliases)
+            if r.gf is not None and r.gf.model() is None:
+                del table[k]
         rec = table[key] = _Record()
     rec.calls += 1
     if rec.failed:
