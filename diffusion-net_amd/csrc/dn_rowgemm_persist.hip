@@ -716,128 +716,6 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     if (g.o_amax) dn_amax_commit<true>(g.o_amax, om);
 }
 
-// ---- one-unit form for SMALL batches (fewer row tiles than CUs: one ~7k-vertex mesh per step is 55 tiles on 256 CUs) ----------------
-// With a single 128-row unit per workgroup the persistent pipeline above has nothing to overlap with: it pays a global-memory latency
-// per 32-wide slice plus prologue and flush, 15-17 us for a K = 128 product that moves 64 KiB per workgroup (rocprof of BASELINE config 2,
-// profiles/r03_cfg2_kernel_stats.csv).  Here every read the unit needs is requested at once -- the four slices of A and B and, once the
-// first registers are free again, the epilogue operands -- then the loader waves split and stage slice after slice (four 32 KiB stages,
-// split-fp16 planes) while the MFMA waves follow one barrier behind, the finished tile is parked over the dead stages and all loader
-// threads stream it out.  One latency instead of five.  Split-fp16 engine, K = 128 (one segment) only; the same helpers, fragments, summation
-// order and epilogue as the persistent kernel, so results are bitwise identical to it.
-#ifndef DN_ONE_MAX
-#define DN_ONE_MAX 1     // used while ntiles <= DN_ONE_MAX x CUs (DN_ONE_MAX_TILES in the environment overrides the product: tests on the emulator)
-#endif
-template <int MODE, bool BCOLK, bool FLAG, bool XMASK>
-__global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(3) void rowgemm_one_kernel(RgArgs g, int ntiles) {
-    constexpr int NP = 2, NOUT = 1, LTHR = DN_WS_LTHR, NSL = 4;
-    constexpr int A_IT = DN_TM * 8 / LTHR, B_IT = DN_KB * 128 / 4 / LTHR;
-    constexpr int SA = DN_TM * 64 * NP;               // bytes of the A planes of one slice (16 KiB)
-    constexpr int STG = SA + 128 * 64 * NP;            // one (A, B) stage (32 KiB); four of them, the parked tile aliases the first two
-    constexpr bool HASQ = false;
-    constexpr bool need_bias = (MODE == DN_EPI_STORE && FLAG) || MODE == DN_EPI_BIAS_RELU || MODE == DN_EPI_BIAS_RESID;
-    const unsigned long long seed = (MODE == DN_EPI_BIAS_RELU && FLAG) ? rg_seed(g) : 0ull;
-    DN_DYN_SMEM(smem_raw);
-    unsigned char* smem = reinterpret_cast<unsigned char*>(smem_raw);
-    float* sE = reinterpret_cast<float*>(smem_raw);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.y * 128;
-    const DnTile tile = g.tiles[blockIdx.x];
-    if (wave < 4) {
-        // ------------------------------------------------ MFMA waves ------------------------------------------------
-        const int wr = wave >> 1, wc = wave & 1;
-        const int li = lane & 31, lg = lane >> 5;
-        f32x16 acc[1][2][2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[0][mt][nt][r] = 0.f;
-#pragma unroll
-        for (int sl = 0; sl < NSL; ++sl) {
-            __syncthreads();   // slice sl staged
-            const unsigned char* cA = smem + sl * STG;
-            const unsigned char* cB = cA + SA;
-            X3Frags<2, 2, 1, NP> F;
-            rg_frag_x3<2, 2, 1, NP>(cA, cB, wr * 64, wc * 64, li, lg, 0, F);
-            rg_frag_x3<2, 2, 1, NP>(cA, cB, wr * 64, wc * 64, li, lg, 1, F);
-            ws_mma<NP>(F, 0, acc);
-            ws_mma<NP>(F, 1, acc);
-        }
-        __syncthreads();       // every wave is done with the stages: the parked tile may overwrite them
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    sE[(wr * 64 + mt * 32 + dn_acc_row(r, lane)) * 128 + wc * 64 + nt * 32 + li] = acc[0][mt][nt][r];
-        __syncthreads();       // parked
-        return;
-    }
-    // ---------------------------------------------------- loader waves ----------------------------------------------------
-    const int lt = (wave - 4) * 64 + lane;
-    const float sa = dn_pow2_scale(dn_amax_eval(g.a_amax)), sb = dn_pow2_scale(dn_amax_eval(g.b_amax));
-    const float so = (1.f / sa) * (1.f / sb);
-    float om = 0.f;
-    float4 bias = dn_f4_zero();
-    {
-        const int col = n0 + 4 * (lt & 31);
-        if (need_bias) bias = *reinterpret_cast<const float4*>(g.bias + (col < g.N ? col : 0));
-    }
-    const float* ap = g.a[0].p;
-    const float* bp = g.b[0][0] + (long long)tile.mesh * g.b_mesh_stride;
-    RgRegs<NOUT, A_IT, B_IT> R[NSL];
-#pragma unroll
-    for (int sl = 0; sl < NSL; ++sl)     // all sixteen reads of the unit in flight
-        ws_load<BCOLK, A_IT, B_IT>(ap, g.a[0].ld, bp, g.ldb, g.N, tile.row0, tile.nrows, n0, DN_KB * sl, lt, R[sl]);
-    WsAux AX[DN_WS_NP];
-#pragma unroll
-    for (int sl = 0; sl < NSL; ++sl) {
-        X3Planes<NOUT, A_IT, B_IT, NP> PLN;
-        rg_split_x3<NOUT, BCOLK, HASQ, A_IT, B_IT, true, true, NP>(R[sl], PLN, sa, sb);
-        rg_put_x3<LTHR, NOUT, BCOLK, A_IT, B_IT, NP>(smem + sl * STG, smem + sl * STG + SA, lt, PLN);
-        // the epilogue operands, half of them as soon as two slices' registers are free, the rest after the last slice
-        if (sl == 1) {
-#pragma unroll
-            for (int k = 0; k < DN_WS_NP / 2; ++k) ws_aux_load<MODE, FLAG, XMASK>(g, seed, k, lt, tile.row0, tile.nrows, n0, AX[k]);
-        }
-        if (sl == NSL - 1) {
-#pragma unroll
-            for (int k = DN_WS_NP / 2; k < DN_WS_NP; ++k) ws_aux_load<MODE, FLAG, XMASK>(g, seed, k, lt, tile.row0, tile.nrows, n0, AX[k]);
-        }
-        __syncthreads();       // slice sl staged
-    }
-    __syncthreads();           // MFMA waves done with the stages
-    __syncthreads();           // parked
-#pragma unroll
-    for (int k = 0; k < DN_WS_NP; ++k)
-        ws_piece_out<MODE, FLAG>(g, *reinterpret_cast<const float4*>(&sE[AX[k].lds]), bias, AX[k], so, om);
-    if (g.o_amax) dn_amax_commit<true>(g.o_amax, om);
-}
-
-template <int MODE, bool BCOLK, bool FLAG, bool XMASK>
-static int one_launch_x(const RgArgs& g, int ntiles, hipStream_t stream) {
-    const size_t smem = (size_t)4 * (DN_TM * 64 * 2 + 128 * 64 * 2);   // 128 KiB
-#ifndef DN_EMULATE
-    static unsigned long long lds_opt_in = 0;   // per-device bitmap
-    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&rowgemm_one_kernel<MODE, BCOLK, FLAG, XMASK>), smem, &lds_opt_in); if (oe_) return oe_; }
-#endif
-    DN_LAUNCH((rowgemm_one_kernel<MODE, BCOLK, FLAG, XMASK>), dim3(ntiles, (g.N + 127) / 128, 1), dim3(256 + DN_WS_LTHR, 1, 1), smem, stream, g, ntiles);
-    return (int)hipGetLastError();
-}
-template <int MODE, bool BCOLK, bool FLAG>
-static int one_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
-    if constexpr (MODE == DN_EPI_BIAS_RELU && FLAG) {
-        if (g.mask) return one_launch_x<MODE, BCOLK, FLAG, true>(g, ntiles, stream);
-    }
-    return one_launch_x<MODE, BCOLK, FLAG, false>(g, ntiles, stream);
-}
-static int one_max_tiles() {
-    const char* e = getenv("DN_ONE_MAX_TILES");   // read per launch: the emulator tier (3 "CUs") switches it to cover the kernel
-    return e ? atoi(e) : DN_ONE_MAX * dn_num_cus();
-}
-
 template <int MODE, bool BCOLK, bool FLAG, int PPI, bool BC, int NP, bool XMASK>
 static int ws_launch_x(const RgArgs& g, int ntiles, hipStream_t stream) {
     const size_t smem = (size_t)(2 * (DN_TM * 64 * 3 + 128 * 64 * 3) + 128 * 128 * 4);   // 160 KiB
@@ -867,7 +745,6 @@ static int pt_launch(const RgArgs& g, int ntiles, hipStream_t stream) {
         for (int s = 0; s < g.nseg; ++s) nsl += g.a[s].w / DN_KB;
         // PPI = ceil(NP / (nsl - 1)) for the two slice counts that matter (K = 128: 4 slices, K = 384: 12)
         if (g.f16) {   // split-fp16 engine (the caller supplies the operand magnitudes)
-            if (nsl == 4 && g.nseg == 1 && ntiles <= one_max_tiles()) return one_launch<MODE, BCOLK, FLAG>(g, ntiles, stream);
             if (nsl >= 9) return ws_launch<MODE, BCOLK, FLAG, (DN_WS_NP + 7) / 8, false, 2>(g, ntiles, stream);
             if (DN_WS_BCACHE && nsl == 4 && g.nseg == 1 && g.b_mesh_stride == 0)
                 return ws_launch<MODE, BCOLK, FLAG, (DN_WS_NP + 2) / 3, true, 2>(g, ntiles, stream);

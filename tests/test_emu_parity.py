@@ -124,12 +124,3 @@ def test_autograph_on_emulator(emu):
     """diffusion_net.autograph with the closure-rerun capture backend (tests the static buffers, the pending gate, the autograd wiring)"""
     import parity_cases
     parity_cases.run_autograph(emu)
-
-
-def test_one_unit_row_kernel_on_emulator(emu, monkeypatch):
-    """The small-batch form of the row GEMM (rowgemm_one_kernel: one 128-row unit per workgroup, all reads requested at once) is chosen while a
-    batch has fewer row tiles than the device has CUs -- three on the emulator; DN_ONE_MAX_TILES widens that so the C = 128 golden (4 tiles,
-    every epilogue mode of the block's forward and backward) runs through it."""
-    import parity_cases
-    monkeypatch.setenv("DN_ONE_MAX_TILES", "64")
-    parity_cases.run_golden("faces_v500_c128_k128", emu)
