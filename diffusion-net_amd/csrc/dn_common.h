@@ -247,6 +247,21 @@ __device__ __forceinline__ void dn_amax_commit(float* word, float m) {
         if (!CHECK || m > *reinterpret_cast<volatile float*>(word)) atomicMax(reinterpret_cast<unsigned*>(word), __float_as_uint(m));
     }
 }
+// One commit per WORKGROUP: every wave leaves its maximum in LDS and the last one to arrive (LDS counter) issues the single check-first
+// atomic.  For small batches all waves of a launch are resident together and all see the word at its start value: a 7k-vertex launch of
+// the wave-specialised row GEMM then queues 440 atomics on one address, 3.5 us behind an otherwise finished kernel.  lds2: two words
+// (maximum, arrivals) zeroed before a barrier that every committing wave has passed.
+__device__ __forceinline__ void dn_amax_commit_group(float* word, float m, unsigned* lds2, int nwaves) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { const float o = __shfl_xor(m, d, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&lds2[0], __float_as_uint(m));
+        if (atomicAdd(&lds2[1], 1u) == (unsigned)(nwaves - 1)) {
+            const float mm = __uint_as_float(*reinterpret_cast<volatile unsigned*>(&lds2[0]));
+            if (mm > 0.f && mm > *reinterpret_cast<volatile float*>(word)) atomicMax(reinterpret_cast<unsigned*>(word), __float_as_uint(mm));
+        }
+    }
+}
 // per-lane form for kernels whose lanes do not all reach the end together: skip the atomic unless this lane would raise the word
 __device__ __forceinline__ void dn_amax_commit_lane(float* word, float m) {
     if (m > *reinterpret_cast<volatile float*>(word)) atomicMax(reinterpret_cast<unsigned*>(word), __float_as_uint(m));

@@ -493,7 +493,19 @@ __global__ __launch_bounds__(256) void smallk_rows_kernel(const float* x, int K,
     }
     // max |out| for the split-fp16 engine of the consumer (first_lin -> block 0, last_lin's input gradient -> last block): the threads are
     // long-lived (grid-stride), so this is one read of the word per wave at the very end and an atomic only from the few that raise it
-    if (o_amax) dn_amax_commit<true>(o_amax, om);
+    // One commit per workgroup, not per wave: all ~3500 waves of a 7k-vertex launch are resident together, every one of them sees the word
+    // still at zero, and 3500 atomics on one address cost 25 us (8 ns each, serialised in one L2 channel) on top of a 7 us kernel.
+    if (o_amax) {
+        __shared__ float wave_max[4];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { const float o = __shfl_xor(om, d, 64); om = o > om ? o : om; }
+        if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = om;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+            if (m > *reinterpret_cast<volatile float*>(o_amax)) atomicMax(reinterpret_cast<unsigned*>(o_amax), __float_as_uint(m));
+        }
+    }
 }
 
 int dn_launch_smallk_rows(const float* x, int K, const float* W, int w_kn, const float* bias, int N, float* out,

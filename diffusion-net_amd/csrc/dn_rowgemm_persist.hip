@@ -252,6 +252,9 @@ __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_pers
 #ifndef DN_WS_KO
 #define DN_WS_KO 0
 #endif
+#ifndef DN_WS_GROUP_COMMIT
+#define DN_WS_GROUP_COMMIT 1   // one magnitude commit per workgroup (0: one per loader wave)
+#endif
 #ifndef DN_WS_LW
 #define DN_WS_LW 8                            // loader waves per workgroup (4 or 8); measured: 4 loader waves made the loaders the pole
 #endif
@@ -401,6 +404,7 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     DN_DYN_SMEM(smem_raw);
     float* smem = reinterpret_cast<float*>(smem_raw);
     float* sE = smem + 2 * SBUF;
+    constexpr int WS_AMAX_LDS = DN_TM * 64 * 2 / 4;   // float index of two spare words: the third A plane of stage 0, unused by the 2-term engine
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = gridDim.x;
@@ -478,6 +482,7 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     // ---------------------------------------------------- loader waves ----------------------------------------------------
     DN_SETPRIO(DN_WS_LOADER_PRIO);
     const int lt = lw * 64 + lane;
+    if (NP == 2 && lt < 2) reinterpret_cast<unsigned*>(smem + WS_AMAX_LDS)[lt] = 0u;   // workgroup-level magnitude commit (before the first barrier)
     // split-fp16: operand scales (powers of two from the producers' amax words) and the exact inverse of their product
     float sa = 1.f, sb = 1.f, so = 1.f, om = 0.f;   // om: running max |o0| of this thread's pieces
     if constexpr (NP == 2) {
@@ -713,7 +718,10 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
         ws_aux_load<MODE, FLAG, XMASK>(g, seed, p_next, lt, p_row0, p_nrows, n0, A1);
         ws_piece_out<MODE, FLAG>(g, *reinterpret_cast<const float4*>(&sE[A1.lds]), bias, A1, so, om);
     }
-    if (g.o_amax) dn_amax_commit<true>(g.o_amax, om);
+    if (g.o_amax) {
+        if constexpr (NP == 2 && DN_WS_PW == DN_WS_LW && DN_WS_GROUP_COMMIT) dn_amax_commit_group(g.o_amax, om, reinterpret_cast<unsigned*>(smem + WS_AMAX_LDS), DN_WS_LW);
+        else dn_amax_commit<true>(g.o_amax, om);
+    }
 }
 
 template <int MODE, bool BCOLK, bool FLAG, int PPI, bool BC, int NP, bool XMASK>

@@ -170,6 +170,7 @@ static inline void __syncthreads() { dnemu::block_barrier(); }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline int atomicOr(int* p, int v) { int o = *p; *p = o | v; return o; }
 static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 
 typedef float dnemu_f32x16 __attribute__((ext_vector_type(16)));
