@@ -799,6 +799,19 @@ int dn_checksum128(const void* data, size_t nbytes, uint64_t salt, uint64_t* acc
     return dn_launch_checksum(data, (long long)(nbytes / 4), (unsigned long long)salt, (unsigned long long*)acc, S(stream));
 }
 
+// the same for up to DN_CK_MAX_JOBS buffers in one launch (host arrays of device pointers, byte counts and salts)
+int dn_checksum128_multi(int n, const void* const* data, const size_t* nbytes, const uint64_t* salts, uint64_t* acc, void* stream) {
+    if (n < 0 || n > DN_CK_MAX_JOBS || !acc || ((uintptr_t)acc & 7) != 0 || (n && (!data || !nbytes || !salts))) return DN_ERR_INVALID;
+    long long nwords[DN_CK_MAX_JOBS];
+    unsigned long long s64[DN_CK_MAX_JOBS];
+    for (int j = 0; j < n; ++j) {
+        if ((nbytes[j] && !data[j]) || nbytes[j] % 4 != 0 || ((uintptr_t)data[j] & 3) != 0) return DN_ERR_INVALID;
+        nwords[j] = (long long)(nbytes[j] / 4);
+        s64[j] = (unsigned long long)salts[j];
+    }
+    return dn_launch_checksum_multi(n, data, nwords, s64, (unsigned long long*)acc, S(stream));
+}
+
 // ------------------------------------------------------------------ output remaps
 int dn_csr_mean_f32(const int32_t* rowptr, const int32_t* col, int n_rows, const float* x, int C, float div, float* out,
                     void* stream) {

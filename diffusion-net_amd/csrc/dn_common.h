@@ -506,6 +506,9 @@ int dn_launch_coo_to_csr(const long long* rows, int row_div, const long long* co
                          int n_cols, int* rowptr, int* col32, int* t_rowptr, int* t_col, float* t_vx, float* t_vy, int* status, int* ws,
                          hipStream_t stream);
 int dn_launch_checksum(const void* data, long long nwords, unsigned long long salt, unsigned long long* acc, hipStream_t stream);
+#define DN_CK_MAX_JOBS 16
+int dn_launch_checksum_multi(int n, const void* const* data, const long long* nwords, const unsigned long long* salts, unsigned long long* acc,
+                             hipStream_t stream);
 // launchers (host), defined in the .hip files; all return hipError_t as int
 int dn_launch_rowgemm(const RgArgs& g, int ntiles, int nout, hipStream_t stream);
 int dn_launch_tngemm(const TnArgs& g, int nchunks, hipStream_t stream);

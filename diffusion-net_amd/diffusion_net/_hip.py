@@ -99,6 +99,7 @@ _SIGNATURES = {
     "dn_coo_to_csr_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "dn_coo_to_csr_i64": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int] + [_vp] * 7 + [_vp, C.c_size_t, _vp]),
     "dn_checksum128": (C.c_int, [_vp, C.c_size_t, C.c_uint64, _vp, _vp]),
+    "dn_checksum128_multi": (C.c_int, [C.c_int, _P(_vp), _P(C.c_size_t), _P(C.c_uint64), _vp, _vp]),
     "dn_csr_mean_f32": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_float, _vp, _vp]),
     "dn_mass_mean_fwd_f32": (C.c_int, [_P(MeshBatchStruct), _vp, C.c_int, _vp, _vp, _vp]),
     "dn_mass_mean_bwd_f32": (C.c_int, [_P(MeshBatchStruct), _vp, _vp, C.c_int, _vp, _vp]),

@@ -315,7 +315,7 @@ def content_checksum(operands) -> bytes:
     L = _hip.lib()
     dev = next(t.device for t in operands if t is not None)
     acc = torch.zeros(2, dtype=torch.int64, device=dev)
-    stream = None
+    keep, ptrs, sizes, salts = [], [], [], []
     for slot, t in enumerate(operands):
         if t is None:
             continue
@@ -324,9 +324,13 @@ def content_checksum(operands) -> bytes:
             u = u.contiguous()
             if u.element_size() % 4 != 0:                 # bool / uint8 / fp16 operands: widen (never the case for the reference's operands)
                 u = u.to(torch.int32 if not u.is_floating_point() else torch.float32)
-            if stream is None:
-                stream = _hip.stream_of(u)
-            _hip.check(L.dn_checksum128(u.data_ptr(), u.numel() * u.element_size(), 4 * slot + k + 1, acc.data_ptr(), stream), "dn_checksum128")
+            keep.append(u)
+            ptrs.append(u.data_ptr()); sizes.append(u.numel() * u.element_size()); salts.append(4 * slot + k + 1)
+    stream = _hip.stream_of(keep[0]) if keep else None
+    for lo in range(0, len(keep), 16):                    # one launch per 16 buffers (a mesh has eight)
+        n = min(16, len(keep) - lo)
+        _hip.check(L.dn_checksum128_multi(n, (C.c_void_p * n)(*ptrs[lo:lo + n]), (C.c_size_t * n)(*sizes[lo:lo + n]),
+                                          (C.c_uint64 * n)(*salts[lo:lo + n]), acc.data_ptr(), stream), "dn_checksum128_multi")
     return acc.cpu().numpy().tobytes()
 
 

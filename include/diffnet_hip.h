@@ -194,6 +194,9 @@ int dn_coo_to_csr_i64(const int64_t* rows, int row_div, const int64_t* cols, con
  *      Adds a 128-bit, order-independent checksum of the nbytes at `data` (multiple of 4, 4-byte aligned) to acc[0..1] (device, zeroed by
  *      the caller).  `salt` separates operands that share one accumulator.  EVERY byte of the operand enters the sum. */
 int dn_checksum128(const void* data, size_t nbytes, uint64_t salt, uint64_t* acc, void* stream);
+/*      The same for up to 16 buffers in ONE launch: data / nbytes / salts are HOST arrays of n entries (device pointers, byte counts, salts).
+ *      Gives exactly the sum the n single calls would. */
+int dn_checksum128_multi(int n, const void* const* data, const size_t* nbytes, const uint64_t* salts, uint64_t* acc, void* stream);
 
 /* ---- output remaps (layers.py:379-397).
  *      csr_mean: out[i] = (sum_{j in row i} x[col[j]]) / div  -- faces (div=3) / edges (div=2) gather-mean, and with the

@@ -689,11 +689,39 @@ def run_real_mesh_pipeline(device, V=400, K=16, C=32, seed=0):
 # ------------------------------------------------------------------------------------------
 # operator packing on the device (dn_coo_to_csr_i64) and the operator cache behind the reference signature
 # ------------------------------------------------------------------------------------------
+def run_checksum(device, seed=21):
+    """dn_checksum128_multi (one launch for all operands of a mesh) gives exactly the sum of the single-buffer calls; any changed word changes it."""
+    import ctypes as C
+    from diffusion_net import _hip
+    L = _hip.lib()
+    g = torch.Generator().manual_seed(seed)
+    bufs = [torch.randn(n, generator=g).to(device) for n in (7, 1000, 70001, 0, 333)] + [torch.randint(0, 1 << 40, (513,), generator=g).to(device)]
+    salts = [4 * i + 1 for i in range(len(bufs))]
+    stream = _hip.stream_of(bufs[0])
+    one = torch.zeros(2, dtype=torch.int64, device=device)
+    for b, s_ in zip(bufs, salts):
+        _hip.check(L.dn_checksum128(b.data_ptr() if b.numel() else None, b.numel() * b.element_size(), s_, one.data_ptr(), stream), "dn_checksum128")
+    def multi(bs):
+        acc = torch.zeros(2, dtype=torch.int64, device=device)
+        n = len(bs)
+        _hip.check(L.dn_checksum128_multi(n, (C.c_void_p * n)(*[b.data_ptr() if b.numel() else None for b in bs]),
+                                          (C.c_size_t * n)(*[b.numel() * b.element_size() for b in bs]), (C.c_uint64 * n)(*salts), acc.data_ptr(), stream),
+                   "dn_checksum128_multi")
+        return acc.cpu()
+    assert torch.equal(multi(bufs), one.cpu())
+    changed = [b.clone() for b in bufs]
+    changed[2][12345] += 1e-3
+    assert not torch.equal(multi(changed), one.cpu())
+    swapped = [bufs[1], bufs[0]] + bufs[2:]                 # same buffers, other slots: the salts make the position part of the sum
+    assert not torch.equal(multi(swapped), one.cpu())
+
+
 def run_packing(device, V=500, seed=13):
     import numpy as np
     import pytest
     import scipy.sparse as sp
     from diffusion_net.batch import coo_to_csr
+    run_checksum(device)
     rng = np.random.RandomState(seed)
     for n_rows, n_cols, density in ((V, V, 7.0 / V), (37, 211, 0.05), (64, 64, 0.0)):
         m = sp.random(n_rows, n_cols, density=density, random_state=rng, format="coo", dtype=np.float32)
