@@ -333,12 +333,12 @@ __device__ __forceinline__ void rg_split_x3(const RgRegs<NOUT, A_IT, B_IT>& R, X
     }
 }
 
-template <int NTHR, int NOUT, bool BCOLK, int A_IT, int B_IT, int NP = 3>
+template <int NTHR, int NOUT, bool BCOLK, int A_IT, int B_IT, int NP = 3, bool DO_A = true, bool DO_B = true>
 __device__ __forceinline__ void rg_put_x3(unsigned char* sA, unsigned char* sB, int tid, const X3Planes<NOUT, A_IT, B_IT, NP>& P) {
     constexpr int PL = DN_TM * 64;    // bytes per A plane (128 rows x 32 bf16)
     constexpr int PLB = 128 * 64;     // bytes per B plane (128 output columns); output o uses planes [3o, 3o+3)
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
+    for (int i = 0; i < (DO_A ? A_IT : 0); ++i) {
         const int idx = tid + i * NTHR;
         const int row = idx >> 3, q = idx & 7;
         const int off = dn_plane_off(row, q >> 1) + (q & 1) * 8;
@@ -346,7 +346,7 @@ __device__ __forceinline__ void rg_put_x3(unsigned char* sA, unsigned char* sB, 
         for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(sA + p * PL + off) = P.a[i][p];
     }
 #pragma unroll
-    for (int o = 0; o < NOUT; ++o) {
+    for (int o = 0; o < (DO_B ? NOUT : 0); ++o) {
         unsigned char* sBo = sB + o * 3 * PLB;
         if (BCOLK) {
 #pragma unroll

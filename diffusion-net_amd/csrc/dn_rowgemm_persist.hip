@@ -252,6 +252,9 @@ __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_pers
 #ifndef DN_WS_KO
 #define DN_WS_KO 0
 #endif
+#ifndef DN_WS_BRES
+#define DN_WS_BRES 0   // B-cached products on the 2-term engine: the four split B slices live in LDS for the whole kernel (the spare 2 x 32 KiB of the
+#endif                 // two slice buffers) instead of being re-written from registers every slice
 #ifndef DN_WS_GROUP_COMMIT
 #define DN_WS_GROUP_COMMIT 1   // one magnitude commit per workgroup (0: one per loader wave)
 #endif
@@ -405,6 +408,9 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     float* smem = reinterpret_cast<float*>(smem_raw);
     float* sE = smem + 2 * SBUF;
     constexpr int WS_AMAX_LDS = DN_TM * 64 * 2 / 4;   // float index of two spare words: the third A plane of stage 0, unused by the 2-term engine
+    constexpr bool BRES = BC && NP == 2 && DN_WS_BRES != 0;
+    // BRES: slice s of B lives at byte offset (s >> 1) * SBUF * 4 + 16 KiB + (s & 1) * 16 KiB (behind the two A planes of either slice buffer)
+#define WS_BRES_PTR(s) (reinterpret_cast<unsigned char*>(smem) + ((s) >> 1) * (SBUF * 4) + 16384 + ((s) & 1) * 16384)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = gridDim.x;
@@ -447,7 +453,7 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
 #endif
         for (int j = 0; j < T; ++j) {
             const unsigned char* cA = reinterpret_cast<const unsigned char*>(smem + (j & 1) * SBUF);
-            const unsigned char* cB = cA + SA * 4;
+            const unsigned char* cB = BRES ? WS_BRES_PTR(j & 3) : cA + SA * 4;
 #if !(DN_WS_KO & 16)
             X3Frags<2, 2, 1, NP> F;
 #endif
@@ -482,7 +488,7 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     // ---------------------------------------------------- loader waves ----------------------------------------------------
     DN_SETPRIO(DN_WS_LOADER_PRIO);
     const int lt = lw * 64 + lane;
-    if (NP == 2 && lt < 2) reinterpret_cast<unsigned*>(smem + WS_AMAX_LDS)[lt] = 0u;   // workgroup-level magnitude commit (before the first barrier)
+    if (NP == 2 && !BRES && lt < 2) reinterpret_cast<unsigned*>(smem + WS_AMAX_LDS)[lt] = 0u;   // workgroup-level magnitude commit (before the first barrier)
     // split-fp16: operand scales (powers of two from the producers' amax words) and the exact inverse of their product
     float sa = 1.f, sb = 1.f, so = 1.f, om = 0.f;   // om: running max |o0| of this thread's pieces
     if constexpr (NP == 2) {
@@ -551,11 +557,11 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     do {                                                                                                                \
         X3Planes<NOUT, A_IT, B_IT, NP> PLN;                                                                             \
         rg_split_x3<NOUT, BCOLK, HASQ, A_IT, B_IT, true, !BC, NP>(RS, PLN, sa, sb);                                     \
-        if constexpr (BC) {                                                                                             \
+        if constexpr (BC && !BRES) {                                                                                    \
             _Pragma("unroll") for (int i_ = 0; i_ < B_IT; ++i_)                                                         \
                 _Pragma("unroll") for (int p_ = 0; p_ < NP; ++p_) PLN.b[0][i_][p_] = Bc[SIDX][i_][p_];                  \
         }                                                                                                               \
-        rg_put_x3<LTHR, NOUT, BCOLK, A_IT, B_IT, NP>(reinterpret_cast<unsigned char*>(buf),                             \
+        rg_put_x3<LTHR, NOUT, BCOLK, A_IT, B_IT, NP, true, !BRES>(reinterpret_cast<unsigned char*>(buf),                \
                                                  reinterpret_cast<unsigned char*>((buf) + SA), lt, PLN);                \
     } while (0)
 
@@ -565,13 +571,13 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
 #define WS_SPLIT(RS, SIDX, PLN)                                                                                         \
     do {                                                                                                                \
         rg_split_x3<NOUT, BCOLK, HASQ, A_IT, B_IT, true, !BC, NP>(RS, PLN, sa, sb);                                     \
-        if constexpr (BC) {                                                                                             \
+        if constexpr (BC && !BRES) {                                                                                    \
             _Pragma("unroll") for (int i_ = 0; i_ < B_IT; ++i_)                                                         \
                 _Pragma("unroll") for (int p_ = 0; p_ < NP; ++p_) PLN.b[0][i_][p_] = Bc[SIDX][i_][p_];                  \
         }                                                                                                               \
     } while (0)
 #define WS_PUT(buf, PLN)                                                                                                \
-    rg_put_x3<LTHR, NOUT, BCOLK, A_IT, B_IT, NP>(reinterpret_cast<unsigned char*>(buf), reinterpret_cast<unsigned char*>((buf) + SA), lt, PLN)
+    rg_put_x3<LTHR, NOUT, BCOLK, A_IT, B_IT, NP, true, !BRES>(reinterpret_cast<unsigned char*>(buf), reinterpret_cast<unsigned char*>((buf) + SA), lt, PLN)
 #define WS_PIECES()                                                                                                     \
     do {                                                                                                                \
         if (piece_wave) {              /* wave-uniform: only the first DN_WS_PW loader waves stream the parked unit out */ \
@@ -652,7 +658,7 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
 #endif
 
     WS_TR_DECL;
-    uint2 Bc[BC ? 4 : 1][B_IT][NP];
+    uint2 Bc[(BC && !BRES) ? 4 : 1][B_IT][NP];
     if constexpr (BC) {   // split the whole B strip of this workgroup once (4 slices of the one segment)
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
@@ -660,10 +666,14 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
             ws_load<BCOLK, A_IT, B_IT, false, true>(sp0, sl0, sb0, ldb, Ncols, 0, 0, n0, DN_KB * s4, lt, Rb);
             X3Planes<NOUT, A_IT, B_IT, NP> Pb;
             rg_split_x3<NOUT, BCOLK, HASQ, A_IT, B_IT, false, true, NP>(Rb, Pb, sa, sb);
+            if constexpr (BRES) {   // resident in LDS for the whole kernel (the first barrier below publishes it)
+                rg_put_x3<LTHR, NOUT, BCOLK, A_IT, B_IT, NP, false, true>(nullptr, WS_BRES_PTR(s4), lt, Pb);
+            } else {
 #pragma unroll
-            for (int i = 0; i < B_IT; ++i)
+                for (int i = 0; i < B_IT; ++i)
 #pragma unroll
-                for (int p3 = 0; p3 < NP; ++p3) Bc[s4][i][p3] = Pb.b[0][i][p3];
+                    for (int p3 = 0; p3 < NP; ++p3) Bc[s4][i][p3] = Pb.b[0][i][p3];
+            }
         }
     }
     WS_LOAD(R0);
@@ -704,6 +714,7 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
         for (int j = 0; j < T; ++j) WS_ITER(j, R0, 0);
     }
 #endif
+#undef WS_BRES_PTR
 #undef WS_ITER
 #undef WS_PIECES
 #undef WS_PUT
@@ -719,7 +730,7 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
         ws_piece_out<MODE, FLAG>(g, *reinterpret_cast<const float4*>(&sE[A1.lds]), bias, A1, so, om);
     }
     if (g.o_amax) {
-        if constexpr (NP == 2 && DN_WS_PW == DN_WS_LW && DN_WS_GROUP_COMMIT) dn_amax_commit_group(g.o_amax, om, reinterpret_cast<unsigned*>(smem + WS_AMAX_LDS), DN_WS_LW);
+        if constexpr (NP == 2 && !BRES && DN_WS_PW == DN_WS_LW && DN_WS_GROUP_COMMIT) dn_amax_commit_group(g.o_amax, om, reinterpret_cast<unsigned*>(smem + WS_AMAX_LDS), DN_WS_LW);
         else dn_amax_commit<true>(g.o_amax, om);
     }
 }
