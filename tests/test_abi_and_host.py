@@ -146,3 +146,19 @@ def test_shipped_checkpoints_load_strict(name):
     for k, v in model.state_dict().items():
         assert torch.equal(v, params[k]), k
     assert sum(p.numel() for p in model.parameters()) == 462344 + (meta["ctor"]["C_in"] - 3) * 128
+
+
+def test_integration_stub_struct_matches_the_binding():
+    """INTEGRATION.md shows the ctypes stub a maintainer would add to the reference: its dn_mesh_batch_t must be the struct the library reads
+    (a stub with fewer fields hands over a shorter struct and the library reads past its end)."""
+    import ctypes as C
+    import re
+    from diffusion_net import _hip
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"class dn_mesh_batch_t\(C\.Structure\):.*?\n(    _fields_ = .*?\n)\n", text, re.S)
+    assert m, "stub not found"
+    ns = {"C": C}
+    exec("class dn_mesh_batch_t(C.Structure):\n" + m.group(1), ns)
+    stub = ns["dn_mesh_batch_t"]
+    assert [f[0] for f in stub._fields_] == [f[0] for f in _hip.MeshBatchStruct._fields_]
+    assert C.sizeof(stub) == C.sizeof(_hip.MeshBatchStruct)
