@@ -252,6 +252,9 @@ __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_pers
 #ifndef DN_WS_KO
 #define DN_WS_KO 0
 #endif
+#ifndef DN_WS_DIRECT
+#define DN_WS_DIRECT 0   // plain-store products (no epilogue operand): the MFMA waves store the finished tile straight from their accumulators
+#endif                   // (dword stores, 128 B per half-wave) instead of parking it in LDS for the loaders to stream out
 #ifndef DN_WS_BRES
 #define DN_WS_BRES 0   // B-cached products on the 2-term engine: the four split B slices live in LDS for the whole kernel (the spare 2 x 32 KiB of the
 #endif                 // two slice buffers) instead of being re-written from registers every slice
@@ -409,6 +412,7 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     float* sE = smem + 2 * SBUF;
     constexpr int WS_AMAX_LDS = DN_TM * 64 * 2 / 4;   // float index of two spare words: the third A plane of stage 0, unused by the 2-term engine
     constexpr bool BRES = BC && NP == 2 && DN_WS_BRES != 0;
+    constexpr bool DIRECT = DN_WS_DIRECT != 0 && MODE == DN_EPI_STORE && !FLAG;
     // BRES: slice s of B lives at byte offset (s >> 1) * SBUF * 4 + 16 KiB + (s & 1) * 16 KiB (behind the two A planes of either slice buffer)
 #define WS_BRES_PTR(s) (reinterpret_cast<unsigned char*>(smem) + ((s) >> 1) * (SBUF * 4) + 16384 + ((s) & 1) * 16384)
 
@@ -446,6 +450,9 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][mt][nt][r] = 0.f;
         int cs = 0;
+        int ucur = blockIdx.x;          // (DIRECT) the unit being multiplied
+        float so_m = 1.f, om_m = 0.f;
+        if constexpr (DIRECT && NP == 2) so_m = (1.f / dn_pow2_scale(dn_amax_eval(g.a_amax))) * (1.f / dn_pow2_scale(dn_amax_eval(g.b_amax)));
         WS_TR_DECL;
         __syncthreads();   // slice 0 staged
 #if DN_WS_KO & 16
@@ -467,7 +474,28 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
                 ws_mma<NP>(F, 1, acc);
             }
             WS_TR();   // m1: reads + MFMAs issued
-            if (++cs == nsl) {   // unit complete: park it (fragment layout -> row-major) for the loader waves to stream out
+            if (DIRECT && ++cs == nsl) {   // unit complete: store it from the accumulators (lane = column, 32 lanes = 128 contiguous bytes)
+                cs = 0;
+                const DnTile t = g.tiles[ucur];
+                ucur += G;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const int col = n0 + wc * 64 + nt * 32 + li;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = wr * 64 + mt * 32 + dn_acc_row(r, lane);
+                            const float v = acc[0][mt][nt][r] * so_m;
+                            if (row < t.nrows && col < g.N) {
+                                g.o0[(long long)(t.row0 + row) * g.ldo + col] = v;
+                                om_m = fabsf(v) > om_m ? fabsf(v) : om_m;
+                            }
+                            acc[0][mt][nt][r] = 0.f;
+                        }
+                    }
+            }
+            if (!DIRECT && ++cs == nsl) {   // unit complete: park it (fragment layout -> row-major) for the loader waves to stream out
                 cs = 0;
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
@@ -482,6 +510,7 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
             WS_TR();   // m2: before the barrier
             __syncthreads();
         }
+        if (DIRECT && g.o_amax) dn_amax_commit<true>(g.o_amax, om_m);
         return;
     }
 
@@ -628,13 +657,13 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
         WS_TR_WAITV(); WS_TR();        /* l1: the prefetched slice has arrived (explicit wait in the trace build only) */ \
         WS_SPLIT(RS, SIDX, PLN);       /* slice j+1 (the last iteration stages a stale copy nobody reads) */            \
         WS_TR();                       /* l2: split */                                                                  \
-        if (DN_WS_ORDER == 1 && !(DN_WS_KO & 1)) WS_PIECES();                                                           \
+        if (DN_WS_ORDER == 1 && !(DN_WS_KO & 1) && !DIRECT) WS_PIECES();                                                           \
         WS_ADVANCE((j) + 1 + DN_WS_DEPTH < T);                                                                          \
         if (!(DN_WS_KO & 4)) WS_LOAD(RS);   /* slice j+1+DEPTH */                                                       \
         WS_TR();                       /* l3: prefetch issued */                                                        \
         if (!(DN_WS_KO & 2)) WS_PUT(nxt, PLN);                                                                          \
         WS_TR();                       /* l4: LDS writes issued */                                                      \
-        if (DN_WS_ORDER == 0 && !(DN_WS_KO & 1)) WS_PIECES();                                                           \
+        if (DN_WS_ORDER == 0 && !(DN_WS_KO & 1) && !DIRECT) WS_PIECES();                                                           \
         WS_TR();                       /* l5: pieces out + next pieces' operands requested */                           \
         __syncthreads();                                                                                                \
     } while (0)
@@ -723,7 +752,7 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
 #undef WS_LOAD
 #undef WS_ADVANCE
     // flush the last parked unit
-    if (!piece_wave) return;
+    if (!piece_wave || DIRECT) return;
     for (; p_next < DN_WS_NP; ++p_next) {
         WsAux A1;
         ws_aux_load<MODE, FLAG, XMASK>(g, seed, p_next, lt, p_row0, p_nrows, n0, A1);
