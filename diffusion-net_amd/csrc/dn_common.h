@@ -173,6 +173,27 @@ struct DnTile {
 };
 
 __device__ __forceinline__ float4 dn_f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// streaming (nontemporal) 16-byte accesses: the hand-written copy runs at 6.2-6.4 TB/s with them against 5.2-5.9 TB/s without (tools/kbench copyk).
+// DN_WS_NT (development knob): 1 = the row GEMM's output stores, 2 = its A-slice loads, 3 = both.
+#ifndef DN_WS_NT
+#define DN_WS_NT 0
+#endif
+typedef float dn_vf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dn_store_f4_nt(float* p, const float4& v) {
+#ifdef DN_EMULATE
+    *reinterpret_cast<float4*>(p) = v;
+#else
+    __builtin_nontemporal_store(dn_vf4{v.x, v.y, v.z, v.w}, reinterpret_cast<dn_vf4*>(p));
+#endif
+}
+__device__ __forceinline__ float4 dn_load_f4_nt(const float* p) {
+#ifdef DN_EMULATE
+    return *reinterpret_cast<const float4*>(p);
+#else
+    const dn_vf4 v = __builtin_nontemporal_load(reinterpret_cast<const dn_vf4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#endif
+}
 // Plain multiplies on purpose.  An explicit two-element vector multiply here (v_pk_mul_f32 with a broadcast operand in src1,
 // `op_sel_hi:[1,0]`) produced INTERMITTENTLY wrong low halves on gfx950 / ROCm 7.2: one stale bf16 pair in a few launches per
 // thousand at small sizes, in every launch at the benchmark size -- a whole output column of a tile off by ~1e-1 relative, found

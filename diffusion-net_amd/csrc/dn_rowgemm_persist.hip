@@ -255,6 +255,9 @@ __global__ __launch_bounds__(DN_PT_THREADS) DN_WAVES_PER_EU(2) void rowgemm_pers
 #ifndef DN_WS_DIRECT
 #define DN_WS_DIRECT 0   // plain-store products (no epilogue operand): the MFMA waves store the finished tile straight from their accumulators
 #endif                   // (dword stores, 128 B per half-wave) instead of parking it in LDS for the loaders to stream out
+#ifndef DN_WS_PAIR
+#define DN_WS_PAIR 0     // with DN_WS_DIRECT on the 2-term engine: TWO 32-wide slices per barrier (the parked tile's 64 KiB hold the second pair of
+#endif                   // sub-stages): half the barriers and per-iteration fixed costs per byte
 #ifndef DN_WS_BRES
 #define DN_WS_BRES 0   // B-cached products on the 2-term engine: the four split B slices live in LDS for the whole kernel (the spare 2 x 32 KiB of the
 #endif                 // two slice buffers) instead of being re-written from registers every slice
@@ -371,7 +374,7 @@ __device__ __forceinline__ void ws_load(const float* ap, int ald, const float* b
             const int idx = lt + i * LTHR;
             const int row = idx >> 3, q = idx & 7;
             const long long off = (long long)(row0 + (row < nrows ? row : 0)) * ald + koff + 4 * q;
-            R.a[i] = *reinterpret_cast<const float4*>(ap + off);
+            R.a[i] = (DN_WS_NT & 2) ? dn_load_f4_nt(ap + off) : *reinterpret_cast<const float4*>(ap + off);
         }
     }
     if (!LOAD_B) return;
@@ -413,6 +416,9 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     constexpr int WS_AMAX_LDS = DN_TM * 64 * 2 / 4;   // float index of two spare words: the third A plane of stage 0, unused by the 2-term engine
     constexpr bool BRES = BC && NP == 2 && DN_WS_BRES != 0;
     constexpr bool DIRECT = DN_WS_DIRECT != 0 && MODE == DN_EPI_STORE && !FLAG;
+    constexpr bool PAIR = DIRECT && NP == 2 && !BRES && DN_WS_PAIR != 0;   // (the host sends products with nsl % 4 == 0 here: T / 2 is even)
+    // PAIR: sub-stage u of stage s at byte offset (2 s + u) * 32 KiB: A planes, B planes at + 16 KiB
+#define WS_PAIR_A(s, u) (reinterpret_cast<unsigned char*>(smem) + (2 * (s) + (u)) * 32768)
     // BRES: slice s of B lives at byte offset (s >> 1) * SBUF * 4 + 16 KiB + (s & 1) * 16 KiB (behind the two A planes of either slice buffer)
 #define WS_BRES_PTR(s) (reinterpret_cast<unsigned char*>(smem) + ((s) >> 1) * (SBUF * 4) + 16384 + ((s) & 1) * 16384)
 
@@ -454,7 +460,46 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
         float so_m = 1.f, om_m = 0.f;
         if constexpr (DIRECT && NP == 2) so_m = (1.f / dn_pow2_scale(dn_amax_eval(g.a_amax))) * (1.f / dn_pow2_scale(dn_amax_eval(g.b_amax)));
         WS_TR_DECL;
+        auto store_unit = [&]() {   // (DIRECT) the finished unit straight from the accumulators: lane = column, 32 lanes = 128 contiguous bytes
+            const DnTile t = g.tiles[ucur];
+            ucur += G;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int col = n0 + wc * 64 + nt * 32 + li;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = wr * 64 + mt * 32 + dn_acc_row(r, lane);
+                        const float v = acc[0][mt][nt][r] * so_m;
+                        if (row < t.nrows && col < g.N) {
+                            g.o0[(long long)(t.row0 + row) * g.ldo + col] = v;
+                            om_m = fabsf(v) > om_m ? fabsf(v) : om_m;
+                        }
+                        acc[0][mt][nt][r] = 0.f;
+                    }
+                }
+        };
         __syncthreads();   // slice 0 staged
+        if constexpr (PAIR) {
+            for (int jp = 0; jp < T / 2; ++jp) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const unsigned char* cA = WS_PAIR_A(jp & 1, u);
+                    const unsigned char* cB = cA + 16384;
+                    X3Frags<2, 2, 1, NP> F;
+                    rg_frag_x3<2, 2, 1, NP>(cA, cB, wr * 64, wc * 64, li, lg, 0, F);
+                    rg_frag_x3<2, 2, 1, NP>(cA, cB, wr * 64, wc * 64, li, lg, 1, F);
+                    ws_mma<NP>(F, 0, acc);
+                    ws_mma<NP>(F, 1, acc);
+                }
+                cs += 2;
+                if (cs == nsl) { cs = 0; store_unit(); }
+                __syncthreads();
+            }
+            if (g.o_amax) dn_amax_commit<true>(g.o_amax, om_m);
+            return;
+        }
 #if DN_WS_KO & 16
         X3Frags<2, 2, 1, NP> F;
 #endif
@@ -474,26 +519,9 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
                 ws_mma<NP>(F, 1, acc);
             }
             WS_TR();   // m1: reads + MFMAs issued
-            if (DIRECT && ++cs == nsl) {   // unit complete: store it from the accumulators (lane = column, 32 lanes = 128 contiguous bytes)
+            if (DIRECT && ++cs == nsl) {   // unit complete
                 cs = 0;
-                const DnTile t = g.tiles[ucur];
-                ucur += G;
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        const int col = n0 + wc * 64 + nt * 32 + li;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int row = wr * 64 + mt * 32 + dn_acc_row(r, lane);
-                            const float v = acc[0][mt][nt][r] * so_m;
-                            if (row < t.nrows && col < g.N) {
-                                g.o0[(long long)(t.row0 + row) * g.ldo + col] = v;
-                                om_m = fabsf(v) > om_m ? fabsf(v) : om_m;
-                            }
-                            acc[0][mt][nt][r] = 0.f;
-                        }
-                    }
+                store_unit();
             }
             if (!DIRECT && ++cs == nsl) {   // unit complete: park it (fragment layout -> row-major) for the loader waves to stream out
                 cs = 0;
@@ -517,7 +545,7 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
     // ---------------------------------------------------- loader waves ----------------------------------------------------
     DN_SETPRIO(DN_WS_LOADER_PRIO);
     const int lt = lw * 64 + lane;
-    if (NP == 2 && !BRES && lt < 2) reinterpret_cast<unsigned*>(smem + WS_AMAX_LDS)[lt] = 0u;   // workgroup-level magnitude commit (before the first barrier)
+    if (NP == 2 && !BRES && !PAIR && lt < 2) reinterpret_cast<unsigned*>(smem + WS_AMAX_LDS)[lt] = 0u;   // workgroup-level magnitude commit (before the first barrier)
     // split-fp16: operand scales (powers of two from the producers' amax words) and the exact inverse of their product
     float sa = 1.f, sb = 1.f, so = 1.f, om = 0.f;   // om: running max |o0| of this thread's pieces
     if constexpr (NP == 2) {
@@ -705,6 +733,46 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
             }
         }
     }
+    if constexpr (PAIR) {
+        // two slices per barrier: pair p = slices (2p, 2p + 1) lives in stage p & 1; two register sets, requested one pair ahead
+        RgRegs<NOUT, A_IT, B_IT> Ra, Rc;
+#define WS_PPUT(stg, sub, PL_) rg_put_x3<LTHR, NOUT, BCOLK, A_IT, B_IT, NP>(WS_PAIR_A(stg, sub), WS_PAIR_A(stg, sub) + 16384, lt, PL_)
+#define WS_PAIR_ITER(jp, STG, S0, S1)                                                                                   \
+        do {                                                                                                            \
+            X3Planes<NOUT, A_IT, B_IT, NP> P0, P1;                                                                      \
+            WS_SPLIT(Ra, S0, P0);                                                                                       \
+            WS_SPLIT(Rc, S1, P1);                                                                                       \
+            WS_ADVANCE(2 * (jp) + 4 < T);                                                                               \
+            WS_LOAD(Ra);                                                                                                \
+            WS_ADVANCE(2 * (jp) + 5 < T);                                                                               \
+            WS_LOAD(Rc);                                                                                                \
+            WS_PPUT(STG, 0, P0);                                                                                        \
+            WS_PPUT(STG, 1, P1);                                                                                        \
+            __syncthreads();                                                                                            \
+        } while (0)
+        WS_LOAD(Ra);
+        WS_ADVANCE(T > 1);
+        WS_LOAD(Rc);
+        {
+            X3Planes<NOUT, A_IT, B_IT, NP> P0, P1;
+            WS_SPLIT(Ra, 0, P0);
+            WS_SPLIT(Rc, 1, P1);
+            WS_ADVANCE(T > 2);
+            WS_LOAD(Ra);                   // slice 2
+            WS_ADVANCE(T > 3);
+            WS_LOAD(Rc);                   // slice 3
+            WS_PPUT(0, 0, P0);
+            WS_PPUT(0, 1, P1);
+        }
+        __syncthreads();                   // pair 0 staged
+        for (int jp = 0; jp < T / 2; jp += 2) {     // iteration jp stages pair jp + 1 (slices 2, 3 of a unit), jp + 1 the next unit's slices 0, 1
+            WS_PAIR_ITER(jp, 1, 2, 3);
+            WS_PAIR_ITER(jp + 1, 0, 0, 1);
+        }
+#undef WS_PAIR_ITER
+#undef WS_PPUT
+        return;
+    }
     WS_LOAD(R0);
     WS_STAGE(smem, R0, 0);
     WS_ADVANCE(T > 1);
@@ -743,6 +811,7 @@ __global__ __launch_bounds__(256 + DN_WS_LTHR) DN_WAVES_PER_EU(DN_WS_LW == 4 ? 2
         for (int j = 0; j < T; ++j) WS_ITER(j, R0, 0);
     }
 #endif
+#undef WS_PAIR_A
 #undef WS_BRES_PTR
 #undef WS_ITER
 #undef WS_PIECES
