@@ -327,7 +327,7 @@ int dn_prof_read(int kind, double* out) {
     return 0;
 }
 const char* dn_prof_kind_name(int kind) {
-    static const char* names[DN_K_COUNT] = {"rowgemm_kernel<*,1>", "rowgemm_kernel<*,2>", "tngemm_kernel", "spmm_kernel", "small"};
+    static const char* names[DN_K_COUNT] = {"rowgemm_kernel<*,1>", "rowgemm_kernel<*,2>", "tngemm_kernel", "spmm_kernel", "small", "chain_fwd_kernel"};
     return (kind >= 0 && kind < DN_K_COUNT) ? names[kind] : "";
 }
 
@@ -509,6 +509,13 @@ static bool block_f16_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p) 
     return true;
 }
 static size_t amax_ws(void) { return pad256(AW_COUNT + DN_BLOCK_AMAX_WORDS + 2); }
+// The chained row pipeline (dn_chain.hip) takes the block's row work -- gradient gather, gradient features, MiniMLP -- when the shapes are
+// the ones it is written for and the split-fp16 engine's magnitude words exist.  DN_CHAIN=0 in the environment keeps the unfused launches.
+static bool block_chain_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p) {
+    static const int env = getenv("DN_CHAIN") ? atoi(getenv("DN_CHAIN")) : 1;
+    if (!env || !block_f16_ok(mb, p) || (p->with_grad && !mb->grad_norm)) return false;
+    return dn_chain_eligible(p->C, p->n_mlp, p->widths, p->with_grad, mb->g_nnz, mb->v_total);
+}
 // Product classes of the block; DN_F16_MASK=<bits> (diagnostic) selects which of them run on the split-fp16 engine.
 // Default: the row products (gradient features, MLP, input gradients, backward back-projection).  Not the split-V projections
 // evecs^T x (their lock-step kernel gains nothing: 55 -> 54.6 us, and leaving them out spares the transposed gather a magnitude
@@ -525,6 +532,7 @@ size_t dn_block_fwd_workspace_bytes(const dn_mesh_batch_t* mb, const dn_block_pa
     if (!block_params_ok(p)) return 0;
     const size_t VC = (size_t)mb->v_total * p->C;
     size_t n = pad256((size_t)mb->n_chunks * mb->k_eig * p->C) + pad256((size_t)mb->n_mesh * mb->k_eig * p->C) + amax_ws() + 512;
+    if (block_chain_ok(mb, p)) n += pad256(dn_chain_ws_bytes(p->C, p->with_grad, p->with_rot, p->n_mlp) / sizeof(float));
     if (!with_saved) {
         n += pad256((size_t)mb->n_mesh * mb->k_eig * p->C) + 4 * pad256(VC);          // xs, xd, gx, gy, g
         n += 2 * pad256((size_t)mb->v_total * max_width(p));                            // hidden ping-pong
@@ -541,6 +549,8 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     float* partial = b.f((size_t)mb->n_chunks * K * C);
     float* ys = b.f((size_t)mb->n_mesh * K * C);
     float* aw = b.f(AW_COUNT + DN_BLOCK_AMAX_WORDS + 2);
+    const bool chain = block_chain_ok(mb, p) && (!sv || sv->amax);
+    float* chain_ws = block_chain_ok(mb, p) ? b.f(dn_chain_ws_bytes(p->C, p->with_grad, p->with_rot, p->n_mlp) / sizeof(float)) : nullptr;
     float *xs, *xd, *gx = nullptr, *gy = nullptr, *gf = nullptr, *bre = nullptr, *bim = nullptr;
     float* hbuf[2] = {nullptr, nullptr};
     if (sv) {
@@ -593,6 +603,43 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     DN_CHECK(dn_launch_spec_fwd(partial, mb->mesh_chunk_off, mb->evals, p->time, xs, ys, mb->n_mesh, K, C, st,
                                 (f16 && (f16_mask() & F16_FROMB)) ? aw + AW_YS : nullptr));   // only the split-fp16 back-projection needs max |ys|
     DN_CHECK(from_basis(mb, ys, C, xd, nullptr, false, st, f16 ? f16_if(F16_FROMB, f16_of(ev_amax, aw + AW_YS, sw + SW_XD)) : F16()));
+    if (chain && f16) {   // gather -> gradient features -> MiniMLP + residual in one launch (layers.py:213-239)
+        ChainPrepArgs pa; memset(&pa, 0, sizeof(pa));
+        ChainArgs ca; memset(&ca, 0, sizeof(ca));
+        const int NK = C / 32;
+        int np = 0;
+        auto piece = [&](const float* Wm, const float* word, int ld, int col0) { ChainPrepPiece& q = pa.pc[np++]; q.W = Wm; q.amax = word; q.ld = ld; q.col0 = col0; };
+        if (p->with_grad)
+            for (int rep = 0; rep < 2; ++rep)
+                for (int T = 0; T < NK; ++T) { piece(p->A_re, aw + AW_WA, C, 32 * T); if (p->with_rot) piece(p->A_im, aw + AW_WA, C, 32 * T); }
+        for (int sg = 0; sg < (p->with_grad ? 3 : 2); ++sg) {      // layer 0: the g segment first (columns 2C..), then x, xd
+            const int seg = p->with_grad ? (sg + 2) % 3 : sg;
+            for (int T = 0; T < NK; ++T) piece(p->W[0], aw + AW_W0, p->widths[0], seg * C + 32 * T);
+        }
+        for (int j = 1; j < p->n_mlp; ++j)
+            for (int T = 0; T < NK; ++T) piece(p->W[j], aw + AW_W0 + j, C, 32 * T);
+        pa.out = reinterpret_cast<uint4*>(chain_ws);
+        ca.rowptr = mb->g_rowptr; ca.col = mb->g_col; ca.vx = mb->g_vx; ca.vy = mb->g_vy;
+        ca.x = x; ca.xd = xd; ca.V = mb->v_total;
+        ca.with_grad = p->with_grad; ca.with_rot = p->with_rot; ca.n_mlp = p->n_mlp;
+        ca.wp = reinterpret_cast<const uint4*>(chain_ws);
+        ca.wa_amax = aw + AW_WA;
+        for (int j = 0; j < p->n_mlp; ++j) {
+            ca.w_amax[j] = aw + AW_W0 + j; ca.bias[j] = p->b[j];
+            if (j < p->n_mlp - 1) {
+                ca.mask[j] = p->mask[j + 1];
+                ca.seed[j] = p->mask[j + 1] ? 0ull : layer_seed(p->drop_seed, j + 1);
+                ca.h[j] = sv ? sv->h[j] : nullptr;
+                ca.h_amax[j] = sw + SW_H0 + j;
+            }
+        }
+        ca.seed_dev = (const unsigned long long*)p->drop_seed_dev;
+        if (p->with_grad && sv) { ca.gx = gx; ca.gy = gy; ca.g = gf; ca.bre = bre; ca.bim = bim; }
+        ca.out = out;
+        ca.x_amax = x_amax; ca.xd_amax = sw + SW_XD; ca.grad_norm = mb->grad_norm;
+        ca.g_amax = sw + SW_G; ca.out_amax = p->out_amax;
+        return dn_launch_chain_fwd(pa, np, ca, C, st);
+    }
     // gradient features (layers.py:213-226)
     if (p->with_grad) {
         DN_CHECK(grad_apply_fwd(mb, xd, C, gx, gy, st, f16 ? sw + SW_G : nullptr, f16 ? sw + SW_XD : nullptr));

@@ -1,0 +1,650 @@
+// dn_chain.hip -- the chained row pipeline of DiffusionNetBlock.forward (layers.py:217-239): CSR gradient gather -> complex-linear
+// gradient features + tanh -> MiniMLP (all layers) + residual, ONE launch, activations never leave the registers between stages.
+//
+//   Replaces, per block forward: spmm_kernel (gradX/gradY apply), the two-output gradient-feature row GEMM, and the three MiniMLP row
+//   GEMMs -- five launches and ~18 passes over [V, C] arrays -- by one kernel that reads xd (gathered) and x once and writes, in
+//   training, each saved activation once (gx, gy, bre, bim, g, h_j, out); in inference only `out`.
+//
+// Decomposition (gfx950, wave64): a wave owns 32 consecutive vertex rows for the whole chain, as two 16-row halves on
+// v_mfma_f32_16x16x32_f16.  The products are computed TRANSPOSED, D[n][m] = sum_k W[n][k] act[m][k]: the weights are the MFMA's A
+// operand (rows = output channels), the activations its B operand (columns = vertices).  The accumulator layout of that instruction
+// -- lane (m = l & 15, q = l >> 4) holds output channels 16 nt + 4 q + r, r < 4, of vertex m -- is, channel for channel, what the SAME
+// lane must supply as the B operand of the next layer once the contraction index is enumerated in the order
+//        slot j of k-group q in 32-channel step T  <->  channel 32 T + 16 (j >> 2) + 4 q + (j & 3),
+// so a layer's output becomes the next layer's operand with no data movement: bias / ReLU / dropout / tanh in registers, a two-term
+// fp16 split (dn_split2_pair, as the split-fp16 row GEMMs), done.  The weights are permuted to that order once per call by
+// chain_prep_kernel, which also splits them into fp16 (hi, lo) planes laid out as the LDS image of a "piece" (one matrix, one
+// 32-channel contraction step: [plane][nt][lane] x 16 bytes, conflict-free ds_read_b128).  Pieces stream through a two-slot LDS ring,
+// one barrier per piece; every wave of the workgroup consumes every piece (the weights are the only thing the waves share).
+// The gradient features of the two 16-row halves are computed one after the other (the stage that needs gx, gy AND both accumulators
+// in registers); their pieces are therefore listed twice in the stream.
+//
+// Arithmetic: the split-fp16 engine of dn_rowgemm_persist.hip (three MFMAs per product term pair: hi*lo, lo*hi, hi*hi; fp32
+// accumulation; operands scaled by powers of two and the result scaled back exactly).  Operand scales: x, xd from the producers'
+// magnitude words, gx / gy from the bound ||G||_inf max|xd| (as the unfused path), tanh features by 1, hidden activations by the
+// largest magnitude of the wave's own 32 x C tile (a wave reduces it with shuffles -- tighter than the per-tensor word of the
+// unfused path, and available without a grid-wide dependency).
+#include "dn_common.h"
+#include <stdlib.h>
+
+typedef float dn_f32x4 __attribute__((ext_vector_type(4)));
+
+// One 16x16x32 f16 MFMA step (fp32 accumulate): lane l supplies A[i = l & 15][k = 8 (l >> 4) + j] and B[k = 8 (l >> 4) + j][col = l & 15],
+// j < 8, packed in a uint4; accumulator register r of lane l is D[4 (l >> 4) + r][l & 15].
+__device__ __forceinline__ dn_f32x4 dn_mfma16_f16(uint4 a, uint4 b, dn_f32x4 c) {
+#ifdef DN_EMULATE
+    return dnemu_mfma_f32_16x16x32_f16(a, b, c);
+#else
+    typedef _Float16 dn_f16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dn_f16x8, a), __builtin_bit_cast(dn_f16x8, b), c, 0, 0, 0);
+#endif
+}
+
+// eight values (slots 0..3 = a, 4..7 = b) -> one fragment per plane
+__device__ __forceinline__ void ch_split8(const float (&a)[4], const float (&b)[4], float s, uint4& hi, uint4& lo) {
+    dn_split2_pair(a[0], a[1], s, hi.x, lo.x);
+    dn_split2_pair(a[2], a[3], s, hi.y, lo.y);
+    dn_split2_pair(b[0], b[1], s, hi.z, lo.z);
+    dn_split2_pair(b[2], b[3], s, hi.w, lo.w);
+}
+__device__ __forceinline__ void ch_split8(const float4& a, const float4& b, float s, uint4& hi, uint4& lo) {
+    dn_split2_pair(a.x, a.y, s, hi.x, lo.x);
+    dn_split2_pair(a.z, a.w, s, hi.y, lo.y);
+    dn_split2_pair(b.x, b.y, s, hi.z, lo.z);
+    dn_split2_pair(b.z, b.w, s, hi.w, lo.w);
+}
+// tanh for the gradient-feature epilogue: (1 - t) / (1 + t), t = exp(-2 |x|), through the hardware exp2 / rcp with one Newton step on the
+// quotient; below |x| = 0.25, where 1 - t cancels, the odd Taylor polynomial to x^9.  Measured against double: <= 1.3e-7 absolute
+// (|tanh| <= 1: about one ulp of the result's range); libm's tanhf costs ~44 instructions and several branches per element.
+__device__ __forceinline__ float ch_tanh(float x) {
+    const float ax = fabsf(x);
+    const float x2 = x * x;
+    const float p = x * (1.f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * (-0.053968254f + x2 * 0.021869488f))));
+#ifdef DN_EMULATE
+    const float t = exp2f(-2.885390082f * ax);
+    const float r = 1.f / (1.f + t);
+#else
+    const float t = __builtin_amdgcn_exp2f(-2.885390082f * ax);
+    float r = __builtin_amdgcn_rcpf(1.f + t);
+    r = r * (2.f - (1.f + t) * r);
+#endif
+    const float big = copysignf((1.f - t) * r, x);
+    return ax < 0.25f ? p : big;
+}
+// 1 / s for a power of two s = 2^k, -126 <= k <= 126 (what dn_pow2_scale returns but for its two clamped extremes): exponent arithmetic, exact
+__device__ __forceinline__ float ch_pow2_inv(float s) {
+    const unsigned e = (__float_as_uint(s) >> 23) & 0xffu;
+    return (e >= 1u && e <= 253u) ? __uint_as_float((254u - e) << 23) : 1.f / s;
+}
+// a wave-uniform value that was computed on the vector unit (loaded words, scales): one copy in a scalar register instead of a vector register
+__device__ __forceinline__ float ch_uniform(float v) {
+#ifdef DN_EMULATE
+    return v;
+#else
+    return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v)));
+#endif
+}
+__device__ __forceinline__ float ch_wave_max(float m) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { const float o = __shfl_xor(m, d, 64); m = o > m ? o : m; }
+    return m;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void chain_prep_kernel(ChainPrepArgs a) {
+    constexpr int NT = C / 16;
+    const ChainPrepPiece pc = a.pc[blockIdx.x];
+    uint4* out = a.out + (size_t)blockIdx.x * (2 * NT * 64);
+    const float s = dn_pow2_scale(dn_amax_word(pc.amax));
+    for (int e = threadIdx.x; e < NT * 64; e += 256) {
+        const int nt = e >> 6, lane = e & 63;
+        const int n = 16 * nt + (lane & 15), q = lane >> 4;
+        const float* src = pc.W + (long long)n * pc.ld + pc.col0 + 4 * q;
+        float va[4], vb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { va[t] = src[t]; vb[t] = src[16 + t]; }
+        uint4 hi, lo;
+        ch_split8(va, vb, s, hi, lo);
+        out[e] = hi;
+        out[NT * 64 + e] = lo;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// the chained forward kernel
+// ---------------------------------------------------------------------------------------------------------------------------
+#ifndef DN_CH_RING
+#define DN_CH_RING 4      // LDS slots of the piece stream; DN_CH_RING - 1 pieces are requested ahead of the one being multiplied
+#endif
+#ifndef DN_CH_GCHUNK
+#define DN_CH_GCHUNK 4    // pattern entries gathered per step (all their row pieces in flight together)
+#endif
+#if defined(DN_CH_TRACE) && !defined(DN_EMULATE)   // development build (make variant EXTRA=-DDN_CH_TRACE=<workgroup>): s_memtime stamps of wave 0
+__device__ unsigned long long dn_ch_trace_buf[512];
+extern "C" int dn_debug_ch_trace_read(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dn_ch_trace_buf), (size_t)(n < 512 ? n : 512) * sizeof(unsigned long long));
+}
+#define CH_TR()                                                                                                         \
+    do {                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        if (blockIdx.x == (DN_CH_TRACE) && threadIdx.x == 0 && trn < 512) dn_ch_trace_buf[trn] = __builtin_amdgcn_s_memtime(); \
+        ++trn;                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    } while (0)
+#else
+#define CH_TR() do {} while (0)
+#endif
+
+// One LDS-DMA request: 16 bytes per lane, global -> LDS, lane l's data lands at lds_byte + 16 l (lds_byte wave-uniform).  Inline asm on
+// purpose: the compiler's waitcnt bookkeeping does not see it, so it neither drains the request queue at a barrier nor at the next use of
+// an ordinary load while requests are in flight; the kernel counts them itself (CH_WAIT_PIECES).  Loads return in order, so a compiler-made
+// vmcnt(n) for one of its own loads stays correct with these requests in the queue (it may wait for some of them too: conservative).
+__device__ __forceinline__ void ch_dma16(const uint4* gsrc, uint4* lds_generic, unsigned lds_byte) {
+#ifdef DN_EMULATE
+    (void)lds_byte;
+    lds_generic[threadIdx.x & 63] = *gsrc;
+#else
+    (void)lds_generic;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte) : "memory");
+#endif
+}
+
+template <int C, int NW>
+__global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(ChainArgs a) {
+    constexpr int NT = C / 16;            // 16-channel output tiles
+    constexpr int NK = C / 32;            // 32-channel contraction steps (= pieces per matrix)
+    constexpr int NTHR = 64 * NW;
+    constexpr int PIECE = 2 * NT * 64;    // uint4 per piece
+    constexpr int LPT = PIECE / NTHR;     // DMA requests per thread and piece
+    constexpr int RING = DN_CH_RING;
+    constexpr int GCH = DN_CH_GCHUNK;
+    static_assert(PIECE % NTHR == 0, "piece staging");
+    static_assert(RING >= 2 && RING <= 8 && (RING - 1) * LPT < 60, "ring depth vs the vmcnt range");
+
+    DN_DYN_SMEM(smem_raw);
+    uint4* ring = reinterpret_cast<uint4*>(smem_raw);                      // RING slots of PIECE uint4
+    float* sbias = reinterpret_cast<float*>(ring + RING * PIECE);          // [DN_CH_LAYERS][C]
+#ifdef DN_EMULATE
+    const unsigned lds0 = 0;
+#else
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
+#endif
+#if defined(DN_CH_TRACE) && !defined(DN_EMULATE)
+    int trn = 0;
+#endif
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, q = lane >> 4;
+
+    // XCD-contiguous unit ranges: workgroup b runs on XCD b % 8 and walks units of the b % 8-th eighth of the row axis, so that the
+    // ~7 neighbour rows a row gathers are mostly rows the same L2 has just served
+    const int GX = gridDim.x >> 3;        // workgroups per XCD (the host launches a multiple of 8)
+    const int per_x = (a.units + 7) >> 3;
+    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
+    int npass = 0;
+    if (slot0 < per_x) {
+        int hi_local = a.units - xcd * per_x;       // units of this XCD's range that exist
+        hi_local = hi_local > per_x ? per_x : hi_local;
+        if (slot0 < hi_local) npass = (hi_local - slot0 + GX - 1) / GX;
+    }
+    if (npass == 0) return;
+
+    // ---- operand scales known up front
+    const float s_in = ch_uniform(dn_pow2_scale(fmaxf(fmaxf(dn_amax_word(a.x_amax), dn_amax_word(a.xd_amax)), a.with_grad ? 1.f : 0.f)));   // [x | xd | g]
+    float s_gf = 1.f, so_gf = 1.f;
+    if (a.with_grad) {
+        const float gb = dn_amax_word(a.xd_amax) * dn_amax_word(a.grad_norm);
+        if (blockIdx.x == 0 && tid == 0 && a.g_amax) atomicMax(reinterpret_cast<unsigned*>(a.g_amax), __float_as_uint(gb));
+        s_gf = ch_uniform(dn_pow2_scale(gb));
+        so_gf = ch_uniform(ch_pow2_inv(s_gf) * ch_pow2_inv(dn_pow2_scale(dn_amax_word(a.wa_amax))));
+    }
+    float sw_inv[DN_CH_LAYERS];           // 1 / (power-of-two scale the weights of layer j were split with)
+#pragma unroll
+    for (int j = 0; j < DN_CH_LAYERS; ++j) sw_inv[j] = j < a.n_mlp ? ch_uniform(ch_pow2_inv(dn_pow2_scale(dn_amax_word(a.w_amax[j])))) : 1.f;
+    unsigned long long seed_add = 0ull;
+    if (a.seed_dev) seed_add = *a.seed_dev;
+    for (int i = tid; i < a.n_mlp * C; i += NTHR) sbias[i] = a.bias[i / C][i % C];   // (published by the first barrier below)
+
+    // ---- the piece stream: LDS-DMA fills slot p % RING with piece p, RING - 1 pieces ahead of the one being multiplied.  Every wave
+    //      requests its share of a piece, waits for its share of the NEXT piece at the end of a piece (counted: the younger requests stay in
+    //      flight) and the barrier there publishes it -- and tells everybody that the slot read in this piece may be overwritten.
+    const uint4* src_piece = a.wp;        // piece the NEXT request fetches (wraps at n_pieces: the stream of the next pass)
+    const uint4* const src_end = a.wp + (size_t)a.n_pieces * PIECE;
+#ifdef DN_EMULATE
+    const int wave_u = wave;
+#else
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#endif
+    int rq = 0;                           // slot the next request fills
+    auto issue = [&]() {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int e0 = rq * PIECE + i * NTHR + wave_u * 64;
+            ch_dma16(src_piece + i * NTHR + tid, ring + e0, lds0 + 16u * (unsigned)e0);
+        }
+        src_piece = src_piece + PIECE == src_end ? a.wp : src_piece + PIECE;
+        rq = rq + 1 == RING ? 0 : rq + 1;
+    };
+#ifdef DN_EMULATE
+#define CH_WAIT_PIECES(n) do {} while (0)
+#define CH_BARRIER() __syncthreads()
+#else
+    // wait until at most n * LPT of this wave's vector-memory operations are outstanding (loads return in order: everything older than
+    // the n youngest pieces has landed), and for every LDS read issued so far (the slot just read may be overwritten after the barrier)
+#define CH_WAIT_PIECES(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((n) * LPT) : "memory")
+#define CH_BARRIER() do { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#endif
+    int gp = 0;
+#pragma unroll
+    for (int i = 0; i < RING - 1; ++i) issue();
+    CH_WAIT_PIECES(RING - 2);
+    CH_BARRIER();
+    // start of a piece: request the piece RING - 1 ahead (into the slot everybody finished reading at the last barrier); ws_ = slot to read
+#define CH_PIECE_BEGIN()                                                                                                \
+    const uint4* ws_ = ring + (gp % RING) * PIECE;                                                                     \
+    issue()
+#define CH_PIECE_END() do { CH_WAIT_PIECES(RING - 2); CH_BARRIER(); ++gp; } while (0)
+    // acc[h][nt] += W(piece) * frag[h]   (hi*lo, lo*hi, hi*hi: smallest terms first); two output tiles at a time, so that an MFMA and the
+    // next one into the same accumulator are four issues apart
+#define CH_WLOAD(W_, np_) do { W_[0] = ws_[(np_) * 64 + lane]; W_[1] = ws_[(NT + (np_)) * 64 + lane];                       \
+                               W_[2] = ws_[((np_) + 1) * 64 + lane]; W_[3] = ws_[(NT + (np_) + 1) * 64 + lane]; } while (0)
+#define CH_MMA2(ACC, FH0, FL0, FH1, FL1)                                                                                \
+    do {                                                                                                                \
+        uint4 wq_[2][4];   /* weight fragments of two output tiles (hi a, lo a, hi b, lo b), fetched one pair ahead of their MFMAs */ \
+        CH_WLOAD(wq_[0], 0);                                                                                            \
+        _Pragma("unroll") for (int np_ = 0; np_ < NT; np_ += 2) {                                                       \
+            const int cb_ = (np_ >> 1) & 1;                                                                             \
+            if (np_ + 2 < NT) CH_WLOAD(wq_[cb_ ^ 1], np_ + 2);                                                          \
+            ACC[0][np_] = dn_mfma16_f16(wq_[cb_][0], FL0, ACC[0][np_]);                                                 \
+            ACC[1][np_] = dn_mfma16_f16(wq_[cb_][0], FL1, ACC[1][np_]);                                                 \
+            ACC[0][np_ + 1] = dn_mfma16_f16(wq_[cb_][2], FL0, ACC[0][np_ + 1]);                                         \
+            ACC[1][np_ + 1] = dn_mfma16_f16(wq_[cb_][2], FL1, ACC[1][np_ + 1]);                                         \
+            ACC[0][np_] = dn_mfma16_f16(wq_[cb_][1], FH0, ACC[0][np_]);                                                 \
+            ACC[1][np_] = dn_mfma16_f16(wq_[cb_][1], FH1, ACC[1][np_]);                                                 \
+            ACC[0][np_ + 1] = dn_mfma16_f16(wq_[cb_][3], FH0, ACC[0][np_ + 1]);                                         \
+            ACC[1][np_ + 1] = dn_mfma16_f16(wq_[cb_][3], FH1, ACC[1][np_ + 1]);                                         \
+            ACC[0][np_] = dn_mfma16_f16(wq_[cb_][0], FH0, ACC[0][np_]);                                                 \
+            ACC[1][np_] = dn_mfma16_f16(wq_[cb_][0], FH1, ACC[1][np_]);                                                 \
+            ACC[0][np_ + 1] = dn_mfma16_f16(wq_[cb_][2], FH0, ACC[0][np_ + 1]);                                         \
+            ACC[1][np_ + 1] = dn_mfma16_f16(wq_[cb_][2], FH1, ACC[1][np_ + 1]);                                         \
+        }                                                                                                               \
+    } while (0)
+
+    // the same product with the weight fragments fetched tile pair by tile pair (16 registers less): for the gradient-feature stage, whose
+    // live set (gx, gy, both accumulators, the other half's tanh features) is the kernel's peak
+#define CH_MMA2_LEAN(ACC, FH0, FL0, FH1, FL1)                                                                           \
+    _Pragma("unroll") for (int np_ = 0; np_ < NT; np_ += 2) {                                                           \
+        uint4 w_[4];                                                                                                    \
+        CH_WLOAD(w_, np_);                                                                                              \
+        ACC[0][np_] = dn_mfma16_f16(w_[0], FL0, ACC[0][np_]);                                                           \
+        ACC[1][np_] = dn_mfma16_f16(w_[0], FL1, ACC[1][np_]);                                                           \
+        ACC[0][np_ + 1] = dn_mfma16_f16(w_[2], FL0, ACC[0][np_ + 1]);                                                   \
+        ACC[1][np_ + 1] = dn_mfma16_f16(w_[2], FL1, ACC[1][np_ + 1]);                                                   \
+        ACC[0][np_] = dn_mfma16_f16(w_[1], FH0, ACC[0][np_]);                                                           \
+        ACC[1][np_] = dn_mfma16_f16(w_[1], FH1, ACC[1][np_]);                                                           \
+        ACC[0][np_ + 1] = dn_mfma16_f16(w_[3], FH0, ACC[0][np_ + 1]);                                                   \
+        ACC[1][np_ + 1] = dn_mfma16_f16(w_[3], FH1, ACC[1][np_ + 1]);                                                   \
+        ACC[0][np_] = dn_mfma16_f16(w_[0], FH0, ACC[0][np_]);                                                           \
+        ACC[1][np_] = dn_mfma16_f16(w_[0], FH1, ACC[1][np_]);                                                           \
+        ACC[0][np_ + 1] = dn_mfma16_f16(w_[2], FH0, ACC[0][np_ + 1]);                                                   \
+        ACC[1][np_ + 1] = dn_mfma16_f16(w_[2], FH1, ACC[1][np_ + 1]);                                                   \
+    }
+
+    float hmax[DN_CH_LAYERS];
+#pragma unroll
+    for (int j = 0; j < DN_CH_LAYERS; ++j) hmax[j] = 0.f;
+    float omax = 0.f;
+
+    for (int pass = 0; pass < npass; ++pass) {
+        CH_TR();
+        const int unit = xcd * per_x + slot0 + pass * GX;
+        const int rb = unit * (32 * NW) + 32 * wave;     // first of this wave's 32 rows (row * C fits 32 bits for every batch the library takes)
+        int rowh[2]; bool liveh[2]; int rch[2];
+        int begh[2], endh[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            rowh[hh] = rb + 16 * hh + m;
+            liveh[hh] = rowh[hh] < a.V;
+            rch[hh] = liveh[hh] ? rowh[hh] : a.V - 1;          // dead rows repeat the last row (computed, never stored)
+            if (a.with_grad) { begh[hh] = a.rowptr[rch[hh]]; endh[hh] = a.rowptr[rch[hh] + 1]; }
+        }
+
+        // =================================================== gradient features, one 16-row half at a time
+        uint4 gfh[2][NK], gfl[2][NK];     // tanh features of the two halves as operand fragments (hi / lo planes) for layer 0
+        if (a.with_grad) {
+#pragma unroll 1
+            for (int hh = 0; hh < 2; ++hh) {
+                if (hh == 1) {
+#pragma unroll
+                    for (int T = 0; T < NK; ++T) { gfh[0][T] = gfh[1][T]; gfl[0][T] = gfl[1][T]; }
+                }
+                const long long row = hh ? rowh[1] : rowh[0];
+                const bool live = hh ? liveh[1] : liveh[0];
+                // ---- CSR gather of the row: gx = sum_j vx_j xd[col_j], gy likewise (entry order, fmaf: bit for bit spmm_kernel's sums)
+                float gxv[NT][4], gyv[NT][4];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { gxv[nt][e] = 0.f; gyv[nt][e] = 0.f; }
+                const int beg = hh ? begh[1] : begh[0], end = hh ? endh[1] : endh[0];
+                const int nmax = (int)ch_wave_max((float)(end - beg));
+                int cj[GCH]; float wx[GCH], wy[GCH];
+                auto entries = [&](int j0) {      // pattern entries j0 .. j0 + GCH - 1 of the row (past its end: entry 0 with weight 0)
+#pragma unroll
+                    for (int u = 0; u < GCH; ++u) {
+                        const int idx = beg + j0 + u;
+                        const bool in = idx < end;
+                        const int ii = in ? idx : 0;
+                        cj[u] = a.col[ii];
+                        wx[u] = in ? a.vx[ii] : 0.f;
+                        wy[u] = in ? a.vy[ii] : 0.f;
+                    }
+                };
+                entries(0);
+                for (int j0 = 0; j0 < nmax; j0 += GCH) {
+                    float4 v[GCH][NT];
+                    float cx[GCH], cy[GCH];
+#pragma unroll
+                    for (int u = 0; u < GCH; ++u) {
+                        const float* src = a.xd + (long long)cj[u] * C + 4 * q;
+                        cx[u] = wx[u]; cy[u] = wy[u];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) v[u][nt] = *reinterpret_cast<const float4*>(src + 16 * nt);
+                    }
+                    entries(j0 + GCH);            // the next step's entries travel under this step's row pieces
+#pragma unroll
+                    for (int u = 0; u < GCH; ++u)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            gxv[nt][0] = fmaf(cx[u], v[u][nt].x, gxv[nt][0]); gyv[nt][0] = fmaf(cy[u], v[u][nt].x, gyv[nt][0]);
+                            gxv[nt][1] = fmaf(cx[u], v[u][nt].y, gxv[nt][1]); gyv[nt][1] = fmaf(cy[u], v[u][nt].y, gyv[nt][1]);
+                            gxv[nt][2] = fmaf(cx[u], v[u][nt].z, gxv[nt][2]); gyv[nt][2] = fmaf(cy[u], v[u][nt].z, gyv[nt][2]);
+                            gxv[nt][3] = fmaf(cx[u], v[u][nt].w, gxv[nt][3]); gyv[nt][3] = fmaf(cy[u], v[u][nt].w, gyv[nt][3]);
+                        }
+                }
+                if (a.gx && live) {
+                    float* ox = a.gx + row * C + 4 * q;
+                    float* oy = a.gy + row * C + 4 * q;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        *reinterpret_cast<float4*>(ox + 16 * nt) = make_float4(gxv[nt][0], gxv[nt][1], gxv[nt][2], gxv[nt][3]);
+                        *reinterpret_cast<float4*>(oy + 16 * nt) = make_float4(gyv[nt][0], gyv[nt][1], gyv[nt][2], gyv[nt][3]);
+                    }
+                }
+                CH_TR();
+                // ---- Bre = gx A_re^T - gy A_im^T, Bim = gy A_re^T + gx A_im^T  (layers.py:122-123; without rotations Bre = gx A^T, Bim = gy A^T)
+                dn_f32x4 acc[2][NT];      // [0] = Bre, [1] = Bim of this half
+#pragma unroll
+                for (int o = 0; o < 2; ++o)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[o][nt] = dn_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int T = 0; T < NK; ++T) {
+                    uint4 fxh, fxl, fyh, fyl;
+                    ch_split8(gxv[2 * T], gxv[2 * T + 1], s_gf, fxh, fxl);
+                    ch_split8(gyv[2 * T], gyv[2 * T + 1], s_gf, fyh, fyl);
+                    {   // A_re (or A): Bre += A gx, Bim += A gy
+                        CH_PIECE_BEGIN();
+                        CH_MMA2_LEAN(acc, fxh, fxl, fyh, fyl);
+                        CH_PIECE_END();
+                    }
+                    if (a.with_rot) {   // A_im: Bre -= A_im gy, Bim += A_im gx
+                        const uint4 nyh = make_uint4(fyh.x ^ 0x80008000u, fyh.y ^ 0x80008000u, fyh.z ^ 0x80008000u, fyh.w ^ 0x80008000u);
+                        const uint4 nyl = make_uint4(fyl.x ^ 0x80008000u, fyl.y ^ 0x80008000u, fyl.z ^ 0x80008000u, fyl.w ^ 0x80008000u);
+                        CH_PIECE_BEGIN();
+                        CH_MMA2_LEAN(acc, nyh, nyl, fxh, fxl);
+                        CH_PIECE_END();
+                    }
+                }
+                CH_TR();
+                // ---- g = tanh(gx * Bre + gy * Bim)   (layers.py:128-130), saved tensors, operand fragments for layer 0
+                float gv[NT][4];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[0][nt][e] *= so_gf;                   // Bre, Bim (the accumulator registers keep them for the stores below)
+                        acc[1][nt][e] *= so_gf;
+                        gv[nt][e] = ch_tanh(gxv[nt][e] * acc[0][nt][e] + gyv[nt][e] * acc[1][nt][e]);
+                    }
+                if (live && a.g) {
+                    float* og = a.g + row * C + 4 * q;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<float4*>(og + 16 * nt) = make_float4(gv[nt][0], gv[nt][1], gv[nt][2], gv[nt][3]);
+                }
+                if (live && a.bre) {
+                    float* o0 = a.bre + row * C + 4 * q;
+                    float* o1 = a.bim + row * C + 4 * q;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        *reinterpret_cast<float4*>(o0 + 16 * nt) = make_float4(acc[0][nt][0], acc[0][nt][1], acc[0][nt][2], acc[0][nt][3]);
+                        *reinterpret_cast<float4*>(o1 + 16 * nt) = make_float4(acc[1][nt][0], acc[1][nt][1], acc[1][nt][2], acc[1][nt][3]);
+                    }
+                }
+#pragma unroll
+                for (int T = 0; T < NK; ++T) ch_split8(gv[2 * T], gv[2 * T + 1], s_in, gfh[1][T], gfl[1][T]);
+                CH_TR();
+            }
+        }
+
+        // =================================================== MiniMLP layer 0 on [g | x | xd] (the tanh features first: their fragments die here)
+        dn_f32x4 acc[2][NT];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[hh][nt] = dn_f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            // operands of the 2 NK pieces of the x and xd segments, fetched two pieces ahead
+            float4 nx[3][2][2];
+            auto fetch = [&](int pi, float4 (&d)[2][2]) {
+                const float* p = (pi < NK ? a.x : a.xd) + 32 * (pi < NK ? pi : pi - NK) + 4 * q;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    d[hh][0] = *reinterpret_cast<const float4*>(p + (long long)rch[hh] * C);
+                    d[hh][1] = *reinterpret_cast<const float4*>(p + (long long)rch[hh] * C + 16);
+                }
+            };
+            fetch(0, nx[0]);
+            fetch(1, nx[1]);
+            if (a.with_grad) {
+#pragma unroll
+                for (int T = 0; T < NK; ++T) {
+                    CH_PIECE_BEGIN();
+                    CH_MMA2(acc, gfh[0][T], gfl[0][T], gfh[1][T], gfl[1][T]);
+                    CH_PIECE_END();
+                }
+            }
+#pragma unroll
+            for (int pi = 0; pi < 2 * NK; ++pi) {
+                uint4 fh[2], fl[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) ch_split8(nx[pi % 3][hh][0], nx[pi % 3][hh][1], s_in, fh[hh], fl[hh]);
+                if (pi + 2 < 2 * NK) fetch(pi + 2, nx[(pi + 2) % 3]);
+                CH_PIECE_BEGIN();
+                CH_MMA2(acc, fh[0], fl[0], fh[1], fl[1]);
+                CH_PIECE_END();
+            }
+        }
+        CH_TR();
+        // =================================================== hidden layers: h_j = dropout(relu(acc + b_j)) -> operand fragments -> next product
+        //      (layers.py:143-160: the dropout in front of linear layer j + 1 is applied where h_j is produced)
+        float s_act = s_in;               // scale the operand of the product just finished was split with
+        uint4 hfh[2][NK], hfl[2][NK];     // hidden activations as operand fragments
+#pragma unroll 1
+        for (int j = 0; j + 1 < a.n_mlp; ++j) {
+            const float so = ch_pow2_inv(s_act) * (j == 0 ? sw_inv[0] : (j == 1 ? sw_inv[1] : sw_inv[2]));
+            const float* bj = sbias + j * C + 4 * q;
+            const uint8_t* mk = a.mask[j];
+            const unsigned long long sd = a.seed[j] ? a.seed[j] + seed_add : 0ull;
+            const float dscale = (mk || sd) ? 2.f : 1.f;
+            float* hj = a.h[j];
+            float wm = 0.f;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(bj + 16 * nt);
+                    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+                    unsigned kb = 0x01010101u;
+                    if (mk) kb = *reinterpret_cast<const uint32_t*>(mk + (long long)rch[hh] * C + 16 * nt + 4 * q);
+                    else if (sd) kb = dn_keep_bytes(dn_keep_bits(sd, rch[hh], 4 * nt + q, C / 4));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = acc[hh][nt][e] * so + bb[e];
+                        t = t > 0.f ? t : 0.f;
+                        t = ((kb >> (8 * e)) & 0xffu) ? t * dscale : 0.f;
+                        acc[hh][nt][e] = t;                       // (the accumulator registers now hold h_j)
+                        wm = t > wm ? t : wm;
+                    }
+                }
+            if (hj) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+                    if (liveh[hh]) {
+                        float* oh = hj + (long long)rowh[hh] * C + 4 * q;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            *reinterpret_cast<float4*>(oh + 16 * nt) = make_float4(acc[hh][nt][0], acc[hh][nt][1], acc[hh][nt][2], acc[hh][nt][3]);
+                    }
+            }
+            wm = ch_wave_max(wm);
+#pragma unroll
+            for (int jj = 0; jj < DN_CH_LAYERS; ++jj) hmax[jj] = (jj == j && wm > hmax[jj]) ? wm : hmax[jj];   // (no dynamic register index)
+            s_act = ch_uniform(dn_pow2_scale(wm));
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int T = 0; T < NK; ++T) {
+                    const float va[4] = {acc[hh][2 * T][0], acc[hh][2 * T][1], acc[hh][2 * T][2], acc[hh][2 * T][3]};
+                    const float vb[4] = {acc[hh][2 * T + 1][0], acc[hh][2 * T + 1][1], acc[hh][2 * T + 1][2], acc[hh][2 * T + 1][3]};
+                    ch_split8(va, vb, s_act, hfh[hh][T], hfl[hh][T]);
+                }
+            CH_TR();
+            // ---- product of layer j + 1
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[hh][nt] = dn_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int T = 0; T < NK; ++T) {
+                CH_PIECE_BEGIN();
+                CH_MMA2(acc, hfh[0][T], hfl[0][T], hfh[1][T], hfl[1][T]);
+                CH_PIECE_END();
+            }
+            CH_TR();
+        }
+        // =================================================== last layer: out = acc + b + x   (layers.py:236-239)
+        {
+            const int jl = a.n_mlp - 1;
+            const float so = ch_pow2_inv(s_act) * (jl == 1 ? sw_inv[1] : (jl == 2 ? sw_inv[2] : sw_inv[3]));
+            const float* bj = sbias + jl * C + 4 * q;
+            float4 r4[2][NT];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const float* px = a.x + (long long)rch[hh] * C + 4 * q;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) r4[hh][nt] = *reinterpret_cast<const float4*>(px + 16 * nt);
+            }
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(bj + 16 * nt);
+                    float4 y;
+                    y.x = (acc[hh][nt][0] * so + b4.x) + r4[hh][nt].x;
+                    y.y = (acc[hh][nt][1] * so + b4.y) + r4[hh][nt].y;
+                    y.z = (acc[hh][nt][2] * so + b4.z) + r4[hh][nt].z;
+                    y.w = (acc[hh][nt][3] * so + b4.w) + r4[hh][nt].w;
+                    r4[hh][nt] = y;
+                    omax = dn_f4_amax(omax, y);
+                }
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+                if (liveh[hh]) {
+                    float* oo = a.out + (long long)rowh[hh] * C + 4 * q;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<float4*>(oo + 16 * nt) = r4[hh][nt];
+                }
+            CH_TR();
+        }
+    }
+#undef CH_MMA2
+#undef CH_MMA2_LEAN
+#undef CH_WLOAD
+#undef CH_PIECE_END
+#undef CH_PIECE_BEGIN
+#ifndef DN_EMULATE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the requests that ran past the end of the stream
+#endif
+#undef CH_BARRIER
+#undef CH_WAIT_PIECES
+    // ---- magnitude words of what was produced (one check-first atomic per wave and word)
+#pragma unroll
+    for (int j = 0; j < DN_CH_LAYERS; ++j)
+        if (j < a.n_mlp - 1 && a.h_amax[j]) dn_amax_commit<true>(a.h_amax[j], hmax[j]);
+    if (a.out_amax) dn_amax_commit<true>(a.out_amax, omax);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------------
+int dn_chain_pieces(int C, int with_grad, int with_rot, int n_mlp) {
+    const int NK = C / 32;
+    return (with_grad ? 2 * NK * (with_rot ? 2 : 1) : 0) + (with_grad ? 3 : 2) * NK + (n_mlp - 1) * NK;
+}
+size_t dn_chain_ws_bytes(int C, int with_grad, int with_rot, int n_mlp) {
+    return (size_t)dn_chain_pieces(C, with_grad, with_rot, n_mlp) * (2 * (C / 16) * 64) * sizeof(uint4);
+}
+bool dn_chain_eligible(int C, int n_mlp, const int* widths, int with_grad, long long g_nnz, int V) {
+    if (C != 128 && C != 64) return false;
+    if (n_mlp < 2 || n_mlp > DN_CH_LAYERS) return false;
+    for (int j = 1; j <= n_mlp; ++j) if (widths[j] != C) return false;
+    if (with_grad && g_nnz <= 0) return false;
+    return V > 0;
+}
+
+template <int C, int NW>
+static int chain_launch_nw(ChainArgs a, hipStream_t stream) {
+    a.units = (a.V + 32 * NW - 1) / (32 * NW);
+    int g = (8 / NW) * dn_num_cus();      // eight waves per CU (256 registers per lane each): two 4-wave workgroups or one 8-wave workgroup
+    if (g > a.units) g = a.units;
+    g = (g + 7) / 8 * 8;
+    const size_t smem = (size_t)DN_CH_RING * (2 * (C / 16) * 64) * sizeof(uint4) + (size_t)DN_CH_LAYERS * C * sizeof(float);
+#ifndef DN_EMULATE
+    static unsigned long long lds_opt_in = 0;   // per-device bitmap
+    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&chain_fwd_kernel<C, NW>), smem, &lds_opt_in); if (oe_) return oe_; }
+#endif
+    DN_LAUNCH((chain_fwd_kernel<C, NW>), dim3(g, 1, 1), dim3(64 * NW, 1, 1), smem, stream, a);
+    return (int)hipGetLastError();
+}
+template <int C>
+static int chain_launch(const ChainPrepArgs& pa, int npieces, const ChainArgs& a_in, hipStream_t stream) {
+    static const int nw = getenv("DN_CHAIN_NW") ? atoi(getenv("DN_CHAIN_NW")) : 4;
+    ChainArgs a = a_in;
+    a.n_pieces = npieces;
+    DN_LAUNCH((chain_prep_kernel<C>), dim3(npieces, 1, 1), dim3(256, 1, 1), 0, stream, pa);
+    int err = (int)hipGetLastError();
+    if (err) return err;
+    return nw == 8 ? chain_launch_nw<C, 8>(a, stream) : chain_launch_nw<C, 4>(a, stream);
+}
+
+int dn_launch_chain_fwd(const ChainPrepArgs& pa, int npieces, const ChainArgs& a, int C, hipStream_t stream) {
+    if (npieces > DN_CH_MAX_PIECES) return 1;
+    dn_prof_begin(DN_K_CHAIN, stream);
+    int err;
+    if (C == 128) err = chain_launch<128>(pa, npieces, a, stream);
+    else if (C == 64) err = chain_launch<64>(pa, npieces, a, stream);
+    else err = 1;
+    {
+        // algorithmic traffic: xd gathered once + x read once (+ once more for the residual: L2), every saved tensor written once
+        const double VC = 4.0 * (double)a.V * C;
+        double nw = 1.0;                                     // out
+        if (a.gx) nw += 2.0; if (a.bre) nw += 2.0; if (a.g) nw += 1.0;
+        for (int j = 0; j < DN_CH_LAYERS; ++j) if (j < a.n_mlp - 1 && a.h[j]) nw += 1.0;
+        const double prod = (a.with_grad ? (a.with_rot ? 4.0 : 2.0) : 0.0) + (a.with_grad ? 3.0 : 2.0) + (a.n_mlp - 1);
+        dn_prof_end(DN_K_CHAIN, stream, 2.0 * (double)a.V * C * C * prod, VC * (2.0 + nw));
+    }
+    return err;
+}

@@ -438,6 +438,53 @@ struct SpArgs {
 enum { DN_SP_FWD2 = 0, DN_SP_BWD2 = 1, DN_SP_ONE = 2 };
 
 // ---------------------------------------------------------------------------------------
+// chained row pipeline of the block forward (dn_chain.hip): CSR gather -> gradient features -> MiniMLP in one launch
+// ---------------------------------------------------------------------------------------
+#define DN_CH_LAYERS 4   // MiniMLP depth the chained kernel takes (the default net has 3); deeper nets use the unfused path
+
+struct ChainPrepPiece {
+    const float* W;      // [C, ld] row-major (nn.Linear layout: W[out][in])
+    const float* amax;   // device word: largest magnitude of the matrix (its power-of-two scale puts it into [2^14, 2^15))
+    int ld, col0;        // the piece holds columns col0 .. col0 + 31 (in the permuted order)
+};
+#define DN_CH_MAX_PIECES 48
+struct ChainPrepArgs {
+    ChainPrepPiece pc[DN_CH_MAX_PIECES];
+    uint4* out;          // [npieces][2 * (C / 16) * 64]
+};
+struct ChainArgs {
+    // gradient operators (shared CSR pattern, two value arrays) and the dense inputs
+    const int* rowptr; const int* col; const float* vx; const float* vy;
+    const float* x; const float* xd;
+    int V;
+    int with_grad, with_rot, n_mlp;
+    // weight pieces in stream order: [gradient-feature pieces (T-major: A_re T, A_im T)] x 2, layer 0 ([x | xd | g] segments, T-major
+    // inside a segment), layer 1, ...
+    const uint4* wp;
+    int n_pieces;
+    const float* wa_amax;                 // magnitude word of A_re / A_im (joint)
+    const float* w_amax[DN_CH_LAYERS];    // of W_j
+    const float* bias[DN_CH_LAYERS];
+    const uint8_t* mask[DN_CH_LAYERS];    // explicit keep-mask applied to the OUTPUT of layer j ([V, C] bytes), or null
+    unsigned long long seed[DN_CH_LAYERS];   // != 0 with mask == null: keep bits drawn in the epilogue (dn_keep_bits)
+    const unsigned long long* seed_dev;
+    // outputs (null: not saved)
+    float* gx; float* gy; float* g; float* bre; float* bim;
+    float* h[DN_CH_LAYERS];
+    float* out;
+    // magnitudes
+    const float* x_amax; const float* xd_amax; const float* grad_norm;
+    float* g_amax;                        // receives the bound ||G||_inf max|xd| (the backward's split-fp16 products scale by it)
+    float* h_amax[DN_CH_LAYERS];          // accumulate max |h_j|
+    float* out_amax;                      // accumulates max |out|
+    int units;                            // workgroup passes: ceil(V / (32 waves-per-workgroup))
+};
+int dn_chain_pieces(int C, int with_grad, int with_rot, int n_mlp);
+size_t dn_chain_ws_bytes(int C, int with_grad, int with_rot, int n_mlp);
+bool dn_chain_eligible(int C, int n_mlp, const int* widths, int with_grad, long long g_nnz, int V);
+int dn_launch_chain_fwd(const ChainPrepArgs& pa, int npieces, const ChainArgs& a, int C, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------
 // small reductions / pointwise kernels (dn_pointwise.hip)
 // ---------------------------------------------------------------------------------------
 int dn_launch_spec_fwd(const float* partial, const int* mesh_chunk_off, const float* evals, const float* time,
@@ -539,7 +586,7 @@ int dn_launch_tngemm(const TnArgs& g, int nchunks, hipStream_t stream);
 // hipEvents on its own stream and summed per kernel family.  Off by default; compiled out of the
 // emulator build.
 // ---------------------------------------------------------------------------------------
-enum { DN_K_ROWGEMM = 0, DN_K_ROWGEMM_DUAL = 1, DN_K_TNGEMM = 2, DN_K_SPMM = 3, DN_K_SMALL = 4, DN_K_COUNT = 5 };
+enum { DN_K_ROWGEMM = 0, DN_K_ROWGEMM_DUAL = 1, DN_K_TNGEMM = 2, DN_K_SPMM = 3, DN_K_SMALL = 4, DN_K_CHAIN = 5, DN_K_COUNT = 6 };
 #ifdef DN_EMULATE
 static inline void dn_prof_begin(int, hipStream_t) {}
 static inline void dn_prof_end(int, hipStream_t, double, double) {}

@@ -266,6 +266,29 @@ static inline dnemu_f32x4 dnemu_mfma_f32_16x16x32_bf16(uint4 a, uint4 b, dnemu_f
     }
     return d;
 }
+// v_mfma_f32_16x16x32_f16: the layout of the bf16 form, fp16 operands
+static inline dnemu_f32x4 dnemu_mfma_f32_16x16x32_f16(uint4 a, uint4 b, dnemu_f32x4 c) {
+    dnemu::WaveState& w = dnemu::cur_wave();
+    int l = dnemu::cur_lane();
+    unsigned slot = w.gen & 1;
+    const unsigned aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+    for (int j = 0; j < 8; ++j) {
+        w.ha[slot][l][j] = (unsigned short)((aw[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+        w.hb[slot][l][j] = (unsigned short)((bw[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+    }
+    dnemu::wave_barrier();
+    auto h2f = [](unsigned short u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; };
+    dnemu_f32x4 d;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (l >> 4) + r, col = l & 15;
+        float v = c[r];
+        for (int g = 0; g < 4; ++g)
+            for (int j = 0; j < 8; ++j)
+                v = fmaf(h2f(w.ha[slot][row + 16 * g][j]), h2f(w.hb[slot][col + 16 * g][j]), v);
+        d[r] = v;
+    }
+    return d;
+}
 // ds_read_b64_tr_b16 (semantics probed on gfx950, profiles/r01_exp_tr_read.txt): inside every 16-lane group the lanes'
 // addresses name sixteen 8-byte chunks = a 4x16 matrix of 16-bit elements (row j = chunks of lanes 4j..4j+3); lane l
 // receives column l&15, i.e. element j comes from the address of lane 4j + (l&15)/4 of its group, 16-bit slot (l&15)%4.

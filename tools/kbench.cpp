@@ -408,6 +408,19 @@ int main(int argc, char** argv) {
             }
         }
     }
+    if (trace) {   // libraries built with EXTRA=-DDN_CH_TRACE=<block>: s_memtime stamps of wave 0 of that workgroup of the chained forward kernel (last call)
+        auto rd = (int (*)(unsigned long long*, int))dlsym(L.h, "dn_debug_ch_trace_read");
+        if (rd) {
+            HC(hipStreamSynchronize(st));
+            std::vector<unsigned long long> tb(512, 0);
+            if (rd(tb.data(), 512) == 0) {
+                printf("== chain trace (cycles between consecutive stamps; 0-stamps end the list)\n");
+                int n = 0; while (n < 512 && tb[n]) ++n;
+                for (int i = 1; i < n; ++i) printf(" %7llu%s", tb[i] - tb[i - 1], (i % 12 == 0) ? "\n" : "");
+                printf("\n total %llu cycles over %d stamps\n", n > 1 ? tb[n - 1] - tb[0] : 0ull, n);
+            }
+        }
+    }
     HC(hipStreamSynchronize(st));
     return 0;
 }
