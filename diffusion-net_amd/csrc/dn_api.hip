@@ -512,8 +512,15 @@ static size_t amax_ws(void) { return pad256(AW_COUNT + DN_BLOCK_AMAX_WORDS + 2);
 // The chained row pipeline (dn_chain.hip) takes the block's row work -- gradient gather, gradient features, MiniMLP -- when the shapes are
 // the ones it is written for and the split-fp16 engine's magnitude words exist.  DN_CHAIN=0 in the environment keeps the unfused launches.
 static bool block_chain_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p) {
-    static const int env = getenv("DN_CHAIN") ? atoi(getenv("DN_CHAIN")) : 1;
-    if (!env || !block_f16_ok(mb, p) || (p->with_grad && !mb->grad_norm)) return false;
+    const char* e0 = getenv("DN_CHAIN");            // (read per call: the tests flip it at run time; a getenv is nanoseconds)
+    static const int f16_env = getenv("DN_F16") ? atoi(getenv("DN_F16")) : 1;      // DN_F16=0: split-bf16 engine everywhere (A/B runs)
+    if ((e0 && atoi(e0) == 0) || !f16_env || (p->with_grad && !mb->grad_norm)) return false;
+    // Below a few tens of thousands of vertices the step is bound per launch, not per byte, and the chained kernel's long per-workgroup
+    // sequence has too few workgroups to hide its latencies (measured at 7k / 20k vertices: 109 / 142 us against 109 / 130 us for the
+    // unfused launches, training forward); DN_CHAIN_MIN_ROWS overrides the threshold (the tests run the chain at every size with 0).
+    const char* e1 = getenv("DN_CHAIN_MIN_ROWS");
+    const int min_rows = e1 ? atoi(e1) : 40000;
+    if (mb->v_total < min_rows) return false;
     return dn_chain_eligible(p->C, p->n_mlp, p->widths, p->with_grad, mb->g_nnz, mb->v_total);
 }
 // Product classes of the block; DN_F16_MASK=<bits> (diagnostic) selects which of them run on the split-fp16 engine.
@@ -528,6 +535,10 @@ enum { F16_TOB = 1, F16_FROMB = 2, F16_GF = 4, F16_MLP = 8, F16_LBI = 16, F16_GF
 static int f16_mask(void) { static const int m = getenv("DN_F16_MASK") ? atoi(getenv("DN_F16_MASK")) : (F16_GF | F16_MLP | F16_LBI | F16_GFB | F16_FROMB_B); return m; }
 static F16 f16_if(int bit, const F16& f) { if (f16_mask() & bit) return f; F16 r; r.o = f.o; return r; }   // (the magnitude of the output is still recorded)
 
+int dn_block_tracks_amax(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int backward) {
+    if (!mb || !block_params_ok(p)) return 0;
+    return (block_f16_ok(mb, p) || (!backward && block_chain_ok(mb, p))) ? 1 : 0;
+}
 size_t dn_block_fwd_workspace_bytes(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int with_saved) {
     if (!block_params_ok(p)) return 0;
     const size_t VC = (size_t)mb->v_total * p->C;
@@ -564,30 +575,58 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     if (!b.ok) return DN_ERR_INVALID;
 
     // ---- operand magnitudes for the split-fp16 engine
-    const bool f16 = block_f16_ok(mb, p) && (!sv || sv->amax);
+    const bool f16 = block_f16_ok(mb, p) && (!sv || sv->amax);          // split-fp16 engine for the unfused products
+    const bool words = f16 || chain;                                      // magnitude words are tracked by this call
     float* sw = sv ? sv->amax : aw + AW_COUNT;                 // magnitudes of the saved activations (kept for the backward)
     const float *x_amax = nullptr, *ev_amax = nullptr, *ms_amax = nullptr;
-    if (f16) {
+    ChainPrepArgs pa; memset(&pa, 0, sizeof(pa));
+    int chain_np = 0;
+    const bool use_chain = chain;
+    if (words) {
         // one launch: weight magnitudes (stored), the words the kernels below accumulate into zeroed, the input's word forwarded to the
-        // saved set (the backward multiplies by x again)
+        // saved set (the backward multiplies by x again).  With the chained row kernel that launch is its weight-preparation kernel.
         AmaxInit in; memset(&in, 0, sizeof(in));
-        if (p->with_grad) { in.jobs.push(p->A_re, (long long)C * C, aw + AW_WA); if (p->with_rot) in.jobs.push(p->A_im, (long long)C * C, aw + AW_WA); }
-        for (int j = 0; j < p->n_mlp && in.jobs.count < DN_AMAX_MAX_JOBS; ++j) in.jobs.push(p->W[j], (long long)p->widths[j] * p->widths[j + 1], aw + AW_W0 + j);
+        if (!use_chain) {
+            if (p->with_grad) { in.jobs.push(p->A_re, (long long)C * C, aw + AW_WA); if (p->with_rot) in.jobs.push(p->A_im, (long long)C * C, aw + AW_WA); }
+            for (int j = 0; j < p->n_mlp && in.jobs.count < DN_AMAX_MAX_JOBS; ++j) in.jobs.push(p->W[j], (long long)p->widths[j] * p->widths[j + 1], aw + AW_W0 + j);
+        }
         in.zero_range(aw, AW_WA);                                                  // AW_IN, AW_YS, AW_MISC
         in.zero_range(aw + AW_D0, DN_MAX_MLP_LAYERS + 1 + DN_BLOCK_AMAX_WORDS + 2);
         if (sv) in.zero_range(sw, DN_BLOCK_AMAX_WORDS);
         in.zero_range(p->out_amax, 1);
         x_amax = p->x_amax;
         ev_amax = mb->evecs_amax; ms_amax = mb->mass_amax;
-        const bool measure = !x_amax || !ev_amax || !ms_amax;
+        const bool measure = !x_amax || (f16 && (!ev_amax || !ms_amax));
         if (x_amax && sv && !measure) { in.copy_src = x_amax; in.copy_dst = sw + SW_X; }
-        DN_CHECK(dn_launch_amax_init(in, st));
+        if (use_chain) {
+            const int NK = C / 32;
+            auto piece = [&](const float* Wm, const float* Wm2, float* word, int ld, int col0) {
+                ChainPrepPiece& q = pa.pc[chain_np++]; q.W = Wm; q.W2 = Wm2; q.amax = word; q.ld = ld; q.col0 = col0; };
+            if (p->with_grad)
+                for (int rep = 0; rep < 2; ++rep)
+                    for (int T = 0; T < NK; ++T) {
+                        piece(p->A_re, p->with_rot ? p->A_im : nullptr, aw + AW_WA, C, 32 * T);
+                        if (p->with_rot) piece(p->A_im, p->A_re, aw + AW_WA, C, 32 * T);
+                    }
+            for (int sg = 0; sg < (p->with_grad ? 3 : 2); ++sg) {      // layer 0: the g segment first (columns 2C..), then x, xd
+                const int seg = p->with_grad ? (sg + 2) % 3 : sg;
+                for (int T = 0; T < NK; ++T) piece(p->W[0], nullptr, aw + AW_W0, p->widths[0], seg * C + 32 * T);
+            }
+            for (int j = 1; j < p->n_mlp; ++j)
+                for (int T = 0; T < NK; ++T) piece(p->W[j], nullptr, aw + AW_W0 + j, C, 32 * T);
+            pa.out = reinterpret_cast<uint4*>(chain_ws);
+            for (int r = 0; r < in.nzero; ++r) pa.zero_range(in.zero[r], in.zero_n[r]);
+            pa.copy_src = in.copy_src; pa.copy_dst = in.copy_dst;
+            DN_CHECK(dn_launch_chain_prep(pa, chain_np, C, st));
+        } else {
+            DN_CHECK(dn_launch_amax_init(in, st));
+        }
         if (measure) {   // a caller without magnitudes (plain C users, the first block of a net): one extra pass over what is missing
             AmaxJobs jobs; jobs.count = 0;
             float* fx = sv ? sw + SW_X : aw + AW_IN;
             if (!x_amax) { jobs.push(x, (long long)VC, fx); x_amax = fx; }
-            if (!ev_amax) { jobs.push(mb->evecs, (long long)mb->v_total * K, aw + AW_COUNT + DN_BLOCK_AMAX_WORDS); ev_amax = aw + AW_COUNT + DN_BLOCK_AMAX_WORDS; }
-            if (!ms_amax) { jobs.push(mb->mass, (long long)mb->v_total, aw + AW_COUNT + DN_BLOCK_AMAX_WORDS + 1); ms_amax = aw + AW_COUNT + DN_BLOCK_AMAX_WORDS + 1; }
+            if (f16 && !ev_amax) { jobs.push(mb->evecs, (long long)mb->v_total * K, aw + AW_COUNT + DN_BLOCK_AMAX_WORDS); ev_amax = aw + AW_COUNT + DN_BLOCK_AMAX_WORDS; }
+            if (f16 && !ms_amax) { jobs.push(mb->mass, (long long)mb->v_total, aw + AW_COUNT + DN_BLOCK_AMAX_WORDS + 1); ms_amax = aw + AW_COUNT + DN_BLOCK_AMAX_WORDS + 1; }
             DN_CHECK(dn_launch_amax(jobs, st));
             if (p->x_amax && sv) DN_CHECK((int)hipMemcpyAsync(sw + SW_X, p->x_amax, sizeof(float), hipMemcpyDeviceToDevice, st));
         }
@@ -602,23 +641,14 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     }
     DN_CHECK(dn_launch_spec_fwd(partial, mb->mesh_chunk_off, mb->evals, p->time, xs, ys, mb->n_mesh, K, C, st,
                                 (f16 && (f16_mask() & F16_FROMB)) ? aw + AW_YS : nullptr));   // only the split-fp16 back-projection needs max |ys|
-    DN_CHECK(from_basis(mb, ys, C, xd, nullptr, false, st, f16 ? f16_if(F16_FROMB, f16_of(ev_amax, aw + AW_YS, sw + SW_XD)) : F16()));
-    if (chain && f16) {   // gather -> gradient features -> MiniMLP + residual in one launch (layers.py:213-239)
-        ChainPrepArgs pa; memset(&pa, 0, sizeof(pa));
+    {
+        F16 fb;
+        if (f16) fb = f16_if(F16_FROMB, f16_of(ev_amax, aw + AW_YS, sw + SW_XD));
+        else if (words) fb.o = sw + SW_XD;                                  // (the chained kernel scales xd by its magnitude)
+        DN_CHECK(from_basis(mb, ys, C, xd, nullptr, false, st, fb));
+    }
+    if (use_chain) {   // gather -> gradient features -> MiniMLP + residual in one launch (layers.py:213-239)
         ChainArgs ca; memset(&ca, 0, sizeof(ca));
-        const int NK = C / 32;
-        int np = 0;
-        auto piece = [&](const float* Wm, const float* word, int ld, int col0) { ChainPrepPiece& q = pa.pc[np++]; q.W = Wm; q.amax = word; q.ld = ld; q.col0 = col0; };
-        if (p->with_grad)
-            for (int rep = 0; rep < 2; ++rep)
-                for (int T = 0; T < NK; ++T) { piece(p->A_re, aw + AW_WA, C, 32 * T); if (p->with_rot) piece(p->A_im, aw + AW_WA, C, 32 * T); }
-        for (int sg = 0; sg < (p->with_grad ? 3 : 2); ++sg) {      // layer 0: the g segment first (columns 2C..), then x, xd
-            const int seg = p->with_grad ? (sg + 2) % 3 : sg;
-            for (int T = 0; T < NK; ++T) piece(p->W[0], aw + AW_W0, p->widths[0], seg * C + 32 * T);
-        }
-        for (int j = 1; j < p->n_mlp; ++j)
-            for (int T = 0; T < NK; ++T) piece(p->W[j], aw + AW_W0 + j, C, 32 * T);
-        pa.out = reinterpret_cast<uint4*>(chain_ws);
         ca.rowptr = mb->g_rowptr; ca.col = mb->g_col; ca.vx = mb->g_vx; ca.vy = mb->g_vy;
         ca.x = x; ca.xd = xd; ca.V = mb->v_total;
         ca.with_grad = p->with_grad; ca.with_rot = p->with_rot; ca.n_mlp = p->n_mlp;
@@ -638,7 +668,7 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
         ca.out = out;
         ca.x_amax = x_amax; ca.xd_amax = sw + SW_XD; ca.grad_norm = mb->grad_norm;
         ca.g_amax = sw + SW_G; ca.out_amax = p->out_amax;
-        return dn_launch_chain_fwd(pa, np, ca, C, st);
+        return dn_launch_chain_fwd(chain_np, ca, C, st);
     }
     // gradient features (layers.py:213-226)
     if (p->with_grad) {

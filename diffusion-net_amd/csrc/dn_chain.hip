@@ -93,10 +93,35 @@ __device__ __forceinline__ float ch_wave_max(float m) {
 template <int C>
 __global__ __launch_bounds__(256) void chain_prep_kernel(ChainPrepArgs a) {
     constexpr int NT = C / 16;
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= a.npieces) {          // start-of-call bookkeeping
+        for (int r = 0; r < a.nzero; ++r)
+            for (int i = tid; i < a.zero_n[r]; i += 256) a.zero[r][i] = 0.f;
+        if (tid == 0 && a.copy_src && a.copy_dst) *a.copy_dst = *a.copy_src;
+        return;
+    }
     const ChainPrepPiece pc = a.pc[blockIdx.x];
     uint4* out = a.out + (size_t)blockIdx.x * (2 * NT * 64);
-    const float s = dn_pow2_scale(dn_amax_word(pc.amax));
-    for (int e = threadIdx.x; e < NT * 64; e += 256) {
+    // largest magnitude of the whole matrix (every piece's workgroup measures it: a few tens of KB out of L2)
+    float mx = 0.f;
+    {
+        const long long n4 = (long long)C * pc.ld / 4;   // (ld is a multiple of 4 and the rows 16-byte aligned on this path)
+        for (long long i = tid; i < n4; i += 256) {
+            mx = dn_f4_amax(mx, *reinterpret_cast<const float4*>(pc.W + 4 * i));
+            if (pc.W2) mx = dn_f4_amax(mx, *reinterpret_cast<const float4*>(pc.W2 + 4 * i));
+        }
+    }
+    red[tid] = mx;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (tid < d) red[tid] = red[tid + d] > red[tid] ? red[tid + d] : red[tid];
+        __syncthreads();
+    }
+    mx = red[0];
+    if (tid == 0 && pc.amax) *pc.amax = mx;
+    const float s = dn_pow2_scale(mx);
+    for (int e = tid; e < NT * 64; e += 256) {
         const int nt = e >> 6, lane = e & 63;
         const int n = 16 * nt + (lane & 15), q = lane >> 4;
         const float* src = pc.W + (long long)n * pc.ld + pc.col0 + 4 * q;
@@ -110,9 +135,6 @@ __global__ __launch_bounds__(256) void chain_prep_kernel(ChainPrepArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// the chained forward kernel
-// ---------------------------------------------------------------------------------------------------------------------------
 #ifndef DN_CH_RING
 #define DN_CH_RING 4      // LDS slots of the piece stream; DN_CH_RING - 1 pieces are requested ahead of the one being multiplied
 #endif
@@ -620,22 +642,44 @@ static int chain_launch_nw(ChainArgs a, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 template <int C>
-static int chain_launch(const ChainPrepArgs& pa, int npieces, const ChainArgs& a_in, hipStream_t stream) {
-    static const int nw = getenv("DN_CHAIN_NW") ? atoi(getenv("DN_CHAIN_NW")) : 4;
+static int chain_launch(int npieces, const ChainArgs& a_in, hipStream_t stream) {
+    // Waves per workgroup: every workgroup streams the whole weight set once per 32 * NW rows, so large batches take four (two
+    // workgroups per CU share its matrix pipes out of phase); only batches that would leave most CUs without a workgroup are cut finer
+    // (measured, block forward at 7k / 20k / 160k vertices: NW = 1: 102 / 179 / 658 us, 2: 104 / 140 / 486, 4: 113 / 129 / 388).
+    const int nw_env = getenv("DN_CHAIN_NW") ? atoi(getenv("DN_CHAIN_NW")) : 0;   // (development override)
+    int nw = nw_env;
+    if (nw != 1 && nw != 2 && nw != 4 && nw != 8) {
+        const int half = dn_num_cus() / 2;
+        nw = 4;
+        while (nw > 1 && (a_in.V + 32 * nw - 1) / (32 * nw) < half) nw >>= 1;
+    }
     ChainArgs a = a_in;
     a.n_pieces = npieces;
-    DN_LAUNCH((chain_prep_kernel<C>), dim3(npieces, 1, 1), dim3(256, 1, 1), 0, stream, pa);
-    int err = (int)hipGetLastError();
-    if (err) return err;
-    return nw == 8 ? chain_launch_nw<C, 8>(a, stream) : chain_launch_nw<C, 4>(a, stream);
+    switch (nw) {
+        case 8: return chain_launch_nw<C, 8>(a, stream);
+        case 2: return chain_launch_nw<C, 2>(a, stream);
+        case 1: return chain_launch_nw<C, 1>(a, stream);
+        default: return chain_launch_nw<C, 4>(a, stream);
+    }
 }
 
-int dn_launch_chain_fwd(const ChainPrepArgs& pa, int npieces, const ChainArgs& a, int C, hipStream_t stream) {
+int dn_launch_chain_prep(const ChainPrepArgs& pa, int npieces, int C, hipStream_t stream) {
+    if (npieces > DN_CH_MAX_PIECES || npieces <= 0) return 1;
+    ChainPrepArgs pb = pa;
+    pb.npieces = npieces;
+    dn_prof_begin(DN_K_SMALL, stream);
+    if (C == 128) DN_LAUNCH((chain_prep_kernel<128>), dim3(npieces + 1, 1, 1), dim3(256, 1, 1), 0, stream, pb);
+    else if (C == 64) DN_LAUNCH((chain_prep_kernel<64>), dim3(npieces + 1, 1, 1), dim3(256, 1, 1), 0, stream, pb);
+    else return 1;
+    dn_prof_end(DN_K_SMALL, stream, 0.0, 0.0);
+    return (int)hipGetLastError();
+}
+int dn_launch_chain_fwd(int npieces, const ChainArgs& a, int C, hipStream_t stream) {
     if (npieces > DN_CH_MAX_PIECES) return 1;
     dn_prof_begin(DN_K_CHAIN, stream);
     int err;
-    if (C == 128) err = chain_launch<128>(pa, npieces, a, stream);
-    else if (C == 64) err = chain_launch<64>(pa, npieces, a, stream);
+    if (C == 128) err = chain_launch<128>(npieces, a, stream);
+    else if (C == 64) err = chain_launch<64>(npieces, a, stream);
     else err = 1;
     {
         // algorithmic traffic: xd gathered once + x read once (+ once more for the residual: L2), every saved tensor written once

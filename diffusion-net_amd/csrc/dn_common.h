@@ -444,13 +444,20 @@ enum { DN_SP_FWD2 = 0, DN_SP_BWD2 = 1, DN_SP_ONE = 2 };
 
 struct ChainPrepPiece {
     const float* W;      // [C, ld] row-major (nn.Linear layout: W[out][in])
-    const float* amax;   // device word: largest magnitude of the matrix (its power-of-two scale puts it into [2^14, 2^15))
+    const float* W2;     // optional second matrix of the same shape sharing the magnitude word (A_re / A_im)
+    float* amax;         // device word that RECEIVES the largest magnitude of the matrix (every piece of a matrix stores the same value);
+                         // its power-of-two scale puts the weights into [2^14, 2^15)
     int ld, col0;        // the piece holds columns col0 .. col0 + 31 (in the permuted order)
 };
 #define DN_CH_MAX_PIECES 48
 struct ChainPrepArgs {
     ChainPrepPiece pc[DN_CH_MAX_PIECES];
     uint4* out;          // [npieces][2 * (C / 16) * 64]
+    int npieces;
+    // start-of-call bookkeeping done by the workgroup behind the last piece (what dn_launch_amax_init does for the unfused path):
+    // word ranges zeroed, one word copied
+    float* zero[4]; int zero_n[4]; int nzero; const float* copy_src; float* copy_dst;
+    void zero_range(float* p, int n) { if (p && n > 0 && nzero < 4) { zero[nzero] = p; zero_n[nzero] = n; ++nzero; } }
 };
 struct ChainArgs {
     // gradient operators (shared CSR pattern, two value arrays) and the dense inputs
@@ -482,7 +489,8 @@ struct ChainArgs {
 int dn_chain_pieces(int C, int with_grad, int with_rot, int n_mlp);
 size_t dn_chain_ws_bytes(int C, int with_grad, int with_rot, int n_mlp);
 bool dn_chain_eligible(int C, int n_mlp, const int* widths, int with_grad, long long g_nnz, int V);
-int dn_launch_chain_fwd(const ChainPrepArgs& pa, int npieces, const ChainArgs& a, int C, hipStream_t stream);
+int dn_launch_chain_prep(const ChainPrepArgs& pa, int npieces, int C, hipStream_t stream);
+int dn_launch_chain_fwd(int npieces, const ChainArgs& a, int C, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------
 // small reductions / pointwise kernels (dn_pointwise.hip)

@@ -88,6 +88,7 @@ _SIGNATURES = {
     "dn_linear_fwd_amax_f32": (C.c_int, [_P(MeshBatchStruct), _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "dn_linear_bwd_amax_f32": (C.c_int, [_P(MeshBatchStruct), _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "dn_block_fwd_workspace_bytes": (C.c_size_t, [_P(MeshBatchStruct), _P(BlockParamsStruct), C.c_int]),
+    "dn_block_tracks_amax": (C.c_int, [_P(MeshBatchStruct), _P(BlockParamsStruct), C.c_int]),
     "dn_block_bwd_workspace_bytes": (C.c_size_t, [_P(MeshBatchStruct), _P(BlockParamsStruct)]),
     "dn_block_fwd_f32": (C.c_int, [_P(MeshBatchStruct), _P(BlockParamsStruct), _vp, _vp, _P(BlockSavedStruct), _vp, C.c_size_t, _vp]),
     "dn_block_bwd_f32": (C.c_int, [_P(MeshBatchStruct), _P(BlockParamsStruct), _vp, _P(BlockSavedStruct), _vp,

@@ -31,7 +31,7 @@ _GOLDEN = 0x9E3779B97F4A7C15
 
 class GraphedTrainStep:
     def __init__(self, model, flat: FlatParams, opt: torch.optim.Optimizer, mb: MeshBatch, gather: Optional[GatherPattern], x: torch.Tensor,
-                 labels: torch.Tensor, smoothing: float = 0.0, warmup: int = 3, all_reduce: bool = False):
+                 labels: torch.Tensor, smoothing: float = 0.0, warmup: int = 3, all_reduce: bool = False, pool=None):
         dev = x.device
         if dev.type != "cuda":
             raise RuntimeError("graph capture needs a ROCm device")
@@ -59,14 +59,16 @@ class GraphedTrainStep:
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):              # eager warm-up on a side stream (allocator, per-device kernel attributes)
             for _ in range(warmup):
-                self._body()
+                wl, _ = self._body()
                 self._tail()
+            self.warm_loss = wl.detach().clone()   # loss of the last eager warm-up step (GraphedEpoch returns it for a batch's first visit)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         # thread-local capture mode: the RCCL watchdog thread (event queries on finished collectives) or a data-loader thread may call
         # into HIP while this thread captures; in the default global mode such a call invalidates the capture
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        # pool: graphs that never replay concurrently may share one private memory pool (GraphedEpoch: one graph per packed batch)
+        with torch.cuda.graph(self.graph, pool=pool, capture_error_mode="thread_local"):
             self.loss, self.preds = self._body()
         torch.cuda.synchronize(dev)
 
@@ -102,3 +104,51 @@ class GraphedTrainStep:
         self.graph.replay()
         self._tail()
         return self.loss
+
+
+
+class GraphedEpoch:
+    """Graph replay over CHANGING batches: the reference's loop visits a different mesh (here: a different packed batch) every step
+    (human_segmentation_original.py:105-120), while a ``GraphedTrainStep`` is bound to the operators of ONE batch.  This keeps one captured
+    step per packed batch -- keyed by the identity of its ``MeshBatch`` and gather pattern, least recently used dropped beyond
+    ``max_graphs`` -- all sharing the model, the flat parameter / gradient buffers, the optimizer state and ONE private memory pool (the
+    graphs never replay concurrently, so the activations of one step may live where another step's did).  A batch is captured the first
+    time it is seen: that visit runs ONE eager step (the visit's optimizer step) and captures the graph; from its second visit on a
+    step is one host call.
+
+    ``step(mb, gather, x, labels)`` -> the loss tensor of that replay.  It is a static tensor of the graph just replayed and lives in the
+    shared pool: read it (``.item()``, a copy) before the next ``step``."""
+
+    def __init__(self, model, flat: FlatParams, opt: torch.optim.Optimizer, smoothing: float = 0.0, max_graphs: int = 64, all_reduce=False):
+        from collections import OrderedDict
+        self.model, self.flat, self.opt, self.smoothing, self.max_graphs, self.all_reduce = model, flat, opt, smoothing, int(max_graphs), all_reduce
+        self._graphs = OrderedDict()
+        self._pool = None
+        self.stats = {"captures": 0, "replays": 0, "evictions": 0}
+
+    def step(self, mb: MeshBatch, gather: Optional[GatherPattern], x: torch.Tensor, labels: torch.Tensor):
+        key = (id(mb), id(gather))
+        ent = self._graphs.get(key)
+        if ent is not None and (ent[1] is not mb or ent[2] is not gather):     # an id re-used by a new object
+            ent = None
+        if ent is None:
+            if self._pool is None:
+                self._pool = torch.cuda.graph_pool_handle()
+            # one eager warm-up step (THIS visit's optimizer step) + the capture
+            gs = GraphedTrainStep(self.model, self.flat, self.opt, mb, gather, x, labels, smoothing=self.smoothing,
+                                  warmup=1, all_reduce=self.all_reduce, pool=self._pool)
+            self._graphs[key] = (gs, mb, gather)
+            self.stats["captures"] += 1
+            while len(self._graphs) > self.max_graphs:
+                _, (old, _, _) = self._graphs.popitem(last=False)
+                self.stats["evictions"] += 1
+                del old
+            return gs.warm_loss
+        self._graphs.move_to_end(key)
+        self.stats["replays"] += 1
+        return ent[0].step(x, labels)
+
+    def release(self):
+        for gs, _, _ in self._graphs.values():
+            gs.release()
+        self._graphs.clear()

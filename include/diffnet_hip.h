@@ -78,7 +78,7 @@ typedef struct dn_block_params {
                                               step advances it with a graph node, so that every replay draws new masks without host work */
     /* Optional (round 3), magnitudes for the split-fp16 engine: x_amax = device float holding max |x| of the block input (the previous
      * block's out_amax); NULL: measured by the call (one extra pass over x).  out_amax: device float that receives max |out| (zeroed by
-     * the call), or NULL. */
+     * the call when dn_block_tracks_amax() says the call tracks magnitudes, untouched otherwise), or NULL. */
     const float* x_amax; float* out_amax;
 } dn_block_params_t;
 
@@ -170,6 +170,10 @@ int dn_linear_bwd_amax_f32(const dn_mesh_batch_t* mb, const float* d_out, const 
 /* ---- DiffusionNetBlock.forward (layers.py:200-241) and its backward, fused orchestration.
  *      saved = NULL runs inference (intermediates live in ws). */
 size_t dn_block_fwd_workspace_bytes(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int with_saved);
+/*      1 if dn_block_fwd_f32 (backward = 0) / dn_block_bwd_f32 (backward = 1) on this batch and these parameters writes the optional
+ *      magnitude words (out_amax and saved->amax / d_x_amax), 0 if it leaves them untouched (shapes the split-fp16 engine and the chained
+ *      forward kernel do not take): a caller that hands the words on to the next block must not hand on words nobody wrote. */
+int dn_block_tracks_amax(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int backward);
 size_t dn_block_bwd_workspace_bytes(const dn_mesh_batch_t* mb, const dn_block_params_t* p);
 int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, const float* x, float* out,
                      const dn_block_saved_t* saved, void* ws, size_t ws_bytes, void* stream);

@@ -7,6 +7,10 @@ for p in (os.path.join(ROOT, "diffusion-net_amd"), ROOT, os.path.join(ROOT, "tes
         sys.path.insert(0, p)
 
 
+# the chained forward kernel takes only large batches by default (dn_api.hip: DN_CHAIN_MIN_ROWS); the tests run it at every eligible size
+os.environ.setdefault("DN_CHAIN_MIN_ROWS", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -73,3 +73,33 @@ def rel_l2(a, b):
 def rel_max(a, b):
     a, b = a.double().flatten(), b.double().flatten()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# measured parity margins -> a JSON file (the numbers the tests measure must be auditable from the run that produced
+# them, not only asserted).  Every record is {"case": ..., "device": ..., ...measured values...}; the file is rewritten on every
+# record, so that a run that dies half-way still leaves what it measured.  Default location: gpurun_out/parity_margins.json under
+# the repo root (merged back from the GPU box by gpurun; the round's copy is committed under profiles/); DN_PARITY_MARGINS overrides.
+# ------------------------------------------------------------------------------------------------------------------------------
+_MARGINS = []
+
+
+def margins_path():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return os.environ.get("DN_PARITY_MARGINS", os.path.join(root, "gpurun_out", "parity_margins.json"))
+
+
+def record_margin(case, device, **values):
+    import json
+    rec = {"case": case, "device": str(device)}
+    for k, v in values.items():
+        rec[k] = float(v) if isinstance(v, (float, int)) and not isinstance(v, bool) else v
+    _MARGINS.append(rec)
+    try:
+        path = margins_path()
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(_MARGINS, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+    return rec

@@ -69,6 +69,10 @@ def run_golden(name, device):
         assert e_new < max(FWD_TOL, 2 * e_ref), (name, "forward vs fp64", e_new, e_ref)
         assert err < 4e-5, (name, "forward vs fp32 reference", err)
         worst = max(((helpers.rel_l2(v.double(), g64[k]) / max(helpers.rel_l2(expect["grads"][k].double(), g64[k]), 1e-12), k) for k, v in got.items()))
+        helpers.record_margin("golden_checkpoint_fp64_bracket:" + name, device, fwd_rel_max_new_vs_fp64=e_new, fwd_rel_max_reference_vs_fp64=e_ref,
+                              fwd_rel_max_new_vs_reference=err, worst_gradient_ratio_new_over_reference_vs_fp64=worst[0], worst_gradient=worst[1],
+                              gradients_rel_l2_vs_fp64={k: {"new": helpers.rel_l2(v.double(), g64[k]), "reference": helpers.rel_l2(expect["grads"][k].double(), g64[k])}
+                                                        for k, v in got.items()})
         if os.environ.get("DN_PARITY_VERBOSE"):
             print("[%s] forward vs fp64: new %.3e, reference %.3e; worst gradient ratio new/reference vs fp64: %.2f (%s)" % (name, e_new, e_ref, worst[0], worst[1]))
             for k, v in got.items():
@@ -83,8 +87,57 @@ def run_golden(name, device):
     # the clamp side effect on the Parameter (layers.py:48-49)
     for k, p in model.named_parameters():
         if k.endswith("diffusion_time"):
-            assert float(p.min()) >= 1e-8
+            assert float(p.detach().min()) >= 1e-8
+    wk = max(errs, key=errs.get)
+    helpers.record_margin("golden:" + name, device, fwd_rel_max_vs_reference=err, worst_gradient_rel_l2_vs_reference=errs[wk], worst_gradient=wk,
+                          fwd_tol=FWD_TOL, grad_tol=GRAD_TOL)
     return err, max(errs.values())
+
+
+# ------------------------------------------------------------------------------------------
+# chained forward kernel (dn_chain.hip) vs the unfused launches of the same block
+# ------------------------------------------------------------------------------------------
+def run_chain_vs_unfused(device, sizes=(300, 140), K=128, C=128, N_block=2, dropout=True, seed=5, with_rot=True, with_grad=True,
+                         outputs_at="vertices", fwd_tol=2e-6, grad_tol=2e-5):
+    """Same model, same ragged batch, same dropout seed, forward + backward: once with the chained row kernel, once with the unfused
+    launches (DN_CHAIN is read per call).  The two run the same split-fp16 products with different operand scales (per wave tile vs per
+    tensor), so they must agree to rounding level -- far inside the oracle tolerance -- and must NOT be bitwise equal (which would mean the
+    chain did not run).  Returns the worst forward / gradient differences."""
+    meshes, feats = make_ragged(sizes, K, 3, seed)
+    mb = pack(meshes, device, chunk_rows=64)
+    got = {}
+    saved_env = {k: os.environ.get(k) for k in ("DN_CHAIN", "DN_CHAIN_MIN_ROWS")}
+    try:
+        os.environ["DN_CHAIN_MIN_ROWS"] = "0"
+        for mode in ("chain", "unfused"):
+            os.environ["DN_CHAIN"] = "1" if mode == "chain" else "0"
+            torch.manual_seed(seed)
+            model = diffusion_net.layers.DiffusionNet(3, 5, C_width=C, N_block=N_block, outputs_at=outputs_at, dropout=dropout,
+                                                      with_gradient_features=with_grad, with_gradient_rotations=with_rot)
+            model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=seed))
+            model.to(device).train(dropout)
+            x = torch.cat(feats, 0).to(device).requires_grad_(True)
+            torch.manual_seed(seed + 11)            # the in-kernel dropout seed is drawn from torch's generator
+            out = model.forward_packed(x, mb, None)
+            w = torch.randn(out.shape, generator=torch.Generator().manual_seed(seed + 1)).to(device)
+            (out * w).sum().backward()
+            got[mode] = (out.detach().cpu(), {"x_in": x.grad.cpu(), **{k: p.grad.cpu() for k, p in model.named_parameters()}})
+    finally:
+        for k, v in saved_env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    (oc, gc), (ou, gu) = got["chain"], got["unfused"]
+    assert not torch.equal(oc, ou), "chained and unfused forward are bitwise equal: the chained kernel did not run"
+    e_f = helpers.rel_max(oc, ou)
+    e_g = {k: helpers.rel_l2(gc[k], gu[k]) for k in gc}
+    helpers.record_margin("chain_vs_unfused", device, sizes=list(sizes), K=K, C=C, N_block=N_block, dropout=bool(dropout), with_rot=bool(with_rot),
+                          with_grad=bool(with_grad), fwd_rel_max=e_f, worst_gradient_rel_l2=max(e_g.values()), fwd_tol=fwd_tol, grad_tol=grad_tol)
+    assert e_f < fwd_tol, ("chain vs unfused forward", e_f)
+    bad = {k: v for k, v in e_g.items() if not v < grad_tol}
+    assert not bad, ("chain vs unfused gradients", bad)
+    return e_f, max(e_g.values())
 
 
 # ------------------------------------------------------------------------------------------
@@ -131,23 +184,15 @@ def run_ragged_net(device, sizes=(130, 257, 64), K=24, C=32, C_in=3, C_out=5, N_
     saved_h = None
     if fp64_bracket and masks is None:
         # keep the post-ReLU activations the HIP forward saved for its backward (one list per block): the activation pattern its
-        # gradients belong to (see the flip-aware criterion below)
-        keep_out = {}
-        orig_fp = diffusion_net.layers.DiffusionNetBlock.forward_packed
-        def _fp(self, x2d, mb_):
-            o = orig_fp(self, x2d, mb_)
-            keep_out[id(self)] = o
-            return o
-        diffusion_net.layers.DiffusionNetBlock.forward_packed = _fp
+        # gradients belong to (see the flip-aware criterion below) -- through the named debug hook of ops.BlockFn
+        ops.debug_saved = []
     try:
         out = model.forward_packed(x, mb, gather)
-    finally:
         if fp64_bracket and masks is None:
-            diffusion_net.layers.DiffusionNetBlock.forward_packed = orig_fp
-    if fp64_bracket and masks is None:
-        n_h = len(model.blocks[0].mlp.linears()) - 1
-        n_feat = 5 if model.blocks[0].with_gradient_features else 0
-        saved_h = [[t.cpu() for t in keep_out[id(blk)].grad_fn.saved_tensors[5 + n_feat:5 + n_feat + n_h]] for blk in model.blocks]
+            assert len(ops.debug_saved) == len(model.blocks)
+            saved_h = [[t.cpu() for t in rec["h"]] for rec in ops.debug_saved]
+    finally:
+        ops.debug_saved = None
     wgen = torch.Generator().manual_seed(seed + 1)
     w = torch.randn(out.shape, generator=wgen)
     (out * w.to(device)).sum().backward()
@@ -189,8 +234,11 @@ def run_ragged_net(device, sizes=(130, 257, 64), K=24, C=32, C_in=3, C_out=5, N_
     e_out = helpers.rel_max(out.detach().cpu(), ref_out)
     assert e_out < fwd_tol, ("out", e_out)
     if not fp64_bracket:
-        for k, gk in got.items():
-            e = helpers.rel_l2(gk, ref_grads[k])
+        eg = {k: helpers.rel_l2(gk, ref_grads[k]) for k, gk in got.items()}
+        wk = max(eg, key=eg.get)
+        helpers.record_margin("ragged_net_vs_oracle32", device, sizes=list(sizes), K=K, C=C, N_block=N_block, outputs_at=outputs_at,
+                              dropout=bool(dropout), fwd_rel_max=e_out, worst_gradient_rel_l2=eg[wk], worst_gradient=wk, fwd_tol=fwd_tol, grad_tol=GRAD_TOL)
+        for k, e in eg.items():
             assert e < GRAD_TOL, (k, e)
         return
     # Deep train-mode nets sit at the fp32 oracle's own noise floor (its multi-threaded CPU reductions are not even
@@ -203,6 +251,11 @@ def run_ragged_net(device, sizes=(130, 257, 64), K=24, C=32, C_in=3, C_out=5, N_
     print("[fp64 bracket] sizes=%s K=%d C=%d blocks=%d outputs_at=%s: forward rel-max vs fp64: new %.3e, fp32 oracle %.3e (vs fp32 oracle: %.3e); "
           "gradients rel-L2 vs fp64, largest: %s" % (tuple(sizes), K, C, N_block, outputs_at, e_new, e_ref, e_out,
                                                      "; ".join("%s new %.2e ref %.2e" % (k, a, b) for a, b, k in rows[:4])))
+    rec = helpers.record_margin("ragged_net_fp64_bracket", device, sizes=list(sizes), K=K, C=C, N_block=N_block, outputs_at=outputs_at,
+                                dropout=bool(dropout), fwd_rel_max_new_vs_fp64=e_new, fwd_rel_max_oracle32_vs_fp64=e_ref,
+                                fwd_rel_max_new_vs_oracle32=e_out, fwd_tol_vs_oracle32=fwd_tol,
+                                worst_gradients_rel_l2_vs_fp64=[{"tensor": k, "new": a, "oracle32": b} for a, b, k in rows[:6]],
+                                flip_aware_branch_fired=False)
     assert e_new < max(FWD_TOL, 2 * e_ref), ("out vs fp64", e_new, e_ref)
     bad = [(a, b, k) for a, b, k in rows if not a < max(GRAD_TOL, 2 * b)]
     if bad:
@@ -245,9 +298,13 @@ def run_ragged_net(device, sizes=(130, 257, 64), K=24, C=32, C_in=3, C_out=5, N_
                         grads_p[k] += v
         print("[fp64 bracket] activation pattern of the HIP forward vs exact: %d of %d hidden units differ, largest exact |pre-activation| among "
               "them %.2e of its layer's maximum" % (n_flip, n_units, worst))
+        rec.update(flip_aware_branch_fired=True, flipped_units=n_flip, hidden_units=n_units, largest_flipped_preactivation_rel=worst,
+                   tensors_judged_at_own_pattern=[])
         assert n_flip <= max(1, n_units // 100000) and worst < 2.0 ** -20, (n_flip, n_units, worst)
         for a, b, k in bad:
             a2 = helpers.rel_l2(got[k].double(), grads_p[k])
+            rec["tensors_judged_at_own_pattern"].append({"tensor": k, "vs_exact": a, "oracle32_vs_exact": b, "vs_exact_at_own_pattern": a2})
+            helpers.record_margin("ragged_net_fp64_bracket_flip_detail", device, tensor=k, vs_exact=a, vs_exact_at_own_pattern=a2)
             print("[fp64 bracket] %s: vs exact gradient %.2e (fp32 oracle %.2e); vs exact gradient at the forward's own activation pattern %.2e" % (k, a, b, a2))
             assert k != "x_in" and a2 < max(GRAD_TOL, 2 * b), (k, a, b, a2)
 

@@ -124,3 +124,12 @@ def test_autograph_on_emulator(emu):
     """diffusion_net.autograph with the closure-rerun capture backend (tests the static buffers, the pending gate, the autograd wiring)"""
     import parity_cases
     parity_cases.run_autograph(emu)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(with_rot=False, dropout=False, sizes=(170, 133)), dict(with_grad=False, sizes=(200,), N_block=1),
+                                dict(C=64, K=128, sizes=(160, 140), dropout=False)])
+def test_chained_forward_kernel_vs_unfused_on_emulator(emu, kw):
+    """dn_chain.hip (gather -> gradient features -> MiniMLP in one launch) against the unfused launches: with / without rotations and
+    gradient features, in-kernel dropout, partial last units, C = 128 and 64."""
+    import parity_cases
+    parity_cases.run_chain_vs_unfused(emu, **kw)
