@@ -76,6 +76,42 @@ class _Gate:
 _gate = _Gate()
 
 
+class _Order:
+    """Graphs of one device share pool memory, so their replays must not overlap on the DEVICE either: the gate above serialises the
+    host-side protocol, this orders the streams.  Per device it remembers the stream of the last replay and an event recorded behind it;
+    a replay issued from another stream first waits for that event (forward calls from two streams could otherwise run two
+    graphs concurrently in the same pool memory).  Also the pool-wide forward counter: a backward is valid only while no other forward
+    of ANY graph of the pool has replayed since its own (the activations live in shared memory)."""
+
+    def __init__(self):
+        self._last = {}
+        self.forwards = {}
+
+    def before(self, dev):
+        if dev.type != "cuda":
+            return
+        cur = torch.cuda.current_stream(dev)
+        last = self._last.get(dev)
+        if last is not None and last[0] != cur:
+            cur.wait_event(last[1])
+
+    def after(self, dev):
+        if dev.type != "cuda":
+            return
+        cur = torch.cuda.current_stream(dev)
+        last = self._last.get(dev)
+        ev = last[1] if last is not None else torch.cuda.Event()
+        ev.record(cur)
+        self._last[dev] = (cur, ev)
+
+    def bump(self, dev):
+        self.forwards[dev] = self.forwards.get(dev, 0) + 1
+        return self.forwards[dev]
+
+
+_order = _Order()
+
+
 class _Pool:
     """The memory pool the graphs of one device share.  A pool dies with its last graph (the allocator drops it when its use count
     reaches zero) and its handle must not be used again after that: ``users`` tracks the live owners, and a new handle is drawn when
@@ -209,6 +245,7 @@ class GraphedForward:
                     mod._parameters[name] = p
         self.static_x = x.detach().clone()
         self.generation = 0
+        self._mb = weakref.ref(mb)            # (weak: the batch owns this object through its graph table; a pending backward holds it strongly)
         pool = backend.new_pool(self.device, self)
         drop = model.training and any(blk.dropout for blk in model.blocks)
         self.seed = torch.zeros(1, dtype=torch.int64, device=x.device) if drop else None
@@ -277,37 +314,50 @@ class GraphedForward:
 
     def __call__(self, x):
         if not self.grad:
+            _order.before(self.device)
             self.static_x.copy_(x, non_blocking=True)
             self.fwd_replay()
+            _order.bump(self.device)
             stats["replays_fwd"] += 1
-            return self.static_out.clone()
+            out = self.static_out.clone()
+            _order.after(self.device)
+            return out
         return _Replay.apply(self, x, *self.real_params)
 
 
 class _Replay(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gf, x, *params):
+        _order.before(gf.device)
         gf.static_x.copy_(x, non_blocking=True)
         gf.fwd_replay()
         stats["replays_fwd"] += 1
         gf.generation += 1
-        ctx.gf, ctx.generation, ctx.token = gf, gf.generation, _Token()
+        # generation: of this graph; pool_gen: of the device's shared pool (any other graph's forward replay overwrites these activations too)
+        ctx.gf, ctx.generation, ctx.pool_gen, ctx.token = gf, gf.generation, _order.bump(gf.device), _Token()
+        ctx.mb = gf._mb()         # the packed operators the captured kernels read stay alive until the backward has run
         _gate.arm(gf.device, ctx.token)
-        return gf.static_out.clone()
+        out = gf.static_out.clone()
+        _order.after(gf.device)
+        return out
 
     @staticmethod
     def backward(ctx, g):
         gf = ctx.gf
-        if ctx.generation != gf.generation:
-            raise RuntimeError("diffusion_net.autograph: the activations of this forward were overwritten by a later replay of the same "
-                               "graph before its backward ran (set diffusion_net.autograph.enabled = False for this access pattern)")
+        if ctx.generation != gf.generation or ctx.pool_gen != _order.forwards.get(gf.device):
+            raise RuntimeError("diffusion_net.autograph: the activations of this forward were overwritten by a later replay (of this or "
+                               "another graph of the device's shared pool) before its backward ran (set diffusion_net.autograph.enabled = "
+                               "False for this access pattern)")
+        _order.before(gf.device)
         gf.static_gout.copy_(g, non_blocking=True)
         gf.bwd_replay()
         stats["replays_bwd"] += 1
         _gate.disarm(gf.device, ctx.token)
         if gf.flat is None:
+            _order.after(gf.device)
             return (None, None) + (None,) * len(gf.slices)
         flat = gf.flat.clone()        # the caller owns its gradients: the static buffer is rewritten by the next replay
+        _order.after(gf.device)
         return (None, None) + tuple(None if s is None else flat[s[0]:s[0] + s[1]].view(s[2]) for s in gf.slices)
 
 

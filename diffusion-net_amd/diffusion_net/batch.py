@@ -314,6 +314,10 @@ def content_checksum(operands) -> bytes:
     accumulated on the device, then ONE 16-byte device-to-host copy -- the only host synchronisation of a content lookup."""
     L = _hip.lib()
     dev = next(t.device for t in operands if t is not None)
+    for t in operands:        # the kernel dereferences every operand's pointer on `dev`: a host tensor among device operands would fault
+        if t is not None and t.device != dev:
+            raise RuntimeError("operator cache: operands on different devices (%s and %s); move every operator the forward uses to the "
+                               "model's device" % (dev, t.device))
     acc = torch.zeros(2, dtype=torch.int64, device=dev)
     keep, ptrs, sizes, salts = [], [], [], []
     for slot, t in enumerate(operands):

@@ -362,7 +362,10 @@ class DiffusionNet(nn.Module):
         if x_in.shape[-1] != self.C_in:
             raise ValueError("DiffusionNet was constructed with C_in={}, but x_in has last dim={}".format(
                 self.C_in, x_in.shape[-1]))
-        key_ops = (mass, evals, evecs, gradX, gradY, edges if self.outputs_at == "edges" else faces)   # identity / content keys: as handed over
+        # identity / content keys: the operands as handed over -- only those that enter the pack: the index tensor of the output remap
+        # is keyed (and later read on the device) only when outputs_at uses it (a caller may leave unused faces on the host)
+        idx_key = edges if self.outputs_at == "edges" else (faces if self.outputs_at == "faces" else None)
+        key_ops = (mass, evals, evecs, gradX, gradY, idx_key)
         if x_in.dim() == 2:
             squeeze = True
         elif x_in.dim() == 3:

@@ -182,6 +182,19 @@ def run_checkpoint_case(ref, name, ckpt, C_in, V=600, K=128, seed=21):
         arrays["param." + k] = v.detach().numpy()
     for k, p in model.named_parameters():
         arrays["grad." + k] = p.grad.numpy()
+    # The same reference module in DOUBLE precision on the same inputs ("ref64.*"): with trained weights and |log-softmax| up to 40 the fp32
+    # reference itself sits ~1e-5 from this, so a run that has no oracle at hand (bench.py's in-run parity object) can still report
+    # "distance to fp64" for the library next to the reference's own.
+    model64 = ref.layers.DiffusionNet(last_activation=act, **ctor).double()
+    model64.load_state_dict({k: v.double() for k, v in sd.items()}, strict=True)
+    model64.eval()
+    x64 = feats.double().clone().requires_grad_(True)
+    out64 = model64(x64, mass.double(), L=L.double(), evals=evals.double(), evecs=evecs.double(), gradX=gradX.double(), gradY=gradY.double(), faces=ft)
+    (out64 * w.double()).sum().backward()
+    arrays["ref64.out"] = out64.detach().numpy()
+    arrays["ref64.grad.x_in"] = x64.grad.numpy()
+    for k, p in model64.named_parameters():
+        arrays["ref64.grad." + k] = p.grad.numpy()
     gX, gY = gradX.coalesce(), gradY.coalesce()
     assert torch.equal(gX.indices(), gY.indices())
     edges = torch.cat([ft[:, [0, 1]], ft[:, [1, 2]], ft[:, [2, 0]]], 0)[:8]

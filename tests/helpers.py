@@ -47,6 +47,10 @@ def load_golden(name, dtype=torch.float32, device="cpu"):
                       faces=st("faces"), edges=st("edges"))
     masks = [fl(z[k]) for k in sorted((k for k in z.files if k.startswith("mask")), key=lambda s: int(s[4:]))]
     expect = dict(out=fl(z["out"]), loss_w=fl(z["loss_w"]), grads=grads)
+    if "ref64.out" in z.files:      # the reference module evaluated in double precision on the same inputs (checkpoint fixtures)
+        f64 = lambda a: torch.from_numpy(np.asarray(a)).to(torch.float64)
+        expect["out64"] = f64(z["ref64.out"])
+        expect["grads64"] = {k[len("ref64.grad."):]: f64(z[k]) for k in z.files if k.startswith("ref64.grad.")}
     return meta, params, inputs, masks, expect
 
 

@@ -922,6 +922,71 @@ def run_operator_cache(device, V=300, K=16, C=32, seed=6):
     operator_cache.clear()
 
 
+def run_autograph_modes(device, V=120, K=8, C=32, seed=21):
+    """The automatic graph replay (diffusion_net.autograph) behind the reference-signature forward for the output modes and input forms
+    the main autograph case does not visit: outputs_at = 'vertices' (cfg5), 'global_mean' (cfg3), 'edges', and a batched
+    [B, V, C_in] input with stacked 3-D sparse operators -- the reference's train loop with the replay on must give bitwise the losses and
+    parameters of the eager path, and must actually have replayed."""
+    from diffusion_net import autograph
+    from diffusion_net.batch import operator_cache
+    lsm = lambda t: torch.nn.functional.log_softmax(t, dim=-1)
+    m = synthetic.make_mesh_operators(V, K, seed=seed)
+    m2 = synthetic.make_mesh_operators(V, K, seed=seed + 1)
+    up = lambda mm: {k: mm[k].to(device) for k in ("verts", "mass", "evals", "evecs", "gradX", "gradY", "faces", "edges") if k in mm}
+    a, b = up(m), up(m2)
+    if "edges" not in a:      # the synthetic generator has no edge list: unique undirected edges of the faces
+        for d, mm in ((a, m), (b, m2)):
+            f = mm["faces"]
+            e = torch.cat([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], 0)
+            d["edges"] = torch.unique(torch.sort(e, dim=1).values, dim=0).to(device)
+    batched = {"verts": torch.stack([a["verts"], b["verts"]]), "mass": torch.stack([a["mass"], b["mass"]]), "evals": torch.stack([a["evals"], b["evals"]]),
+               "evecs": torch.stack([a["evecs"], b["evecs"]]), "gradX": _stack_sparse([a["gradX"], b["gradX"]]), "gradY": _stack_sparse([a["gradY"], b["gradY"]])}
+    saved = (autograph.enabled, autograph.backend, autograph.warm_calls)
+    if torch.device(device).type != "cuda":
+        autograph.backend, autograph.warm_calls = autograph.RerunBackend, 1
+    n_steps = autograph.warm_calls + 3
+    try:
+        for mode in ("vertices", "global_mean", "edges", "batched_vertices"):
+            at = "vertices" if mode == "batched_vertices" else mode
+            d = batched if mode == "batched_vertices" else a
+            kw = dict(L=None, evals=d["evals"], evecs=d["evecs"], gradX=d["gradX"], gradY=d["gradY"])
+            if at == "edges":
+                kw["edges"] = d["edges"]
+            n_lab = {"vertices": V, "global_mean": 1, "edges": int(a["edges"].shape[0]), "batched_vertices": 2 * V}[mode]
+            lab = torch.randint(0, 4, (n_lab,), generator=torch.Generator().manual_seed(3)).to(device)
+
+            def loop():
+                torch.manual_seed(seed)
+                model = diffusion_net.layers.DiffusionNet(3, 4, C_width=C, N_block=2, outputs_at=at, dropout=False, last_activation=lsm).to(device)
+                model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=0))
+                model.train()
+                opt = torch.optim.SGD(model.parameters(), lr=0.05)
+                losses = []
+                for _ in range(n_steps):
+                    opt.zero_grad()
+                    loss = torch.nn.functional.nll_loss(model(d["verts"], d["mass"], **kw).reshape(n_lab, 4), lab)
+                    loss.backward()
+                    opt.step()
+                    losses.append(loss.detach().clone())
+                return torch.stack(losses), [p.detach().clone() for p in model.parameters()]
+            operator_cache.clear()
+            autograph.enabled = False
+            l0, p0 = loop()
+            operator_cache.clear()
+            autograph.enabled = True
+            for k in autograph.stats:
+                autograph.stats[k] = 0
+            l1, p1 = loop()
+            st = dict(autograph.stats)
+            assert st["captures"] == 1 and st["failed"] == 0 and st["replays_fwd"] >= 2 and st["replays_bwd"] >= 2, (mode, st)
+            assert torch.equal(l0, l1), (mode, l0, l1)
+            for u, v in zip(p0, p1):
+                assert torch.equal(u, v), mode
+    finally:
+        autograph.enabled, autograph.backend, autograph.warm_calls = saved
+        operator_cache.clear()
+
+
 def run_autograph(device, V=120, K=8, C=32, seed=12):
     """Automatic graph replay behind the reference-signature forward (diffusion_net.autograph): the reference's train loop gives bitwise the
     losses and parameters of the eager path; gradient accumulation, a second forward before the first backward (must go eager), a dropped

@@ -124,6 +124,7 @@ def test_autograph_on_emulator(emu):
     """diffusion_net.autograph with the closure-rerun capture backend (tests the static buffers, the pending gate, the autograd wiring)"""
     import parity_cases
     parity_cases.run_autograph(emu)
+    parity_cases.run_autograph_modes(emu)
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(with_rot=False, dropout=False, sizes=(170, 133)), dict(with_grad=False, sizes=(200,), N_block=1),

@@ -109,6 +109,8 @@ def test_autograph_reference_loop(dev):
     import parity_cases
     parity_cases.run_autograph(dev, V=300, K=16, C=32)
     parity_cases.run_autograph(dev, V=7000, K=128, C=128, seed=3)
+    parity_cases.run_autograph_modes(dev, V=300, K=16, C=32)            # outputs_at = vertices / global_mean / edges, batched input
+    parity_cases.run_autograph_modes(dev, V=3000, K=128, C=128, seed=5)
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(with_rot=False, dropout=False, sizes=(700, 333)), dict(with_grad=False, sizes=(1290,), N_block=1),
@@ -116,6 +118,7 @@ def test_autograph_reference_loop(dev):
 def test_chained_forward_kernel_vs_unfused(dev, kw):
     """dn_chain.hip against the unfused launches of the same block (see parity_cases.run_chain_vs_unfused); the last case is large enough for
     several passes per workgroup and the four-wave workgroups of the benchmark shape"""
+    import parity_cases
     parity_cases.run_chain_vs_unfused(dev, **kw)
 
 
@@ -237,6 +240,57 @@ def test_graph_captured_train_step(dev):
     vals = [float(gs.step()) for _ in range(4)]
     assert len(set(vals)) == 4, vals
     gs.release()
+
+
+def test_graphed_epoch_over_changing_batches(dev):
+    """diffusion_net.graphs.GraphedEpoch: one captured step per packed batch (shared memory pool), cycled over three DIFFERENT batches
+    (different meshes, vertex counts, operators) for three epochs -- losses and final parameters bitwise those of the same steps run
+    eagerly (dropout off); a fourth batch beyond max_graphs evicts the least recently used graph and everything still matches."""
+    import diffusion_net
+    import parity_cases
+    from diffusion_net import synthetic
+    from diffusion_net.batch import GatherPattern
+    from diffusion_net.dist import FlatParams
+    from diffusion_net.graphs import GraphedEpoch
+    lsm = lambda t: torch.nn.functional.log_softmax(t, dim=-1)
+    batches = []
+    for b, sizes in enumerate(((1500, 900), (700, 1300, 400), (2100,), (1000, 1100))):
+        meshes, feats = parity_cases.make_ragged(sizes, 64, 3, seed=20 + b)
+        mb = parity_cases.pack(meshes, dev)
+        offs, rows = 0, []
+        for m, v in zip(meshes, sizes):
+            rows.append(m["faces"] + offs)
+            offs += v
+        gather = GatherPattern(torch.cat(rows, 0).to(dev), offs)
+        labels = torch.randint(0, 8, (gather.n_out,), generator=torch.Generator().manual_seed(b)).to(dev)
+        batches.append((mb, gather, torch.cat(feats, 0).to(dev), labels))
+    order = [0, 1, 2] * 3 + [3, 0, 1, 2, 3]
+    runs = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(4)
+        model = diffusion_net.layers.DiffusionNet(3, 8, C_width=128, N_block=2, outputs_at="faces", dropout=False, last_activation=lsm)
+        model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=4))
+        model.to(dev).train()
+        flat = FlatParams(model)
+        opt = torch.optim.Adam([flat.master], lr=1e-3, capturable=True)
+        losses = []
+        if mode == "graph":
+            ge = GraphedEpoch(model, flat, opt, max_graphs=3)
+            for i in order:
+                losses.append(float(ge.step(*batches[i])))
+            assert ge.stats["captures"] >= 4 and ge.stats["replays"] >= 6 and ge.stats["evictions"] >= 1, ge.stats
+            ge.release()
+        else:
+            for i in order:
+                mb, gather, x, labels = batches[i]
+                flat.zero_grad()
+                _, loss = model.forward_packed_loss(x, mb, gather, labels)
+                loss.backward()
+                opt.step()
+                losses.append(float(loss))
+        runs[mode] = (losses, flat.flat.detach().cpu().clone())
+    assert runs["eager"][0] == runs["graph"][0], (runs["eager"][0], runs["graph"][0])
+    assert torch.equal(runs["eager"][1], runs["graph"][1])
 
 
 def test_graph_captures_the_rccl_gradient_all_reduce(dev):
