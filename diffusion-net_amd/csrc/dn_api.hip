@@ -286,12 +286,12 @@ void dn_prof_begin(int kind, hipStream_t stream) {
         }
     }
     g_prof.pool[g_prof.used].kind = kind;
-    hipEventRecord(g_prof.pool[g_prof.used].e0, stream);
+    (void)hipEventRecord(g_prof.pool[g_prof.used].e0, stream);
     g_prof.pending = true;
 }
 void dn_prof_end(int kind, hipStream_t stream, double flops, double bytes) {
     if (!g_prof.on || !g_prof.pending) return;
-    hipEventRecord(g_prof.pool[g_prof.used].e1, stream);
+    (void)hipEventRecord(g_prof.pool[g_prof.used].e1, stream);
     g_prof.used++;
     g_prof.pending = false;
     g_prof.launches[kind]++;
@@ -333,7 +333,7 @@ const char* dn_prof_kind_name(int kind) {
 
 int dn_version(void) { return 100; }
 int dn_tile_rows(void) { return DN_TM; }
-int dn_tn_target_chunks(void) { return (DN_TN_WS ? 1 : 2) * dn_num_cus(); }
+int dn_tn_target_chunks(void) { return 2 * dn_num_cus(); }
 
 // ------------------------------------------------------------------ to_basis / from_basis
 size_t dn_to_basis_workspace_bytes(const dn_mesh_batch_t* mb, int C) {

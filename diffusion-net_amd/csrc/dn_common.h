@@ -173,11 +173,8 @@ struct DnTile {
 };
 
 __device__ __forceinline__ float4 dn_f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-// streaming (nontemporal) 16-byte accesses: the hand-written copy runs at 6.2-6.4 TB/s with them against 5.2-5.9 TB/s without (tools/kbench copyk).
-// DN_WS_NT (development knob): 1 = the row GEMM's output stores, 2 = its A-slice loads, 3 = both.
-#ifndef DN_WS_NT
-#define DN_WS_NT 0
-#endif
+// streaming (nontemporal) 16-byte accesses: the hand-written copy runs at 6.2-6.4 TB/s with them against 5.2-5.9 TB/s without (tools/kbench copyk);
+// in the row GEMM they moved the block by +-2 % either way (round 3, tools/experiments/rowgemm_ws_knobs/) and are not used there.
 typedef float dn_vf4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void dn_store_f4_nt(float* p, const float4& v) {
 #ifdef DN_EMULATE
@@ -395,12 +392,8 @@ static inline int dn_num_cus() {
 // number of partial results a tngemm launch over `nchunks` chunks with grouping `group` writes
 static inline int dn_tn_npartial(int nchunks, int group) { return (nchunks + (group < 1 ? 1 : group) - 1) / (group < 1 ? 1 : group); }
 // grouping for sums over ALL rows (weight gradients): about two workgroups per CU
-#ifndef DN_TN_WS
-#define DN_TN_WS 0   // 1: wave-specialised split-V kernel (dn_tngemm_ws.hip), one workgroup per CU.  Measured (round 3): 45 vs 48.5 us for the
-#endif               // projection alone (tools/kbench), but inside the training step the weight-gradient launches got SLOWER (avg 65 vs 56 us; the
-                     // three-tile dW0 139 vs 115 us: 768 one-per-CU workgroups against 512 two-per-CU ones) -- the lock-step kernel stays the default
 #ifndef DN_TN_TARGET_PARTIALS
-#define DN_TN_TARGET_PARTIALS (DN_TN_WS ? 256 : 512)   // about one (wave-specialised) or two (lock-step) workgroups per CU
+#define DN_TN_TARGET_PARTIALS 512   // about two (lock-step) workgroups per CU (a wave-specialised one-per-CU kernel was measured and rejected: tools/experiments/tngemm_ws/)
 #endif
 static inline int dn_tn_global_group(int nchunks) { int g = (nchunks + DN_TN_TARGET_PARTIALS - 1) / DN_TN_TARGET_PARTIALS; return g < 1 ? 1 : g; }
 // the same for an M x N result of several 128 x 128 output tiles: every (partial, tile) pair is a workgroup, so the partial count --
@@ -409,7 +402,6 @@ static inline int dn_tn_global_group(int nchunks) { int g = (nchunks + DN_TN_TAR
 static inline int dn_tn_global_group_mn(int nchunks, int M, int N) {
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
     const int g0 = dn_tn_global_group(nchunks);
-    if (DN_TN_WS) return g0;   // one workgroup per CU: (partials x tiles) workgroups are whole rounds when the chunk table has dn_tn_target_chunks() entries
     int target = DN_TN_TARGET_PARTIALS / (tiles < 1 ? 1 : tiles);
     if (target < 128) target = 128;
     int g = (nchunks + target - 1) / target;

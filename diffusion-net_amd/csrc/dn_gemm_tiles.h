@@ -474,7 +474,7 @@ __device__ __forceinline__ float4 pt_piece_store(const RgArgs& g, const PtPiece&
         else y[e] = x[e];
     }
     const float4 yv = make_float4(y[0], y[1], y[2], y[3]);
-    if (P.ok) { if (DN_WS_NT & 1) dn_store_f4_nt(g.o0 + P.off, yv); else *reinterpret_cast<float4*>(g.o0 + P.off) = yv; }
+    if (P.ok) *reinterpret_cast<float4*>(g.o0 + P.off) = yv;
     return P.ok ? yv : dn_f4_zero();     // what was stored (zeros for a dead piece): the caller may track max |o0|
 }
 

@@ -214,10 +214,16 @@ class MeshBatch:
             words = [self.evecs.detach().abs().amax(), self.mass.detach().abs().amax()]
             if self.g_rowptr is not None and self.g_vx is not None and self.g_vx.numel() > 0:
                 # infinity norm of the stacked gradient operators: max |gradX x|, |gradY x| <= it * max |x|
-                rows = torch.repeat_interleave(torch.arange(vt, device=self.device), (self.g_rowptr[1:] - self.g_rowptr[:-1]).long())
-                rs = torch.zeros(2, vt, dtype=torch.float32, device=self.device)
-                rs[0].index_add_(0, rows, self.g_vx.abs())
-                rs[1].index_add_(0, rows, self.g_vy.abs())
+                # row sums of |gradX|, |gradY| in entry order with the library's CSR gather (one lane group per row, fixed order: the word
+                # is bitwise reproducible -- index_add_'s float atomics were the one non-deterministic reduction left; the word
+                # feeds a power-of-two scale, so a sum straddling 2^k could change the rounding of a product from run to run)
+                nnz = int(self.g_vx.numel())
+                ident = torch.arange(nnz, dtype=torch.int32, device=self.device)
+                rs = torch.empty(2, vt, dtype=torch.float32, device=self.device)
+                for k, v in enumerate((self.g_vx, self.g_vy)):
+                    a = v.detach().abs().contiguous()
+                    _hip.check(_hip.lib().dn_csr_mean_f32(self.g_rowptr.data_ptr(), ident.data_ptr(), vt, a.data_ptr(), 1, 1.0, rs[k].data_ptr(),
+                                                          _hip.stream_of(a)), "dn_csr_mean_f32")
                 words.append(rs.amax())
             else:
                 words.append(torch.zeros((), dtype=torch.float32, device=self.device))

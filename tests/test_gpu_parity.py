@@ -430,8 +430,8 @@ def test_large_inference_shape(dev):
     print("cfg4: V=%d K=C=%d 4 blocks inference through the reference signature: %.2f ms/forward = %.2f M vertices/s" % (V, K, dt * 1e3, V / dt / 1e6))
     ref = orc.net_forward(params, m["verts"], m["mass"], m["evals"], m["evecs"], m["gradX"], m["gradY"])
     e_cfg4 = helpers.rel_max(out.cpu(), ref)
-    helpers.record_margin("cfg4_large_inference", dev, V=V, K=K, C=C, fwd_rel_max_vs_oracle32=e_cfg4, fwd_tol=2e-5, ms_per_forward=dt * 1e3)
-    assert e_cfg4 < 2e-5
+    helpers.record_margin("cfg4_large_inference", dev, V=V, K=K, C=C, fwd_rel_max_vs_oracle32=e_cfg4, fwd_tol=1e-5, ms_per_forward=dt * 1e3)
+    assert e_cfg4 < 1e-5      # (measured 1.0e-6 on MI355X, profiles/r04_parity_margins.json)
     # mesh locality in a ragged packed batch
     m2 = synthetic.make_mesh_operators(3000, K, seed=5)
     mb = parity_cases.pack([m, m2], dev)

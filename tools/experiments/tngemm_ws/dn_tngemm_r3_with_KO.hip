@@ -225,6 +225,11 @@ static int tn_launch(const TnArgs& g, dim3 grid, hipStream_t stream) {
 // =======================================================================================
 // (staging / fragment / MFMA helpers of this kernel: dn_tn_tiles.h, shared with the fused diffusion kernel)
 // single 60 KiB step buffer, two workgroups per CU (measured 60.1 vs 62.2 us against a double-buffered one-workgroup form)
+// DN_TN_KO (development, timing only -- results are wrong): 1 = no chunk loads after a chunk's first step, 2 = no fragment reads / MFMAs,
+// 4 = no split + LDS staging after the first step (its loads become dead too)
+#ifndef DN_TN_KO
+#define DN_TN_KO 0
+#endif
 template <int FLAVOR, int NP>
 __global__ __launch_bounds__(DN_TX_THREADS, 4) void tngemm_x3_kernel(TnArgs g) {
     float sa = 1.f, sb = 1.f, so = 1.f;
@@ -282,11 +287,11 @@ __global__ __launch_bounds__(DN_TX_THREADS, 4) void tngemm_x3_kernel(TnArgs g) {
         tx_store<FLAVOR, NP>(smem, smem + 3 * DN_TX_PLANE, kr0, q, R, csum, sa, sb);
         __syncthreads();
         for (int st = 0; st < nsteps; ++st) {
-            if (st + 1 < nsteps) tx_load<FLAVOR>(g, ch, st + 1, kr0, a_ok, b_ok, ap, aq, ald, bp, bld, R);
-            tx_compute<NP>(smem, smem + 3 * DN_TX_PLANE, wr, wc, lane, acc);
+            if (st + 1 < nsteps && !(DN_TN_KO & 1)) tx_load<FLAVOR>(g, ch, st + 1, kr0, a_ok, b_ok, ap, aq, ald, bp, bld, R);
+            if (!(DN_TN_KO & 2)) tx_compute<NP>(smem, smem + 3 * DN_TX_PLANE, wr, wc, lane, acc);
             __syncthreads();
             if (st + 1 < nsteps) {
-                tx_store<FLAVOR, NP>(smem, smem + 3 * DN_TX_PLANE, kr0, q, R, csum, sa, sb);
+                if (!(DN_TN_KO & 4)) tx_store<FLAVOR, NP>(smem, smem + 3 * DN_TX_PLANE, kr0, q, R, csum, sa, sb);
                 __syncthreads();
             }
         }
@@ -334,6 +339,7 @@ static int tx_launch(const TnArgs& g, dim3 grid, hipStream_t stream) {
 #define DN_TN_X3 1   // -DDN_TN_X3=0: exact-f32 MFMA in the split-V kernels
 #endif
 
+bool dn_tngemm_try_ws(const TnArgs& g, int flavor, dim3 grid, hipStream_t stream, int* err);   // dn_tngemm_ws.hip
 
 // returns the number of partials written (= gridDim.x) through *npartial
 int dn_launch_tngemm(const TnArgs& g_in, int nchunks, hipStream_t stream) {
@@ -352,7 +358,9 @@ int dn_launch_tngemm(const TnArgs& g_in, int nchunks, hipStream_t stream) {
     const double rows = g.acct_rows;
     dn_prof_begin(DN_K_TNGEMM, stream);
     int err;
-    if (g.aligned && DN_TN_X3) {
+    if (g.aligned && DN_TN_X3 && dn_tngemm_try_ws(g, flavor, grid, stream, &err)) {
+        // wave-specialised split kernel (dn_tngemm_ws.hip)
+    } else if (g.aligned && DN_TN_X3) {
         switch (flavor) {
             case DN_TN_QA: err = tx_launch<DN_TN_QA>(g, grid, stream); break;
             case DN_TN_COLSUM: err = tx_launch<DN_TN_COLSUM>(g, grid, stream); break;
