@@ -708,6 +708,7 @@ size_t dn_block_bwd_workspace_bytes(const dn_mesh_batch_t* mb, const dn_block_pa
     n += pad256((size_t)mb->n_chunks * mb->k_eig * p->C);           // split-V partials of the diffusion backward
     n += pad256((size_t)mb->n_mesh * mb->k_eig * p->C) + pad256((size_t)mb->n_mesh * p->C);
     n += pad256((size_t)4 * p->C * p->C) + amax_ws();
+    if (block_chain_ok(mb, p)) n += pad256((size_t)dn_chain_bwd_pieces(p->C, p->with_grad, p->with_rot, p->n_mlp) * (2 * (p->C / 16) * 64) * 4);
     return n + 512;
 }
 int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, const float* x, const dn_block_saved_t* sv,
@@ -734,6 +735,7 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     float* dtp = b.f((size_t)mb->n_mesh * C);
     float* psum = b.f((size_t)4 * C * C);
     float* aw = b.f(AW_COUNT + DN_BLOCK_AMAX_WORDS + 2);
+    float* chain_ws = block_chain_ok(mb, p) ? b.f((size_t)dn_chain_bwd_pieces(C, p->with_grad, p->with_rot, p->n_mlp) * (2 * (C / 16) * 64) * 4) : nullptr;
     if (!b.ok) return DN_ERR_INVALID;
 
     // ---- operand magnitudes for the split-fp16 engine (the saved activations' words come from the forward)
@@ -745,20 +747,47 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     static const bool wgrad_f16 = getenv("DN_F16_WGRAD") && atoi(getenv("DN_F16_WGRAD")) != 0;
     const float* sw = sv->amax;
     const float *dout_amax = nullptr, *ev_amax = nullptr;
-    if (f16) {
+    // the chained backward kernel (dn_chain_bwd.hip) takes the row-local part -- MiniMLP input gradients, tanh', gradient-feature backward --
+    // under the conditions of the chained forward (two hidden-gradient buffers: MiniMLPs of up to three layers)
+    const bool chainb = block_chain_ok(mb, p) && sv->amax && !wgrad_f16 && p->n_mlp <= 3;
+    const bool words = f16 || chainb;
+    ChainPrepArgs pa; memset(&pa, 0, sizeof(pa));
+    int chain_np = 0;
+    if (words) {
         AmaxInit in; memset(&in, 0, sizeof(in));
-        if (p->with_grad) { in.jobs.push(p->A_re, (long long)C * C, aw + AW_WA); if (p->with_rot) in.jobs.push(p->A_im, (long long)C * C, aw + AW_WA); }
-        for (int j = 0; j < p->n_mlp && in.jobs.count < DN_AMAX_MAX_JOBS; ++j) in.jobs.push(p->W[j], (long long)p->widths[j] * p->widths[j + 1], aw + AW_W0 + j);
+        if (!chainb) {
+            if (p->with_grad) { in.jobs.push(p->A_re, (long long)C * C, aw + AW_WA); if (p->with_rot) in.jobs.push(p->A_im, (long long)C * C, aw + AW_WA); }
+            for (int j = 0; j < p->n_mlp && in.jobs.count < DN_AMAX_MAX_JOBS; ++j) in.jobs.push(p->W[j], (long long)p->widths[j] * p->widths[j + 1], aw + AW_W0 + j);
+        }
         in.zero_range(aw, AW_WA);
         in.zero_range(aw + AW_D0, DN_MAX_MLP_LAYERS + 1 + DN_BLOCK_AMAX_WORDS + 2);
-        in.zero_range(gr->d_x_amax, 1);
-        DN_CHECK(dn_launch_amax_init(in, st));
+        if (f16) in.zero_range(gr->d_x_amax, 1);
+        if (chainb) {      // the weight-preparation kernel of the chained backward does this call's bookkeeping (one launch)
+            const int NK = C / 32;
+            auto piece = [&](const float* Wm, const float* Wm2, float* word, int ld, int row0, int T) {
+                ChainPrepPiece& q = pa.pc[chain_np++]; q.W = Wm; q.W2 = Wm2; q.amax = word; q.ld = ld; q.col0 = 32 * T; q.transposed = 1; q.row0 = row0; };
+            for (int j = p->n_mlp - 1; j >= 1; --j)
+                for (int T = 0; T < NK; ++T) piece(p->W[j], nullptr, aw + AW_W0 + j, C, 0, T);
+            for (int sg = 0; sg < (p->with_grad ? 3 : 2); ++sg)
+                for (int T = 0; T < NK; ++T) piece(p->W[0], nullptr, aw + AW_W0, p->widths[0], sg * C, T);
+            if (p->with_grad)
+                for (int rep = 0; rep < 2; ++rep)
+                    for (int T = 0; T < NK; ++T) {
+                        piece(p->A_re, p->with_rot ? p->A_im : nullptr, aw + AW_WA, C, 0, T);
+                        if (p->with_rot) piece(p->A_im, p->A_re, aw + AW_WA, C, 0, T);
+                    }
+            pa.out = reinterpret_cast<uint4*>(chain_ws);
+            for (int r = 0; r < in.nzero; ++r) pa.zero_range(in.zero[r], in.zero_n[r]);
+            DN_CHECK(dn_launch_chain_prep(pa, chain_np, C, st));
+        } else {
+            DN_CHECK(dn_launch_amax_init(in, st));
+        }
         dout_amax = gr->d_out_amax;
         ev_amax = mb->evecs_amax;
-        if (!dout_amax || !ev_amax) {
+        if (!dout_amax || (f16 && !ev_amax)) {
             AmaxJobs jobs; jobs.count = 0;
             if (!dout_amax) { jobs.push(d_out, (long long)VC, aw + AW_IN); dout_amax = aw + AW_IN; }
-            if (!ev_amax) { jobs.push(mb->evecs, (long long)mb->v_total * K, aw + AW_COUNT + DN_BLOCK_AMAX_WORDS); ev_amax = aw + AW_COUNT + DN_BLOCK_AMAX_WORDS; }
+            if (f16 && !ev_amax) { jobs.push(mb->evecs, (long long)mb->v_total * K, aw + AW_COUNT + DN_BLOCK_AMAX_WORDS); ev_amax = aw + AW_COUNT + DN_BLOCK_AMAX_WORDS; }
             DN_CHECK(dn_launch_amax(jobs, st));
         }
     }
@@ -768,47 +797,83 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     // The fixed-order sums of the weight / bias / rotation-matrix partials are deferred: every product writes its partials to its
     // own region and ONE launch reduces them all once the last one is written (5 launches -> 1 per block).
     MrJobs jobs; jobs.count = 0;
-    // ---- MiniMLP backward (autograd of layers.py:236); d_a = gradient w.r.t. a layer's pre-activation output
-    const float* d_a = d_out;   // last layer has no activation; the residual branch is added into d_xacc below
-    const float* da_amax = dout_amax;
-    for (int j = p->n_mlp - 1; j >= 0; --j) {
-        const int wo = p->widths[j + 1], wi = p->widths[j];
-        if (j > 0) {
-            const float* ins[1] = {sv->h[j - 1]};
-            const int iw[1] = {wi};
-            DN_CHECK(linear_bwd_weights(mb, d_a, wo, ins, iw, 1, gr->dW[j], gr->db[j], part_w[j], part_b[j], st, &jobs,
-                                        (f16 && wgrad_f16) ? f16_of(da_amax, sw + SW_H0 + j - 1) : F16()));
-            float* nxt = da[j & 1];
-            // d(pre-act of layer j-1) = (d_a W_j) * relu'(.) * dropout scale; h>0 <=> kept and active
-            DN_CHECK(linear_bwd_input(mb, d_a, wo, p->W[j], wi, 0, wi, DN_EPI_MUL_DFAC, sv->h[j - 1],
-                                      (p->mask[j] || p->drop_seed) ? 2.f : 1.f, nxt, st, f16 ? f16_if(F16_LBI, f16_of(da_amax, W(j), D(j))) : F16()));
-            d_a = nxt; da_amax = D(j);
-        } else {
-            const float* ins[3] = {x, sv->xd, sv->g};
-            const int iw[3] = {C, C, C};
-            F16 fw;
-            if (f16 && wgrad_f16) { fw = f16_of(da_amax, sw + SW_X); fw.b.p[1] = sw + SW_XD; fw.b.c = p->with_grad ? 1.f : 0.f; }
-            DN_CHECK(linear_bwd_weights(mb, d_a, wo, ins, iw, p->with_grad ? 3 : 2, gr->dW[0], gr->db[0], part_w[0], part_b[0], st, &jobs, fw));
-            // d_h0 = d_a W_0 split into its column groups [x | xd | g]
-            const F16 fi = f16 ? f16_if(F16_LBI, f16_of(da_amax, W(0))) : F16();
-            DN_CHECK(linear_bwd_input(mb, d_a, wo, p->W[0], wi, 0, C, DN_EPI_ADD, d_out, 1.f, d_xacc, st, fi));       // + residual
-            F16 fxd = fi; if (f16 && !p->with_grad) fxd.o = aw + AW_MISC;     // without gradient features this IS the d_xd the diffusion backward reads
-            DN_CHECK(linear_bwd_input(mb, d_a, wo, p->W[0], wi, C, C, DN_EPI_STORE, nullptr, 1.f, d_xd, st, fxd));
-            if (p->with_grad) {
-                F16 fd = fi; if (f16) fd.o = D(0);                             // D(0): magnitude of d_dots
-                DN_CHECK(linear_bwd_input(mb, d_a, wo, p->W[0], wi, 2 * C, C, DN_EPI_DTANH, sv->g, 1.f, d_dots, st, fd));
+    if (chainb) {
+        // ---- row-local gradients in one launch, then the weight-gradient products over what it wrote
+        ChainBwdArgs cb; memset(&cb, 0, sizeof(cb));
+        cb.d_out = d_out; cb.V = mb->v_total; cb.with_grad = p->with_grad; cb.with_rot = p->with_rot; cb.n_mlp = p->n_mlp;
+        for (int j = 1; j < p->n_mlp; ++j) {
+            cb.h[j - 1] = sv->h[j - 1];
+            cb.dscale[j - 1] = (p->mask[j] || p->drop_seed) ? 2.f : 1.f;
+            cb.d_a[j - 1] = da[j & 1];
+        }
+        cb.g = sv->g; cb.gx = sv->gx; cb.gy = sv->gy; cb.bre = sv->bre; cb.bim = sv->bim;
+        cb.wp = reinterpret_cast<const uint4*>(chain_ws);
+        cb.wa_amax = aw + AW_WA;
+        for (int j = 0; j < p->n_mlp; ++j) cb.w_amax[j] = aw + AW_W0 + j;
+        cb.d_out_amax = dout_amax;
+        cb.d_xacc = d_xacc; cb.d_xd = d_xd; cb.d_dots = d_dots; cb.d_gx = d_gx; cb.d_gy = d_gy;
+        DN_CHECK(dn_launch_chain_bwd(chain_np, cb, C, st));
+        const float* d_a = d_out;
+        for (int j = p->n_mlp - 1; j >= 0; --j) {
+            const int wo = p->widths[j + 1], wi = p->widths[j];
+            if (j > 0) {
+                const float* ins[1] = {sv->h[j - 1]};
+                const int iw[1] = {wi};
+                DN_CHECK(linear_bwd_weights(mb, d_a, wo, ins, iw, 1, gr->dW[j], gr->db[j], part_w[j], part_b[j], st, &jobs));
+                d_a = da[j & 1];
+            } else {
+                const float* ins[3] = {x, sv->xd, sv->g};
+                const int iw[3] = {C, C, C};
+                DN_CHECK(linear_bwd_weights(mb, d_a, wo, ins, iw, p->with_grad ? 3 : 2, gr->dW[0], gr->db[0], part_w[0], part_b[0], st, &jobs));
             }
         }
-    }
-    // ---- gradient features + gradient apply backward
-    if (p->with_grad) {
-        const float* A_im = p->with_rot ? p->A_im : nullptr;
-        DN_CHECK(gradfeat_bwd_weights(mb, d_dots, sv->gx, sv->gy, C, gr->dA_re, p->with_rot ? gr->dA_im : nullptr, part_a, psum, st, &jobs,
-                                      (f16 && wgrad_f16) ? D(0) : nullptr, (f16 && wgrad_f16) ? sw + SW_G : nullptr));
-        F16 fg;
-        if (f16) { fg = f16_of(D(0), aw + AW_WA); fg.a.mul = sw + SW_G; }     // A = d_dots * (gx | gy)
-        DN_CHECK(gradfeat_bwd_inputs(mb, d_dots, sv->gx, sv->gy, sv->bre, sv->bim, p->A_re, A_im, C, d_gx, d_gy, st, f16_if(F16_GFB, fg)));
-        DN_CHECK(grad_apply_bwd(mb, d_gx, d_gy, d_xd, C, d_xd, st, (f16 && (f16_mask() & F16_TOB_B)) ? aw + AW_MISC : nullptr));   // d_xd += gradX^T d_gx + gradY^T d_gy (in place)
+        if (p->with_grad) {
+            DN_CHECK(gradfeat_bwd_weights(mb, d_dots, sv->gx, sv->gy, C, gr->dA_re, p->with_rot ? gr->dA_im : nullptr, part_a, psum, st, &jobs));
+            DN_CHECK(grad_apply_bwd(mb, d_gx, d_gy, d_xd, C, d_xd, st, (f16 && (f16_mask() & F16_TOB_B)) ? aw + AW_MISC : nullptr));   // d_xd += gradX^T d_gx + gradY^T d_gy (in place)
+        }
+    } else {
+        // ---- MiniMLP backward (autograd of layers.py:236); d_a = gradient w.r.t. a layer's pre-activation output
+        const float* d_a = d_out;   // last layer has no activation; the residual branch is added into d_xacc below
+        const float* da_amax = dout_amax;
+        for (int j = p->n_mlp - 1; j >= 0; --j) {
+            const int wo = p->widths[j + 1], wi = p->widths[j];
+            if (j > 0) {
+                const float* ins[1] = {sv->h[j - 1]};
+                const int iw[1] = {wi};
+                DN_CHECK(linear_bwd_weights(mb, d_a, wo, ins, iw, 1, gr->dW[j], gr->db[j], part_w[j], part_b[j], st, &jobs,
+                                            (f16 && wgrad_f16) ? f16_of(da_amax, sw + SW_H0 + j - 1) : F16()));
+                float* nxt = da[j & 1];
+                // d(pre-act of layer j-1) = (d_a W_j) * relu'(.) * dropout scale; h>0 <=> kept and active
+                DN_CHECK(linear_bwd_input(mb, d_a, wo, p->W[j], wi, 0, wi, DN_EPI_MUL_DFAC, sv->h[j - 1],
+                                          (p->mask[j] || p->drop_seed) ? 2.f : 1.f, nxt, st, f16 ? f16_if(F16_LBI, f16_of(da_amax, W(j), D(j))) : F16()));
+                d_a = nxt; da_amax = D(j);
+            } else {
+                const float* ins[3] = {x, sv->xd, sv->g};
+                const int iw[3] = {C, C, C};
+                F16 fw;
+                if (f16 && wgrad_f16) { fw = f16_of(da_amax, sw + SW_X); fw.b.p[1] = sw + SW_XD; fw.b.c = p->with_grad ? 1.f : 0.f; }
+                DN_CHECK(linear_bwd_weights(mb, d_a, wo, ins, iw, p->with_grad ? 3 : 2, gr->dW[0], gr->db[0], part_w[0], part_b[0], st, &jobs, fw));
+                // d_h0 = d_a W_0 split into its column groups [x | xd | g]
+                const F16 fi = f16 ? f16_if(F16_LBI, f16_of(da_amax, W(0))) : F16();
+                DN_CHECK(linear_bwd_input(mb, d_a, wo, p->W[0], wi, 0, C, DN_EPI_ADD, d_out, 1.f, d_xacc, st, fi));       // + residual
+                F16 fxd = fi; if (f16 && !p->with_grad) fxd.o = aw + AW_MISC;     // without gradient features this IS the d_xd the diffusion backward reads
+                DN_CHECK(linear_bwd_input(mb, d_a, wo, p->W[0], wi, C, C, DN_EPI_STORE, nullptr, 1.f, d_xd, st, fxd));
+                if (p->with_grad) {
+                    F16 fd = fi; if (f16) fd.o = D(0);                             // D(0): magnitude of d_dots
+                    DN_CHECK(linear_bwd_input(mb, d_a, wo, p->W[0], wi, 2 * C, C, DN_EPI_DTANH, sv->g, 1.f, d_dots, st, fd));
+                }
+            }
+        }
+        // ---- gradient features + gradient apply backward
+        if (p->with_grad) {
+            const float* A_im = p->with_rot ? p->A_im : nullptr;
+            DN_CHECK(gradfeat_bwd_weights(mb, d_dots, sv->gx, sv->gy, C, gr->dA_re, p->with_rot ? gr->dA_im : nullptr, part_a, psum, st, &jobs,
+                                          (f16 && wgrad_f16) ? D(0) : nullptr, (f16 && wgrad_f16) ? sw + SW_G : nullptr));
+            F16 fg;
+            if (f16) { fg = f16_of(D(0), aw + AW_WA); fg.a.mul = sw + SW_G; }     // A = d_dots * (gx | gy)
+            DN_CHECK(gradfeat_bwd_inputs(mb, d_dots, sv->gx, sv->gy, sv->bre, sv->bim, p->A_re, A_im, C, d_gx, d_gy, st, f16_if(F16_GFB, fg)));
+            DN_CHECK(grad_apply_bwd(mb, d_gx, d_gy, d_xd, C, d_xd, st, (f16 && (f16_mask() & F16_TOB_B)) ? aw + AW_MISC : nullptr));   // d_xd += gradX^T d_gx + gradY^T d_gy (in place)
+        }
     }
     DN_CHECK(dn_launch_multi_reduce(jobs, st));
     // ---- diffusion backward

@@ -1,0 +1,139 @@
+// dn_chain_tiles.h -- device-side building blocks shared by the chained row kernels (dn_chain.hip: block forward, dn_chain_bwd.hip: block
+// backward): the transposed 16x16x32 f16 MFMA step, the two-term fp16 split of eight values into operand fragments, the LDS-DMA request of
+// the weight-piece ring and the piece-times-fragment product macros.  See dn_chain.hip for the decomposition.
+#pragma once
+#include "dn_common.h"
+
+typedef float dn_f32x4 __attribute__((ext_vector_type(4)));
+
+// One 16x16x32 f16 MFMA step (fp32 accumulate): lane l supplies A[i = l & 15][k = 8 (l >> 4) + j] and B[k = 8 (l >> 4) + j][col = l & 15],
+// j < 8, packed in a uint4; accumulator register r of lane l is D[4 (l >> 4) + r][l & 15].
+__device__ __forceinline__ dn_f32x4 dn_mfma16_f16(uint4 a, uint4 b, dn_f32x4 c) {
+#ifdef DN_EMULATE
+    return dnemu_mfma_f32_16x16x32_f16(a, b, c);
+#else
+    typedef _Float16 dn_f16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dn_f16x8, a), __builtin_bit_cast(dn_f16x8, b), c, 0, 0, 0);
+#endif
+}
+
+// eight values (slots 0..3 = a, 4..7 = b) -> one fragment per plane
+__device__ __forceinline__ void ch_split8(const float (&a)[4], const float (&b)[4], float s, uint4& hi, uint4& lo) {
+    dn_split2_pair(a[0], a[1], s, hi.x, lo.x);
+    dn_split2_pair(a[2], a[3], s, hi.y, lo.y);
+    dn_split2_pair(b[0], b[1], s, hi.z, lo.z);
+    dn_split2_pair(b[2], b[3], s, hi.w, lo.w);
+}
+__device__ __forceinline__ void ch_split8(const float4& a, const float4& b, float s, uint4& hi, uint4& lo) {
+    dn_split2_pair(a.x, a.y, s, hi.x, lo.x);
+    dn_split2_pair(a.z, a.w, s, hi.y, lo.y);
+    dn_split2_pair(b.x, b.y, s, hi.z, lo.z);
+    dn_split2_pair(b.z, b.w, s, hi.w, lo.w);
+}
+// tanh for the gradient-feature epilogue: (1 - t) / (1 + t), t = exp(-2 |x|), through the hardware exp2 / rcp with one Newton step on the
+// quotient; below |x| = 0.25, where 1 - t cancels, the odd Taylor polynomial to x^9.  Measured against double: <= 1.3e-7 absolute
+// (|tanh| <= 1: about one ulp of the result's range); libm's tanhf costs ~44 instructions and several branches per element.
+__device__ __forceinline__ float ch_tanh(float x) {
+    const float ax = fabsf(x);
+    const float x2 = x * x;
+    const float p = x * (1.f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * (-0.053968254f + x2 * 0.021869488f))));
+#ifdef DN_EMULATE
+    const float t = exp2f(-2.885390082f * ax);
+    const float r = 1.f / (1.f + t);
+#else
+    const float t = __builtin_amdgcn_exp2f(-2.885390082f * ax);
+    float r = __builtin_amdgcn_rcpf(1.f + t);
+    r = r * (2.f - (1.f + t) * r);
+#endif
+    const float big = copysignf((1.f - t) * r, x);
+    return ax < 0.25f ? p : big;
+}
+// 1 / s for a power of two s = 2^k, -126 <= k <= 126 (what dn_pow2_scale returns but for its two clamped extremes): exponent arithmetic, exact
+__device__ __forceinline__ float ch_pow2_inv(float s) {
+    const unsigned e = (__float_as_uint(s) >> 23) & 0xffu;
+    return (e >= 1u && e <= 253u) ? __uint_as_float((254u - e) << 23) : 1.f / s;
+}
+// a wave-uniform value that was computed on the vector unit (loaded words, scales): one copy in a scalar register instead of a vector register
+__device__ __forceinline__ float ch_uniform(float v) {
+#ifdef DN_EMULATE
+    return v;
+#else
+    return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v)));
+#endif
+}
+__device__ __forceinline__ float ch_wave_max(float m) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { const float o = __shfl_xor(m, d, 64); m = o > m ? o : m; }
+    return m;
+}
+
+#ifndef DN_CH_RING
+#define DN_CH_RING 4      // LDS slots of the piece stream; DN_CH_RING - 1 pieces are requested ahead of the one being multiplied
+#endif
+#ifndef DN_CH_GCHUNK
+#define DN_CH_GCHUNK 4    // pattern entries gathered per step (all their row pieces in flight together)
+#endif
+// One LDS-DMA request: 16 bytes per lane, global -> LDS, lane l's data lands at lds_byte + 16 l (lds_byte wave-uniform).  Inline asm on
+// purpose: the compiler's waitcnt bookkeeping does not see it, so it neither drains the request queue at a barrier nor at the next use of
+// an ordinary load while requests are in flight; the kernel counts them itself (CH_WAIT_PIECES).  Loads return in order, so a compiler-made
+// vmcnt(n) for one of its own loads stays correct with these requests in the queue (it may wait for some of them too: conservative).
+__device__ __forceinline__ void ch_dma16(const uint4* gsrc, uint4* lds_generic, unsigned lds_byte) {
+#ifdef DN_EMULATE
+    (void)lds_byte;
+    lds_generic[threadIdx.x & 63] = *gsrc;
+#else
+    (void)lds_generic;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte) : "memory");
+#endif
+}
+
+
+// ---- piece x fragment products (inside a kernel that defines NT, lane and ws_ = the ring slot being read) --------------------------
+// acc[h][nt] += W(piece) * frag[h]   (hi*lo, lo*hi, hi*hi: smallest terms first); two output tiles at a time, so that an MFMA and the
+// next one into the same accumulator are four issues apart
+#define CH_WLOAD(W_, np_) do { W_[0] = ws_[(np_) * 64 + lane]; W_[1] = ws_[(NT + (np_)) * 64 + lane];                       \
+                           W_[2] = ws_[((np_) + 1) * 64 + lane]; W_[3] = ws_[(NT + (np_) + 1) * 64 + lane]; } while (0)
+#define CH_MMA2(ACC, FH0, FL0, FH1, FL1)                                                                                \
+do {                                                                                                                \
+    uint4 wq_[2][4];   /* weight fragments of two output tiles (hi a, lo a, hi b, lo b), fetched one pair ahead of their MFMAs */ \
+    CH_WLOAD(wq_[0], 0);                                                                                            \
+    _Pragma("unroll") for (int np_ = 0; np_ < NT; np_ += 2) {                                                       \
+        const int cb_ = (np_ >> 1) & 1;                                                                             \
+        if (np_ + 2 < NT) CH_WLOAD(wq_[cb_ ^ 1], np_ + 2);                                                          \
+        ACC[0][np_] = dn_mfma16_f16(wq_[cb_][0], FL0, ACC[0][np_]);                                                 \
+        ACC[1][np_] = dn_mfma16_f16(wq_[cb_][0], FL1, ACC[1][np_]);                                                 \
+        ACC[0][np_ + 1] = dn_mfma16_f16(wq_[cb_][2], FL0, ACC[0][np_ + 1]);                                         \
+        ACC[1][np_ + 1] = dn_mfma16_f16(wq_[cb_][2], FL1, ACC[1][np_ + 1]);                                         \
+        ACC[0][np_] = dn_mfma16_f16(wq_[cb_][1], FH0, ACC[0][np_]);                                                 \
+        ACC[1][np_] = dn_mfma16_f16(wq_[cb_][1], FH1, ACC[1][np_]);                                                 \
+        ACC[0][np_ + 1] = dn_mfma16_f16(wq_[cb_][3], FH0, ACC[0][np_ + 1]);                                         \
+        ACC[1][np_ + 1] = dn_mfma16_f16(wq_[cb_][3], FH1, ACC[1][np_ + 1]);                                         \
+        ACC[0][np_] = dn_mfma16_f16(wq_[cb_][0], FH0, ACC[0][np_]);                                                 \
+        ACC[1][np_] = dn_mfma16_f16(wq_[cb_][0], FH1, ACC[1][np_]);                                                 \
+        ACC[0][np_ + 1] = dn_mfma16_f16(wq_[cb_][2], FH0, ACC[0][np_ + 1]);                                         \
+        ACC[1][np_ + 1] = dn_mfma16_f16(wq_[cb_][2], FH1, ACC[1][np_ + 1]);                                         \
+    }                                                                                                               \
+} while (0)
+
+// the same product with the weight fragments fetched tile pair by tile pair (16 registers less): for the gradient-feature stage, whose
+// live set (gx, gy, both accumulators, the other half's tanh features) is the kernel's peak
+#define CH_MMA2_LEAN(ACC, FH0, FL0, FH1, FL1)                                                                           \
+_Pragma("unroll") for (int np_ = 0; np_ < NT; np_ += 2) {                                                           \
+    uint4 w_[4];                                                                                                    \
+    CH_WLOAD(w_, np_);                                                                                              \
+    ACC[0][np_] = dn_mfma16_f16(w_[0], FL0, ACC[0][np_]);                                                           \
+    ACC[1][np_] = dn_mfma16_f16(w_[0], FL1, ACC[1][np_]);                                                           \
+    ACC[0][np_ + 1] = dn_mfma16_f16(w_[2], FL0, ACC[0][np_ + 1]);                                                   \
+    ACC[1][np_ + 1] = dn_mfma16_f16(w_[2], FL1, ACC[1][np_ + 1]);                                                   \
+    ACC[0][np_] = dn_mfma16_f16(w_[1], FH0, ACC[0][np_]);                                                           \
+    ACC[1][np_] = dn_mfma16_f16(w_[1], FH1, ACC[1][np_]);                                                           \
+    ACC[0][np_ + 1] = dn_mfma16_f16(w_[3], FH0, ACC[0][np_ + 1]);                                                   \
+    ACC[1][np_ + 1] = dn_mfma16_f16(w_[3], FH1, ACC[1][np_ + 1]);                                                   \
+    ACC[0][np_] = dn_mfma16_f16(w_[0], FH0, ACC[0][np_]);                                                           \
+    ACC[1][np_] = dn_mfma16_f16(w_[0], FH1, ACC[1][np_]);                                                           \
+    ACC[0][np_ + 1] = dn_mfma16_f16(w_[2], FH0, ACC[0][np_ + 1]);                                                   \
+    ACC[1][np_ + 1] = dn_mfma16_f16(w_[2], FH1, ACC[1][np_ + 1]);                                                   \
+}
+

@@ -440,6 +440,8 @@ struct ChainPrepPiece {
     float* amax;         // device word that RECEIVES the largest magnitude of the matrix (every piece of a matrix stores the same value);
                          // its power-of-two scale puts the weights into [2^14, 2^15)
     int ld, col0;        // the piece holds columns col0 .. col0 + 31 (in the permuted order)
+    int transposed, row0;   // transposed (backward products d_in = d_out W): the piece's rows are W's COLUMNS row0 .. row0 + C - 1 and its
+                            // contraction slots W's ROWS col0 .. col0 + 31: element (r, slot) = W[(col0 + slot) * ld + row0 + r]
 };
 #define DN_CH_MAX_PIECES 48
 struct ChainPrepArgs {
@@ -478,6 +480,28 @@ struct ChainArgs {
     float* out_amax;                      // accumulates max |out|
     int units;                            // workgroup passes: ceil(V / (32 waves-per-workgroup))
 };
+// backward of the same stages: d_out -> d(pre-activations) of every layer -> [d_x | d_xd | d_dots] -> d_gx, d_gy (dn_chain_bwd.hip)
+struct ChainBwdArgs {
+    const float* d_out;                   // [V, C] gradient of the block output
+    const float* h[DN_CH_LAYERS];         // saved post-ReLU(+dropout) hidden activations h_j, j < n_mlp - 1
+    const float* g; const float* gx; const float* gy; const float* bre; const float* bim;   // saved gradient-feature tensors (with_grad)
+    int V;
+    int with_grad, with_rot, n_mlp;
+    float dscale[DN_CH_LAYERS];           // dropout scale of h_j (2 with dropout, else 1): d(pre-act j) = (d_a W_{j+1}) * (h_j > 0 ? dscale : 0)
+    const uint4* wp; int n_pieces;        // transposed weight pieces in stream order: W_{n-1}, ..., W_1, W_0 segments [x | xd | g], then
+                                          // [A_re T, A_im T] x 2 (the two 16-row halves of the gradient-feature stage)
+    const float* wa_amax; const float* w_amax[DN_CH_LAYERS];
+    const float* d_out_amax;              // magnitude word of d_out
+    // outputs
+    float* d_a[DN_CH_LAYERS];             // d_a[j]: d(pre-activation of layer j), j < n_mlp - 1  (the weight-gradient products read them)
+    float* d_xacc;                        // d_out + d_a0 W_0[:, x segment]   (residual + x branch)
+    float* d_xd;                          // d_a0 W_0[:, xd segment]
+    float* d_dots;                        // (d_a0 W_0[:, g segment]) * (1 - g^2)
+    float* d_gx; float* d_gy;             // d_dots * Bre + (d_dots gx) A_re + (d_dots gy) A_im ;  d_dots * Bim - (d_dots gx) A_im + (d_dots gy) A_re
+    int units;
+};
+int dn_chain_bwd_pieces(int C, int with_grad, int with_rot, int n_mlp);
+int dn_launch_chain_bwd(int npieces, const ChainBwdArgs& a, int C, hipStream_t stream);
 int dn_chain_pieces(int C, int with_grad, int with_rot, int n_mlp);
 size_t dn_chain_ws_bytes(int C, int with_grad, int with_rot, int n_mlp);
 bool dn_chain_eligible(int C, int n_mlp, const int* widths, int with_grad, long long g_nnz, int V);
