@@ -29,7 +29,7 @@ import torch.nn.functional as F
 PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: exact-f32 MFMA = f32 vector peak
 PEAK_HBM_GBPS = 8000.0            # HBM3E spec (6.29 TB/s measured copy ceiling)
 PEAK_MFMA_BF16_TFLOPS = 2500.0    # dense bf16 MFMA (no sparsity)
-TRAFFIC_JSON = "r03_traffic.json"  # PMC FETCH/WRITE passes of the same kernels (tools/pmc_run.sh + tools/traffic_summary.py), committed under profiles/
+TRAFFIC_JSON = "r04_traffic.json"  # PMC FETCH/WRITE passes of the same kernels (tools/pmc_run.sh + tools/traffic_summary.py), committed under profiles/
 
 
 def mesh_sizes(n_meshes, v_mean, rank):

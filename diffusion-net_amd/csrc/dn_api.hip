@@ -327,7 +327,7 @@ int dn_prof_read(int kind, double* out) {
     return 0;
 }
 const char* dn_prof_kind_name(int kind) {
-    static const char* names[DN_K_COUNT] = {"rowgemm_kernel<*,1>", "rowgemm_kernel<*,2>", "tngemm_kernel", "spmm_kernel", "small", "chain_fwd_kernel"};
+    static const char* names[DN_K_COUNT] = {"rowgemm_kernel<*,1>", "rowgemm_kernel<*,2>", "tngemm_kernel", "spmm_kernel", "small", "chain_fwd_kernel", "chain_bwd_kernel"};
     return (kind >= 0 && kind < DN_K_COUNT) ? names[kind] : "";
 }
 
@@ -509,18 +509,26 @@ static bool block_f16_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p) 
     return true;
 }
 static size_t amax_ws(void) { return pad256(AW_COUNT + DN_BLOCK_AMAX_WORDS + 2); }
-// The chained row pipeline (dn_chain.hip) takes the block's row work -- gradient gather, gradient features, MiniMLP -- when the shapes are
-// the ones it is written for and the split-fp16 engine's magnitude words exist.  DN_CHAIN=0 in the environment keeps the unfused launches.
-static bool block_chain_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p) {
-    const char* e0 = getenv("DN_CHAIN");            // (read per call: the tests flip it at run time; a getenv is nanoseconds)
+// The chained row kernels (dn_chain.hip forward, dn_chain_bwd.hip backward) take the block's row work -- gradient gather, gradient features,
+// MiniMLP and their gradients -- when the shapes are the ones they are written for and the magnitude words exist.  DN_CHAIN=0 in the
+// environment keeps the unfused launches (read per call: the tests flip it at run time; a getenv is nanoseconds).
+// kind: 0 = forward without saved activations (inference), 1 = forward saving activations (training), 2 = backward.
+// Measured on MI355X (tools/kbench, block at C = K = 128, chain / unfused, us; profiles/r04_chain_size_sweep.txt):
+//     vertices      3k        7k        14k       20k       40k       80k       160k
+//     inference   92/99    103/107   115/119   131/131   175/196   251/299   402/515
+//     training   102/102   109/110   120/120   140/129   216/205   319/315   480/512
+//     backward   162/198   169/207   186/222   229/253   349/383   555/588   869/950
+// The backward and the inference forward win at every size.  The training forward (it also writes the seven saved tensors) is level up to
+// ~15k vertices, behind between 20k and 80k -- one long pass per workgroup and too few workgroups to hide its latencies -- and ahead from
+// ~100k: it is taken from DN_CHAIN_MIN_ROWS rows on (default 100000; the tests run it at every size with 0).
+static bool block_chain_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int kind) {
+    const char* e0 = getenv("DN_CHAIN");
     static const int f16_env = getenv("DN_F16") ? atoi(getenv("DN_F16")) : 1;      // DN_F16=0: split-bf16 engine everywhere (A/B runs)
     if ((e0 && atoi(e0) == 0) || !f16_env || (p->with_grad && !mb->grad_norm)) return false;
-    // Below a few tens of thousands of vertices the step is bound per launch, not per byte, and the chained kernel's long per-workgroup
-    // sequence has too few workgroups to hide its latencies (measured at 7k / 20k vertices: 109 / 142 us against 109 / 130 us for the
-    // unfused launches, training forward); DN_CHAIN_MIN_ROWS overrides the threshold (the tests run the chain at every size with 0).
-    const char* e1 = getenv("DN_CHAIN_MIN_ROWS");
-    const int min_rows = e1 ? atoi(e1) : 40000;
-    if (mb->v_total < min_rows) return false;
+    if (kind == 1) {
+        const char* e1 = getenv("DN_CHAIN_MIN_ROWS");
+        if (mb->v_total < (e1 ? atoi(e1) : 100000)) return false;
+    }
     return dn_chain_eligible(p->C, p->n_mlp, p->widths, p->with_grad, mb->g_nnz, mb->v_total);
 }
 // Product classes of the block; DN_F16_MASK=<bits> (diagnostic) selects which of them run on the split-fp16 engine.
@@ -535,15 +543,16 @@ enum { F16_TOB = 1, F16_FROMB = 2, F16_GF = 4, F16_MLP = 8, F16_LBI = 16, F16_GF
 static int f16_mask(void) { static const int m = getenv("DN_F16_MASK") ? atoi(getenv("DN_F16_MASK")) : (F16_GF | F16_MLP | F16_LBI | F16_GFB | F16_FROMB_B); return m; }
 static F16 f16_if(int bit, const F16& f) { if (f16_mask() & bit) return f; F16 r; r.o = f.o; return r; }   // (the magnitude of the output is still recorded)
 
-int dn_block_tracks_amax(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int backward) {
-    if (!mb || !block_params_ok(p)) return 0;
-    return (block_f16_ok(mb, p) || (!backward && block_chain_ok(mb, p))) ? 1 : 0;
+int dn_block_tracks_amax(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int call) {
+    if (!mb || !block_params_ok(p) || call < 0 || call > 2) return 0;
+    if (block_f16_ok(mb, p)) return 1;
+    return (call < 2 && block_chain_ok(mb, p, call)) ? 1 : 0;      // (the chained backward alone does not produce max |d_x|)
 }
 size_t dn_block_fwd_workspace_bytes(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int with_saved) {
     if (!block_params_ok(p)) return 0;
     const size_t VC = (size_t)mb->v_total * p->C;
     size_t n = pad256((size_t)mb->n_chunks * mb->k_eig * p->C) + pad256((size_t)mb->n_mesh * mb->k_eig * p->C) + amax_ws() + 512;
-    if (block_chain_ok(mb, p)) n += pad256(dn_chain_ws_bytes(p->C, p->with_grad, p->with_rot, p->n_mlp) / sizeof(float));
+    if (block_chain_ok(mb, p, with_saved ? 1 : 0)) n += pad256(dn_chain_ws_bytes(p->C, p->with_grad, p->with_rot, p->n_mlp) / sizeof(float));
     if (!with_saved) {
         n += pad256((size_t)mb->n_mesh * mb->k_eig * p->C) + 4 * pad256(VC);          // xs, xd, gx, gy, g
         n += 2 * pad256((size_t)mb->v_total * max_width(p));                            // hidden ping-pong
@@ -560,8 +569,8 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     float* partial = b.f((size_t)mb->n_chunks * K * C);
     float* ys = b.f((size_t)mb->n_mesh * K * C);
     float* aw = b.f(AW_COUNT + DN_BLOCK_AMAX_WORDS + 2);
-    const bool chain = block_chain_ok(mb, p) && (!sv || sv->amax);
-    float* chain_ws = block_chain_ok(mb, p) ? b.f(dn_chain_ws_bytes(p->C, p->with_grad, p->with_rot, p->n_mlp) / sizeof(float)) : nullptr;
+    const bool chain = block_chain_ok(mb, p, sv ? 1 : 0) && (!sv || sv->amax);
+    float* chain_ws = block_chain_ok(mb, p, sv ? 1 : 0) ? b.f(dn_chain_ws_bytes(p->C, p->with_grad, p->with_rot, p->n_mlp) / sizeof(float)) : nullptr;
     float *xs, *xd, *gx = nullptr, *gy = nullptr, *gf = nullptr, *bre = nullptr, *bim = nullptr;
     float* hbuf[2] = {nullptr, nullptr};
     if (sv) {
@@ -665,6 +674,8 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
         }
         ca.seed_dev = (const unsigned long long*)p->drop_seed_dev;
         if (p->with_grad && sv) { ca.gx = gx; ca.gy = gy; ca.g = gf; ca.bre = bre; ca.bim = bim; }
+        // (Measured and rejected: gathering gx, gy with the stand-alone CSR kernel first and letting the training chain read them -- the chained
+        // kernel drops from 357 to 293 us, but the 87 us gather launch more than eats it: block forward 480 vs 465 us, profiles/r04_pregather.txt.)
         ca.out = out;
         ca.x_amax = x_amax; ca.xd_amax = sw + SW_XD; ca.grad_norm = mb->grad_norm;
         ca.g_amax = sw + SW_G; ca.out_amax = p->out_amax;
@@ -708,7 +719,7 @@ size_t dn_block_bwd_workspace_bytes(const dn_mesh_batch_t* mb, const dn_block_pa
     n += pad256((size_t)mb->n_chunks * mb->k_eig * p->C);           // split-V partials of the diffusion backward
     n += pad256((size_t)mb->n_mesh * mb->k_eig * p->C) + pad256((size_t)mb->n_mesh * p->C);
     n += pad256((size_t)4 * p->C * p->C) + amax_ws();
-    if (block_chain_ok(mb, p)) n += pad256((size_t)dn_chain_bwd_pieces(p->C, p->with_grad, p->with_rot, p->n_mlp) * (2 * (p->C / 16) * 64) * 4);
+    if (block_chain_ok(mb, p, 2)) n += pad256((size_t)dn_chain_bwd_pieces(p->C, p->with_grad, p->with_rot, p->n_mlp) * (2 * (p->C / 16) * 64) * 4);
     return n + 512;
 }
 int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, const float* x, const dn_block_saved_t* sv,
@@ -735,7 +746,7 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     float* dtp = b.f((size_t)mb->n_mesh * C);
     float* psum = b.f((size_t)4 * C * C);
     float* aw = b.f(AW_COUNT + DN_BLOCK_AMAX_WORDS + 2);
-    float* chain_ws = block_chain_ok(mb, p) ? b.f((size_t)dn_chain_bwd_pieces(C, p->with_grad, p->with_rot, p->n_mlp) * (2 * (C / 16) * 64) * 4) : nullptr;
+    float* chain_ws = block_chain_ok(mb, p, 2) ? b.f((size_t)dn_chain_bwd_pieces(C, p->with_grad, p->with_rot, p->n_mlp) * (2 * (C / 16) * 64) * 4) : nullptr;
     if (!b.ok) return DN_ERR_INVALID;
 
     // ---- operand magnitudes for the split-fp16 engine (the saved activations' words come from the forward)
@@ -749,7 +760,7 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     const float *dout_amax = nullptr, *ev_amax = nullptr;
     // the chained backward kernel (dn_chain_bwd.hip) takes the row-local part -- MiniMLP input gradients, tanh', gradient-feature backward --
     // under the conditions of the chained forward (two hidden-gradient buffers: MiniMLPs of up to three layers)
-    const bool chainb = block_chain_ok(mb, p) && sv->amax && !wgrad_f16 && p->n_mlp <= 3;
+    const bool chainb = block_chain_ok(mb, p, 2) && sv->amax && !wgrad_f16 && p->n_mlp <= 3;
     const bool words = f16 || chainb;
     ChainPrepArgs pa; memset(&pa, 0, sizeof(pa));
     int chain_np = 0;

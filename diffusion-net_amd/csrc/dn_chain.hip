@@ -45,10 +45,18 @@ __global__ __launch_bounds__(256) void chain_prep_kernel(ChainPrepArgs a) {
     // largest magnitude of the whole matrix (every piece's workgroup measures it: a few tens of KB out of L2)
     float mx = 0.f;
     {
-        const long long n4 = (long long)C * pc.ld / 4;   // (ld is a multiple of 4 and the rows 16-byte aligned on this path)
-        for (long long i = tid; i < n4; i += 256) {
-            mx = dn_f4_amax(mx, *reinterpret_cast<const float4*>(pc.W + 4 * i));
-            if (pc.W2) mx = dn_f4_amax(mx, *reinterpret_cast<const float4*>(pc.W2 + 4 * i));
+        const int n4 = C * pc.ld / 4;   // (ld is a multiple of 4 and the rows 16-byte aligned on this path)
+        // eight loads in flight per thread and step (one workgroup: latency, not bandwidth -- a load per step made this kernel 25 us)
+        for (int i0 = tid; i0 < n4; i0 += 8 * 256) {
+            float4 v[8], w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 256 * u < n4 ? i0 + 256 * u : i0;
+                v[u] = *reinterpret_cast<const float4*>(pc.W + 4 * (long long)i);
+                w[u] = pc.W2 ? *reinterpret_cast<const float4*>(pc.W2 + 4 * (long long)i) : dn_f4_zero();
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { mx = dn_f4_amax(mx, v[u]); mx = dn_f4_amax(mx, w[u]); }
         }
     }
     red[tid] = mx;

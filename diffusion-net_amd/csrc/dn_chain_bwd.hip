@@ -377,7 +377,7 @@ static int chain_bwd_launch(int npieces, const ChainBwdArgs& a_in, hipStream_t s
 
 int dn_launch_chain_bwd(int npieces, const ChainBwdArgs& a, int C, hipStream_t stream) {
     if (npieces > DN_CH_MAX_PIECES || npieces <= 0) return 1;
-    dn_prof_begin(DN_K_CHAIN, stream);
+    dn_prof_begin(DN_K_CHAIN_BWD, stream);
     int err;
     if (C == 128) err = chain_bwd_launch<128>(npieces, a, stream);
     else if (C == 64) err = chain_bwd_launch<64>(npieces, a, stream);
@@ -388,7 +388,7 @@ int dn_launch_chain_bwd(int npieces, const ChainBwdArgs& a, int C, hipStream_t s
         const double nr = 1.0 + (a.n_mlp - 1) + (a.with_grad ? 5.0 : 0.0);
         const double nw = (a.n_mlp - 1) + 2.0 + (a.with_grad ? 3.0 : 0.0);
         const double prod = (a.n_mlp - 1) + (a.with_grad ? 3.0 : 2.0) + (a.with_grad ? (a.with_rot ? 4.0 : 2.0) : 0.0);
-        dn_prof_end(DN_K_CHAIN, stream, 2.0 * (double)a.V * C * C * prod, VC * (nr + nw));
+        dn_prof_end(DN_K_CHAIN_BWD, stream, 2.0 * (double)a.V * C * C * prod, VC * (nr + nw));
     }
     return err;
 }

@@ -610,7 +610,7 @@ int dn_launch_tngemm(const TnArgs& g, int nchunks, hipStream_t stream);
 // hipEvents on its own stream and summed per kernel family.  Off by default; compiled out of the
 // emulator build.
 // ---------------------------------------------------------------------------------------
-enum { DN_K_ROWGEMM = 0, DN_K_ROWGEMM_DUAL = 1, DN_K_TNGEMM = 2, DN_K_SPMM = 3, DN_K_SMALL = 4, DN_K_CHAIN = 5, DN_K_COUNT = 6 };
+enum { DN_K_ROWGEMM = 0, DN_K_ROWGEMM_DUAL = 1, DN_K_TNGEMM = 2, DN_K_SPMM = 3, DN_K_SMALL = 4, DN_K_CHAIN = 5, DN_K_CHAIN_BWD = 6, DN_K_COUNT = 7 };
 #ifdef DN_EMULATE
 static inline void dn_prof_begin(int, hipStream_t) {}
 static inline void dn_prof_end(int, hipStream_t, double, double) {}

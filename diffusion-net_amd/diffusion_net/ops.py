@@ -402,7 +402,10 @@ class BlockFn(torch.autograd.Function):
         # magnitude words of the split-fp16 engine (dn_api.hip): the input's travels with the tensor from the block that produced it,
         # this block's output gets one for the next block; a tensor without one is measured by the library (one extra pass)
         x_amax = _amax_of(x)
-        words = torch.zeros(_hip.BLOCK_AMAX_WORDS + 1, dtype=torch.float32, device=dev)          # [saved-activation words | max |out|]
+        # [saved-activation words | max |out|].  Uninitialised on purpose (a fill per block and step is a launch): a call that tracks
+        # magnitudes zeroes and writes them itself; one that does not leaves them alone, and then nothing reads them -- the tag below and the
+        # backward's use are both conditional on dn_block_tracks_amax
+        words = new(_hip.BLOCK_AMAX_WORDS + 1)
         out_amax = words[_hip.BLOCK_AMAX_WORDS:]
         p = _params_struct(cfg, time, A_re, A_im, Ws, bs, masks, x_amax, out_amax)
         out = new(V, Cc)
@@ -432,7 +435,7 @@ class BlockFn(torch.autograd.Function):
                                   *([A_re] if A_re is not None else []), *([A_im] if A_im is not None else []))
             if debug_saved is not None:
                 debug_saved.append({"xs": xs, "xd": xd, **dict(zip(("gx", "gy", "g", "bre", "bim"), feats)), "h": list(hs)})
-        if L.dn_block_tracks_amax(mb.ref(), C.byref(p), 0):
+        if L.dn_block_tracks_amax(mb.ref(), C.byref(p), 1 if need_grad else 0):
             _tag_amax(out, out_amax)  # the next block reads it off its input (a call that does not track magnitudes leaves the word alone: no tag)
         return out
 
@@ -472,7 +475,7 @@ class BlockFn(torch.autograd.Function):
         dWs = [_grad_out(sk[3 + 2 * i], w) for i, w in enumerate(Ws)]
         dbs = [_grad_out(sk[4 + 2 * i], b) for i, b in enumerate(bs)]
         gr.d_x, gr.d_time, gr.dA_re, gr.dA_im = d_x.data_ptr(), d_time.data_ptr(), _hip.ptr(dA_re), _hip.ptr(dA_im)
-        dx_amax = torch.zeros(1, dtype=torch.float32, device=d_x.device)
+        dx_amax = torch.empty(1, dtype=torch.float32, device=d_x.device)      # (written only, and tagged only, when the call tracks magnitudes)
         gr.d_out_amax, gr.d_x_amax = _hip.ptr(_amax_of(d_out)), dx_amax.data_ptr()
         for i in range(cfg.n_mlp):
             gr.dW[i], gr.db[i] = dWs[i].data_ptr(), dbs[i].data_ptr()
@@ -486,7 +489,7 @@ class BlockFn(torch.autograd.Function):
         hook = getattr(cfg, "grad_hook", None)
         if hook is not None:          # dist.FlatParams: this block's gradient range may go out now
             hook()
-        if L.dn_block_tracks_amax(mb.ref(), C.byref(p), 1):
+        if L.dn_block_tracks_amax(mb.ref(), C.byref(p), 2):
             _tag_amax(d_x, dx_amax)   # the block before this one finds it on the gradient it receives
         return (None, None, None, d_x, d_time, dA_re, dA_im, *wb)
 

@@ -111,7 +111,7 @@ int dn_tn_target_chunks(void);  /* how many entries dn_mesh_batch_t.chunks shoul
 
 /* ---- opt-in per-kernel timing for benchmarks (no reference counterpart; the one piece of mutable global
  *      state, off by default): every launch is bracketed by hipEvents on its stream and summed per kernel
- *      family kind in [0, 5).  read: out[0..3] = {ms, launches, algorithmic flops, algorithmic bytes}. */
+ *      family kind in [0, 7) (dn_prof_kind_name(kind) is "" past the last one).  read: out[0..3] = {ms, launches, algorithmic flops, algorithmic bytes}. */
 int dn_prof_enable(int on);
 int dn_prof_reset(void);
 int dn_prof_read(int kind, double* out);
@@ -170,10 +170,11 @@ int dn_linear_bwd_amax_f32(const dn_mesh_batch_t* mb, const float* d_out, const 
 /* ---- DiffusionNetBlock.forward (layers.py:200-241) and its backward, fused orchestration.
  *      saved = NULL runs inference (intermediates live in ws). */
 size_t dn_block_fwd_workspace_bytes(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int with_saved);
-/*      1 if dn_block_fwd_f32 (backward = 0) / dn_block_bwd_f32 (backward = 1) on this batch and these parameters writes the optional
- *      magnitude words (out_amax and saved->amax / d_x_amax), 0 if it leaves them untouched (shapes the split-fp16 engine and the chained
- *      forward kernel do not take): a caller that hands the words on to the next block must not hand on words nobody wrote. */
-int dn_block_tracks_amax(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int backward);
+/*      1 if the block call `call` (0: dn_block_fwd_f32 without saved activations, 1: dn_block_fwd_f32 with them, 2: dn_block_bwd_f32) on this batch
+ *      and these parameters writes the optional magnitude words (out_amax and saved->amax / d_x_amax), 0 if it leaves them untouched (shapes
+ *      neither the split-fp16 engine nor the chained kernels take): a caller that hands the words on to the next block must not hand on words
+ *      nobody wrote. */
+int dn_block_tracks_amax(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int call);
 size_t dn_block_bwd_workspace_bytes(const dn_mesh_batch_t* mb, const dn_block_params_t* p);
 int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, const float* x, float* out,
                      const dn_block_saved_t* saved, void* ws, size_t ws_bytes, void* stream);

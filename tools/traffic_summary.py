@@ -29,6 +29,10 @@ def family(name):
         return "tngemm_kernel"
     if "spmm_kernel" in name:
         return "spmm_kernel"
+    if "chain_fwd_kernel" in name:
+        return "chain_fwd_kernel"
+    if "chain_bwd_kernel" in name:
+        return "chain_bwd_kernel"
     return None
 
 
