@@ -215,8 +215,11 @@ int linear_bwd_input(const dn_mesh_batch_t* mb, const float* d_a, int C_out, con
     return dn_launch_rowgemm(g, mb->n_tiles, 1, st);
 }
 // dW[o][i] = sum_r d_a[r,o] in[r,i] ; db[o] = sum_r d_a[r,o]
+// launches collected for ONE multi-problem launch (dn_launch_tngemm_multi)
+struct TnBatch { TnArgs g[3]; int nchunks[3]; int count = 0; };
 int linear_bwd_weights(const dn_mesh_batch_t* mb, const float* d_a, int C_out, const float* const* ins, const int* ws_, int nseg,
-                       float* dW, float* db, float* partial, float* colsum, hipStream_t st, MrJobs* defer = nullptr, const F16& f = F16()) {
+                       float* dW, float* db, float* partial, float* colsum, hipStream_t st, MrJobs* defer = nullptr, const F16& f = F16(),
+                       TnBatch* batch = nullptr) {
     TnArgs g = tn_new(mb);
     tn_f16(g, f);
     tn_a(g, d_a, nullptr, C_out, C_out);
@@ -225,9 +228,11 @@ int linear_bwd_weights(const dn_mesh_batch_t* mb, const float* d_a, int C_out, c
     g.group = dn_tn_global_group_mn(mb->n_chunks, g.M, g.N);
     tn_finish(g);
     const int npart = dn_tn_npartial(mb->n_chunks, g.group);
-    DN_CHECK(dn_launch_tngemm(g, mb->n_chunks, st));
-    if (defer && g.M % 4 == 0 && defer->count + 2 <= DN_MR_MAX_JOBS && al16(partial) && al16(colsum) &&
-        defer->push(partial, npart, (long long)g.M * g.N, dW)) {          // summed with the block's other gradients, one launch
+    const bool can_defer = defer && g.M % 4 == 0 && defer->count + 2 <= DN_MR_MAX_JOBS && al16(partial) && al16(colsum);
+    // (a product whose launch is handed to the caller must have its sums deferred too: they run after the caller's launch)
+    if (batch && batch->count < 3 && can_defer) { batch->g[batch->count] = g; batch->nchunks[batch->count] = mb->n_chunks; ++batch->count; }
+    else DN_CHECK(dn_launch_tngemm(g, mb->n_chunks, st));
+    if (can_defer && defer->push(partial, npart, (long long)g.M * g.N, dW)) {          // summed with the block's other gradients, one launch
         if (db && !defer->push(colsum, npart, g.M, db)) return dn_launch_reduce(colsum, db, npart, g.M, g.M, st);
         return 0;
     }
@@ -824,20 +829,23 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
         cb.d_out_amax = dout_amax;
         cb.d_xacc = d_xacc; cb.d_xd = d_xd; cb.d_dots = d_dots; cb.d_gx = d_gx; cb.d_gy = d_gy;
         DN_CHECK(dn_launch_chain_bwd(chain_np, cb, C, st));
+        // every d_a exists now: the (up to three) weight-gradient products of the MiniMLP go out as ONE launch
+        TnBatch tb;
         const float* d_a = d_out;
         for (int j = p->n_mlp - 1; j >= 0; --j) {
             const int wo = p->widths[j + 1], wi = p->widths[j];
             if (j > 0) {
                 const float* ins[1] = {sv->h[j - 1]};
                 const int iw[1] = {wi};
-                DN_CHECK(linear_bwd_weights(mb, d_a, wo, ins, iw, 1, gr->dW[j], gr->db[j], part_w[j], part_b[j], st, &jobs));
+                DN_CHECK(linear_bwd_weights(mb, d_a, wo, ins, iw, 1, gr->dW[j], gr->db[j], part_w[j], part_b[j], st, &jobs, F16(), &tb));
                 d_a = da[j & 1];
             } else {
                 const float* ins[3] = {x, sv->xd, sv->g};
                 const int iw[3] = {C, C, C};
-                DN_CHECK(linear_bwd_weights(mb, d_a, wo, ins, iw, p->with_grad ? 3 : 2, gr->dW[0], gr->db[0], part_w[0], part_b[0], st, &jobs));
+                DN_CHECK(linear_bwd_weights(mb, d_a, wo, ins, iw, p->with_grad ? 3 : 2, gr->dW[0], gr->db[0], part_w[0], part_b[0], st, &jobs, F16(), &tb));
             }
         }
+        DN_CHECK(dn_launch_tngemm_multi(tb.g, tb.nchunks, tb.count, st));
         if (p->with_grad) {
             DN_CHECK(gradfeat_bwd_weights(mb, d_dots, sv->gx, sv->gy, C, gr->dA_re, p->with_rot ? gr->dA_im : nullptr, part_a, psum, st, &jobs));
             DN_CHECK(grad_apply_bwd(mb, d_gx, d_gy, d_xd, C, d_xd, st, (f16 && (f16_mask() & F16_TOB_B)) ? aw + AW_MISC : nullptr));   // d_xd += gradX^T d_gx + gradY^T d_gy (in place)

@@ -604,6 +604,7 @@ int dn_launch_checksum_multi(int n, const void* const* data, const long long* nw
 // launchers (host), defined in the .hip files; all return hipError_t as int
 int dn_launch_rowgemm(const RgArgs& g, int ntiles, int nout, hipStream_t stream);
 int dn_launch_tngemm(const TnArgs& g, int nchunks, hipStream_t stream);
+int dn_launch_tngemm_multi(const TnArgs* gs, const int* nchunks, int count, hipStream_t stream);   // several products, one launch
 
 // ---------------------------------------------------------------------------------------
 // opt-in per-kernel timing (bench.py's roofline leg): when enabled, every launch is bracketed by

@@ -3,6 +3,7 @@
 // Replaces: geometry.to_basis (geometry.py:582-583) and every weight gradient dW = dY^T X of backward.
 // Two kernels: exact-f32 MFMA (any shape) and split-bf16 MFMA with k-major planes read through ds_read_b64_tr_b16.
 #include "dn_tn_tiles.h"
+#include <string.h>
 
 // =======================================================================================
 // tngemm
@@ -225,8 +226,10 @@ static int tn_launch(const TnArgs& g, dim3 grid, hipStream_t stream) {
 // =======================================================================================
 // (staging / fragment / MFMA helpers of this kernel: dn_tn_tiles.h, shared with the fused diffusion kernel)
 // single 60 KiB step buffer, two workgroups per CU (measured 60.1 vs 62.2 us against a double-buffered one-workgroup form)
+// body of the kernel for workgroup (bx, by, bz) of problem g (the plain kernel passes its blockIdx; the multi-problem kernel the indices of
+// the workgroup inside its problem)
 template <int FLAVOR, int NP>
-__global__ __launch_bounds__(DN_TX_THREADS, 4) void tngemm_x3_kernel(TnArgs g) {
+__device__ __forceinline__ void tn_x3_body(const TnArgs& g, const int bx, const int by, const int bz) {
     float sa = 1.f, sb = 1.f, so = 1.f;
     if constexpr (NP == 2) {   // split-fp16: operand scales from the producers' amax words, exact inverse on the way out
         sa = dn_pow2_scale(dn_amax_eval(g.a_amax));
@@ -241,8 +244,8 @@ __global__ __launch_bounds__(DN_TX_THREADS, 4) void tngemm_x3_kernel(TnArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;           // 2 x 4 waves, 64 x 32 outputs each
     const int li = lane & 31;
-    const int n0 = blockIdx.y * DN_TO, m0 = blockIdx.z * DN_TO;
-    const bool do_colsum = FLAVOR == DN_TN_COLSUM && blockIdx.y == 0;
+    const int n0 = by * DN_TO, m0 = bz * DN_TO;
+    const bool do_colsum = FLAVOR == DN_TN_COLSUM && by == 0;
     const bool wave_active = (m0 + wr * 64 < g.M) && (n0 + wc * 32 < g.N);
 
     f32x16 acc[2];
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(DN_TX_THREADS, 4) void tngemm_x3_kernel(TnArgs g) {
     float4 csum = dn_f4_zero();
     TxRegs R;
 
-    const int c_beg = blockIdx.x * g.group;
+    const int c_beg = bx * g.group;
     const int c_end = (c_beg + g.group < g.nchunks) ? c_beg + g.group : g.nchunks;
     for (int ci = c_beg; ci < c_end; ++ci) {
         const DnTile ch = g.chunks[ci];
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(DN_TX_THREADS, 4) void tngemm_x3_kernel(TnArgs g) {
             }
         }
     }
-    float* out = g.partial + (long long)blockIdx.x * g.M * g.N;
+    float* out = g.partial + (long long)bx * g.M * g.N;
     if (wave_active) {
         const int n = n0 + wc * 32 + li;
 #pragma unroll
@@ -310,9 +313,29 @@ __global__ __launch_bounds__(DN_TX_THREADS, 4) void tngemm_x3_kernel(TnArgs g) {
             float sum = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) sum += red[k * DN_TO + tid];
-            g.colsum[(long long)blockIdx.x * g.M + m0 + tid] = sum;
+            g.colsum[(long long)bx * g.M + m0 + tid] = sum;
         }
     }
+}
+
+template <int FLAVOR, int NP>
+__global__ __launch_bounds__(DN_TX_THREADS, 4) void tngemm_x3_kernel(TnArgs g) {
+    tn_x3_body<FLAVOR, NP>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+// several independent products in ONE launch (the three weight-gradient products of a block's backward: one ramp and one tail instead of
+// three, and a single mesh's handful of chunks share the device): workgroup blockIdx.x belongs to the problem whose range it falls into
+#define DN_TN_MULTI 3
+struct TnMulti { TnArgs p[DN_TN_MULTI]; int first[DN_TN_MULTI + 1]; int nblk[DN_TN_MULTI]; int ny[DN_TN_MULTI]; int count; };
+template <int FLAVOR, int NP>
+__global__ __launch_bounds__(DN_TX_THREADS, 4) void tngemm_x3_multi_kernel(TnMulti mm) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < DN_TN_MULTI; ++i) pi = (i < mm.count && (int)blockIdx.x >= mm.first[i]) ? i : pi;
+    const int local = (int)blockIdx.x - mm.first[pi];
+    // (selection instead of dynamic indexing of the by-value argument block: an indexed copy would land in scratch)
+    if (pi == 0) tn_x3_body<FLAVOR, NP>(mm.p[0], local % mm.nblk[0], (local / mm.nblk[0]) % mm.ny[0], local / (mm.nblk[0] * mm.ny[0]));
+    else if (pi == 1) tn_x3_body<FLAVOR, NP>(mm.p[1], local % mm.nblk[1], (local / mm.nblk[1]) % mm.ny[1], local / (mm.nblk[1] * mm.ny[1]));
+    else tn_x3_body<FLAVOR, NP>(mm.p[2], local % mm.nblk[2], (local / mm.nblk[2]) % mm.ny[2], local / (mm.nblk[2] * mm.ny[2]));
 }
 
 template <int FLAVOR, int NP>
@@ -379,3 +402,46 @@ int dn_launch_tngemm(const TnArgs& g_in, int nchunks, hipStream_t stream) {
     return err;
 }
 
+// Up to DN_TN_MULTI aligned, bias-column-sum ("COLSUM") split-bf16 products in one launch; anything else falls back to separate launches.
+int dn_launch_tngemm_multi(const TnArgs* gs, const int* nchunks, int count, hipStream_t stream) {
+    if (count <= 0) return 0;
+    bool ok = count <= DN_TN_MULTI && DN_TN_X3 != 0;
+    for (int i = 0; i < count && ok; ++i) {
+        const TnArgs& g = gs[i];
+        bool has_qa = false;
+        for (int k = 0; k < g.na; ++k) has_qa = has_qa || g.a[k].q != nullptr;
+        ok = g.aligned && !g.f16 && !has_qa && g.colsum && !g.b_rowscale && nchunks[i] > 0 && g.M > 0 && g.N > 0;
+    }
+    if (!ok || count == 1) {
+        for (int i = 0; i < count; ++i) { const int e = dn_launch_tngemm(gs[i], nchunks[i], stream); if (e) return e; }
+        return 0;
+    }
+    TnMulti mm;
+    memset(&mm, 0, sizeof(mm));
+    mm.count = count;
+    double flops = 0.0, bytes = 0.0;
+    int total = 0;
+    for (int i = 0; i < count; ++i) {
+        mm.p[i] = gs[i];
+        mm.p[i].nchunks = nchunks[i];
+        if (mm.p[i].group < 1) mm.p[i].group = 1;
+        mm.nblk[i] = (nchunks[i] + mm.p[i].group - 1) / mm.p[i].group;
+        mm.ny[i] = (gs[i].N + DN_TO - 1) / DN_TO;
+        const int nz = (gs[i].M + DN_TO - 1) / DN_TO;
+        mm.first[i] = total;
+        total += mm.nblk[i] * mm.ny[i] * nz;
+        const double rows = gs[i].acct_rows;
+        flops += 2.0 * rows * gs[i].M * gs[i].N;
+        bytes += 4.0 * (rows * (gs[i].M + gs[i].N) + (double)mm.nblk[i] * gs[i].M * gs[i].N);
+    }
+    mm.first[count] = total;
+    const size_t smem = (size_t)6 * DN_TX_PLANE;
+#ifndef DN_EMULATE
+    static unsigned long long lds_opt_in = 0;   // per-device bitmap
+    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&tngemm_x3_multi_kernel<DN_TN_COLSUM, 3>), smem, &lds_opt_in); if (oe_) return oe_; }
+#endif
+    dn_prof_begin(DN_K_TNGEMM, stream);
+    DN_LAUNCH((tngemm_x3_multi_kernel<DN_TN_COLSUM, 3>), dim3(total, 1, 1), dim3(DN_TX_THREADS, 1, 1), smem, stream, mm);
+    dn_prof_end(DN_K_TNGEMM, stream, flops, bytes);
+    return (int)hipGetLastError();
+}
