@@ -229,7 +229,7 @@ int linear_bwd_weights(const dn_mesh_batch_t* mb, const float* d_a, int C_out, c
     // several products in one launch: the launch has 3-5x the workgroups of one product, so two chunks per workgroup still fill the device and
     // halve the partial tiles written here and read by the deferred sum (measured, block backward at 160k vertices: 1 / 2 / 3 / 4 chunks per
     // workgroup 889 / 879 / 891 / 909 us)
-    if (batch && g.group < 2 && mb->n_chunks >= 4 * dn_num_cus() / 2) g.group = 2;
+    if (batch && g.group < 2 && mb->n_chunks >= dn_num_cus()) g.group = 2;
     tn_finish(g);
     const int npart = dn_tn_npartial(mb->n_chunks, g.group);
     const bool can_defer = defer && g.M % 4 == 0 && defer->count + 2 <= DN_MR_MAX_JOBS && al16(partial) && al16(colsum);
