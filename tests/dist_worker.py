@@ -86,3 +86,31 @@ def run_accumulate(rank, world, port, emu_so, sizes, out_dir):
         grads[mode] = flat.grad.clone()
     torch.save(grads, os.path.join(out_dir, f"acc_rank{rank}.pt"))
     dist.destroy_process_group()
+
+
+def run_autograph_dropout(rank, world, port, emu_so, out_dir):
+    """Data-parallel replicas are seeded identically; their dropout masks must not be (the check for the automatic
+    graph replay path).  Every rank runs the reference-signature forward of the SAME model on the SAME mesh in train mode with the
+    automatic capture on (closure-rerun backend on the CPU emulator: same seed plumbing as the HIP-graph backend) and keeps the
+    outputs of the replayed calls; the test compares them across ranks."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import diffusion_net
+    from diffusion_net import _hip, autograph, synthetic
+    from diffusion_net.batch import operator_cache
+    _hip._use_library_for_tests(emu_so, True)
+    autograph.backend, autograph.warm_calls, autograph.enabled = autograph.RerunBackend, 1, True
+    operator_cache.clear()
+    torch.manual_seed(0)                                   # identical replicas, identical torch RNG streams
+    model = diffusion_net.layers.DiffusionNet(3, 4, C_width=32, N_block=2, dropout=True)
+    model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=0))
+    model.train()
+    m = synthetic.make_mesh_operators(90, 8, seed=3)
+    outs = []
+    with torch.no_grad():
+        for _ in range(5):
+            outs.append(model(m["verts"], m["mass"], L=None, evals=m["evals"], evecs=m["evecs"], gradX=m["gradX"], gradY=m["gradY"]).clone())
+    st = dict(autograph.stats)
+    torch.save({"outs": torch.stack(outs), "replays": st["replays_fwd"], "captures": st["captures"]}, os.path.join(out_dir, f"ag_rank{rank}.pt"))
+    dist.destroy_process_group()

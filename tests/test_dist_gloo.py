@@ -72,6 +72,22 @@ def test_gradient_accumulation_with_overlap_two_ranks():
     assert float((r0["overlap"] - ref).norm() / ref.norm()) < 1e-6       # (S1/R + g2) summed over ranks: round-off only
 
 
+def test_autograph_dropout_masks_differ_across_ranks():
+    """Two identically seeded replicas, automatic graph replay on: the replayed forwards must draw different dropout masks on the two
+    ranks (the rank is mixed into the captured seed) and fresh masks on every replay."""
+    subprocess.run(["make", "-C", CSRC, "-j8", "emu"], check=True, capture_output=True)
+    import torch.multiprocessing as mp
+    import dist_worker
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(dist_worker.run_autograph_dropout, args=(2, _free_port(), EMU_SO, tmp), nprocs=2, join=True)
+        r0, r1 = (torch.load(os.path.join(tmp, f"ag_rank{r}.pt")) for r in range(2))
+    assert r0["captures"] == 1 and r1["captures"] == 1 and r0["replays"] >= 3 and r1["replays"] >= 3, (r0["replays"], r1["replays"])
+    for k in range(2, 5):                                   # the replayed calls
+        assert not torch.equal(r0["outs"][k], r1["outs"][k]), k          # different masks on the two ranks
+    for r in (r0, r1):
+        assert not torch.equal(r["outs"][3], r["outs"][4])               # and fresh masks per replay
+
+
 def test_bench_gpus_n_launches_n_ranks():
     """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the driver's command) must become its own launcher: two ranks
     under torch.distributed.run on 127.0.0.1, each seeing WORLD_SIZE == --gpus.  The DN_BENCH_LAUNCH_CHECK hook stops every rank

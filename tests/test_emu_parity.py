@@ -127,8 +127,8 @@ def test_autograph_on_emulator(emu):
     parity_cases.run_autograph_modes(emu)
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(with_rot=False, dropout=False, sizes=(170, 133)), dict(with_grad=False, sizes=(200,), N_block=1),
-                                dict(C=64, K=128, sizes=(160, 140), dropout=False)])
+@pytest.mark.parametrize("kw", [dict(sizes=(150, 135)), dict(with_rot=False, dropout=False, sizes=(133,), N_block=1), dict(with_grad=False, sizes=(150,), N_block=1),
+                                dict(C=64, K=128, sizes=(160, 140), dropout=False, N_block=1)])
 def test_chained_forward_kernel_vs_unfused_on_emulator(emu, kw):
     """dn_chain.hip (gather -> gradient features -> MiniMLP in one launch) against the unfused launches: with / without rotations and
     gradient features, in-kernel dropout, partial last units, C = 128 and 64."""
