@@ -34,7 +34,36 @@ def register_handle(obj) -> int:
 
 
 def handle_object(k: int):
-    return _handles[int(k)] if k else None
+    if not k:
+        return None
+    try:
+        return _handles[int(k)]
+    except KeyError:
+        raise RuntimeError(f"diffusion_net: handle {int(k)} names a packed object (MeshBatch / BlockConfig / GatherPattern) that has been "
+                           "garbage-collected; the caller owns these objects and must keep them alive while an op that received the handle "
+                           "-- or the backward of one -- can still run") from None
+
+
+# strong references for the lifetime of an autograd node (torchlib.py: the eager autograd formulas of the custom ops pin the objects their
+# backward will look up, so that dropping ``mb`` between forward and backward is harmless, as it is on the direct path)
+_pins = {}
+
+
+def pin_handle(k: int) -> None:
+    if k:
+        ent = _pins.get(int(k))
+        if ent is None:
+            _pins[int(k)] = [handle_object(k), 1]
+        else:
+            ent[1] += 1
+
+
+def unpin_handle(k: int) -> None:
+    ent = _pins.get(int(k)) if k else None
+    if ent is not None:
+        ent[1] -= 1
+        if ent[1] <= 0:
+            del _pins[int(k)]
 
 
 def default_chunk_rows(v_total: int) -> int:

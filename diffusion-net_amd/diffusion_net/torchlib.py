@@ -9,7 +9,12 @@ test_torch_compile_packed_forward``: ``fullgraph=True``).  The implementations a
 forward / backward of the matching ``ops.*Fn`` on a stand-in context.  ``layers.py`` routes through these ops only while a compiler is
 tracing (``torch.compiler.is_compiling()``); eager execution keeps its direct path (gradient sinks, dist hooks, magnitude tags).
 
-Non-tensor operands travel as integer handles into a weak registry (the caller owns the objects, as with the eager path).
+Non-tensor operands travel as integer handles into a weak registry (the caller owns the objects, as with the eager path).  The eager
+autograd formulas pin the objects their backward looks up for as long as the autograd node lives (``_hold``); a COMPILED graph calls the
+forward and backward ops directly and holds only the integers: there the caller must keep ``mb`` / ``gather`` alive until the backward has
+run (a dead handle raises a RuntimeError that says so).  Handles are graph constants for ``torch.compile``: a compiled
+``forward_packed`` is specialised to its ``MeshBatch`` and recompiles for another one -- compile per static batch (as
+``graphs.GraphedTrainStep`` captures per batch), not inside a loop over meshes.
 """
 from __future__ import annotations
 
@@ -20,7 +25,24 @@ from torch import Tensor
 from torch.library import custom_op
 
 from . import _hip, ops
+import weakref
+
 from .batch import handle_object as _obj   # handles are attributes of the objects (MeshBatch.handle, ...), assigned at construction
+from .batch import pin_handle as _pin, unpin_handle as _unpin
+
+
+def _hold(ctx, *handles):
+    """Keep the objects behind ``handles`` alive as long as the autograd context ``ctx`` is (no-op while a compiler traces with fake tensors:
+    nothing will look the handles up through this context)."""
+    if torch.compiler.is_compiling():
+        return
+    for k in handles:
+        if isinstance(k, int) and k:
+            try:
+                _pin(k)
+                weakref.finalize(ctx, _unpin, k)
+            except TypeError:          # a context type that cannot be weakly referenced: fall back to the caller-owns rule
+                _unpin(k)
 
 
 class _Ctx:
@@ -66,6 +88,7 @@ def _linear_setup(ctx, inputs, output):
     x, W, b, mb = inputs
     ctx.save_for_backward(x, W)
     ctx.mb = mb
+    _hold(ctx, mb)
 
 
 def _linear_backward(ctx, g):
@@ -131,6 +154,7 @@ def _block_setup(ctx, inputs, output):
     ctx.n_wb = len(wb)
     ctx.has = (A_re is not None, A_im is not None, seed_dev is not None)
     ctx.ints = (mb, cfg, seed)
+    _hold(ctx, mb, cfg)
     ctx.save_for_backward(x, time, *([A_re] if A_re is not None else []), *([A_im] if A_im is not None else []), *wb, *output[1:],
                           *([seed_dev] if seed_dev is not None else []))
 
@@ -183,6 +207,7 @@ def _(d_out, pat, n_src):
 
 def _gm_setup(ctx, inputs, output):
     ctx.pat, ctx.n_src = inputs[1], inputs[0].shape[0]
+    _hold(ctx, ctx.pat)
 
 
 gather_mean.register_autograd(lambda ctx, g: (gather_mean_bwd(g.contiguous(), ctx.pat, ctx.n_src), None, None), setup_context=_gm_setup)
@@ -214,6 +239,7 @@ def _(d_out, msum, mb, v_total):
 
 def _mm_setup(ctx, inputs, output):
     ctx.mb, ctx.v_total = inputs[1], inputs[0].shape[0]
+    _hold(ctx, ctx.mb)
     ctx.save_for_backward(output[1])
 
 
@@ -257,6 +283,7 @@ def _(d_logp, d_loss, logp, labels, count, pat, log_softmax, smoothing, n_src):
 def _head_setup(ctx, inputs, output):
     x, pat, labels, lsm, smoothing, _n_out = inputs
     ctx.meta = (pat, lsm, smoothing, x.shape[0], labels is not None)
+    _hold(ctx, pat)
     ctx.save_for_backward(output[0], *([labels, output[2]] if labels is not None else []))
 
 

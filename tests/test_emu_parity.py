@@ -134,3 +134,34 @@ def test_chained_forward_kernel_vs_unfused_on_emulator(emu, kw):
     gradient features, in-kernel dropout, partial last units, C = 128 and 64."""
     import parity_cases
     parity_cases.run_chain_vs_unfused(emu, **kw)
+
+
+def test_torchlib_handles_outlive_their_objects_or_say_so(emu):
+    """the custom operators take the packed objects as integer handles into a weak registry.  The eager autograd formula pins the
+    object until its node dies (dropping ``mb`` between forward and backward is harmless, as on the direct path); a handle whose object is
+    gone raises an error that names the cause instead of a bare KeyError."""
+    import gc
+    import torch
+    import parity_cases
+    from diffusion_net import torchlib
+    from diffusion_net.batch import handle_object
+    meshes, feats = parity_cases.make_ragged((70, 90), 8, 16, seed=5)
+    mb = parity_cases.pack(meshes, "cpu")
+    x = torch.cat(feats, 0).requires_grad_(True)
+    lin = torch.nn.Linear(16, 32)
+    ref = torch.nn.functional.linear(x, lin.weight, lin.bias)
+    out = torchlib.linear(x, lin.weight, lin.bias, mb.handle)
+    assert helpers.rel_max(out.detach(), ref.detach()) < 1e-5
+    k = mb.handle
+    del mb
+    gc.collect()
+    assert handle_object(k) is not None          # pinned by the autograd node of `out`
+    out.square().sum().backward()
+    gx = x.grad.clone()
+    x.grad = None
+    ref.square().sum().backward()
+    assert helpers.rel_max(gx, x.grad) < 1e-4
+    del out
+    gc.collect()
+    with pytest.raises(RuntimeError, match="garbage-collected"):
+        handle_object(k)
