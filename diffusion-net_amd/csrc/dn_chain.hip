@@ -276,8 +276,8 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
                     float* oy = a.gy + row * C + 4 * q;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        *reinterpret_cast<float4*>(ox + 16 * nt) = make_float4(gxv[nt][0], gxv[nt][1], gxv[nt][2], gxv[nt][3]);
-                        *reinterpret_cast<float4*>(oy + 16 * nt) = make_float4(gyv[nt][0], gyv[nt][1], gyv[nt][2], gyv[nt][3]);
+                        ch_st4(ox + 16 * nt, make_float4(gxv[nt][0], gxv[nt][1], gxv[nt][2], gxv[nt][3]));
+                        ch_st4(oy + 16 * nt, make_float4(gyv[nt][0], gyv[nt][1], gyv[nt][2], gyv[nt][3]));
                     }
                 }
                 CH_TR();
@@ -319,15 +319,15 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
                 if (live && a.g) {
                     float* og = a.g + row * C + 4 * q;
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<float4*>(og + 16 * nt) = make_float4(gv[nt][0], gv[nt][1], gv[nt][2], gv[nt][3]);
+                    for (int nt = 0; nt < NT; ++nt) ch_st4(og + 16 * nt, make_float4(gv[nt][0], gv[nt][1], gv[nt][2], gv[nt][3]));
                 }
                 if (live && a.bre) {
                     float* o0 = a.bre + row * C + 4 * q;
                     float* o1 = a.bim + row * C + 4 * q;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        *reinterpret_cast<float4*>(o0 + 16 * nt) = make_float4(acc[0][nt][0], acc[0][nt][1], acc[0][nt][2], acc[0][nt][3]);
-                        *reinterpret_cast<float4*>(o1 + 16 * nt) = make_float4(acc[1][nt][0], acc[1][nt][1], acc[1][nt][2], acc[1][nt][3]);
+                        ch_st4(o0 + 16 * nt, make_float4(acc[0][nt][0], acc[0][nt][1], acc[0][nt][2], acc[0][nt][3]));
+                        ch_st4(o1 + 16 * nt, make_float4(acc[1][nt][0], acc[1][nt][1], acc[1][nt][2], acc[1][nt][3]));
                     }
                 }
 #pragma unroll
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
                         float* oh = hj + (long long)rowh[hh] * C + 4 * q;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
-                            *reinterpret_cast<float4*>(oh + 16 * nt) = make_float4(acc[hh][nt][0], acc[hh][nt][1], acc[hh][nt][2], acc[hh][nt][3]);
+                            ch_st4(oh + 16 * nt, make_float4(acc[hh][nt][0], acc[hh][nt][1], acc[hh][nt][2], acc[hh][nt][3]));
                     }
             }
             wm = ch_wave_max(wm);
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
             for (int hh = 0; hh < 2; ++hh) {
                 const float* px = a.x + (long long)rch[hh] * C + 4 * q;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) r4[hh][nt] = *reinterpret_cast<const float4*>(px + 16 * nt);
+                for (int nt = 0; nt < NT; ++nt) r4[hh][nt] = *reinterpret_cast<const float4*>(px + 16 * nt);   // (x: second read, out of L2)
             }
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh)
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
                 if (liveh[hh]) {
                     float* oo = a.out + (long long)rowh[hh] * C + 4 * q;
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<float4*>(oo + 16 * nt) = r4[hh][nt];
+                    for (int nt = 0; nt < NT; ++nt) ch_st4(oo + 16 * nt, r4[hh][nt]);
                 }
             CH_TR();
         }

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
             for (int hh = 0; hh < 2; ++hh) {
                 const float* p = a.d_out + (long long)rch[hh] * C + 4 * q;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) v[hh][nt] = *reinterpret_cast<const float4*>(p + 16 * nt);
+                for (int nt = 0; nt < NT; ++nt) v[hh][nt] = *reinterpret_cast<const float4*>(p + 16 * nt);   // (d_out is read again for the residual)
             }
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh)
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
             for (int hh = 0; hh < 2; ++hh) {
                 const float* p = hp + (long long)rch[hh] * C + 4 * q;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) hv[hh][nt] = *reinterpret_cast<const float4*>(p + 16 * nt);
+                for (int nt = 0; nt < NT; ++nt) hv[hh][nt] = *reinterpret_cast<const float4*>(p + 16 * nt);   // (d_out is read again for the residual)
             }
             float wm = 0.f;
 #pragma unroll
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
                 if (liveh[hh]) {
                     float* o = dj + (long long)rowh[hh] * C + 4 * q;
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<float4*>(o + 16 * nt) = make_float4(acc[hh][nt][0], acc[hh][nt][1], acc[hh][nt][2], acc[hh][nt][3]);
+                    for (int nt = 0; nt < NT; ++nt) ch_st4(o + 16 * nt, make_float4(acc[hh][nt][0], acc[hh][nt][1], acc[hh][nt][2], acc[hh][nt][3]));
                 }
             s_act = ch_uniform(dn_pow2_scale(ch_wave_max(wm)));
             CH_PACK(acc, s_act, fh, fl);
@@ -194,8 +194,8 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
                     float* o = a.d_xacc + (long long)rowh[hh] * C + 4 * q;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        *reinterpret_cast<float4*>(o + 16 * nt) = make_float4(acc[hh][nt][0] * so0 + r4[hh][nt].x, acc[hh][nt][1] * so0 + r4[hh][nt].y,
-                                                                              acc[hh][nt][2] * so0 + r4[hh][nt].z, acc[hh][nt][3] * so0 + r4[hh][nt].w);
+                        ch_st4(o + 16 * nt, make_float4(acc[hh][nt][0] * so0 + r4[hh][nt].x, acc[hh][nt][1] * so0 + r4[hh][nt].y,
+                                                                              acc[hh][nt][2] * so0 + r4[hh][nt].z, acc[hh][nt][3] * so0 + r4[hh][nt].w));
                 }
         }
         {   // xd group
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
                     float* o = a.d_xd + (long long)rowh[hh] * C + 4 * q;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        *reinterpret_cast<float4*>(o + 16 * nt) = make_float4(acc[hh][nt][0] * so0, acc[hh][nt][1] * so0, acc[hh][nt][2] * so0, acc[hh][nt][3] * so0);
+                        ch_st4(o + 16 * nt, make_float4(acc[hh][nt][0] * so0, acc[hh][nt][1] * so0, acc[hh][nt][2] * so0, acc[hh][nt][3] * so0));
                 }
         }
         if (a.with_grad) {
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
                 for (int hh = 0; hh < 2; ++hh) {
                     const float* p = a.g + (long long)rch[hh] * C + 4 * q;
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) gq[hh][nt] = *reinterpret_cast<const float4*>(p + 16 * nt);
+                    for (int nt = 0; nt < NT; ++nt) gq[hh][nt] = ch_ld4(p + 16 * nt);
                 }
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh)
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
                     if (liveh[hh]) {
                         float* o = a.d_dots + (long long)rowh[hh] * C + 4 * q;
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<float4*>(o + 16 * nt) = make_float4(acc[hh][nt][0], acc[hh][nt][1], acc[hh][nt][2], acc[hh][nt][3]);
+                        for (int nt = 0; nt < NT; ++nt) ch_st4(o + 16 * nt, make_float4(acc[hh][nt][0], acc[hh][nt][1], acc[hh][nt][2], acc[hh][nt][3]));
                     }
             }
             // ---- gradient features backward, one 16-row half at a time:
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
                     const float* py = a.gy + (long long)rc * C + 4 * q;
                     float4 tx[NT], ty[NT];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) { tx[nt] = *reinterpret_cast<const float4*>(px + 16 * nt); ty[nt] = *reinterpret_cast<const float4*>(py + 16 * nt); }
+                    for (int nt = 0; nt < NT; ++nt) { tx[nt] = ch_ld4(px + 16 * nt); ty[nt] = ch_ld4(py + 16 * nt); }
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         u[nt][0] = dd[nt][0] * tx[nt].x; u[nt][1] = dd[nt][1] * tx[nt].y; u[nt][2] = dd[nt][2] * tx[nt].z; u[nt][3] = dd[nt][3] * tx[nt].w;
@@ -308,16 +308,16 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
                     const float* pi = a.bim + (long long)rc * C + 4 * q;
                     float4 br[NT], bi[NT];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) { br[nt] = *reinterpret_cast<const float4*>(pr + 16 * nt); bi[nt] = *reinterpret_cast<const float4*>(pi + 16 * nt); }
+                    for (int nt = 0; nt < NT; ++nt) { br[nt] = ch_ld4(pr + 16 * nt); bi[nt] = ch_ld4(pi + 16 * nt); }
                     if (live) {
                         float* ox = a.d_gx + (long long)row * C + 4 * q;
                         float* oy = a.d_gy + (long long)row * C + 4 * q;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
-                            *reinterpret_cast<float4*>(ox + 16 * nt) = make_float4(ag[0][nt][0] * sog + dd[nt][0] * br[nt].x, ag[0][nt][1] * sog + dd[nt][1] * br[nt].y,
-                                                                                   ag[0][nt][2] * sog + dd[nt][2] * br[nt].z, ag[0][nt][3] * sog + dd[nt][3] * br[nt].w);
-                            *reinterpret_cast<float4*>(oy + 16 * nt) = make_float4(ag[1][nt][0] * sog + dd[nt][0] * bi[nt].x, ag[1][nt][1] * sog + dd[nt][1] * bi[nt].y,
-                                                                                   ag[1][nt][2] * sog + dd[nt][2] * bi[nt].z, ag[1][nt][3] * sog + dd[nt][3] * bi[nt].w);
+                            ch_st4(ox + 16 * nt, make_float4(ag[0][nt][0] * sog + dd[nt][0] * br[nt].x, ag[0][nt][1] * sog + dd[nt][1] * br[nt].y,
+                                                                                   ag[0][nt][2] * sog + dd[nt][2] * br[nt].z, ag[0][nt][3] * sog + dd[nt][3] * br[nt].w));
+                            ch_st4(oy + 16 * nt, make_float4(ag[1][nt][0] * sog + dd[nt][0] * bi[nt].x, ag[1][nt][1] * sog + dd[nt][1] * bi[nt].y,
+                                                                                   ag[1][nt][2] * sog + dd[nt][2] * bi[nt].z, ag[1][nt][3] * sog + dd[nt][3] * bi[nt].w));
                         }
                     }
                 }
