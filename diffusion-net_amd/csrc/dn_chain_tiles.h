@@ -61,25 +61,21 @@ __device__ __forceinline__ float ch_uniform(float v) {
     return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v)));
 #endif
 }
-// Streaming global accesses of the chained kernels (DN_CH_STREAM, default on): every activation tile is read or written exactly once per
-// launch and consumed by a LATER kernel, so it should not displace what the L2 is there for in these kernels -- the neighbour rows of the
-// gather and the weight pieces.  Nontemporal stores / loads (the hand-written copy gains 6.2 vs 5.2-5.9 TB/s from them).
+// Streaming global accesses of the chained kernels (dn_common.h): every activation tile is written exactly once per launch and consumed by
+// a LATER kernel; the single-use tiles of the backward are read the same way.  Build with -DDN_CH_STREAM=0 for plain accesses (A/B).
 #ifndef DN_CH_STREAM
 #define DN_CH_STREAM 1
 #endif
-typedef float ch_v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void ch_st4(float* p, const float4 v) {
-#if !defined(DN_EMULATE) && DN_CH_STREAM
-    ch_v4f t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
-    __builtin_nontemporal_store(t, reinterpret_cast<ch_v4f*>(p));
+#if DN_CH_STREAM
+    dn_st4_stream(p, v);
 #else
     *reinterpret_cast<float4*>(p) = v;
 #endif
 }
 __device__ __forceinline__ float4 ch_ld4(const float* p) {
-#if !defined(DN_EMULATE) && DN_CH_STREAM
-    const ch_v4f t = __builtin_nontemporal_load(reinterpret_cast<const ch_v4f*>(p));
-    return make_float4(t.x, t.y, t.z, t.w);
+#if DN_CH_STREAM
+    return dn_ld4_stream(p);
 #else
     return *reinterpret_cast<const float4*>(p);
 #endif

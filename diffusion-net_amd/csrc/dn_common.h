@@ -173,6 +173,25 @@ struct DnTile {
 };
 
 __device__ __forceinline__ float4 dn_f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// Streaming (nontemporal) 16-byte accesses for data a kernel touches once and a LATER kernel consumes: they should not displace what the L2
+// is needed for inside the kernel (gathered neighbour rows, weight pieces).  The hand-written copy gains 6.2 vs 5.2-5.9 TB/s from them.
+typedef float dn_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dn_st4_stream(float* p, const float4 v) {
+#ifndef DN_EMULATE
+    dn_v4f t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<dn_v4f*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+__device__ __forceinline__ float4 dn_ld4_stream(const float* p) {
+#ifndef DN_EMULATE
+    const dn_v4f t = __builtin_nontemporal_load(reinterpret_cast<const dn_v4f*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+#else
+    return *reinterpret_cast<const float4*>(p);
+#endif
+}
 // streaming (nontemporal) 16-byte accesses: the hand-written copy runs at 6.2-6.4 TB/s with them against 5.2-5.9 TB/s without (tools/kbench copyk);
 // in the row GEMM they moved the block by +-2 % either way (round 3, tools/experiments/rowgemm_ws_knobs/) and are not used there.
 typedef float dn_vf4 __attribute__((ext_vector_type(4)));
