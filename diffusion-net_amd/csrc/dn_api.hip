@@ -5,6 +5,7 @@
 #include "../../include/diffnet_hip.h"
 #include <string.h>
 #include <stdlib.h>
+#define DN_MIN_TIME 1e-8f       /* layers.py:49 */
 
 static_assert(sizeof(dn_tile_t) == sizeof(DnTile), "tile layout");
 #define DN_ERR_INVALID 1   /* hipErrorInvalidValue */
@@ -600,6 +601,11 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     ChainPrepArgs pa; memset(&pa, 0, sizeof(pa));
     int chain_np = 0;
     const bool use_chain = chain;
+    if (!words && p->clamp_time) {           // no bookkeeping launch on this path: the clamp is the launch
+        AmaxInit in; memset(&in, 0, sizeof(in));
+        in.clamp_p = const_cast<float*>(p->time); in.clamp_n = C; in.clamp_min = DN_MIN_TIME;
+        DN_CHECK(dn_launch_amax_init(in, st));
+    }
     if (words) {
         // one launch: weight magnitudes (stored), the words the kernels below accumulate into zeroed, the input's word forwarded to the
         // saved set (the backward multiplies by x again).  With the chained row kernel that launch is its weight-preparation kernel.
@@ -616,6 +622,7 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
         ev_amax = mb->evecs_amax; ms_amax = mb->mass_amax;
         const bool measure = !x_amax || (f16 && (!ev_amax || !ms_amax));
         if (x_amax && sv && !measure) { in.copy_src = x_amax; in.copy_dst = sw + SW_X; }
+        if (p->clamp_time) { in.clamp_p = const_cast<float*>(p->time); in.clamp_n = C; in.clamp_min = DN_MIN_TIME; }     // layers.py:48-49, in this launch
         if (use_chain) {
             const int NK = C / 32;
             auto piece = [&](const float* Wm, const float* Wm2, float* word, int ld, int col0) {
@@ -635,6 +642,7 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
             pa.out = reinterpret_cast<uint4*>(chain_ws);
             for (int r = 0; r < in.nzero; ++r) pa.zero_range(in.zero[r], in.zero_n[r]);
             pa.copy_src = in.copy_src; pa.copy_dst = in.copy_dst;
+            pa.clamp_p = in.clamp_p; pa.clamp_n = in.clamp_n; pa.clamp_min = in.clamp_min;
             DN_CHECK(dn_launch_chain_prep(pa, chain_np, C, st));
         } else {
             DN_CHECK(dn_launch_amax_init(in, st));

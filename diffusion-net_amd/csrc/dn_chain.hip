@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void chain_prep_kernel(ChainPrepArgs a) {
         for (int r = 0; r < a.nzero; ++r)
             for (int i = tid; i < a.zero_n[r]; i += 256) a.zero[r][i] = 0.f;
         if (tid == 0 && a.copy_src && a.copy_dst) *a.copy_dst = *a.copy_src;
+        for (int i = tid; i < a.clamp_n; i += 256) { const float v = a.clamp_p[i]; a.clamp_p[i] = v < a.clamp_min ? a.clamp_min : v; }   // (NaN stays NaN, as torch.clamp)
         return;
     }
     const ChainPrepPiece pc = a.pc[blockIdx.x];

@@ -470,6 +470,7 @@ struct ChainPrepArgs {
     // start-of-call bookkeeping done by the workgroup behind the last piece (what dn_launch_amax_init does for the unfused path):
     // word ranges zeroed, one word copied
     float* zero[4]; int zero_n[4]; int nzero; const float* copy_src; float* copy_dst;
+    float* clamp_p; int clamp_n; float clamp_min;       // as AmaxInit's
     void zero_range(float* p, int n) { if (p && n > 0 && nzero < 4) { zero[nzero] = p; zero_n[nzero] = n; ++nzero; } }
 };
 struct ChainArgs {
@@ -543,6 +544,7 @@ int dn_launch_amax(const AmaxJobs& jobs, hipStream_t stream);
 // one-launch start of a block call: stored maxima of small tensors (jobs with the same destination must be adjacent), zeroing of up to
 // four word ranges, one word copy
 struct AmaxInit { AmaxJobs jobs; int same[DN_AMAX_MAX_JOBS]; float* zero[4]; int zero_n[4]; int nzero; const float* copy_src; float* copy_dst;
+    float* clamp_p; int clamp_n; float clamp_min;       // clamp_p[0..clamp_n) raised to >= clamp_min in place (the diffusion times, layers.py:48-49)
     void zero_range(float* p, int n) { if (p && n > 0 && nzero < 4) { zero[nzero] = p; zero_n[nzero] = n; ++nzero; } } };
 int dn_launch_amax_init(const AmaxInit& a, hipStream_t stream);
 int dn_launch_reduce(const float* partial, float* out, int n, long long stride, long long len, hipStream_t stream);

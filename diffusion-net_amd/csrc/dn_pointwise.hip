@@ -373,6 +373,7 @@ __global__ __launch_bounds__(1024) void amax_init_kernel(AmaxInit a) {
         for (int r = 0; r < a.nzero; ++r)
             for (int i = tid; i < a.zero_n[r]; i += 1024) a.zero[r][i] = 0.f;
         if (tid == 0 && a.copy_src && a.copy_dst) *a.copy_dst = *a.copy_src;
+        for (int i = tid; i < a.clamp_n; i += 1024) { const float v = a.clamp_p[i]; a.clamp_p[i] = v < a.clamp_min ? a.clamp_min : v; }   // (NaN stays NaN, as torch.clamp)
         return;
     }
     if (a.same[j]) return;                      // merged into the previous job's workgroup

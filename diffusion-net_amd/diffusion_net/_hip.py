@@ -43,7 +43,7 @@ class BlockParamsStruct(C.Structure):
         ("widths", C.c_int32 * (MAX_MLP + 1)),
         ("time", _vp), ("A_re", _vp), ("A_im", _vp),
         ("W", _vp * MAX_MLP), ("b", _vp * MAX_MLP), ("mask", _vp * MAX_MLP), ("drop_seed", C.c_uint64), ("drop_seed_dev", _vp),
-        ("x_amax", _vp), ("out_amax", _vp),
+        ("x_amax", _vp), ("out_amax", _vp), ("clamp_time", C.c_int32),
     ]
 
 

@@ -184,6 +184,7 @@ class DiffusionNetBlock(nn.Module):
             self.MLP_C += C_width
         self.mlp = MiniMLP([self.MLP_C] + list(mlp_hidden_dims) + [C_width], dropout=dropout)
         self._cfg = ops.BlockConfig(C_width, self.mlp.layer_sizes, with_gradient_features, with_gradient_rotations)
+        self._cfg.clamp_time = True       # forward_packed: the in-place clamp of diffusion_time rides in the block call (layers.py:48-49)
         self.mask_provider = None   # test hook: callable(layer_index, shape, device) -> uint8 keep mask
         self.drop_seed_provider = None   # test hook: callable() -> int seed of the in-kernel dropout
 
@@ -221,7 +222,9 @@ class DiffusionNetBlock(nn.Module):
             raise NotImplementedError("the HIP block implements diffusion_method='spectral' with ReLU MLPs")
         if self.with_gradient_features and not mb.has_grad:
             raise ValueError("gradient features need gradX/gradY")
-        self.diffusion.clamp_time_()
+        if _compiling():
+            self.diffusion.clamp_time_()
+        # (eager: the clamp of layers.py:48-49 happens in place inside the block call's first launch, BlockConfig.clamp_time)
         A_re = A_im = None
         if self.with_gradient_features:
             A_re, A_im = self.gradient_features.matrices()

@@ -311,6 +311,7 @@ class BlockConfig:
         self.handle = register_handle(self)
         self.grad_hook = None        # dist.FlatParams: called after the block's gradients were delivered
         self.grad_pre_hook = None    # ... and before they are written
+        self.clamp_time = False      # True: the block forward clamps diffusion_time to >= 1e-8 in place inside its first launch (layers.py:48-49)
         if self.n_mlp > _hip.MAX_MLP:
             raise ValueError("MiniMLP deeper than %d layers is not supported by the HIP block" % _hip.MAX_MLP)
 
@@ -392,7 +393,12 @@ class BlockFn(torch.autograd.Function):
         _require(x, mb)
         ctx.sinks = _sinks([time, A_re, A_im, *wb])
         L = _hip.lib()
+        time_param = time
         x, time = _f32c(x), _f32c(time)
+        clamp_in_call = bool(getattr(cfg, "clamp_time", False))
+        if clamp_in_call and time.data_ptr() != time_param.data_ptr():     # a converted copy: the library would clamp the copy, not the Parameter
+            time_param.data.clamp_(min=1e-8)
+            time, clamp_in_call = _f32c(time_param), False
         A_re = _f32c(A_re) if A_re is not None else None
         A_im = _f32c(A_im) if A_im is not None else None
         Ws = [_f32c(w) for w in wb[0::2]]
@@ -408,6 +414,7 @@ class BlockFn(torch.autograd.Function):
         words = new(_hip.BLOCK_AMAX_WORDS + 1)
         out_amax = words[_hip.BLOCK_AMAX_WORDS:]
         p = _params_struct(cfg, time, A_re, A_im, Ws, bs, masks, x_amax, out_amax)
+        p.clamp_time = 1 if clamp_in_call else 0
         out = new(V, Cc)
         need_grad = any(ctx.needs_input_grad)
         if need_grad:

@@ -64,7 +64,7 @@ typedef struct dn_mesh_batch {
 typedef struct dn_block_params {
     int32_t C, n_mlp, with_grad, with_rot;
     int32_t widths[DN_MAX_MLP_LAYERS + 1]; /* MiniMLP sizes: widths[0] = 3C (2C w/o gradient features), ..., widths[n_mlp] = C */
-    const float* time;                     /* [C] diffusion_time, already clamped to >= 1e-8 (layers.py:48-49) */
+    const float* time;                     /* [C] diffusion_time, clamped to >= 1e-8 (layers.py:48-49) -- by the caller, or see clamp_time */
     const float* A_re; const float* A_im;  /* [C,C] (with_rot=0: A_re holds A, A_im ignored), layers.py:110-113 */
     const float* W[DN_MAX_MLP_LAYERS];     /* [widths[i+1], widths[i]] */
     const float* b[DN_MAX_MLP_LAYERS];     /* [widths[i+1]] */
@@ -80,6 +80,10 @@ typedef struct dn_block_params {
      * block's out_amax); NULL: measured by the call (one extra pass over x).  out_amax: device float that receives max |out| (zeroed by
      * the call when dn_block_tracks_amax() says the call tracks magnitudes, untouched otherwise), or NULL. */
     const float* x_amax; float* out_amax;
+    /* Optional (round 4): != 0 makes dn_block_fwd_f32 raise `time` to >= 1e-8 IN PLACE before anything reads it -- the clamp the reference
+     * applies to the parameter in every forward (layers.py:48-49: the Parameter keeps the clamped values) -- as part of the call's first
+     * launch, instead of a separate elementwise kernel of the caller.  `time` must then be writable.  The backward ignores the field. */
+    int32_t clamp_time;
 } dn_block_params_t;
 
 /* Activations the forward saves for the backward (caller-allocated). */

@@ -10,6 +10,7 @@ timeout 200 python bench.py --eager --no-cpu-baseline --no-other-configs > gpuru
 DN_CHAIN=0 timeout 200 python bench.py --no-cpu-baseline --no-other-configs > gpurun_out/bench_chain_off.json 2>> gpurun_out/bench.err < /dev/null
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_b && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o trace -- python "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs > "$R/gpurun_out/prof_bench.json" 2> "$R/gpurun_out/prof.err" < /dev/null)
 f=$(find /tmp/prof_b -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" gpurun_out/bench_kernel_stats.csv
+f=$(find /tmp/prof_b -name "*kernel_trace.csv" 2>/dev/null | head -1); [ -n "$f" ] && python tools/step_kernels.py "$f" > gpurun_out/step_kernels.txt 2>&1
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_c2 && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c2 -o trace -- python "$R/bench.py" --config cfg2 --steps 40 > /dev/null 2>&1 < /dev/null)
 f=$(find /tmp/prof_c2 -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" gpurun_out/cfg2_kernel_stats.csv
 timeout 300 ./tools/kbench --check > gpurun_out/kbench.txt 2>&1 < /dev/null
