@@ -364,7 +364,7 @@ int dn_from_basis_f32(const dn_mesh_batch_t* mb, const float* spec, int C, int s
 // ------------------------------------------------------------------ learned-time diffusion
 size_t dn_diffusion_workspace_bytes(const dn_mesh_batch_t* mb, int C) {
     return pad256((size_t)mb->n_chunks * mb->k_eig * C) + pad256((size_t)mb->n_mesh * mb->k_eig * C) +
-           pad256((size_t)mb->n_mesh * C) + 512;
+           pad256((size_t)dn_spec_bwd_dt_rows(mb->n_mesh, mb->k_eig) * C) + 512;
 }
 int dn_diffusion_fwd_f32(const dn_mesh_batch_t* mb, const float* x, const float* time, int C, float* xs, float* xd,
                          void* ws, size_t ws_bytes, void* stream) {
@@ -381,12 +381,18 @@ int dn_diffusion_bwd_f32(const dn_mesh_batch_t* mb, const float* d_xd, const flo
     Bump b(ws, ws_bytes);
     float* partial = b.f((size_t)mb->n_chunks * mb->k_eig * C);
     float* dxs = b.f((size_t)mb->n_mesh * mb->k_eig * C);
-    float* dtp = b.f((size_t)mb->n_mesh * C);
+    const int dt_rows = dn_spec_bwd_dt_rows(mb->n_mesh, mb->k_eig);
+    float* dtp = b.f((size_t)dt_rows * C);
     if (!b.ok) return DN_ERR_INVALID;
     DN_CHECK(to_basis_partials(mb, d_xd, C, false, partial, S(stream)));
-    DN_CHECK(dn_launch_seg_reduce(partial, mb->mesh_chunk_off, mb->n_mesh, 0, dxs, (long long)mb->k_eig * C, S(stream)));
-    DN_CHECK(dn_launch_spec_bwd(dxs, mb->evals, time, xs, dtp, mb->n_mesh, mb->k_eig, C, S(stream)));
-    DN_CHECK(dn_launch_reduce(dtp, d_time, mb->n_mesh, C, C, S(stream)));
+    if (dn_spec_bwd_fused_ok(partial, time, xs, dxs, dtp, C)) {
+        DN_CHECK(dn_launch_spec_bwd_fused(partial, mb->mesh_chunk_off, mb->evals, time, xs, dxs, dtp, mb->n_mesh, mb->k_eig, C, S(stream), nullptr));
+        DN_CHECK(dn_launch_reduce(dtp, d_time, dt_rows, C, C, S(stream)));
+    } else {
+        DN_CHECK(dn_launch_seg_reduce(partial, mb->mesh_chunk_off, mb->n_mesh, 0, dxs, (long long)mb->k_eig * C, S(stream)));
+        DN_CHECK(dn_launch_spec_bwd(dxs, mb->evals, time, xs, dtp, mb->n_mesh, mb->k_eig, C, S(stream)));
+        DN_CHECK(dn_launch_reduce(dtp, d_time, mb->n_mesh, C, C, S(stream)));
+    }
     return from_basis(mb, dxs, C, d_x, d_x_add, true, S(stream));   // d_x_add may be NULL
 }
 
@@ -734,7 +740,7 @@ size_t dn_block_bwd_workspace_bytes(const dn_mesh_batch_t* mb, const dn_block_pa
         n += pad256((size_t)mb->n_chunks * p->widths[j] * p->widths[j + 1]) + pad256((size_t)mb->n_chunks * p->widths[j + 1]);   // are deferred
     if (p->with_grad) n += pad256((size_t)mb->n_chunks * 4 * p->C * p->C);
     n += pad256((size_t)mb->n_chunks * mb->k_eig * p->C);           // split-V partials of the diffusion backward
-    n += pad256((size_t)mb->n_mesh * mb->k_eig * p->C) + pad256((size_t)mb->n_mesh * p->C);
+    n += pad256((size_t)mb->n_mesh * mb->k_eig * p->C) + pad256((size_t)dn_spec_bwd_dt_rows(mb->n_mesh, mb->k_eig) * p->C);
     n += pad256((size_t)4 * p->C * p->C) + amax_ws();
     if (block_chain_ok(mb, p, 2)) n += pad256((size_t)dn_chain_bwd_pieces(p->C, p->with_grad, p->with_rot, p->n_mlp) * (2 * (p->C / 16) * 64) * 4);
     return n + 512;
@@ -760,7 +766,7 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     float* part_a = p->with_grad ? b.f((size_t)mb->n_chunks * 4 * C * C) : nullptr;
     float* partial = b.f((size_t)mb->n_chunks * K * C);
     float* dxs = b.f((size_t)mb->n_mesh * K * C);
-    float* dtp = b.f((size_t)mb->n_mesh * C);
+    float* dtp = b.f((size_t)dn_spec_bwd_dt_rows(mb->n_mesh, K) * C);
     float* psum = b.f((size_t)4 * C * C);
     float* aw = b.f(AW_COUNT + DN_BLOCK_AMAX_WORDS + 2);
     float* chain_ws = block_chain_ok(mb, p, 2) ? b.f((size_t)dn_chain_bwd_pieces(C, p->with_grad, p->with_rot, p->n_mlp) * (2 * (C / 16) * 64) * 4) : nullptr;
@@ -906,12 +912,20 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
             DN_CHECK(grad_apply_bwd(mb, d_gx, d_gy, d_xd, C, d_xd, st, (f16 && (f16_mask() & F16_TOB_B)) ? aw + AW_MISC : nullptr));   // d_xd += gradX^T d_gx + gradY^T d_gy (in place)
         }
     }
-    DN_CHECK(dn_launch_multi_reduce(jobs, st));
     // ---- diffusion backward
     DN_CHECK(to_basis_partials(mb, d_xd, C, false, partial, st, f16 ? f16_if(F16_TOB_B, f16_of(ev_amax, aw + AW_MISC)) : F16()));
-    DN_CHECK(dn_launch_seg_reduce(partial, mb->mesh_chunk_off, mb->n_mesh, 0, dxs, (long long)K * C, st));
-    DN_CHECK(dn_launch_spec_bwd(dxs, mb->evals, p->time, sv->xs, dtp, mb->n_mesh, K, C, st, f16 ? aw + AW_YS : nullptr));
-    DN_CHECK(dn_launch_reduce(dtp, gr->d_time, mb->n_mesh, C, C, st));
+    if (dn_spec_bwd_fused_ok(partial, p->time, sv->xs, dxs, dtp, C)) {
+        // one launch: per-mesh sums of the partials, exp(-lambda t), d_t contributions; their sum over (mesh, eigenvalue group) joins the block's
+        // other deferred gradient sums below
+        DN_CHECK(dn_launch_spec_bwd_fused(partial, mb->mesh_chunk_off, mb->evals, p->time, sv->xs, dxs, dtp, mb->n_mesh, K, C, st, f16 ? aw + AW_YS : nullptr));
+        if (!jobs.push(dtp, dn_spec_bwd_dt_rows(mb->n_mesh, K), C, gr->d_time))
+            DN_CHECK(dn_launch_reduce(dtp, gr->d_time, dn_spec_bwd_dt_rows(mb->n_mesh, K), C, C, st));
+    } else {
+        DN_CHECK(dn_launch_seg_reduce(partial, mb->mesh_chunk_off, mb->n_mesh, 0, dxs, (long long)K * C, st));
+        DN_CHECK(dn_launch_spec_bwd(dxs, mb->evals, p->time, sv->xs, dtp, mb->n_mesh, K, C, st, f16 ? aw + AW_YS : nullptr));
+        DN_CHECK(dn_launch_reduce(dtp, gr->d_time, mb->n_mesh, C, C, st));
+    }
+    DN_CHECK(dn_launch_multi_reduce(jobs, st));       // every parameter gradient of the block: one fixed-order reduction launch
     return from_basis(mb, dxs, C, gr->d_x, d_xacc, true, st, f16 ? f16_if(F16_FROMB_B, f16_of(ev_amax, aw + AW_YS, gr->d_x_amax)) : F16());
 }
 

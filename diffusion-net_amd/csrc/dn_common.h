@@ -533,6 +533,11 @@ int dn_launch_chain_fwd(int npieces, const ChainArgs& a, int C, hipStream_t stre
 // ---------------------------------------------------------------------------------------
 int dn_launch_spec_fwd(const float* partial, const int* mesh_chunk_off, const float* evals, const float* time,
                        float* xs, float* ys, int n_mesh, int K, int C, hipStream_t stream, float* ys_amax = nullptr);
+// the spectral step of the diffusion backward in one launch (partials -> scaled spectrum + d_t contributions [dn_spec_bwd_dt_rows][C])
+int dn_spec_bwd_dt_rows(int n_mesh, int K);
+bool dn_spec_bwd_fused_ok(const float* partial, const float* time, const float* xs, const float* dys, const float* dt_part, int C);
+int dn_launch_spec_bwd_fused(const float* partial, const int* mesh_chunk_off, const float* evals, const float* time, const float* xs, float* dys,
+                             float* dt_part, int n_mesh, int K, int C, hipStream_t stream, float* dys_amax);
 int dn_launch_spec_bwd(float* dys_inplace, const float* evals, const float* time, const float* xs, float* dt_part,
                        int n_mesh, int K, int C, hipStream_t stream, float* dys_amax = nullptr);
 // max |x| of up to DN_AMAX_MAX_JOBS buffers in one launch (job j -> *dst[j], accumulated by atomic max: the caller zeroes the words);

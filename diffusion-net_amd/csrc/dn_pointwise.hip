@@ -64,6 +64,80 @@ int dn_launch_spec_bwd(float* dys, const float* evals, const float* time, const 
     return (int)hipGetLastError();
 }
 
+// The three launches of the diffusion backward's spectral step in one: per-mesh sum of the split-V partials of evecs^T d_xd (chunks in
+// ascending order), scaling by exp(-lambda t) (the spectrum handed to from_basis), and the d_t contributions summed over the 8 eigenvalues a
+// workgroup owns.  block = 32 channel quads x 8 eigenvalues; grid = (ceil(C/128) * ceil(K/8), n_mesh).
+// dt_part: [n_mesh * ceil(K/8)][C] -- its fixed-order sum over the rows (dn_spec_bwd_dt_rows) is d_t; the caller hands it to the reduction
+// launch it issues anyway.
+__global__ __launch_bounds__(256) void spec_bwd_fused_kernel(const float* partial, const int* mco, const float* evals, const float* time,
+                                                             const float* xs, float* dys, float* dt_part, int K, int C, int kgroups, float* dys_amax) {
+    __shared__ float red[8][128];
+    const int m = blockIdx.y;
+    const int cb = blockIdx.x / kgroups, kg = blockIdx.x % kgroups;
+    const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
+    const int c = cb * 128 + 4 * cl, k = kg * 8 + kl;
+    const long long KC = (long long)K * C;
+    float dt[4] = {0.f, 0.f, 0.f, 0.f}, amax = 0.f;
+    if (c < C && k < K) {
+        const int beg = mco[m], end = mco[m + 1];
+        const float* src = partial + (long long)k * C + c;
+        float4 a = dn_f4_zero();
+        int ch = beg;
+        for (; ch + 7 < end; ch += 8) {          // eight chunk loads in flight, added in chunk order
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (long long)(ch + u) * KC);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+        }
+        for (; ch < end; ++ch) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (long long)ch * KC);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        const float lam = evals[m * K + k];
+        const long long o = m * KC + (long long)k * C + c;
+        const float4 t4 = *reinterpret_cast<const float4*>(time + c);
+        const float4 x4 = *reinterpret_cast<const float4*>(xs + o);
+        const float d[4] = {a.x, a.y, a.z, a.w}, tt[4] = {t4.x, t4.y, t4.z, t4.w}, xx[4] = {x4.x, x4.y, x4.z, x4.w};
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float coef = expf(-lam * tt[e]);
+            y[e] = coef * d[e];
+            dt[e] = -(lam * d[e] * coef * xx[e]);
+            amax = fabsf(y[e]) > amax ? fabsf(y[e]) : amax;
+        }
+        *reinterpret_cast<float4*>(dys + o) = make_float4(y[0], y[1], y[2], y[3]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[kl][4 * cl + e] = dt[e];
+    __syncthreads();
+    if (kl == 0 && c < C) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] += red[j][4 * cl + e];
+        *reinterpret_cast<float4*>(dt_part + ((long long)m * kgroups + kg) * C + c) = make_float4(s[0], s[1], s[2], s[3]);
+    }
+    if (dys_amax) dn_amax_commit(dys_amax, amax);
+}
+
+int dn_spec_bwd_dt_rows(int n_mesh, int K) { return n_mesh * ((K + 7) / 8); }
+bool dn_spec_bwd_fused_ok(const float* partial, const float* time, const float* xs, const float* dys, const float* dt_part, int C) {
+    return C % 4 == 0 && (((uintptr_t)partial | (uintptr_t)time | (uintptr_t)xs | (uintptr_t)dys | (uintptr_t)dt_part) & 15) == 0;
+}
+int dn_launch_spec_bwd_fused(const float* partial, const int* mesh_chunk_off, const float* evals, const float* time, const float* xs, float* dys,
+                             float* dt_part, int n_mesh, int K, int C, hipStream_t stream, float* dys_amax) {
+    if (n_mesh <= 0 || K <= 0 || C <= 0) return 0;
+    const int kgroups = (K + 7) / 8;
+    dim3 grid((unsigned)(((C + 127) / 128) * kgroups), n_mesh, 1);
+    dn_prof_begin(DN_K_SMALL, stream);
+    DN_LAUNCH(spec_bwd_fused_kernel, grid, dim3(256, 1, 1), 0, stream, partial, mesh_chunk_off, evals, time, xs, dys, dt_part, K, C, kgroups, dys_amax);
+    dn_prof_end(DN_K_SMALL, stream, 0.0, 0.0);
+    return (int)hipGetLastError();
+}
+
 // Fixed-order segmented sum of split-V partials: out[s][i] = sum_{ch in segment s} partial[ch][i].
 // block = 32 column groups x 8 chunk lanes: lane kl sums chunks beg+kl, beg+kl+8, ... (several loads in flight),
 // the 8 lane sums are then combined in order through LDS -> bitwise reproducible, bandwidth-bound.
