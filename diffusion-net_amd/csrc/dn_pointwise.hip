@@ -71,34 +71,55 @@ int dn_launch_spec_bwd(float* dys, const float* evals, const float* time, const 
 // launch it issues anyway.
 __global__ __launch_bounds__(256) void spec_bwd_fused_kernel(const float* partial, const int* mco, const float* evals, const float* time,
                                                              const float* xs, float* dys, float* dt_part, int K, int C, int kgroups, float* dys_amax) {
-    __shared__ float red[8][128];
+    __shared__ __attribute__((aligned(16))) float red[8][8][128];          // [eigenvalue of the group][chunk lane][channel]; reused for the d_t sums
     const int m = blockIdx.y;
     const int cb = blockIdx.x / kgroups, kg = blockIdx.x % kgroups;
     const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
-    const int c = cb * 128 + 4 * cl, k = kg * 8 + kl;
+    const int c = cb * 128 + 4 * cl;
     const long long KC = (long long)K * C;
+    const int beg = mco[m], end = mco[m + 1];
+    // phase 1: lane kl sums chunks beg + kl, beg + kl + 8, ... for each of the group's 8 eigenvalues; a pass of 4 chunks x 8 eigenvalues has
+    // its 32 loads in flight together (one latency per pass: a mesh has ~32 chunks)
+    float4 a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = dn_f4_zero();
+    if (c < C) {
+        for (int ch0 = beg + kl; ch0 < end; ch0 += 32) {
+            float4 v[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ch = ch0 + 8 * u;
+                const bool cok = ch < end;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = kg * 8 + j;
+                    v[u][j] = (cok && k < K) ? *reinterpret_cast<const float4*>(partial + (long long)ch * KC + (long long)k * C + c) : dn_f4_zero();
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { a[j].x += v[u][j].x; a[j].y += v[u][j].y; a[j].z += v[u][j].z; a[j].w += v[u][j].w; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(&red[j][kl][4 * cl]) = a[j];
+    __syncthreads();
+    // phase 2: thread (cl, kl) finishes eigenvalue kg * 8 + kl: the 8 lane sums in order, exp(-lambda t), d_t contribution
+    const int k = kg * 8 + kl;
     float dt[4] = {0.f, 0.f, 0.f, 0.f}, amax = 0.f;
     if (c < C && k < K) {
-        const int beg = mco[m], end = mco[m + 1];
-        const float* src = partial + (long long)k * C + c;
-        float4 a = dn_f4_zero();
-        int ch = beg;
-        for (; ch + 7 < end; ch += 8) {          // eight chunk loads in flight, added in chunk order
-            float4 v[8];
+        float d[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (long long)(ch + u) * KC);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
-        }
-        for (; ch < end; ++ch) {
-            const float4 v = *reinterpret_cast<const float4*>(src + (long long)ch * KC);
-            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        for (int l = 0; l < 8; ++l) {
+            const float4 t = *reinterpret_cast<const float4*>(&red[kl][l][4 * cl]);
+            d[0] += t.x; d[1] += t.y; d[2] += t.z; d[3] += t.w;
         }
         const float lam = evals[m * K + k];
         const long long o = m * KC + (long long)k * C + c;
         const float4 t4 = *reinterpret_cast<const float4*>(time + c);
         const float4 x4 = *reinterpret_cast<const float4*>(xs + o);
-        const float d[4] = {a.x, a.y, a.z, a.w}, tt[4] = {t4.x, t4.y, t4.z, t4.w}, xx[4] = {x4.x, x4.y, x4.z, x4.w};
+        const float tt[4] = {t4.x, t4.y, t4.z, t4.w}, xx[4] = {x4.x, x4.y, x4.z, x4.w};
         float y[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -109,15 +130,16 @@ __global__ __launch_bounds__(256) void spec_bwd_fused_kernel(const float* partia
         }
         *reinterpret_cast<float4*>(dys + o) = make_float4(y[0], y[1], y[2], y[3]);
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) red[kl][4 * cl + e] = dt[e];
+    __syncthreads();                          // everybody has read its lane sums: the array is reused
+    *reinterpret_cast<float4*>(&red[0][kl][4 * cl]) = make_float4(dt[0], dt[1], dt[2], dt[3]);
     __syncthreads();
     if (kl == 0 && c < C) {
         float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s[e] += red[j][4 * cl + e];
+        for (int j = 0; j < 8; ++j) {
+            const float4 t = *reinterpret_cast<const float4*>(&red[0][j][4 * cl]);
+            s[0] += t.x; s[1] += t.y; s[2] += t.z; s[3] += t.w;
+        }
         *reinterpret_cast<float4*>(dt_part + ((long long)m * kgroups + kg) * C + c) = make_float4(s[0], s[1], s[2], s[3]);
     }
     if (dys_amax) dn_amax_commit(dys_amax, amax);
