@@ -1,6 +1,6 @@
 // kbench.cpp -- standalone timing + spot-check harness for the C ABI of libdiffnet_hip.so (development aid, GPU only).
 // No torch: starts in milliseconds, so one GPU call can compare many library build variants.
-//   hipcc -O2 -std=c++17 tools/kbench.cpp -o tools/kbench -ldl
+//   hipcc --offload-arch=gfx950 -O2 -std=c++17 tools/kbench.cpp -o tools/kbench -ldl
 //   tools/kbench [--lib path.so] [--meshes 16] [--verts 10000] [--C 128] [--K 128] [--reps 20] [--ops a,b,..] [--check]
 // Ops: to_basis from_basis diffusion diffusion_bwd spmm gradfeat gradfeat_bwd linear linear_relu linear_bwd
 //      block_inf block_fwd block_bwd copy copyk (hand-written float4 copy / read / fill kernels on 2 GiB of rotating buffers)
