@@ -485,11 +485,29 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
 #endif
 #undef CH_BARRIER
 #undef CH_WAIT_PIECES
-    // ---- magnitude words of what was produced (one check-first atomic per wave and word)
+    // ---- magnitude words of what was produced: one check-first atomic per WORKGROUP and word.  The persistent workgroups finish within a few
+    //      microseconds of each other, most of them read the words before anybody has raised them, and atomics on one cache line retire at
+    //      ~8 ns each: one per wave (2048 x 3) cost 13 us of a 345 us kernel, one per workgroup 5-6 us (measured against a build that leaves the words unwritten).  The waves of a workgroup arrive here together (same pass count,
+    //      a barrier per piece); the piece ring is idle by now and lends its first words.
+    {
+        float* wmax = reinterpret_cast<float*>(ring);          // [NW][DN_CH_LAYERS + 1]
+        float vals[DN_CH_LAYERS + 1];
 #pragma unroll
-    for (int j = 0; j < DN_CH_LAYERS; ++j)
-        if (j < a.n_mlp - 1 && a.h_amax[j]) dn_amax_commit<true>(a.h_amax[j], hmax[j]);
-    if (a.out_amax) dn_amax_commit<true>(a.out_amax, omax);
+        for (int j = 0; j < DN_CH_LAYERS; ++j) vals[j] = ch_wave_max(hmax[j]);
+        vals[DN_CH_LAYERS] = ch_wave_max(omax);
+        __syncthreads();          // every wave has waited for its last DMA requests (above): nothing lands in the ring any more
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j <= DN_CH_LAYERS; ++j) wmax[wave * (DN_CH_LAYERS + 1) + j] = vals[j];
+        }
+        __syncthreads();
+        if (tid <= DN_CH_LAYERS) {
+            float mm = 0.f;
+            for (int w = 0; w < NW; ++w) { const float t = wmax[w * (DN_CH_LAYERS + 1) + tid]; mm = t > mm ? t : mm; }
+            float* word = tid == DN_CH_LAYERS ? a.out_amax : (tid < a.n_mlp - 1 ? a.h_amax[tid] : nullptr);
+            if (word && mm > 0.f && mm > *reinterpret_cast<volatile float*>(word)) atomicMax(reinterpret_cast<unsigned*>(word), __float_as_uint(mm));
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
