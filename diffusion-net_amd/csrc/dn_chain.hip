@@ -30,15 +30,16 @@
 #include "dn_chain_tiles.h"
 
 template <int C>
-__global__ __launch_bounds__(256) void chain_prep_kernel(ChainPrepArgs a) {
+__global__ __launch_bounds__(1024) void chain_prep_kernel(ChainPrepArgs a) {
     constexpr int NT = C / 16;
-    __shared__ float red[256];
+    constexpr int NTHR = 1024;            // one workgroup per piece: what it costs is latency, so many threads with few steps each
+    __shared__ float red[NTHR];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= a.npieces) {          // start-of-call bookkeeping
         for (int r = 0; r < a.nzero; ++r)
-            for (int i = tid; i < a.zero_n[r]; i += 256) a.zero[r][i] = 0.f;
+            for (int i = tid; i < a.zero_n[r]; i += NTHR) a.zero[r][i] = 0.f;
         if (tid == 0 && a.copy_src && a.copy_dst) *a.copy_dst = *a.copy_src;
-        for (int i = tid; i < a.clamp_n; i += 256) { const float v = a.clamp_p[i]; a.clamp_p[i] = v < a.clamp_min ? a.clamp_min : v; }   // (NaN stays NaN, as torch.clamp)
+        for (int i = tid; i < a.clamp_n; i += NTHR) { const float v = a.clamp_p[i]; a.clamp_p[i] = v < a.clamp_min ? a.clamp_min : v; }   // (NaN stays NaN, as torch.clamp)
         return;
     }
     const ChainPrepPiece pc = a.pc[blockIdx.x];
@@ -47,29 +48,30 @@ __global__ __launch_bounds__(256) void chain_prep_kernel(ChainPrepArgs a) {
     float mx = 0.f;
     {
         const int n4 = C * pc.ld / 4;   // (ld is a multiple of 4 and the rows 16-byte aligned on this path)
-        // eight loads in flight per thread and step (one workgroup: latency, not bandwidth -- a load per step made this kernel 25 us)
-        for (int i0 = tid; i0 < n4; i0 += 8 * 256) {
-            float4 v[8], w[8];
+        // four loads in flight per thread and step (one workgroup: latency, not bandwidth -- a load per step made this kernel 25 us, 256 threads
+        // with eight in flight 12 us)
+        for (int i0 = tid; i0 < n4; i0 += 4 * NTHR) {
+            float4 v[4], w[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0 + 256 * u < n4 ? i0 + 256 * u : i0;
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + NTHR * u < n4 ? i0 + NTHR * u : i0;
                 v[u] = *reinterpret_cast<const float4*>(pc.W + 4 * (long long)i);
                 w[u] = pc.W2 ? *reinterpret_cast<const float4*>(pc.W2 + 4 * (long long)i) : dn_f4_zero();
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { mx = dn_f4_amax(mx, v[u]); mx = dn_f4_amax(mx, w[u]); }
+            for (int u = 0; u < 4; ++u) { mx = dn_f4_amax(mx, v[u]); mx = dn_f4_amax(mx, w[u]); }
         }
     }
     red[tid] = mx;
     __syncthreads();
-    for (int d = 128; d > 0; d >>= 1) {
+    for (int d = NTHR / 2; d > 0; d >>= 1) {
         if (tid < d) red[tid] = red[tid + d] > red[tid] ? red[tid + d] : red[tid];
         __syncthreads();
     }
     mx = red[0];
     if (tid == 0 && pc.amax) *pc.amax = mx;
     const float s = dn_pow2_scale(mx);
-    for (int e = tid; e < NT * 64; e += 256) {
+    for (int e = tid; e < NT * 64; e += NTHR) {
         const int nt = e >> 6, lane = e & 63;
         const int n = 16 * nt + (lane & 15), q = lane >> 4;
         float va[4], vb[4];
@@ -569,8 +571,8 @@ int dn_launch_chain_prep(const ChainPrepArgs& pa, int npieces, int C, hipStream_
     ChainPrepArgs pb = pa;
     pb.npieces = npieces;
     dn_prof_begin(DN_K_SMALL, stream);
-    if (C == 128) DN_LAUNCH((chain_prep_kernel<128>), dim3(npieces + 1, 1, 1), dim3(256, 1, 1), 0, stream, pb);
-    else if (C == 64) DN_LAUNCH((chain_prep_kernel<64>), dim3(npieces + 1, 1, 1), dim3(256, 1, 1), 0, stream, pb);
+    if (C == 128) DN_LAUNCH((chain_prep_kernel<128>), dim3(npieces + 1, 1, 1), dim3(1024, 1, 1), 0, stream, pb);
+    else if (C == 64) DN_LAUNCH((chain_prep_kernel<64>), dim3(npieces + 1, 1, 1), dim3(1024, 1, 1), 0, stream, pb);
     else return 1;
     dn_prof_end(DN_K_SMALL, stream, 0.0, 0.0);
     return (int)hipGetLastError();
