@@ -40,6 +40,7 @@ def test_ops_on_emulator(emu):
     import parity_cases
     parity_cases.run_ops(emu)
     parity_cases.run_ops(emu, sizes=(96,), K=32, C=64, chunk_rows=32)   # aligned fast paths, several chunks
+    parity_cases.run_ops(emu, sizes=(1100, 90), K=20, C=32, chunk_rows=32)   # > 32 chunks in a mesh (second pass of the fused spectral backward's chunk lanes), K % 8 != 0
 
 
 @pytest.mark.parametrize("outputs_at", ["vertices", "faces", "global_mean"])
