@@ -134,20 +134,44 @@ struct CkJobs {
     long long nwords[DN_CK_MAX_JOBS];
     unsigned long long salt[DN_CK_MAX_JOBS];
 };
+// Few, fat workgroups: every workgroup ends with two 64-bit atomics on the same cache line, and atomics on one line retire at ~8 ns each --
+// with ~8 words per thread a 5 MB key was ~1000 workgroups and 55 us, most of it the atomic queue.  At most DN_CK_WGS workgroups per operand,
+// 16-byte loads with four in flight (the per-word terms are the same: the sum does not depend on who adds them).
+#define DN_CK_WGS 48
+__device__ __forceinline__ void ck_word(unsigned long long i, unsigned w, unsigned long long k0, unsigned long long k1, unsigned long long& s0, unsigned long long& s1) {
+    const unsigned long long v = (i << 32) ^ (i >> 32) ^ (unsigned long long)w;
+    s0 += dn_mix64(v ^ k0);
+    s1 += dn_mix64((v + k1) * 0xff51afd7ed558ccdull);
+}
 __global__ __launch_bounds__(256) void checksum_multi_kernel(CkJobs jobs, unsigned long long* acc) {
     __shared__ unsigned long long red[2][256];
     const int j = blockIdx.y;
     const unsigned* w = jobs.w[j];
     const long long nwords = jobs.nwords[j];
-    if ((long long)blockIdx.x * 256 >= nwords) return;      // (uniform per block)
+    if ((long long)blockIdx.x * 256 >= nwords) return;      // (uniform per block; nothing for it in either loop form)
     const unsigned long long salt = jobs.salt[j];
     const unsigned long long k0 = dn_mix64(salt + 0x9E3779B97F4A7C15ull), k1 = dn_mix64(salt ^ 0xD1B54A32D192ED03ull);
     unsigned long long s0 = 0, s1 = 0;
-    const long long stride = (long long)gridDim.x * 256;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nwords; i += stride) {
-        const unsigned long long v = ((unsigned long long)i << 32) ^ ((unsigned long long)i >> 32) ^ (unsigned long long)w[i];
-        s0 += dn_mix64(v ^ k0);
-        s1 += dn_mix64((v + k1) * 0xff51afd7ed558ccdull);
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, nthr = (long long)gridDim.x * 256;
+    if ((((uintptr_t)w) & 15) == 0) {
+        const long long n4 = nwords / 4;
+        const uint4* w4 = reinterpret_cast<const uint4*>(w);
+        for (long long i0 = tid; i0 < n4; i0 += 4 * nthr) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const long long i = i0 + u * nthr; v[u] = w4[i < n4 ? i : i0]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long i = i0 + u * nthr;
+                if (i < n4) {
+                    ck_word(4ull * i, v[u].x, k0, k1, s0, s1); ck_word(4ull * i + 1, v[u].y, k0, k1, s0, s1);
+                    ck_word(4ull * i + 2, v[u].z, k0, k1, s0, s1); ck_word(4ull * i + 3, v[u].w, k0, k1, s0, s1);
+                }
+            }
+        }
+        for (long long i = 4 * n4 + tid; i < nwords; i += nthr) ck_word((unsigned long long)i, w[i], k0, k1, s0, s1);
+    } else {
+        for (long long i = tid; i < nwords; i += nthr) ck_word((unsigned long long)i, w[i], k0, k1, s0, s1);
     }
     red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
     __syncthreads();
@@ -169,8 +193,8 @@ int dn_launch_checksum_multi(int n, const void* const* data, const long long* nw
         ++m;
     }
     if (m == 0) return 0;
-    long long nb = (most + 256 * 8 - 1) / (256 * 8);      // ~8 words per thread of the largest operand
-    if (nb > 2048) nb = 2048;
+    long long nb = (most + 256 * 16 - 1) / (256 * 16);     // >= 16 words per thread of the largest operand, few workgroups (see the kernel)
+    if (nb > DN_CK_WGS) nb = DN_CK_WGS;
     DN_LAUNCH(checksum_multi_kernel, dim3((unsigned)nb, (unsigned)m, 1), dim3(256, 1, 1), 0, stream, jobs, acc);
     return (int)hipGetLastError();
 }
