@@ -109,24 +109,6 @@ __device__ __forceinline__ unsigned long long dn_mix64(unsigned long long z) {
     z ^= z >> 31;
     return z;
 }
-__global__ __launch_bounds__(256) void checksum_kernel(const unsigned* w, long long nwords, unsigned long long salt, unsigned long long* acc) {
-    __shared__ unsigned long long red[2][256];
-    const unsigned long long k0 = dn_mix64(salt + 0x9E3779B97F4A7C15ull), k1 = dn_mix64(salt ^ 0xD1B54A32D192ED03ull);
-    unsigned long long s0 = 0, s1 = 0;
-    const long long stride = (long long)gridDim.x * 256;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nwords; i += stride) {
-        const unsigned long long v = ((unsigned long long)i << 32) ^ ((unsigned long long)i >> 32) ^ (unsigned long long)w[i];
-        s0 += dn_mix64(v ^ k0);
-        s1 += dn_mix64((v + k1) * 0xff51afd7ed558ccdull);
-    }
-    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
-    __syncthreads();
-    for (int d = 128; d > 0; d >>= 1) {
-        if ((int)threadIdx.x < d) { red[0][threadIdx.x] += red[0][threadIdx.x + d]; red[1][threadIdx.x] += red[1][threadIdx.x + d]; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { atomicAdd(&acc[0], red[0][0]); atomicAdd(&acc[1], red[1][0]); }
-}
 // several operands in ONE launch (blockIdx.y = operand): a mesh's content key covers eight buffers, and at the sizes of the reference's own
 // experiments a launch costs more than the sum itself
 struct CkJobs {
@@ -199,9 +181,6 @@ int dn_launch_checksum_multi(int n, const void* const* data, const long long* nw
     return (int)hipGetLastError();
 }
 int dn_launch_checksum(const void* data, long long nwords, unsigned long long salt, unsigned long long* acc, hipStream_t stream) {
-    if (nwords <= 0) return 0;
-    long long nb = (nwords + 256 * 8 - 1) / (256 * 8);      // ~8 words per thread
-    if (nb > 4096) nb = 4096;
-    DN_LAUNCH(checksum_kernel, dim3((unsigned)nb, 1, 1), dim3(256, 1, 1), 0, stream, (const unsigned*)data, nwords, salt, acc);
-    return (int)hipGetLastError();
+    const void* d[1] = {data};
+    return dn_launch_checksum_multi(1, d, &nwords, &salt, acc, stream);     // (one operand of the same kernel: the same per-word terms)
 }
