@@ -395,7 +395,9 @@ class BlockFn(torch.autograd.Function):
         L = _hip.lib()
         time_param = time
         x, time = _f32c(x), _f32c(time)
-        clamp_in_call = bool(getattr(cfg, "clamp_time", False))
+        # (the torch.library form of this op must not write to an input it does not declare as mutated: layers.py clamps before it, torchlib.py
+        # sets ctx.no_clamp)
+        clamp_in_call = bool(getattr(cfg, "clamp_time", False)) and not getattr(ctx, "no_clamp", False)
         if clamp_in_call and time.data_ptr() != time_param.data_ptr():     # a converted copy: the library would clamp the copy, not the Parameter
             time_param.data.clamp_(min=1e-8)
             time, clamp_in_call = _f32c(time_param), False
