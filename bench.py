@@ -29,7 +29,7 @@ import torch.nn.functional as F
 PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: exact-f32 MFMA = f32 vector peak
 PEAK_HBM_GBPS = 8000.0            # HBM3E spec (6.29 TB/s measured copy ceiling)
 PEAK_MFMA_BF16_TFLOPS = 2500.0    # dense bf16 MFMA (no sparsity)
-TRAFFIC_JSON = "r04_traffic.json"  # PMC FETCH/WRITE passes of the same kernels (tools/pmc_run.sh + tools/traffic_summary.py), committed under profiles/
+TRAFFIC_JSON = "r05_traffic.json"  # PMC FETCH/WRITE passes of the same kernels (tools/pmc_run.sh + tools/traffic_summary.py), committed under profiles/
 
 
 def mesh_sizes(n_meshes, v_mean, rank):
@@ -229,8 +229,10 @@ def parity_in_run(device):
 
 
 def kernel_family_report(lib):
-    """Per-kernel-family timing from the library's hipEvent brackets (this rank, timed region) and the roofline object of the family
-    with the largest share."""
+    """Per-KERNEL timing from the library's hipEvent brackets (this rank, timed region) and the roofline object of the kernel with the
+    largest share of kernel time.  Since round 5 every bracket kind is one kernel as rocprofv3 names it (the round-4 `tngemm_kernel` bucket
+    lumped the projection, the weight-gradient and the dA kernels: it out-weighed the actual dominant kernel) -- except the
+    `rowgemm_kernel<*,N>` kinds (instantiations of one kernel template) and `small` (everything under ~30 us)."""
     fam = []
     buf = (ctypes.c_double * 4)()
     for k in range(16):
@@ -245,12 +247,13 @@ def kernel_family_report(lib):
                         "flops_per_launch": fl / n, "bytes_per_launch": by / n})
     if not fam:          # nothing went through the library's brackets (the timed region replayed graphs)
         return [], None
-    dom = max(fam, key=lambda f: f["ms_total"])
+    dom = max((f for f in fam if f["kernel"] != "small"), key=lambda f: f["ms_total"], default=max(fam, key=lambda f: f["ms_total"]))
     # Binding roof of a family = the lower of the two roofs at its arithmetic intensity.  The GEMM families run on
     # split-bf16 MFMA (6 bf16 MFMAs per fp32 product: effective fp32 peak = 2.5 PF / 6); the sparse family is HBM-bound.
     def bind(f):
         # (the chained forward kernel runs on the 2-term fp16 split: 3 MFMAs per fp32 product)
-        eff_peak = PEAK_MFMA_BF16_TFLOPS / 3.0 if "chain" in f["kernel"] else (PEAK_MFMA_BF16_TFLOPS / 6.0 if "gemm" in f["kernel"] else PEAK_MFMA_F32_TFLOPS)
+        eff_peak = PEAK_MFMA_BF16_TFLOPS / 3.0 if "chain" in f["kernel"] else (
+            PEAK_MFMA_BF16_TFLOPS / 6.0 if ("gemm" in f["kernel"] or "diffuse" in f["kernel"] or "backproject" in f["kernel"]) else PEAK_MFMA_F32_TFLOPS)
         ai = f["flops_per_launch"] / max(f["bytes_per_launch"], 1.0)
         ridge = eff_peak * 1e12 / (PEAK_HBM_GBPS * 1e9)
         if f["flops_per_launch"] > 0 and ai > ridge:
@@ -263,11 +266,12 @@ def kernel_family_report(lib):
     # HBM bytes per launch of that family from the committed FETCH_SIZE / WRITE_SIZE PMC passes (separate rocprofv3
     # --pmc runs of the same workload, gfx950 x2 read correction applied; tools/traffic_summary.py)
     try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_JSON)))
+        tj = TRAFFIC_JSON if os.path.exists(os.path.join(ROOT, "profiles", TRAFFIC_JSON)) else "r04_traffic.json"
+        tr = json.load(open(os.path.join(ROOT, "profiles", tj)))
         roof["traffic"] = tr[dom["kernel"]]["hbm_bytes_per_launch"]
         roof["traffic_source"] = ("NOT measured in this run: read from profiles/%s -- separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; "
                                   "(2*FETCH_SIZE+WRITE_SIZE)*1024 B per launch, gfx950 read correction) over tools/microbench.py at this batch shape; "
-                                  "algorithmic bytes per launch = %.4g" % (TRAFFIC_JSON, dom["bytes_per_launch"]))
+                                  "algorithmic bytes per launch = %.4g" % (tj, dom["bytes_per_launch"]))
     except Exception:
         pass
     roof.update({"kernel": dom["kernel"], "avg_launch_us": dom["avg_us"], "launches": dom["launches"],
@@ -404,7 +408,8 @@ def run_other_config(args, device, lib, world, rank):
 
 
 def _engine_note():
-    return ("split-bf16 MFMA only (DN_F16=0)" if os.environ.get("DN_F16") == "0" else
+    from diffusion_net import _hip
+    return ("split-bf16 MFMA only (library option f16=0)" if _hip.get_option("f16") == 0 else
             "row products (gradient features, MLP, input gradients, backward back-projection) on 2-term split-fp16 MFMA with producer-side "
             "power-of-two scales; projections, forward back-projection and all parameter-gradient sums on 3-term split-bf16 MFMA")
 
@@ -505,7 +510,8 @@ def other_configs_brief(args):
     for name, extra in runs:
         t0 = time.perf_counter()
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra, capture_output=True, text=True, timeout=300)
+            lib_flags = [f for kv in args.lib_opt for f in ("--lib-opt", kv)]
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra + lib_flags, capture_output=True, text=True, timeout=300)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or not line:
                 out[name] = {"error": (r.stderr or r.stdout)[-300:]}
@@ -537,6 +543,8 @@ def main():
     ap.add_argument("--eager", action="store_true", help="headline: enqueue the ~190 launches of every step from the host instead of replaying the captured HIP graph")
     ap.add_argument("--epoch", type=int, default=0, help="headline: cycle this many DISTINCT packed batches (graph replay over changing batches: one captured step per "
                                                      "batch, diffusion_net.graphs.GraphedEpoch) instead of replaying one static batch")
+    ap.add_argument("--lib-opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="tuning option of the library for this run (include/diffnet_hip.h: dn_set_option), e.g. chain=0, diffuse=0; repeatable")
     ap.add_argument("--config", default="headline", choices=["headline", "cfg2", "cfg3", "cfg4", "cfg5"],
                     help="headline: BASELINE metric workload (default, what the driver runs); cfg2/cfg3/cfg4: the other BASELINE.json configs, same JSON contract; "
                          "cfg5: the headline step at the rna_mesh_segmentation shape (8 meshes x ~15k vertices per GPU, 260 classes at the vertices; works with --gpus N)")
@@ -579,6 +587,9 @@ def main():
     import diffusion_net
     from diffusion_net import _hip, synthetic
     from diffusion_net.dist import FlatParams
+    for kv in args.lib_opt:                    # applied when the library is bound (and to every sub-run: they get the same flags)
+        k_, v_ = kv.split("=", 1)
+        _hip.default_options[k_] = int(v_)
     if not os.path.exists(_hip.LIB_PATH):      # fresh checkout: compile the HIP sources once (rank 0), never a fallback
         if rank == 0:
             import __graft_entry__
@@ -749,6 +760,11 @@ def main():
         # the brackets inflate: event records sit between the launches and the eager pass has host gaps the replay does not
         roof["families_ms_per_step"] = fam_ms
         roof["bracket_inflation_vs_timed_step"] = fam_ms / (1e3 * elapsed / args.steps)
+        # real inter-kernel idle of the TIMED (replayed) step = step time - sum of kernel time.  The sum here is the library's own kernels from the
+        # bracketed eager pass (torch's fill / Adam kernels, ~0.1 ms, are not bracketed; a bracket also counts the launch ramp), so the
+        # difference is an upper bound of the idle only when positive; rocprofv3's per-kernel durations of the replays are the reference
+        # (profiles/r0N_step_kernels.txt: the profiler itself inserts ~10 us between kernels, which the unprofiled replay does not have)
+        roof["timed_step_ms_minus_bracketed_kernel_ms"] = 1e3 * elapsed / args.steps - fam_ms
         if eager_ms is not None:
             roof["eager_pass_ms_per_step"] = eager_ms
 
@@ -781,12 +797,45 @@ def main():
         return e0.elapsed_time(e1) * 1e-3 / reps
     t_diff = time_diffusion(8)        # 8 inputs + 8 live outputs x 81 MB = 1.3 GB in rotation: HBM
     t_diff_cached = time_diffusion(1)
+
+    def time_diffusion_bwd(n_rot):
+        # the gradient of the same operator (dn_diffusion_bwd_f32: d_x = add + M Phi (coef * Phi^T d_xd), d_time), called as ops.DiffusionFn.backward calls it
+        Lb = _hip.lib()
+        gs_ = [torch.randn(v_sub0, Cw, device=device) for _ in range(n_rot)]
+        adds = [torch.randn(v_sub0, Cw, device=device) for _ in range(n_rot)]
+        outs = [torch.empty(v_sub0, Cw, device=device) for _ in range(n_rot)]
+        xs_sp = torch.randn(mb.n_mesh, K, Cw, device=device)
+        d_t = torch.empty(Cw, device=device)
+        nws = Lb.dn_diffusion_workspace_bytes(mb.ref(), Cw)
+        ws_ = torch.empty(nws + 4096, dtype=torch.uint8, device=device)
+        st_ = torch.cuda.current_stream(device).cuda_stream
+
+        def call(i):
+            _hip.check(Lb.dn_diffusion_bwd_f32(mb.ref(), gs_[i % n_rot].data_ptr(), xs_sp.data_ptr(), tt.data_ptr(), Cw, adds[i % n_rot].data_ptr(),
+                                               outs[i % n_rot].data_ptr(), d_t.data_ptr(), ws_.data_ptr(), nws, st_), "dn_diffusion_bwd_f32")
+        for i in range(3):
+            call(i)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(24):
+            call(i)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / 24
+    t_dbwd = time_diffusion_bwd(6)     # 6 x (d_xd, addend, d_x) x 81 MB = 1.5 GB in rotation
+    bytes_dbwd = sum(4.0 * (v * (3 * Cw + 2 * K + 1) + 3 * K * Cw + K + Cw) for v in sizes)   # read d_xd, Phi twice, the addend, mass; write d_x; 3 x (K, C)
     diff = {"ms": t_diff * 1e3, "gbps": bytes_diff / t_diff / 1e9, "frac_hbm_8TBs": bytes_diff / t_diff / 1e9 / PEAK_HBM_GBPS,
             "frac_of_measured_copy_6p3TBs": bytes_diff / t_diff / 1e9 / 6300.0,
             "buffers": "8 rotating input / output sets (1.3 GB): operands come from HBM as inside the network; one re-used set (Infinity-Cache assisted): "
                        "%.3f ms = %.3f of 8 TB/s" % (t_diff_cached * 1e3, bytes_diff / t_diff_cached / 1e9 / PEAK_HBM_GBPS),
             "copy_calibration": "hand-written float4 nontemporal copy on 2 GiB of rotating buffers: 6.2-6.36 TB/s = 0.79 of 8 TB/s; hipMemcpy D2D 5.3 TB/s "
                                 "(tools/kbench --ops copyk, profiles/r03_copy_calibration.txt)",
+            "backward": {"ms": t_dbwd * 1e3, "gbps": bytes_dbwd / t_dbwd / 1e9, "frac_hbm_8TBs": bytes_dbwd / t_dbwd / 1e9 / PEAK_HBM_GBPS,
+                         "what": "dn_diffusion_bwd_f32 with an addend (the block's residual gradient), 6 rotating operand sets; algorithmic bytes "
+                                 "4 [V (3C + 2K + 1) + 3KC + K + C] per mesh"},
+            "launches": "projection (split-V, k-major bf16 planes) + per-mesh partial sum with exp(-lambda t) + direct back-projection (dn_diffuse.hip: backproject_kernel)"
+                        if _hip.get_option("diffuse") == 2 else ("one persistent launch (dn_diffuse.hip: diffuse_kernel)" if _hip.get_option("diffuse") == 1 else
+                                                                  "projection + per-mesh partial sum + wave-specialised row GEMM"),
             "tflops": flops_diff / t_diff / 1e12, "frac_mfma_f32": flops_diff / t_diff / 1e12 / PEAK_MFMA_F32_TFLOPS,
             "frac_mfma_bf16x3": flops_diff / t_diff / 1e12 / (PEAK_MFMA_BF16_TFLOPS / 6.0),
             "note": "arithmetic intensity KC/(2(K+C)) = %.0f flop/B; ridge 19.7 (f32 MFMA) / 52 (split-bf16 MFMA, used) -> HBM-bound" % (K * Cw / (2.0 * (K + Cw)))}

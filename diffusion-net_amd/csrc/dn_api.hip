@@ -12,6 +12,21 @@ static_assert(sizeof(dn_tile_t) == sizeof(DnTile), "tile layout");
 #define DN_SMALLN_BLOCKS 2048
 #define DN_CHECK(expr) do { int _e = (expr); if (_e) return _e; } while (0)
 
+// ---- tuning options (dn_set_option / dn_get_option): plain ints read at call time; nothing on the compute path writes them or reads the
+// environment.  Kernel selection for A/B measurements and for tests that must run a particular kernel.
+enum { F16_TOB = 1, F16_FROMB = 2, F16_GF = 4, F16_MLP = 8, F16_LBI = 16, F16_GFB = 32, F16_TOB_B = 64, F16_FROMB_B = 128 };
+namespace {
+struct Opt { const char* name; int value; };
+enum { O_CHAIN, O_CHAIN_MIN_ROWS, O_CHAIN_SMALL_ROWS, O_CHAIN_NW, O_F16, O_F16_MASK, O_F16_WGRAD, O_DIFFUSE, O_DIFFUSE_GROUPS, O_DIFFUSE_ORDER, O_DIFFUSE_FLAGS, O_DIFFUSE_SPLIT, O_COUNT };
+Opt g_opt[O_COUNT] = {
+    {"chain", 1}, {"chain_min_rows", 100000}, {"chain_small_rows", 16384}, {"chain_nw", 0}, {"f16", 1},
+    {"f16_mask", F16_GF | F16_MLP | F16_LBI | F16_GFB | F16_FROMB_B}, {"f16_wgrad", 0},
+    {"diffuse", 2}, {"diffuse_groups", 1}, {"diffuse_order", 0}, {"diffuse_flags", DN_DF_FLAG_DEFER}, {"diffuse_split", 0},
+};
+inline int opt(int i) { return g_opt[i].value; }
+}  // namespace
+int dn_opt_chain_nw(void) { return opt(O_CHAIN_NW); }
+
 namespace {
 struct Bump {
     char* p; size_t left; bool ok;
@@ -80,6 +95,31 @@ void tn_finish(TnArgs& g) {
     g.aligned = ok ? 1 : 0;
 }
 
+// ---- dn_diffuse.hip, for batches that carry a plan, K = C = 128, 16-byte aligned operands.  Option "diffuse":
+//   2 (default)  the back-projection of every diffusion (and of dn_from_basis_f32) is the DIRECT row product launch (bp_ok)
+//   1            the whole operator as one persistent launch (diffuse_ok): correct on any residency, measured slower than the launches on
+//                every batch but many-small-meshes ones -- kept selectable
+//   0            the wave-specialised row GEMM of rounds 1-4
+bool diffuse_ok(const dn_mesh_batch_t* mb, int C) {
+    return opt(O_DIFFUSE) == 1 && mb->df_plan && mb->df_n_wg > 0 && mb->df_n_groups > 0 && mb->df_n_groups <= DN_DF_MAX_GROUPS && mb->k_eig == 128 && C == 128;
+}
+bool bp_ok(const dn_mesh_batch_t* mb, int C) {
+    return opt(O_DIFFUSE) != 0 && mb->df_plan && mb->df_n_wg > 0 && mb->df_n_groups == 1 && mb->k_eig == 128 && C == 128;
+}
+size_t diffuse_ws_floats(const dn_mesh_batch_t* mb) { return dn_diffuse_ws_bytes(mb->df_n_wg, mb->df_n_groups, mb->n_mesh) / sizeof(float); }
+int diffuse_dt_rows(const dn_mesh_batch_t* mb) { return dn_diffuse_dt_rows(mb->df_n_wg, mb->df_n_groups); }
+DfLaunch diffuse_new(const dn_mesh_batch_t* mb, void* ws) {
+    DfLaunch L;
+    memset(&L, 0, sizeof(L));
+    L.plan = T(mb->df_plan); L.n_wg = mb->df_n_wg; L.n_groups = mb->df_n_groups; L.n_mesh = mb->n_mesh;
+    L.evecs = mb->evecs; L.mass = mb->mass; L.evals = mb->evals; L.ws = ws;
+    L.order = opt(O_DIFFUSE_ORDER); L.flags = opt(O_DIFFUSE_FLAGS); L.split = opt(O_DIFFUSE_SPLIT); L.acct_rows = mb->v_total;
+    return L;
+}
+bool diffuse_aligned(const void* a, const void* b, const void* c, const void* d, const void* e, const void* f) {
+    return al16(a) && al16(b) && al16(c) && al16(d) && al16(e) && al16(f);
+}
+
 // ---- building blocks shared by the per-op and the fused-block entry points ----
 int to_basis_partials(const dn_mesh_batch_t* mb, const float* x, int C, bool use_mass, float* partial, hipStream_t st, const F16& f = F16()) {
     TnArgs g = tn_new(mb);
@@ -93,6 +133,8 @@ int to_basis_partials(const dn_mesh_batch_t* mb, const float* x, int C, bool use
 }
 int from_basis(const dn_mesh_batch_t* mb, const float* spec, int C, float* out, const float* add, bool mass_epi, hipStream_t st,
                const F16& f = F16()) {
+    if (bp_ok(mb, C) && al16(spec) && al16(out) && al16(add) && al16(mb->evecs))       // direct row product (3-term engine whatever f asks for)
+        return dn_launch_backproject(T(mb->df_plan), mb->df_n_wg, mb->evecs, spec, out, add, mass_epi ? mb->mass : nullptr, f.o, mb->v_total, st);
     RgArgs g = rg_new(mb);
     rg_f16(g, f);
     rg_seg(g, mb->evecs, nullptr, mb->k_eig, mb->k_eig);
@@ -337,13 +379,29 @@ int dn_prof_read(int kind, double* out) {
     return 0;
 }
 const char* dn_prof_kind_name(int kind) {
-    static const char* names[DN_K_COUNT] = {"rowgemm_kernel<*,1>", "rowgemm_kernel<*,2>", "tngemm_kernel", "spmm_kernel", "small", "chain_fwd_kernel", "chain_bwd_kernel"};
+    static const char* names[DN_K_COUNT] = {"rowgemm_kernel<*,1>", "rowgemm_kernel<*,2>", "tngemm_kernel", "spmm_kernel", "small", "chain_fwd_kernel", "chain_bwd_kernel", "diffuse_kernel", "tngemm_x3_multi_kernel", "tngemm_da_kernel", "backproject_kernel"};
     return (kind >= 0 && kind < DN_K_COUNT) ? names[kind] : "";
 }
 
-int dn_version(void) { return 100; }
+int dn_set_option(const char* name, int value) {
+    if (!name) return DN_ERR_INVALID;
+    for (int i = 0; i < O_COUNT; ++i) if (strcmp(name, g_opt[i].name) == 0) { g_opt[i].value = value; return 0; }
+    return DN_ERR_INVALID;
+}
+int dn_get_option(const char* name, int* value) {
+    if (!name || !value) return DN_ERR_INVALID;
+    for (int i = 0; i < O_COUNT; ++i) if (strcmp(name, g_opt[i].name) == 0) { *value = g_opt[i].value; return 0; }
+    return DN_ERR_INVALID;
+}
+
+int dn_version(void) { return 500; }
 int dn_tile_rows(void) { return DN_TM; }
 int dn_tn_target_chunks(void) { return 2 * dn_num_cus(); }
+int dn_diffusion_plan_wgs(void) { return dn_num_cus(); }
+int dn_diffusion_plan(const int32_t* sizes, int n_mesh, int n_wg, int n_groups, dn_tile_t* plan) {
+    if (!sizes || !plan) return 0;
+    return dn_diffuse_plan_host(sizes, n_mesh, n_wg, n_groups > 0 ? n_groups : opt(O_DIFFUSE_GROUPS), reinterpret_cast<DnTile*>(plan));
+}
 
 // ------------------------------------------------------------------ to_basis / from_basis
 size_t dn_to_basis_workspace_bytes(const dn_mesh_batch_t* mb, int C) {
@@ -363,12 +421,21 @@ int dn_from_basis_f32(const dn_mesh_batch_t* mb, const float* spec, int C, int s
 
 // ------------------------------------------------------------------ learned-time diffusion
 size_t dn_diffusion_workspace_bytes(const dn_mesh_batch_t* mb, int C) {
-    return pad256((size_t)mb->n_chunks * mb->k_eig * C) + pad256((size_t)mb->n_mesh * mb->k_eig * C) +
-           pad256((size_t)dn_spec_bwd_dt_rows(mb->n_mesh, mb->k_eig) * C) + 512;
+    size_t n = pad256((size_t)mb->n_chunks * mb->k_eig * C) + pad256((size_t)mb->n_mesh * mb->k_eig * C) +
+               pad256((size_t)dn_spec_bwd_dt_rows(mb->n_mesh, mb->k_eig) * C) + 512;
+    if (diffuse_ok(mb, C)) n += pad256(diffuse_ws_floats(mb)) + pad256((size_t)diffuse_dt_rows(mb) * C);      // (the hybrid form uses both sets)
+    return n;
 }
 int dn_diffusion_fwd_f32(const dn_mesh_batch_t* mb, const float* x, const float* time, int C, float* xs, float* xd,
                          void* ws, size_t ws_bytes, void* stream) {
     Bump b(ws, ws_bytes);
+    if (diffuse_ok(mb, C) && time && diffuse_aligned(x, xd, xs, mb->evecs, time, mb->evals)) {      // one launch
+        float* dws = b.f(diffuse_ws_floats(mb));
+        if (!b.ok) return DN_ERR_INVALID;
+        DfLaunch L = diffuse_new(mb, dws);
+        L.x = x; L.time = time; L.xs = xs; L.out = xd;
+        return dn_launch_diffuse(L, S(stream));
+    }
     float* partial = b.f((size_t)mb->n_chunks * mb->k_eig * C);
     float* ys = b.f((size_t)mb->n_mesh * mb->k_eig * C);
     if (!b.ok) return DN_ERR_INVALID;
@@ -379,6 +446,15 @@ int dn_diffusion_fwd_f32(const dn_mesh_batch_t* mb, const float* x, const float*
 int dn_diffusion_bwd_f32(const dn_mesh_batch_t* mb, const float* d_xd, const float* xs, const float* time, int C,
                          const float* d_x_add, float* d_x, float* d_time, void* ws, size_t ws_bytes, void* stream) {
     Bump b(ws, ws_bytes);
+    if (diffuse_ok(mb, C) && xs && diffuse_aligned(d_xd, d_x, xs, mb->evecs, time, d_x_add)) {      // one launch + the d_t row sum
+        float* dws = b.f(diffuse_ws_floats(mb));
+        float* dtp = b.f((size_t)diffuse_dt_rows(mb) * C);
+        if (!b.ok) return DN_ERR_INVALID;
+        DfLaunch L = diffuse_new(mb, dws);
+        L.bwd = 1; L.x = d_xd; L.time = time; L.xs = const_cast<float*>(xs); L.out = d_x; L.add = d_x_add; L.dt_part = dtp;
+        DN_CHECK(dn_launch_diffuse(L, S(stream)));
+        return dn_launch_reduce(dtp, d_time, diffuse_dt_rows(mb), C, C, S(stream));
+    }
     float* partial = b.f((size_t)mb->n_chunks * mb->k_eig * C);
     float* dxs = b.f((size_t)mb->n_mesh * mb->k_eig * C);
     const int dt_rows = dn_spec_bwd_dt_rows(mb->n_mesh, mb->k_eig);
@@ -510,15 +586,14 @@ int dn_linear_bwd_amax_f32(const dn_mesh_batch_t* mb, const float* d_out, const 
 // workspace; those of the saved activations in dn_block_saved_t.amax; the block input / output (and d_out / d_x) words travel
 // through dn_block_params_t / dn_block_grads_t, and are measured by the call when the caller passes none.
 // Eligible: aligned operands and widths the split kernels take (C, K and every MLP width multiples of 32 and >= 128); anything else
-// -- and DN_F16=0 in the environment -- runs the split-bf16 / exact-f32 engines exactly as before.
+// -- and option "f16" = 0 -- runs the split-bf16 / exact-f32 engines exactly as before.
 enum { AW_IN = 0, AW_YS, AW_MISC, AW_WA, AW_W0, AW_D0 = AW_W0 + DN_MAX_MLP_LAYERS, AW_COUNT = AW_D0 + DN_MAX_MLP_LAYERS + 1 };   // call-local words:
 // [0, AW_WA) and [AW_D0, ..) are accumulated into (zeroed by the start-of-call launch), [AW_WA, AW_D0) are STORED by that same launch -- the two
 // sets must not overlap: the zeroing workgroup runs concurrently with the storing ones (it once wiped the weight magnitude in 1 call of 2000)
 enum { SW_X = 0, SW_XD, SW_G, SW_H0 };                                                                                          // saved words
 static_assert(SW_H0 + DN_MAX_MLP_LAYERS <= DN_BLOCK_AMAX_WORDS, "saved amax words");
 static bool block_f16_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p) {
-    static const int env = getenv("DN_F16") ? atoi(getenv("DN_F16")) : 1;
-    if (!env) return false;
+    if (!opt(O_F16)) return false;
     auto ok = [](int w) { return w >= 128 && w % 32 == 0; };
     if (!ok(p->C) || !ok(mb->k_eig)) return false;
     for (int j = 1; j < p->n_mlp; ++j) if (!ok(p->widths[j])) return false;
@@ -526,8 +601,8 @@ static bool block_f16_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p) 
 }
 static size_t amax_ws(void) { return pad256(AW_COUNT + DN_BLOCK_AMAX_WORDS + 2); }
 // The chained row kernels (dn_chain.hip forward, dn_chain_bwd.hip backward) take the block's row work -- gradient gather, gradient features,
-// MiniMLP and their gradients -- when the shapes are the ones they are written for and the magnitude words exist.  DN_CHAIN=0 in the
-// environment keeps the unfused launches (read per call: the tests flip it at run time; a getenv is nanoseconds).
+// MiniMLP and their gradients -- when the shapes are the ones they are written for and the magnitude words exist.  Option "chain" = 0
+// keeps the unfused launches (dn_set_option: the tests flip it at run time).
 // kind: 0 = forward without saved activations (inference), 1 = forward saving activations (training), 2 = backward.
 // Measured on MI355X (tools/kbench, block at C = K = 128, chain / unfused, us; profiles/r04_chain_size_sweep.txt):
 //     vertices      3k        7k        14k       20k       40k       80k       160k
@@ -536,18 +611,26 @@ static size_t amax_ws(void) { return pad256(AW_COUNT + DN_BLOCK_AMAX_WORDS + 2);
 //     backward   162/198   169/207   186/222   229/253   349/383   555/588   869/950
 // The backward and the inference forward win at every size.  The training forward (it also writes the seven saved tensors) is level up to
 // ~15k vertices, behind between 20k and 80k -- one long pass per workgroup and too few workgroups to hide its latencies -- and ahead from
-// ~100k: it is taken from DN_CHAIN_MIN_ROWS rows on (default 100000; the tests run it at every size with 0).
-static bool block_chain_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int kind) {
-    const char* e0 = getenv("DN_CHAIN");
-    static const int f16_env = getenv("DN_F16") ? atoi(getenv("DN_F16")) : 1;      // DN_F16=0: split-bf16 engine everywhere (A/B runs)
-    if ((e0 && atoi(e0) == 0) || !f16_env || (p->with_grad && !mb->grad_norm)) return false;
-    if (kind == 1) {
-        const char* e1 = getenv("DN_CHAIN_MIN_ROWS");
-        if (mb->v_total < (e1 ? atoi(e1) : 100000)) return false;
+// ~100k: it is taken from "chain_min_rows" rows on (default 100000; the tests run it at every size with 0) AND up to "chain_small_rows"
+// (default 16384: level in time, four launches fewer per block -- at the sizes the reference trains on, one ~7k-12k-vertex mesh per step,
+// launches are the time: human_segmentation_original.py:105-148).
+// The chained kernels use 16-byte vector accesses throughout and have no scalar fallback: every tensor they touch must be 16-byte aligned
+// (a plain-C caller, or a torch view with an odd storage offset, takes the unfused launches, which check per operand).  ADVICE r4.
+static bool chain_aligned(const dn_block_params_t* p, const dn_block_saved_t* sv, const float* a, const float* b_, const float* c = nullptr, const float* d = nullptr) {
+    bool ok = al16(a) && al16(b_) && al16(c) && al16(d) && al16(p->A_re) && al16(p->A_im) && al16(p->time);
+    for (int j = 0; j < p->n_mlp; ++j) ok = ok && al16(p->W[j]) && al16(p->b[j]) && al16(p->mask[j]);
+    if (sv) {
+        ok = ok && al16(sv->xs) && al16(sv->xd) && al16(sv->gx) && al16(sv->gy) && al16(sv->g) && al16(sv->bre) && al16(sv->bim);
+        for (int j = 0; j < p->n_mlp; ++j) ok = ok && al16(sv->h[j]);
     }
+    return ok;
+}
+static bool block_chain_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int kind) {
+    if (!opt(O_CHAIN) || !opt(O_F16) || (p->with_grad && !mb->grad_norm)) return false;      // "f16" = 0: split-bf16 engine everywhere (A/B runs)
+    if (kind == 1 && mb->v_total < opt(O_CHAIN_MIN_ROWS) && mb->v_total > opt(O_CHAIN_SMALL_ROWS)) return false;
     return dn_chain_eligible(p->C, p->n_mlp, p->widths, p->with_grad, mb->g_nnz, mb->v_total);
 }
-// Product classes of the block; DN_F16_MASK=<bits> (diagnostic) selects which of them run on the split-fp16 engine.
+// Product classes of the block; option "f16_mask" (diagnostic) selects which of them run on the split-fp16 engine.
 // Default: the row products (gradient features, MLP, input gradients, backward back-projection).  Not the split-V projections
 // evecs^T x (their lock-step kernel gains nothing: 55 -> 54.6 us, and leaving them out spares the transposed gather a magnitude
 // pass that cost it +60 %), and not the FORWARD back-projection x_diffuse = evecs * spectrum: its output is what the sparse gradient operators
@@ -555,8 +638,7 @@ static bool block_chain_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p
 // decay over many orders of magnitude with the eigenvalue -- is the one tensor a single power-of-two scale serves badly.  Measured on
 // the trained-checkpoint golden (error against fp64, fp32 reference = 8.4e-5 on the worst tensor): every class on fp16 3.2e-4, every
 // class but this one 6e-5 ... 1.0e-4 -- the level of the split-bf16 engine and of the reference itself.
-enum { F16_TOB = 1, F16_FROMB = 2, F16_GF = 4, F16_MLP = 8, F16_LBI = 16, F16_GFB = 32, F16_TOB_B = 64, F16_FROMB_B = 128 };
-static int f16_mask(void) { static const int m = getenv("DN_F16_MASK") ? atoi(getenv("DN_F16_MASK")) : (F16_GF | F16_MLP | F16_LBI | F16_GFB | F16_FROMB_B); return m; }
+static int f16_mask(void) { return opt(O_F16_MASK); }
 static F16 f16_if(int bit, const F16& f) { if (f16_mask() & bit) return f; F16 r; r.o = f.o; return r; }   // (the magnitude of the output is still recorded)
 
 int dn_block_tracks_amax(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int call) {
@@ -569,6 +651,7 @@ size_t dn_block_fwd_workspace_bytes(const dn_mesh_batch_t* mb, const dn_block_pa
     const size_t VC = (size_t)mb->v_total * p->C;
     size_t n = pad256((size_t)mb->n_chunks * mb->k_eig * p->C) + pad256((size_t)mb->n_mesh * mb->k_eig * p->C) + amax_ws() + 512;
     if (block_chain_ok(mb, p, with_saved ? 1 : 0)) n += pad256(dn_chain_ws_bytes(p->C, p->with_grad, p->with_rot, p->n_mlp) / sizeof(float));
+    if (diffuse_ok(mb, p->C)) n += pad256(diffuse_ws_floats(mb));
     if (!with_saved) {
         n += pad256((size_t)mb->n_mesh * mb->k_eig * p->C) + 4 * pad256(VC);          // xs, xd, gx, gy, g
         n += 2 * pad256((size_t)mb->v_total * max_width(p));                            // hidden ping-pong
@@ -585,8 +668,9 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     float* partial = b.f((size_t)mb->n_chunks * K * C);
     float* ys = b.f((size_t)mb->n_mesh * K * C);
     float* aw = b.f(AW_COUNT + DN_BLOCK_AMAX_WORDS + 2);
-    const bool chain = block_chain_ok(mb, p, sv ? 1 : 0) && (!sv || sv->amax);
+    const bool chain = block_chain_ok(mb, p, sv ? 1 : 0) && (!sv || sv->amax) && chain_aligned(p, sv, x, out);
     float* chain_ws = block_chain_ok(mb, p, sv ? 1 : 0) ? b.f(dn_chain_ws_bytes(p->C, p->with_grad, p->with_rot, p->n_mlp) / sizeof(float)) : nullptr;
+    float* diffuse_ws = diffuse_ok(mb, C) ? b.f(diffuse_ws_floats(mb)) : nullptr;
     float *xs, *xd, *gx = nullptr, *gy = nullptr, *gf = nullptr, *bre = nullptr, *bim = nullptr;
     float* hbuf[2] = {nullptr, nullptr};
     if (sv) {
@@ -665,15 +749,21 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     }
     auto W = [&](int j) { return (const float*)(aw + AW_W0 + j); };
 
-    // diffusion (layers.py:210)
-    {
-        F16 f;
-        if (f16) { f = f16_of(ev_amax, x_amax); f.b.mul = ms_amax; }
-        DN_CHECK(to_basis_partials(mb, x, C, true, partial, st, f16_if(F16_TOB, f)));
-    }
-    DN_CHECK(dn_launch_spec_fwd(partial, mb->mesh_chunk_off, mb->evals, p->time, xs, ys, mb->n_mesh, K, C, st,
-                                (f16 && (f16_mask() & F16_FROMB)) ? aw + AW_YS : nullptr));   // only the split-fp16 back-projection needs max |ys|
-    {
+    // diffusion (layers.py:210): one persistent launch (dn_diffuse.hip) when the batch carries its plan -- both products on the 3-term
+    // engine, as the three-launch form runs them by default -- else projection, spectral step, back-projection
+    if (diffuse_ws && !(f16 && (f16_mask() & (F16_TOB | F16_FROMB))) && diffuse_aligned(x, xd, xs, mb->evecs, p->time, mb->evals)) {
+        DfLaunch L = diffuse_new(mb, diffuse_ws);
+        L.x = x; L.time = p->time; L.xs = xs; L.out = xd;
+        L.out_amax = words ? sw + SW_XD : nullptr;                           // (the chained kernel scales xd by its magnitude)
+        DN_CHECK(dn_launch_diffuse(L, st));
+    } else {
+        {
+            F16 f;
+            if (f16) { f = f16_of(ev_amax, x_amax); f.b.mul = ms_amax; }
+            DN_CHECK(to_basis_partials(mb, x, C, true, partial, st, f16_if(F16_TOB, f)));
+        }
+        DN_CHECK(dn_launch_spec_fwd(partial, mb->mesh_chunk_off, mb->evals, p->time, xs, ys, mb->n_mesh, K, C, st,
+                                    (f16 && (f16_mask() & F16_FROMB)) ? aw + AW_YS : nullptr));   // only the split-fp16 back-projection needs max |ys|
         F16 fb;
         if (f16) fb = f16_if(F16_FROMB, f16_of(ev_amax, aw + AW_YS, sw + SW_XD));
         else if (words) fb.o = sw + SW_XD;                                  // (the chained kernel scales xd by its magnitude)
@@ -743,6 +833,7 @@ size_t dn_block_bwd_workspace_bytes(const dn_mesh_batch_t* mb, const dn_block_pa
     n += pad256((size_t)mb->n_mesh * mb->k_eig * p->C) + pad256((size_t)dn_spec_bwd_dt_rows(mb->n_mesh, mb->k_eig) * p->C);
     n += pad256((size_t)4 * p->C * p->C) + amax_ws();
     if (block_chain_ok(mb, p, 2)) n += pad256((size_t)dn_chain_bwd_pieces(p->C, p->with_grad, p->with_rot, p->n_mlp) * (2 * (p->C / 16) * 64) * 4);
+    if (diffuse_ok(mb, p->C)) n += pad256(diffuse_ws_floats(mb)) + pad256((size_t)diffuse_dt_rows(mb) * p->C);
     return n + 512;
 }
 int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, const float* x, const dn_block_saved_t* sv,
@@ -770,6 +861,8 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     float* psum = b.f((size_t)4 * C * C);
     float* aw = b.f(AW_COUNT + DN_BLOCK_AMAX_WORDS + 2);
     float* chain_ws = block_chain_ok(mb, p, 2) ? b.f((size_t)dn_chain_bwd_pieces(C, p->with_grad, p->with_rot, p->n_mlp) * (2 * (C / 16) * 64) * 4) : nullptr;
+    float* diffuse_ws = diffuse_ok(mb, C) ? b.f(diffuse_ws_floats(mb)) : nullptr;
+    float* diffuse_dtp = diffuse_ok(mb, C) ? b.f((size_t)diffuse_dt_rows(mb) * C) : nullptr;
     if (!b.ok) return DN_ERR_INVALID;
 
     // ---- operand magnitudes for the split-fp16 engine (the saved activations' words come from the forward)
@@ -778,12 +871,14 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     // precision times a condition number of ~1e3, and the two-term fp16 split carries 22 bits against fp32's 24 -- measured on the
     // trained-checkpoint golden: 2.9e-4 from fp64 where the fp32 reference itself is 0.8e-4 away.  They stay on the split-bf16
     // engine (24 bits); the row products (activations, input gradients: 128..384-term sums) take the split-fp16 one.
-    static const bool wgrad_f16 = getenv("DN_F16_WGRAD") && atoi(getenv("DN_F16_WGRAD")) != 0;
+    const bool wgrad_f16 = opt(O_F16_WGRAD) != 0;
     const float* sw = sv->amax;
     const float *dout_amax = nullptr, *ev_amax = nullptr;
     // the chained backward kernel (dn_chain_bwd.hip) takes the row-local part -- MiniMLP input gradients, tanh', gradient-feature backward --
     // under the conditions of the chained forward (two hidden-gradient buffers: MiniMLPs of up to three layers)
-    const bool chainb = block_chain_ok(mb, p, 2) && sv->amax && !wgrad_f16 && p->n_mlp <= 3;
+    const bool chainb = block_chain_ok(mb, p, 2) && sv->amax && !wgrad_f16 && p->n_mlp <= 3 && chain_aligned(p, sv, x, d_out, gr->d_x) &&
+                        // (the chained backward does not record max |d_xd|: the diagnostic class that needs it keeps the unfused launches)
+                        !(block_f16_ok(mb, p) && (f16_mask() & F16_TOB_B) && !p->with_grad);
     const bool words = f16 || chainb;
     ChainPrepArgs pa; memset(&pa, 0, sizeof(pa));
     int chain_np = 0;
@@ -912,7 +1007,17 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
             DN_CHECK(grad_apply_bwd(mb, d_gx, d_gy, d_xd, C, d_xd, st, (f16 && (f16_mask() & F16_TOB_B)) ? aw + AW_MISC : nullptr));   // d_xd += gradX^T d_gx + gradY^T d_gy (in place)
         }
     }
-    // ---- diffusion backward
+    // ---- diffusion backward: one persistent launch (3-term engine throughout) when the batch carries its plan; its d_t rows join the block's
+    // deferred gradient sums
+    if (diffuse_ws && !(f16 && (f16_mask() & F16_TOB_B)) && diffuse_aligned(d_xd, gr->d_x, sv->xs, mb->evecs, p->time, d_xacc)) {
+        DfLaunch L = diffuse_new(mb, diffuse_ws);
+        L.bwd = 1; L.x = d_xd; L.time = p->time; L.xs = sv->xs; L.out = gr->d_x; L.add = d_xacc; L.dt_part = diffuse_dtp;
+        L.out_amax = f16 ? gr->d_x_amax : nullptr;
+        DN_CHECK(dn_launch_diffuse(L, st));
+        if (!jobs.push(diffuse_dtp, diffuse_dt_rows(mb), C, gr->d_time))
+            DN_CHECK(dn_launch_reduce(diffuse_dtp, gr->d_time, diffuse_dt_rows(mb), C, C, st));
+        return dn_launch_multi_reduce(jobs, st);          // every parameter gradient of the block: one fixed-order reduction launch
+    }
     DN_CHECK(to_basis_partials(mb, d_xd, C, false, partial, st, f16 ? f16_if(F16_TOB_B, f16_of(ev_amax, aw + AW_MISC)) : F16()));
     if (dn_spec_bwd_fused_ok(partial, p->time, sv->xs, dxs, dtp, C)) {
         // one launch: per-mesh sums of the partials, exp(-lambda t), d_t contributions; their sum over (mesh, eigenvalue group) joins the block's

@@ -549,7 +549,7 @@ static int chain_launch(int npieces, const ChainArgs& a_in, hipStream_t stream) 
     // Waves per workgroup: every workgroup streams the whole weight set once per 32 * NW rows, so large batches take four (two
     // workgroups per CU share its matrix pipes out of phase); only batches that would leave most CUs without a workgroup are cut finer
     // (measured, block forward at 7k / 20k / 160k vertices: NW = 1: 102 / 179 / 658 us, 2: 104 / 140 / 486, 4: 113 / 129 / 388).
-    const int nw_env = getenv("DN_CHAIN_NW") ? atoi(getenv("DN_CHAIN_NW")) : 0;   // (development override)
+    const int nw_env = dn_opt_chain_nw();   // (development override)
     int nw = nw_env;
     if (nw != 1 && nw != 2 && nw != 4 && nw != 8) {
         const int half = dn_num_cus() / 2;

@@ -359,7 +359,7 @@ static int chain_bwd_launch_nw(ChainBwdArgs a, hipStream_t stream) {
 }
 template <int C>
 static int chain_bwd_launch(int npieces, const ChainBwdArgs& a_in, hipStream_t stream) {
-    const int nw_env = getenv("DN_CHAIN_NW") ? atoi(getenv("DN_CHAIN_NW")) : 0;   // (development override; see dn_chain.hip for the choice)
+    const int nw_env = dn_opt_chain_nw();   // (development override; see dn_chain.hip for the choice)
     int nw = nw_env;
     if (nw != 1 && nw != 2 && nw != 4) {
         const int half = dn_num_cus() / 2;

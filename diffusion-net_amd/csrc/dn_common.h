@@ -210,6 +210,21 @@ __device__ __forceinline__ float4 dn_load_f4_nt(const float* p) {
     return make_float4(v.x, v.y, v.z, v.w);
 #endif
 }
+// L1-bypassing ("sc1") 8-byte loads: agent-scope relaxed atomics.  What a workgroup reads of another workgroup's write-through (sc1)
+// stores inside ONE launch (dn_diffuse.hip): MI355X_MICROARCH.md, inter-workgroup visibility -- "sc1 loads may replace the acquire only
+// when the producer stored sc1".  Compiler-tracked (no inline asm: an asm load's destination may be spilled before the data arrives).
+__device__ __forceinline__ float2 dn_ld2_coherent(const float* p) {
+#ifdef DN_EMULATE
+    return *reinterpret_cast<const float2*>(p);
+#else
+    const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
+#endif
+}
+__device__ __forceinline__ float4 dn_ld4_coherent(const float* p) {
+    const float2 lo = dn_ld2_coherent(p), hi = dn_ld2_coherent(p + 2);
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
 // Plain multiplies on purpose.  An explicit two-element vector multiply here (v_pk_mul_f32 with a broadcast operand in src1,
 // `op_sel_hi:[1,0]`) produced INTERMITTENTLY wrong low halves on gfx950 / ROCm 7.2: one stale bf16 pair in a few launches per
 // thousand at small sizes, in every launch at the benchmark size -- a whole output column of a tile off by ~1e-1 relative, found
@@ -529,6 +544,37 @@ int dn_launch_chain_prep(const ChainPrepArgs& pa, int npieces, int C, hipStream_
 int dn_launch_chain_fwd(int npieces, const ChainArgs& a, int C, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------
+// one-launch learned-time diffusion, forward and backward (dn_diffuse.hip; K = C = 128)
+// ---------------------------------------------------------------------------------------
+#define DN_DF_MAX_GROUPS 4
+#define DN_DF_MAX_SCHED 12
+enum { DN_DF_OP_P1 = 1, DN_DF_OP_R = 2, DN_DF_OP_P3 = 3 };
+enum { DN_DF_FLAG_DEFER = 1,       // an arrival is posted from inside the NEXT projection loop (its stores drain under that loop's loads)
+       DN_DF_FLAG_SOLO_R = 2,      // tests: half of the workgroups pretend their poll for the partials ran out
+       DN_DF_FLAG_SOLO_P3 = 4 };   // tests: the other half pretend their poll for the scaled spectrum ran out
+struct DfLaunch {
+    const DnTile* plan;            // device: [n_groups * n_wg], dn_diffuse_plan_host()
+    int n_wg, n_groups, n_mesh;
+    const float* evecs; const float* x; const float* mass; const float* evals; const float* time;
+    float* xs;                     // forward: receives the unscaled spectrum (may be null); backward: the forward's spectrum (read)
+    float* out; const float* add;  // backward: out = add + mass * (...) (add may be null)
+    float* dt_part;                // backward: [dn_diffuse_dt_rows()][128]
+    float* out_amax;               // optional: max |out| is accumulated into it (atomic max)
+    void* ws;                      // dn_diffuse_ws_bytes()
+    int bwd, order, flags;
+    int split;                     // bit i: kernel boundary after schedule step i (0: one launch)
+    long long acct_rows;           // host-side accounting only
+};
+size_t dn_diffuse_ws_bytes(int n_wg, int n_groups, int n_mesh);
+int dn_diffuse_dt_rows(int n_wg, int n_groups);
+int dn_diffuse_schedule(int G, int order, int* sched);
+int dn_diffuse_plan_host(const int* sizes, int n_mesh, int n_wg, int n_groups, DnTile* plan);
+int dn_launch_diffuse(const DfLaunch& L, hipStream_t stream);
+int dn_launch_backproject(const DnTile* plan, int n_wg, const float* evecs, const float* ys, float* out, const float* add, const float* mass,
+                          float* out_amax, double acct_rows, hipStream_t stream);
+int dn_opt_chain_nw(void);   // option "chain_nw" (dn_api.hip): development override of the chained kernels' workgroup width
+
+// ---------------------------------------------------------------------------------------
 // small reductions / pointwise kernels (dn_pointwise.hip)
 // ---------------------------------------------------------------------------------------
 int dn_launch_spec_fwd(const float* partial, const int* mesh_chunk_off, const float* evals, const float* time,
@@ -637,7 +683,7 @@ int dn_launch_tngemm_multi(const TnArgs* gs, const int* nchunks, int count, hipS
 // hipEvents on its own stream and summed per kernel family.  Off by default; compiled out of the
 // emulator build.
 // ---------------------------------------------------------------------------------------
-enum { DN_K_ROWGEMM = 0, DN_K_ROWGEMM_DUAL = 1, DN_K_TNGEMM = 2, DN_K_SPMM = 3, DN_K_SMALL = 4, DN_K_CHAIN = 5, DN_K_CHAIN_BWD = 6, DN_K_COUNT = 7 };
+enum { DN_K_ROWGEMM = 0, DN_K_ROWGEMM_DUAL = 1, DN_K_TNGEMM = 2, DN_K_SPMM = 3, DN_K_SMALL = 4, DN_K_CHAIN = 5, DN_K_CHAIN_BWD = 6, DN_K_DIFFUSE = 7, DN_K_TN_MULTI = 8, DN_K_TN_DA = 9, DN_K_BACKPROJECT = 10, DN_K_COUNT = 11 };   // one kind per KERNEL (rocprof name), except the small-kernel bucket
 #ifdef DN_EMULATE
 static inline void dn_prof_begin(int, hipStream_t) {}
 static inline void dn_prof_end(int, hipStream_t, double, double) {}

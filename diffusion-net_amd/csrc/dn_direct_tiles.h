@@ -1,7 +1,6 @@
-// dn_direct_tiles.h -- "direct" row product for K = 128: out[r, 0..127] = sum_k A[r, k] B[k, n] with the long operand A read straight
+// dn_direct_tiles.h -- "direct" row product for K = 128 (the back-projection phase of the one-launch diffusion operator, dn_diffuse.hip): out[r, 0..127] = sum_k A[r, k] B[k, n] with the long operand A read straight
 // from global memory into MFMA fragments (no LDS round trip, no barrier) and the 128 x 128 operand B split once per workgroup into
-// fragment-ordered bf16 planes resident in LDS.  Developed and measured as tools/experiments/rowgemm_direct (see its README); used
-// by the fused diffusion kernel for the back-projection phase, where B -- the spectrum -- only exists inside the kernel.
+// fragment-ordered bf16 planes resident in LDS.  Developed and measured as tools/experiments/rowgemm_direct (see its README).
 //   * unit = 16 rows x 128 columns per wave, eight 16x16 accumulators, v_mfma_f32_16x16x32_bf16 with the operands swapped
 //     (D^T = B^T A^T): a lane's four registers of a tile are four consecutive output columns of one row -> float4 stores;
 //   * A fragment of a lane = eight k-consecutive floats of one row = two float4 loads; k is permuted inside a 32-float line (the
@@ -47,7 +46,8 @@ __device__ __forceinline__ int rd_k0(int s, int lg, int h) { return 32 * s + 16 
 
 // Split a 128 x 128 operand B[k][n] (row-major, n contiguous, leading dimension ldb) into the fragment-ordered planes: a thread
 // fetches an 8 (k) x 4 (n) block as eight float4 along n -- the eight k of four items (four consecutive lanes).  NTHR threads.
-template <int NTHR>
+// COH: B was written by other workgroups of the SAME launch (write-through stores): L1-bypassing loads.
+template <int NTHR, bool COH = false>
 __device__ __forceinline__ void rd_stage_b_nn(const float* bp, int ldb, unsigned char* sB, int tid) {
 #pragma unroll
     for (int h = 0; h < 512 / NTHR; ++h) {                     // 4 steps x 4 lane groups x 32 column quads = 512 blocks
@@ -57,8 +57,10 @@ __device__ __forceinline__ void rd_stage_b_nn(const float* bp, int ldb, unsigned
         float4 r[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            r[j] = *reinterpret_cast<const float4*>(cp + (long long)(rd_k0(s, lg, 0) + j) * ldb);
-            r[4 + j] = *reinterpret_cast<const float4*>(cp + (long long)(rd_k0(s, lg, 1) + j) * ldb);
+            const float* p0 = cp + (long long)(rd_k0(s, lg, 0) + j) * ldb;
+            const float* p1 = cp + (long long)(rd_k0(s, lg, 1) + j) * ldb;
+            r[j] = COH ? dn_ld4_coherent(p0) : *reinterpret_cast<const float4*>(p0);
+            r[4 + j] = COH ? dn_ld4_coherent(p1) : *reinterpret_cast<const float4*>(p1);
         }
         const int t = nq >> 2;                                   // 16-column tile of columns 4 nq .. 4 nq + 3
 #pragma unroll
@@ -104,7 +106,7 @@ __device__ __forceinline__ void rd_read_plane(const unsigned char* sB, int lane,
 template <int MODE>
 __device__ __forceinline__ void rd_unit_body(const RgArgs& g, const unsigned char* sB, const RdUnit& cur, const float* np_x,
                                              const float* np_y, int n0, int lane, float4 (&X)[8], float4 (&Y)[8], uint4 (&a)[3],
-                                             uint4 (&F)[2][3][2]) {
+                                             uint4 (&F)[2][3][2], float& om) {
     const int li = lane & 15, lg = lane >> 4;
     // auxiliary operands of the epilogue: requested first (vmcnt is an in-order counter: waiting for them later must not drain the
     // prefetch loads issued during the MFMA steps)
@@ -169,18 +171,20 @@ __device__ __forceinline__ void rd_unit_body(const RgArgs& g, const unsigned cha
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         P[t].v = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
-        pt_piece_store<MODE, false>(g, P[t]);
+        om = dn_f4_amax(om, pt_piece_store<MODE, false>(g, P[t]));     // om: running max |stored value| of this lane
     }
 }
 
-// All 16-row units of the contiguous rows [rs, re) for one wave of an eight-wave workgroup (B planes already staged in sB)
+// All 16-row units of the contiguous rows [rs, re) for one wave of an eight-wave workgroup (B planes already staged in sB).
+// Returns this lane's max |stored value|.
 template <int MODE>
-__device__ __forceinline__ void rd_run_rows(const RgArgs& g, const unsigned char* sB, const float* ap, int ald, int rs, int re, int n0,
-                                            int wave, int lane) {
+__device__ __forceinline__ float rd_run_rows(const RgArgs& g, const unsigned char* sB, const float* ap, int ald, int rs, int re, int n0,
+                                             int wave, int lane) {
     const int li = lane & 15, lg = lane >> 4;
     const int nu = (re - rs + DN_RD_ROWS - 1) / DN_RD_ROWS;
     int j = wave;
-    if (j >= nu) return;
+    float om = 0.f;
+    if (j >= nu) return om;
     float4 A0[8], A1[8];
     RdUnit c0 = rd_unit(rs, re, j), c1 = rd_unit(rs, re, j + DN_RD_WAVES);
     {
@@ -206,13 +210,14 @@ __device__ __forceinline__ void rd_run_rows(const RgArgs& g, const unsigned char
     for (; j < nu; j += 2 * DN_RD_WAVES) {
         {
             const RdUnit n2 = rd_unit(rs, re, j + 2 * DN_RD_WAVES), n3 = rd_unit(rs, re, j + 3 * DN_RD_WAVES);
-            rd_unit_body<MODE>(g, sB, c0, rd_row_ptr(ap, ald, n2, li, lg), rd_row_ptr(ap, ald, n3, li, lg), n0, lane, A0, A1, a, F);
+            rd_unit_body<MODE>(g, sB, c0, rd_row_ptr(ap, ald, n2, li, lg), rd_row_ptr(ap, ald, n3, li, lg), n0, lane, A0, A1, a, F, om);
             c0 = n2;
         }
         if (j + DN_RD_WAVES < nu) {                            // wave-uniform
             const RdUnit n3 = rd_unit(rs, re, j + 3 * DN_RD_WAVES), n4 = rd_unit(rs, re, j + 4 * DN_RD_WAVES);
-            rd_unit_body<MODE>(g, sB, c1, rd_row_ptr(ap, ald, n3, li, lg), rd_row_ptr(ap, ald, n4, li, lg), n0, lane, A1, A0, a, F);
+            rd_unit_body<MODE>(g, sB, c1, rd_row_ptr(ap, ald, n3, li, lg), rd_row_ptr(ap, ald, n4, li, lg), n0, lane, A1, A0, a, F, om);
             c1 = n3;
         }
     }
+    return om;
 }

@@ -193,10 +193,10 @@ int dn_launch_tn_da(const float* dd, const float* gx, const float* gy, long long
     static unsigned long long lds_opt_in2 = 0;
     { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&tngemm_da_kernel<2>), DN_DA_LDS, &lds_opt_in2); if (oe_) return oe_; }
 #endif
-    dn_prof_begin(DN_K_TNGEMM, stream);
+    dn_prof_begin(DN_K_TN_DA, stream);
     if (g.f16) DN_LAUNCH(tngemm_da_kernel<2>, dim3(nwg, 1, 1), dim3(DN_DA_THREADS, 1, 1), DN_DA_LDS, stream, g);
     else DN_LAUNCH(tngemm_da_kernel<3>, dim3(nwg, 1, 1), dim3(DN_DA_THREADS, 1, 1), DN_DA_LDS, stream, g);
     // four 128 x 128 products over V rows; three arrays read once, the partials written
-    dn_prof_end(DN_K_TNGEMM, stream, 8.0 * (double)V * 128.0 * 128.0, 4.0 * (3.0 * (double)V * 128.0 + 2.0 * nwg * 128.0 * 128.0));
+    dn_prof_end(DN_K_TN_DA, stream, 8.0 * (double)V * 128.0 * 128.0, 4.0 * (3.0 * (double)V * 128.0 + 2.0 * nwg * 128.0 * 128.0));
     return (int)hipGetLastError();
 }

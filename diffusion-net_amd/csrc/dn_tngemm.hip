@@ -440,8 +440,8 @@ int dn_launch_tngemm_multi(const TnArgs* gs, const int* nchunks, int count, hipS
     static unsigned long long lds_opt_in = 0;   // per-device bitmap
     { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&tngemm_x3_multi_kernel<DN_TN_COLSUM, 3>), smem, &lds_opt_in); if (oe_) return oe_; }
 #endif
-    dn_prof_begin(DN_K_TNGEMM, stream);
+    dn_prof_begin(DN_K_TN_MULTI, stream);
     DN_LAUNCH((tngemm_x3_multi_kernel<DN_TN_COLSUM, 3>), dim3(total, 1, 1), dim3(DN_TX_THREADS, 1, 1), smem, stream, mm);
-    dn_prof_end(DN_K_TNGEMM, stream, flops, bytes);
+    dn_prof_end(DN_K_TN_MULTI, stream, flops, bytes);
     return (int)hipGetLastError();
 }

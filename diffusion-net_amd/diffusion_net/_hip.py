@@ -34,6 +34,7 @@ class MeshBatchStruct(C.Structure):
         ("g_rowptr", _vp), ("g_col", _vp), ("g_vx", _vp), ("g_vy", _vp),
         ("gt_rowptr", _vp), ("gt_col", _vp), ("gt_vx", _vp), ("gt_vy", _vp),
         ("evecs_amax", _vp), ("mass_amax", _vp), ("grad_norm", _vp),
+        ("df_plan", _vp), ("df_n_wg", C.c_int32), ("df_n_groups", C.c_int32),
     ]
 
 
@@ -67,6 +68,10 @@ _SIGNATURES = {
     "dn_version": (C.c_int, []),
     "dn_tile_rows": (C.c_int, []),
     "dn_tn_target_chunks": (C.c_int, []),
+    "dn_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "dn_get_option": (C.c_int, [C.c_char_p, _P(C.c_int)]),
+    "dn_diffusion_plan_wgs": (C.c_int, []),
+    "dn_diffusion_plan": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
     "dn_prof_enable": (C.c_int, [C.c_int]),
     "dn_prof_reset": (C.c_int, []),
     "dn_prof_read": (C.c_int, [C.c_int, _P(C.c_double)]),
@@ -111,12 +116,18 @@ _lib = None
 _allow_host_tensors = False   # flipped ONLY by the CPU-emulator test fixture (tests/emu)
 
 
+default_options = {}   # tuning options applied to every library this module binds (the test suite: {"chain_min_rows": 0})
+
+
 def _bind(path):
     lib = C.CDLL(path)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    for k, v in default_options.items():
+        if lib.dn_set_option(k.encode(), int(v)) != 0:
+            raise RuntimeError("unknown library option %r" % k)
     return lib
 
 
@@ -131,6 +142,24 @@ def lib():
                 "There is no fallback path for the DiffusionNet hot ops.")
         _lib = _bind(LIB_PATH)
     return _lib
+
+
+def set_option(name: str, value: int) -> int:
+    """Set a tuning option of the library (include/diffnet_hip.h: dn_set_option); returns the previous value."""
+    L = lib()
+    old = C.c_int(0)
+    check(L.dn_get_option(name.encode(), C.byref(old)), "dn_get_option(%s)" % name)
+    check(L.dn_set_option(name.encode(), int(value)), "dn_set_option(%s)" % name)
+    return old.value
+
+
+def get_option(name: str) -> int:
+    v = C.c_int(0)
+    check(lib().dn_get_option(name.encode(), C.byref(v)), "dn_get_option(%s)" % name)
+    return v.value
+
+
+DIFFUSION_MAX_GROUPS = 4    # include/diffnet_hip.h: DN_DIFFUSION_MAX_GROUPS
 
 
 def _use_library_for_tests(path, allow_host_tensors):

@@ -113,6 +113,32 @@ def build_tables(sizes: Sequence[int], chunk_rows, tile_rows: int):
     return as_t(tiles), as_t(chunks), np.array(mco, dtype=np.int32), as_t(mrows)
 
 
+def diffusion_plan(sizes: Sequence[int], n_groups: int = 0):
+    """Work plan of the one-launch diffusion operator (dn_diffuse.hip) for meshes of the given vertex counts: which rows of which mesh every
+    workgroup owns in each mesh group.  The arithmetic is the library's (``dn_diffusion_plan``, host side).  Returns (plan [groups * n_wg, 4]
+    int32, n_wg, groups) or None when the batch is not plannable."""
+    L = _hip.lib()
+    n_wg = int(L.dn_diffusion_plan_wgs())
+    arr = np.ascontiguousarray(np.asarray(sizes, dtype=np.int32))
+    plan = np.zeros((_hip.DIFFUSION_MAX_GROUPS * n_wg, 4), dtype=np.int32)
+    g = int(L.dn_diffusion_plan(arr.ctypes.data, len(arr), n_wg, int(n_groups), plan.ctypes.data))
+    if g <= 0:
+        return None
+    return plan[: g * n_wg].copy(), n_wg, g
+
+
+def _plan_on(device, sizes, n_groups):
+    key = ("df_plan", str(device), tuple(sizes), int(n_groups), _hip.get_option("diffuse_groups") if not n_groups else 0)
+    hit = _table_cache.get(key)
+    if hit is None:
+        if len(_table_cache) > 256:
+            _table_cache.clear()
+        p = diffusion_plan(sizes, n_groups)
+        hit = (torch.from_numpy(p[0]).to(device), p[1], p[2]) if p is not None else (None, 0, 0)
+        _table_cache[key] = hit
+    return hit
+
+
 def _tables_on(device, sizes, chunk_rows):
     tile_rows = _hip.lib().dn_tile_rows()
     key = (str(device), tuple(sizes), tuple(chunk_rows) if isinstance(chunk_rows, (list, tuple)) else chunk_rows, tile_rows)
@@ -238,6 +264,11 @@ class MeshBatch:
         for name in ("tiles", "chunks", "mesh_chunk_off", "mesh_rows", "mass", "evals", "evecs",
                      "g_rowptr", "g_col", "g_vx", "g_vy", "gt_rowptr", "gt_col", "gt_vx", "gt_vy"):
             setattr(s, name, _hip.ptr(getattr(self, name)))
+        # the one-launch diffusion operator's work plan (K = C = 128 batches; the library ignores it otherwise)
+        self.df_plan = None
+        if self.k_eig == 128 and self.evecs is not None and vt > 0:
+            self.df_plan, s.df_n_wg, s.df_n_groups = _plan_on(self.device, self.sizes, 0)
+            s.df_plan = _hip.ptr(self.df_plan)
         if self.evecs is not None and self.evecs.numel() > 0 and self.mass is not None:
             # once per packed batch (two small reductions, no host synchronisation)
             words = [self.evecs.detach().abs().amax(), self.mass.detach().abs().amax()]

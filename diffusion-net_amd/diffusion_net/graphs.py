@@ -11,7 +11,12 @@ What makes the step capturable:
     (``dn_block_params_t.drop_seed_dev``) that the graph itself advances with its first node, so every replay draws fresh masks;
   * the parameters live in ``dist.FlatParams`` (one buffer, gradients delivered by the ops straight into it), the optimizer is torch's
     Adam with ``capturable=True``;
-  * inputs are static buffers owned by the object: ``step(x=..., labels=...)`` copies new values in before the replay.
+  * inputs are static buffers owned by the object: ``step(x=..., labels=...)`` copies new values in before the replay;
+  * the learning rate is a DEVICE tensor: a captured ``opt.step()`` would otherwise bake the Python float of capture time into the graph
+    and silently ignore the reference loop's schedule (``param_group['lr'] = lr`` every 50 epochs, human_segmentation_original.py:91-96).
+    The object installs one float32 device tensor per parameter group (shared by every graph of the optimizer) and, before each
+    replay, copies in whatever the caller has assigned to ``param_group['lr']`` since -- a float or a tensor -- and re-installs the
+    tensor, so the reference's idiom keeps working unchanged.
 Data-parallel runs: ``all_reduce="eager"`` replays forward + loss + backward from the graph and then issues ONE flat RCCL all-reduce
 and the optimizer update from the host (no collective is ever captured: the robust choice, and at 1.85 MB of gradients the lost
 overlap is ~20 us); ``all_reduce=True`` captures the bucketed all-reduce of ``FlatParams`` with the step (the per-block collectives
@@ -45,6 +50,13 @@ class GraphedTrainStep:
             flat.suspend_overlap = True            # backward only ever runs inside the graph: no collective may be launched from it
         self.x = x.detach().clone()
         self.labels = labels.detach().clone()
+        self._lr = []                              # one device tensor per parameter group: what the captured update reads
+        for pg in opt.param_groups:
+            lr = pg["lr"]
+            if not (isinstance(lr, torch.Tensor) and lr.device == dev):
+                lr = torch.tensor(float(lr), dtype=torch.float32, device=dev)
+                pg["lr"] = lr
+            self._lr.append(lr)
         # dropout: constant host part per block + one device word advanced by the graph.  The host part is drawn from torch's CPU
         # generator (so torch.manual_seed governs the masks, as in the eager path, layers._dropout_masks) and mixed with the rank:
         # replicas of a data-parallel job are seeded identically, their masks must not be
@@ -95,8 +107,20 @@ class GraphedTrainStep:
         if self.all_reduce == "eager":
             self.flat.suspend_overlap = False
 
+    def _sync_lr(self):
+        """A learning rate assigned since the capture (``param_group['lr'] = 5e-4``) goes INTO the tensor the graph reads."""
+        for pg, t in zip(self.opt.param_groups, self._lr):
+            cur = pg["lr"]
+            if cur is not t:
+                if isinstance(cur, torch.Tensor):
+                    t.copy_(cur.detach().reshape(()).to(t.dtype), non_blocking=True)
+                else:
+                    t.fill_(float(cur))
+                pg["lr"] = t
+
     def step(self, x: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None):
         """One optimizer step.  Returns the (static) loss tensor of this replay; ``self.preds`` holds the log-probabilities."""
+        self._sync_lr()
         if x is not None:
             self.x.copy_(x, non_blocking=True)
         if labels is not None:
@@ -132,6 +156,9 @@ class GraphedEpoch:
         if ent is not None and (ent[1] is not mb or ent[2] is not gather):     # an id re-used by a new object
             ent = None
         if ent is None:
+            for gs_, _, _ in self._graphs.values():      # (a learning rate assigned since the last step: into the shared tensors first)
+                gs_._sync_lr()
+                break
             if self._pool is None:
                 self._pool = torch.cuda.graph_pool_handle()
             # one eager warm-up step (THIS visit's optimizer step) + the capture

@@ -14,8 +14,12 @@
  *   - dense arrays are row-major contiguous fp32; index arrays int32; masks uint8 (1 = keep);
  *   - `ws` is caller-provided device scratch of at least the size the matching
  *     dn_*_workspace_bytes() reports; contents are undefined on return;
- *   - re-entrant: no mutable global state on the compute path.  Two process-wide pieces of bookkeeping exist: the opt-in timing of
- *     dn_prof_* (off by default) and a per-device "large-LDS attribute set" bitmap per kernel instantiation (set-once, idempotent).
+ *   - re-entrant: the compute path reads no environment variables and writes no global state.  Three process-wide pieces of
+ *     bookkeeping exist: the opt-in timing of dn_prof_* (off by default), a per-device "large-LDS attribute set" bitmap per kernel
+ *     instantiation (set-once, idempotent), and the table of tuning options behind dn_set_option() (kernel selection for A/B runs and
+ *     tests; written only by that call, read by the entry points at call time);
+ *   - every struct below must be ZERO-INITIALISED by the caller before its fields are filled (memset): fields are only ever appended, and
+ *     an appended field's zero value selects the behaviour of the versions before it.  dn_version() identifies the layout generation.
  *
  * A "mesh batch" is a ragged batch of independent meshes whose vertex axes are concatenated:
  * mesh m owns rows [mesh_rows[m].row0, +nrows) of every [v_total, *] array; the sparse gradient
@@ -58,6 +62,9 @@ typedef struct dn_mesh_batch {
      * summed as sum_j |gradX_ij| resp. sum_j |gradY_ij| (the larger of the two row sums): max |gradX x|, |gradY x| <= it * max |x| is
      * the magnitude bound the split-fp16 gradient-feature products scale by (about 3x the true maximum on a mesh).  NULL: measured. */
     const float* grad_norm;
+    /* Optional (round 5): the work plan of the one-launch diffusion operator (dn_diffusion_plan()): device array of df_n_groups * df_n_wg
+     * entries.  NULL / 0: the diffusion runs as three launches (projection, spectral step, back-projection). */
+    const dn_tile_t* df_plan; int32_t df_n_wg, df_n_groups;
 } dn_mesh_batch_t;
 
 /* Weights of one DiffusionNetBlock (layers.py:167-198), nn.Linear layout: W[out][in]. */
@@ -108,14 +115,33 @@ typedef struct dn_block_grads {
     float* d_x_amax;                   /* optional: device float that receives max |d_x| */
 } dn_block_grads_t;
 
-int dn_version(void);
+int dn_version(void);         /* 500: round-5 layout (dn_mesh_batch_t.df_plan ..., dn_set_option) */
 int dn_tile_rows(void);      /* rows per entry of dn_mesh_batch_t.tiles (128) */
 int dn_tn_target_chunks(void);  /* how many entries dn_mesh_batch_t.chunks should have on the current device for the split-V products to fill it in
                                    whole rounds: one workgroup slot per CU (wave-specialised kernel).  Any chunk list is CORRECT; this one is fastest. */
 
+/* ---- tuning options (no reference counterpart): process-wide integers the entry points read at call time, for A/B measurements and for
+ *      tests that must run a particular kernel.  Unknown names return non-zero.  Defaults in parentheses.
+ *        "chain" (1)            chained row kernels of the fused block (0: unfused launches)
+ *        "chain_min_rows" (100000)   smallest batch the TRAINING forward takes the chained kernel for
+ *        "chain_small_rows" (16384)  ... and the largest small batch it takes it for (level in time, four launches fewer per block)
+ *        "chain_nw" (0)         waves per workgroup of the chained kernels (0: chosen by batch size)
+ *        "f16" (1)              split-fp16 matrix engine for the row products of the fused block (0: split-bf16 everywhere)
+ *        "f16_mask" (188)       product classes on the split-fp16 engine (diagnostic bit mask, dn_api.hip)
+ *        "f16_wgrad" (0)        parameter-gradient products on the split-fp16 engine (diagnostic)
+ *        "diffuse" (2)          batches that carry a plan (dn_diffusion_plan), K = C = 128: 2 = the back-projection of the diffusion is the direct
+ *                               row-product launch (dn_diffuse.hip: backproject_kernel); 1 = the whole operator as ONE persistent launch
+ *                               (diffuse_kernel; any number of groups); 0 = the wave-specialised row GEMM of the earlier rounds
+ *        "diffuse_groups" (1)   mesh groups dn_diffusion_plan() deals the batch into when asked for 0 (the direct back-projection needs 1)
+ *        "diffuse_order" (0)    schedule of the one-launch operator (0: interleaved groups, 1: projections first)
+ *        "diffuse_flags" (1)    one-launch kernel: bit 0 = arrivals posted from inside the next projection loop; bits 1, 2 = tests (forced solo path)
+ *        "diffuse_split" (0)    one-launch kernel: bit i = a kernel boundary after schedule step i (measurements) */
+int dn_set_option(const char* name, int value);
+int dn_get_option(const char* name, int* value);
+
 /* ---- opt-in per-kernel timing for benchmarks (no reference counterpart; the one piece of mutable global
  *      state, off by default): every launch is bracketed by hipEvents on its stream and summed per kernel
- *      family kind in [0, 7) (dn_prof_kind_name(kind) is "" past the last one).  read: out[0..3] = {ms, launches, algorithmic flops, algorithmic bytes}. */
+ *      kernel kind in [0, 11) (dn_prof_kind_name(kind) is "" past the last one).  read: out[0..3] = {ms, launches, algorithmic flops, algorithmic bytes}. */
 int dn_prof_enable(int on);
 int dn_prof_reset(void);
 int dn_prof_read(int kind, double* out);
@@ -133,6 +159,15 @@ int dn_from_basis_f32(const dn_mesh_batch_t* mb, const float* spec, int C, int s
 /* ---- LearnedTimeDiffusion.forward, method='spectral' (layers.py:44-67) and its gradient.
  *      fwd: xs = to_basis(x), xd = from_basis(exp(-evals*time) * xs).
  *      bwd: d_x = d_x_add + mass * (evecs (coef * evecs^T d_xd)), d_time[c] = -sum lambda*coef*xs*(evecs^T d_xd). */
+/*      dn_diffuse.hip (direct back-projection launch; one-launch form): taken when mb->df_plan is set, k_eig = C = 128 and every operand is
+ *      16-byte aligned (option "diffuse").
+ *      dn_diffusion_plan_wgs(): workgroups the plan should be made for on the current device (one per CU).
+ *      dn_diffusion_plan(): HOST arithmetic -- sizes[n_mesh] = vertices per mesh in row order; n_groups = 0: the "diffuse_groups" option;
+ *      plan: HOST array of DN_DIFFUSION_MAX_GROUPS * n_wg entries; returns the number of groups used (0: batch not plannable, leave
+ *      df_plan NULL).  The caller uploads plan[0 .. groups * n_wg) and sets df_plan / df_n_wg / df_n_groups. */
+#define DN_DIFFUSION_MAX_GROUPS 4
+int dn_diffusion_plan_wgs(void);
+int dn_diffusion_plan(const int32_t* sizes, int n_mesh, int n_wg, int n_groups, dn_tile_t* plan);
 size_t dn_diffusion_workspace_bytes(const dn_mesh_batch_t* mb, int C);
 int dn_diffusion_fwd_f32(const dn_mesh_batch_t* mb, const float* x, const float* time, int C,
                          float* xs, float* xd, void* ws, size_t ws_bytes, void* stream);

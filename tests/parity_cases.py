@@ -18,8 +18,13 @@ from diffusion_net import ops, synthetic
 from diffusion_net.batch import GatherPattern, MeshBatch
 from oracle import diffusionnet_oracle as orc
 
-FWD_TOL = 1e-5
-GRAD_TOL = 2e-4
+FWD_TOL = 1e-5       # north_star: outputs within 1e-5 relative of the reference
+GRAD_TOL = 2e-5      # gradients, every synthetic-weight case: measured worst 4.2e-6 (profiles/r04_parity_margins.json); the only fallback is the
+                     # fp64 bracket (err_new <= 2 err_ref against the fp64 oracle).  Round 4 had 2e-4 here: a regression of two orders of
+                     # magnitude would have passed.
+GRAD_TOL_CKPT = 2e-4  # floor of the fp64 bracket for the TRAINED-checkpoint goldens only: there the reference's own fp32 gradients sit 0.8-1.2e-4 from fp64
+CKPT_FWD_VS_REF = 3.0e-5   # trained-checkpoint goldens, forward vs the reference's fp32 output: measured 2.12e-5 / 9.2e-6 (+ 25 % head-room and the emulator's
+                           # different MFMA summation order); the reference itself is 1.15e-5 / 1.23e-5 from fp64, this library 1.03e-5 / 6.9e-6
 
 
 def _stack_sparse(items):
@@ -67,10 +72,18 @@ def run_golden(name, device):
                                             keep_masks=None, loss_weights=e64["loss_w"])
         e_new, e_ref = helpers.rel_max(out.detach().cpu().double(), o64), helpers.rel_max(expect["out"].double(), o64)
         assert e_new < max(FWD_TOL, 2 * e_ref), (name, "forward vs fp64", e_new, e_ref)
-        assert err < 4e-5, (name, "forward vs fp32 reference", err)
+        assert err < CKPT_FWD_VS_REF, (name, "forward vs fp32 reference", err)
+        # WHERE the largest forward difference sits: output row (face / vertex), class, and the magnitudes there
+        dflat = (out.detach().cpu() - expect["out"]).abs().reshape(-1, out.shape[-1])
+        wi = int(dflat.argmax())
+        wrow, wcls = wi // dflat.shape[1], wi % dflat.shape[1]
+        where = {"row": wrow, "class": wcls, "reference_value": float(expect["out"].reshape(-1, out.shape[-1])[wrow, wcls]),
+                 "abs_difference": float(dflat[wrow, wcls]), "fp64_value": float(o64.reshape(-1, out.shape[-1])[wrow, wcls]),
+                 "largest_reference_magnitude": float(expect["out"].abs().max())}
         worst = max(((helpers.rel_l2(v.double(), g64[k]) / max(helpers.rel_l2(expect["grads"][k].double(), g64[k]), 1e-12), k) for k, v in got.items()))
         helpers.record_margin("golden_checkpoint_fp64_bracket:" + name, device, fwd_rel_max_new_vs_fp64=e_new, fwd_rel_max_reference_vs_fp64=e_ref,
-                              fwd_rel_max_new_vs_reference=err, worst_gradient_ratio_new_over_reference_vs_fp64=worst[0], worst_gradient=worst[1],
+                              fwd_rel_max_new_vs_reference=err, fwd_largest_difference_at=where, fwd_tol_vs_reference=CKPT_FWD_VS_REF,
+                              worst_gradient_ratio_new_over_reference_vs_fp64=worst[0], worst_gradient=worst[1],
                               gradients_rel_l2_vs_fp64={k: {"new": helpers.rel_l2(v.double(), g64[k]), "reference": helpers.rel_l2(expect["grads"][k].double(), g64[k])}
                                                         for k, v in got.items()})
         if os.environ.get("DN_PARITY_VERBOSE"):
@@ -79,7 +92,7 @@ def run_golden(name, device):
                 print("   %-50s new %.3e  ref %.3e" % (k, helpers.rel_l2(v.double(), g64[k]), helpers.rel_l2(expect["grads"][k].double(), g64[k])))
         for k, v in got.items():
             gn, gr = helpers.rel_l2(v.double(), g64[k]), helpers.rel_l2(expect["grads"][k].double(), g64[k])
-            assert gn < max(GRAD_TOL, 2 * gr), (name, k, gn, gr)
+            assert gn < max(GRAD_TOL_CKPT, 2 * gr), (name, k, gn, gr)
     else:
         assert err < FWD_TOL, (name, "forward", err)
         bad = {k: v for k, v in errs.items() if not v < GRAD_TOL}
@@ -100,17 +113,19 @@ def run_golden(name, device):
 def run_chain_vs_unfused(device, sizes=(300, 140), K=128, C=128, N_block=2, dropout=True, seed=5, with_rot=True, with_grad=True,
                          outputs_at="vertices", fwd_tol=2e-6, grad_tol=2e-5):
     """Same model, same ragged batch, same dropout seed, forward + backward: once with the chained row kernel, once with the unfused
-    launches (DN_CHAIN is read per call).  The two run the same split-fp16 products with different operand scales (per wave tile vs per
+    launches (option "chain", read per call).  The two run the same split-fp16 products with different operand scales (per wave tile vs per
     tensor), so they must agree to rounding level -- far inside the oracle tolerance -- and must NOT be bitwise equal (which would mean the
     chain did not run).  Returns the worst forward / gradient differences."""
     meshes, feats = make_ragged(sizes, K, 3, seed)
     mb = pack(meshes, device, chunk_rows=64)
     got = {}
-    saved_env = {k: os.environ.get(k) for k in ("DN_CHAIN", "DN_CHAIN_MIN_ROWS")}
+    from diffusion_net import _hip
+    saved = {k: _hip.get_option(k) for k in ("chain", "chain_min_rows")}
     try:
-        os.environ["DN_CHAIN_MIN_ROWS"] = "0"
-        for mode in ("chain", "unfused"):
-            os.environ["DN_CHAIN"] = "1" if mode == "chain" else "0"
+        # "mixed" = the SHIPPED dispatch below 100k rows: unfused training forward + chained backward (every single-mesh training loop)
+        for mode in ("chain", "unfused", "mixed"):
+            _hip.set_option("chain", 0 if mode == "unfused" else 1)
+            _hip.set_option("chain_min_rows", 100000 if mode == "mixed" else 0)
             torch.manual_seed(seed)
             model = diffusion_net.layers.DiffusionNet(3, 5, C_width=C, N_block=N_block, outputs_at=outputs_at, dropout=dropout,
                                                       with_gradient_features=with_grad, with_gradient_rotations=with_rot)
@@ -123,11 +138,12 @@ def run_chain_vs_unfused(device, sizes=(300, 140), K=128, C=128, N_block=2, drop
             (out * w).sum().backward()
             got[mode] = (out.detach().cpu(), {"x_in": x.grad.cpu(), **{k: p.grad.cpu() for k, p in model.named_parameters()}})
     finally:
-        for k, v in saved_env.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        for k, v in saved.items():
+            _hip.set_option(k, v)
+    (om, gm), (ou0, gu0) = got["mixed"], got["unfused"]
+    assert torch.equal(om, ou0), "mixed mode: the training forward below chain_min_rows must be the unfused launches bit for bit"
+    bad_m = {k: helpers.rel_l2(gm[k], gu0[k]) for k in gm if not helpers.rel_l2(gm[k], gu0[k]) < grad_tol}
+    assert not bad_m, ("mixed mode (unfused forward + chained backward) vs unfused gradients", bad_m)
     (oc, gc), (ou, gu) = got["chain"], got["unfused"]
     assert not torch.equal(oc, ou), "chained and unfused forward are bitwise equal: the chained kernel did not run"
     e_f = helpers.rel_max(oc, ou)
@@ -138,6 +154,97 @@ def run_chain_vs_unfused(device, sizes=(300, 140), K=128, C=128, N_block=2, drop
     bad = {k: v for k, v in e_g.items() if not v < grad_tol}
     assert not bad, ("chain vs unfused gradients", bad)
     return e_f, max(e_g.values())
+
+
+# ------------------------------------------------------------------------------------------
+# one-launch diffusion operator (dn_diffuse.hip) vs the oracle and vs the three-launch form
+# ------------------------------------------------------------------------------------------
+def run_diffuse_fused(device, sizes=(300, 140, 210), seed=3, configs=((1, 0, 1), (2, 0, 1), (3, 0, 1), (2, 1, 0), (3, 0, 7)), reps=2,
+                      fwd_tol=None, grad_tol=None):
+    """LearnedTimeDiffusion forward + backward at K = C = 128 through ops.DiffusionFn: the persistent one-launch kernel for every
+    (groups, schedule order, flags) in ``configs`` against the fp32 oracle (layers.py:44-67) and against the three-launch form of the same
+    library; flags & 6 force the "solo" recovery path (a workgroup whose poll ran out recomputes its mesh's partial sums itself), which must
+    reproduce the cooperative result BIT FOR BIT.  ``reps`` different inputs go through the SAME workspace addresses (stale-line check of
+    the inter-workgroup hand-offs: a reader that saw the previous repetition's partials would be far outside the tolerance)."""
+    from diffusion_net import _hip
+    fwd_tol = FWD_TOL if fwd_tol is None else fwd_tol
+    grad_tol = GRAD_TOL if grad_tol is None else grad_tol
+    K = C = 128
+    meshes, _ = make_ragged(sizes, K, 3, seed)
+    vt = sum(sizes)
+    offs = [0]
+    for v in sizes:
+        offs.append(offs[-1] + v)
+    per = lambda t: [t[offs[i]:offs[i + 1]] for i in range(len(sizes))]
+    g = torch.Generator().manual_seed(seed)
+    inputs = [(torch.randn(vt, C, generator=g) * (1.0 + r), 0.01 + 0.3 * torch.rand(C, generator=g), torch.randn(vt, C, generator=g)) for r in range(reps)]
+
+    def run(mb, x, time, w):
+        xi = x.clone().to(device).requires_grad_(True)
+        ti = time.clone().to(device).requires_grad_(True)
+        xd = ops.DiffusionFn.apply(xi, ti, mb)
+        (xd * w.to(device)).sum().backward()
+        return xd.detach().cpu(), xi.grad.cpu(), ti.grad.cpu()
+
+    refs = []
+    for x, time, w in inputs:
+        xr, tr = x.clone().requires_grad_(True), time.clone().requires_grad_(True)
+        ref = torch.cat([orc.spectral_diffusion(per(xr)[i][None], m["mass"][None], m["evals"][None], m["evecs"][None], tr)[0]
+                         for i, m in enumerate(meshes)], 0)
+        (ref * w).sum().backward()
+        refs.append((ref.detach(), xr.grad, tr.grad))
+    names = ("diffuse", "diffuse_groups", "diffuse_order", "diffuse_flags", "diffuse_split")
+    saved = {k: _hip.get_option(k) for k in names}
+    worst = {"fwd": 0.0, "d_x": 0.0, "d_t": 0.0, "vs3_fwd": 0.0}
+    try:
+        _hip.set_option("diffuse", 0)
+        mb0 = pack(meshes, device, chunk_rows=64)
+        three = [run(mb0, *inp) for inp in inputs]
+        for (rx, rdx, rdt), (xd, dx, dt) in zip(refs, three):
+            assert helpers.rel_max(xd, rx) < fwd_tol and helpers.rel_l2(dx, rdx) < grad_tol and helpers.rel_l2(dt, rdt) < grad_tol
+        # the shipped form: split-V projection + spectral step + the DIRECT back-projection launch (option "diffuse" = 2, one-group plan)
+        _hip.set_option("diffuse", 2)
+        _hip.set_option("diffuse_groups", 1)
+        mb2 = pack(meshes, device, chunk_rows=64)
+        assert mb2.df_plan is not None and mb2._struct.df_n_groups == 1
+        for r, inp in enumerate(inputs):
+            xd, dx, dt = run(mb2, *inp)
+            rx, rdx, rdt = refs[r]
+            e = (helpers.rel_max(xd, rx), helpers.rel_l2(dx, rdx), helpers.rel_l2(dt, rdt))
+            assert e[0] < fwd_tol and e[1] < grad_tol and e[2] < grad_tol, ("direct back-projection vs oracle", r, e)
+            assert not torch.equal(xd, three[r][0]), "direct and row-GEMM back-projection are bitwise equal: the direct kernel did not run"
+            assert helpers.rel_max(xd, three[r][0]) < 5e-6
+            worst["fwd"], worst["d_x"], worst["d_t"] = max(worst["fwd"], e[0]), max(worst["d_x"], e[1]), max(worst["d_t"], e[2])
+        coop = {}
+        for groups, order, flags in configs:
+            _hip.set_option("diffuse", 1)
+            _hip.set_option("diffuse_groups", groups)
+            _hip.set_option("diffuse_order", order)
+            _hip.set_option("diffuse_flags", flags)
+            mb = pack(meshes, device, chunk_rows=64)
+            assert mb.df_plan is not None and mb._struct.df_n_groups == min(groups, len(sizes)), "no diffusion plan on the batch"
+            for r, inp in enumerate(inputs):
+                xd, dx, dt = run(mb, *inp)
+                rx, rdx, rdt = refs[r]
+                e = (helpers.rel_max(xd, rx), helpers.rel_l2(dx, rdx), helpers.rel_l2(dt, rdt))
+                assert e[0] < fwd_tol and e[1] < grad_tol and e[2] < grad_tol, ("fused diffusion vs oracle", (groups, order, flags), r, e)
+                assert not torch.equal(xd, three[r][0]), "fused and three-launch diffusion are bitwise equal: the fused kernel did not run"
+                e3 = helpers.rel_max(xd, three[r][0])
+                assert e3 < 5e-6, ("fused vs three-launch diffusion", e3)
+                worst = {"fwd": max(worst["fwd"], e[0]), "d_x": max(worst["d_x"], e[1]), "d_t": max(worst["d_t"], e[2]), "vs3_fwd": max(worst["vs3_fwd"], e3)}
+                key = (mb._struct.df_n_groups, r)
+                if flags & 6:      # the solo path: the same bits as the cooperative run of the same plan
+                    if key in coop:
+                        for a, b, what in zip((xd, dx, dt), coop[key], ("x_diffuse", "d_x", "d_time")):
+                            assert torch.equal(a, b), ("solo path differs from the cooperative result", what, (groups, order, flags))
+                else:
+                    coop.setdefault(key, (xd, dx, dt))
+    finally:
+        for k, v in saved.items():
+            _hip.set_option(k, v)
+    helpers.record_margin("diffuse_fused", device, sizes=list(sizes), configs=[list(c) for c in configs], fwd_rel_max=worst["fwd"],
+                          d_x_rel_l2=worst["d_x"], d_time_rel_l2=worst["d_t"], fused_vs_three_launch_fwd=worst["vs3_fwd"])
+    return worst
 
 
 # ------------------------------------------------------------------------------------------
@@ -158,14 +265,27 @@ def pack(meshes, device, with_grad=True, chunk_rows=None):
 
 
 def run_ragged_net(device, sizes=(130, 257, 64), K=24, C=32, C_in=3, C_out=5, N_block=2, outputs_at="vertices",
-                   chunk_rows=None, seed=3, dropout=False, fp64_bracket=False, fwd_tol=FWD_TOL):
+                   chunk_rows=None, seed=3, dropout=False, fp64_bracket=False, fwd_tol=FWD_TOL, mlp_hidden_dims=None, empty_grad_rows=0,
+                   equal_rows=False):
+    """mlp_hidden_dims: MiniMLP hidden widths (layers.py:259-260; default [C, C]: three layers).  empty_grad_rows = n: every n-th vertex
+    loses ALL its gradient-operator entries (CSR rows with no entries).  equal_rows: every vertex carries the same input features (hidden
+    units of all rows coincide: the flip regime of a ReLU net; use with fp64_bracket)."""
     torch.manual_seed(seed)
-    model = diffusion_net.layers.DiffusionNet(C_in, C_out, C_width=C, N_block=N_block, outputs_at=outputs_at, dropout=dropout)
+    model = diffusion_net.layers.DiffusionNet(C_in, C_out, C_width=C, N_block=N_block, outputs_at=outputs_at, dropout=dropout,
+                                              mlp_hidden_dims=mlp_hidden_dims)
     sd = synthetic.randomize_times(model.state_dict(), seed=seed)
     model.load_state_dict(sd)
     params = {k: v.clone() for k, v in model.state_dict().items()}
     model.to(device).train(dropout)
     meshes, feats = make_ragged(sizes, K, C_in, seed)
+    if empty_grad_rows:
+        for m in meshes:
+            for key in ("gradX", "gradY"):
+                gm_ = m[key].coalesce()
+                keep = gm_.indices()[0] % int(empty_grad_rows) != 0
+                m[key] = torch.sparse_coo_tensor(gm_.indices()[:, keep], gm_.values()[keep], gm_.shape).coalesce()
+    if equal_rows:
+        feats = [torch.full_like(f, 0.37) * torch.tensor([1.0, -0.5, 0.25][:C_in] + [1.0] * max(0, C_in - 3)) for f in feats]
     masks = None
     if dropout:   # train mode with injected keep-masks: [block][layer-1] -> [Vtot, C] uint8
         gm = torch.Generator().manual_seed(seed + 7)

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"
 rocminfo 2>/dev/null | grep -m1 gfx > gpurun_out/gpu.txt; nproc >> gpurun_out/gpu.txt
 : > gpurun_out/gpu_tests.log
-for t in test_native_library_is_the_loaded_one test_golden_vectors test_single_ops test_ragged_batches test_train_mode_dropout_masks_headline_width \
+for t in test_native_library_is_the_loaded_one test_golden_vectors test_single_ops test_one_launch_diffusion test_ragged_batches test_train_mode_dropout_masks_headline_width test_chain_probes_against_the_oracle \
          test_rna_like_wide_head test_nll_loss test_fused_head test_torch_compile_packed_forward test_real_mesh_pipeline test_device_packing_and_operator_cache test_autograph_reference_loop test_mismatched_patterns test_bitwise_determinism test_run_to_run_determinism_stress test_hks_and_label_smoothing test_gradient_sinks_accumulate_into_flat_bucket test_rccl_bucketed_all_reduce_world_size_one test_graph_captured_train_step test_graph_captures_the_rccl_gradient_all_reduce test_bench_two_ranks_on_one_gpu_over_gloo test_inkernel_dropout_matches_explicit_masks test_headline_shape_against_fp32_and_fp64_oracle \
          test_large_inference_shape test_size_independent_properties_at_full_size; do
   echo "=== $t" >> gpurun_out/gpu_tests.log

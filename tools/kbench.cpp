@@ -77,20 +77,25 @@ static std::vector<float> host(const float* d, size_t n) { std::vector<float> v(
 
 int main(int argc, char** argv) {
     std::string libpath = "diffusion-net_amd/diffusion_net/libdiffnet_hip.so", ops = "all";
-    int n_mesh = 16, verts = 10000, C = 128, K = 128, reps = 20, chunk_rows = 0;
-    bool check = false, trace = false;
+    int n_mesh = 16, verts = 10000, C = 128, K = 128, reps = 20, chunk_rows = 0, df_groups = 0;
+    bool check = false, trace = false, no_plan = false;
+    std::vector<std::pair<std::string, int>> lib_opts;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto nxt = [&]() { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(1); } return std::string(argv[++i]); };
         if (a == "--lib") libpath = nxt(); else if (a == "--meshes") n_mesh = atoi(nxt().c_str()); else if (a == "--verts") verts = atoi(nxt().c_str());
         else if (a == "--C") C = atoi(nxt().c_str()); else if (a == "--K") K = atoi(nxt().c_str()); else if (a == "--reps") reps = atoi(nxt().c_str());
         else if (a == "--ops") ops = nxt(); else if (a == "--check") check = true; else if (a == "--trace") trace = true; else if (a == "--chunk") chunk_rows = atoi(nxt().c_str());
+        else if (a == "--groups") df_groups = atoi(nxt().c_str()); else if (a == "--no-plan") no_plan = true;
+        else if (a == "--opt") { const std::string kv = nxt(); const size_t eq = kv.find('='); if (eq == std::string::npos) { fprintf(stderr, "--opt name=value\n"); return 1; }
+            lib_opts.push_back({kv.substr(0, eq), atoi(kv.substr(eq + 1).c_str())}); }
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 1; }
     }
     auto want = [&](const char* o) { return ops == "all" || ("," + ops + ",").find(std::string(",") + o + ",") != std::string::npos; };
     Lib L{dlopen(libpath.c_str(), RTLD_NOW | RTLD_LOCAL)};
     if (!L.h) { fprintf(stderr, "dlopen %s: %s\n", libpath.c_str(), dlerror()); return 4; }
     auto tile_rows = L.sym<int (*)()>("dn_tile_rows")();
+    for (auto& kv : lib_opts) if (L.sym<int (*)(const char*, int)>("dn_set_option")(kv.first.c_str(), kv.second)) { fprintf(stderr, "unknown library option %s\n", kv.first.c_str()); return 1; }
 
     // ---- synthetic ragged batch
     std::mt19937 rng(1234);
@@ -142,6 +147,13 @@ int main(int argc, char** argv) {
     mb.mass = dev(mass); mb.evals = dev(evals); mb.evecs = dev(evecs);
     mb.g_rowptr = dev(rowptr); mb.g_col = dev(col); mb.g_vx = dev(vx); mb.g_vy = dev(vy);
     mb.gt_rowptr = dev(t_rowptr); mb.gt_col = dev(t_col); mb.gt_vx = dev(t_vx); mb.gt_vy = dev(t_vy);
+    int df_used = 0;
+    if (!no_plan && K == 128) {   // work plan of the one-launch diffusion operator, as diffusion_net.batch.MeshBatch attaches it
+        const int nwg = L.sym<int (*)()>("dn_diffusion_plan_wgs")();
+        std::vector<dn_tile_t> plan((size_t)DN_DIFFUSION_MAX_GROUPS * nwg);
+        df_used = L.sym<int (*)(const int32_t*, int, int, int, dn_tile_t*)>("dn_diffusion_plan")(sizes.data(), n_mesh, nwg, df_groups, plan.data());
+        if (df_used > 0) { plan.resize((size_t)df_used * nwg); mb.df_plan = dev(plan); mb.df_n_wg = nwg; mb.df_n_groups = df_used; }
+    }
     {   // operand magnitudes for the split-fp16 engine, as diffusion_net.batch.MeshBatch provides them
         float am[2] = {0.f, 0.f};
         for (float v : evecs) am[0] = std::max(am[0], fabsf(v));
@@ -198,7 +210,13 @@ int main(int argc, char** argv) {
     void* ws; HC(hipMalloc(&ws, wsb));
     hipStream_t st; HC(hipStreamCreate(&st));
     hipEvent_t e0, e1; HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
-    printf("# lib=%s V=%lld meshes=%d K=%d C=%d tiles=%d chunks=%d (rows %d) nnz=%lld ws=%.0f MB\n", libpath.c_str(), V, n_mesh, K, C, mb.n_tiles, mb.n_chunks, chunk_rows, nnz, wsb / 1e6);
+    printf("# lib=%s V=%lld meshes=%d K=%d C=%d tiles=%d chunks=%d (rows %d) nnz=%lld ws=%.0f MB diffusion-plan groups=%d wgs=%d\n", libpath.c_str(), V, n_mesh, K, C, mb.n_tiles, mb.n_chunks, chunk_rows, nnz, wsb / 1e6, df_used, mb.df_n_wg);
+    auto df_trace = [&]() {   // libraries built with -DDN_DF_TRACE: s_memtime stamps of the first 16 workgroups of the one-launch diffusion kernel
+        auto rd = (int (*)(unsigned long long*, int))dlsym(L.h, "dn_debug_df_trace_read");
+        if (!rd) return;
+        std::vector<unsigned long long> tb(16 * 32); rd(tb.data(), 16 * 32);
+        for (int w = 0; w < 16; ++w) { printf("  wg %2d:", w); for (int i = 1; i < 24; ++i) printf(" %lld", tb[w * 32 + i] >= tb[w * 32] ? (long long)(tb[w * 32 + i] - tb[w * 32]) : -1ll); printf("\n"); }
+    };
 
     auto timeit = [&](const char* name, double bytes, double flops, auto fn) {
         for (int i = 0; i < 3; ++i) fn(i);
@@ -306,11 +324,37 @@ int main(int argc, char** argv) {
             report(errs, refs); report(err, ref);
         }
         endl_();
+        if (trace) { DC(f(&mb, xr[0], tm, C, sv.xs, o0r[0], ws, wsb, st)); HC(hipStreamSynchronize(st)); df_trace(); }
     }
-    if (want("diffusion_bwd")) {
+    if (want("diffusion_bwd")) {   // needs sv.xs of the forward above (run --ops diffusion,diffusion_bwd for the check)
         auto f = L.sym<int (*)(const dn_mesh_batch_t*, const float*, const float*, const float*, int, const float*, float*, float*, void*, size_t, void*)>("dn_diffusion_bwd_f32");
-        timeit("diffusion_bwd", 3 * VC + 2 * VK, 4.0 * V * K * C, [&](int it) { DC(f(&mb, yr[it % NROT], sv.xs, tm, C, xr[it % NROT], o1r[it % NROT], dt, ws, wsb, st)); });
+        double byts = 0; for (int s : sizes) byts += 4.0 * ((double)s * (3 * C + 2 * K + 1) + 3.0 * K * C + K + C);
+        double us = timeit("diffusion_bwd", byts, 4.0 * V * K * C, [&](int it) { DC(f(&mb, yr[it % NROT], sv.xs, tm, C, xr[it % NROT], o1r[it % NROT], dt, ws, wsb, st)); });
+        printf("  frac_hbm_8TBs %.3f", byts / us / 1e3 / 8000.0);
+        if (check) {   // meshes 0 and last: d_x = add + mass * (Phi (coef * (Phi^T d_xd))) in fp64 on sampled rows; d_time against the fp64 sum over ALL meshes' sampled channels
+            auto got = host(o1r[0], (size_t)V * C), gxs = host(sv.xs, (size_t)n_mesh * K * C), gdt = host(dt, C);
+            double err = 0, ref = 0;
+            std::vector<double> dts(C, 0.0);
+            for (int m = 0; m < n_mesh; ++m) {
+                const bool rows_too = (m == 0 || m == n_mesh - 1);
+                std::vector<double> sp((size_t)K * C, 0.0);
+                for (int r = mrows[m].row0; r < mrows[m].row0 + mrows[m].nrows; ++r)
+                    for (int k = 0; k < K; ++k) { const double w = (double)evecs[(size_t)r * K + k]; const float* yr_ = &hy[(size_t)r * C]; double* sk = &sp[(size_t)k * C];
+                        for (int c = 0; c < C; ++c) sk[c] += w * yr_[c]; }
+                for (int k = 0; k < K; ++k) for (int c = 0; c < C; ++c) { const double lam = evals[(size_t)m * K + k], coef = exp(-lam * htime[c]);
+                    dts[c] += -lam * coef * sp[(size_t)k * C + c] * gxs[((size_t)m * K + k) * C + c]; sp[(size_t)k * C + c] *= coef; }
+                if (!rows_too) continue;
+                for (int i = 0; i < 40; ++i) { const long long r = mrows[m].row0 + (i == 39 ? mrows[m].nrows - 1 : (long long)(i * 997 % mrows[m].nrows));
+                    for (int c = 0; c < C; ++c) { double s2 = 0; for (int k = 0; k < K; ++k) s2 += (double)evecs[(size_t)r * K + k] * sp[(size_t)k * C + c];
+                        s2 = hx[(size_t)r * C + c] + (double)mass[r] * s2;
+                        err = std::max(err, fabs(s2 - got[(size_t)r * C + c])); ref = std::max(ref, fabs(s2)); } }
+            }
+            double errt = 0, reft = 0;
+            for (int c = 0; c < C; ++c) { errt = std::max(errt, fabs(dts[c] - gdt[c])); reft = std::max(reft, fabs(dts[c])); }
+            report(err, ref); report(errt, reft);
+        }
         endl_();
+        if (trace) { DC(f(&mb, yr[0], sv.xs, tm, C, xr[0], o1r[0], dt, ws, wsb, st)); HC(hipStreamSynchronize(st)); df_trace(); }
     }
     if (want("spmm")) {
         auto f = L.sym<int (*)(const dn_mesh_batch_t*, const float*, int, float*, float*, void*)>("dn_grad_apply_fwd_f32");
