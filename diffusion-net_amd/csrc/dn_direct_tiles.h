@@ -175,26 +175,35 @@ __device__ __forceinline__ void rd_unit_body(const RgArgs& g, const unsigned cha
     }
 }
 
-// All 16-row units of the contiguous rows [rs, re) for one wave of an eight-wave workgroup (B planes already staged in sB).
-// Returns this lane's max |stored value|.
-template <int MODE>
-__device__ __forceinline__ float rd_run_rows(const RgArgs& g, const unsigned char* sB, const float* ap, int ald, int rs, int re, int n0,
-                                             int wave, int lane) {
+// All 16-row units of the contiguous rows [rs, re) for one wave of an eight-wave workgroup, in two parts: rd_rows_begin requests the
+// wave's first two units (no dependence on B: a kernel may issue it BEFORE it stages the B planes), rd_rows_run does the rest (B planes
+// staged in sB).  Returns this lane's max |stored value|.
+struct RdStart { float4 A0[8], A1[8]; RdUnit c0, c1; int j, nu; };
+__device__ __forceinline__ void rd_rows_begin(const float* ap, int ald, int rs, int re, int wave, int lane, RdStart& S) {
     const int li = lane & 15, lg = lane >> 4;
-    const int nu = (re - rs + DN_RD_ROWS - 1) / DN_RD_ROWS;
-    int j = wave;
+    S.nu = (re - rs + DN_RD_ROWS - 1) / DN_RD_ROWS;
+    S.j = wave;
+    if (S.j >= S.nu) return;
+    S.c0 = rd_unit(rs, re, S.j);
+    S.c1 = rd_unit(rs, re, S.j + DN_RD_WAVES);
+    const float* p0 = rd_row_ptr(ap, ald, S.c0, li, lg);
+    const float* p1 = rd_row_ptr(ap, ald, S.c1, li, lg);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) S.A0[i] = *reinterpret_cast<const float4*>(p0 + 16 * i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) S.A1[i] = *reinterpret_cast<const float4*>(p1 + 16 * i);
+}
+template <int MODE>
+__device__ __forceinline__ float rd_rows_run(const RgArgs& g, const unsigned char* sB, const float* ap, int ald, int rs, int re, int n0,
+                                             int lane, RdStart& S) {
+    const int li = lane & 15, lg = lane >> 4;
+    const int nu = S.nu;
+    int j = S.j;
     float om = 0.f;
     if (j >= nu) return om;
-    float4 A0[8], A1[8];
-    RdUnit c0 = rd_unit(rs, re, j), c1 = rd_unit(rs, re, j + DN_RD_WAVES);
-    {
-        const float* p0 = rd_row_ptr(ap, ald, c0, li, lg);
-        const float* p1 = rd_row_ptr(ap, ald, c1, li, lg);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) A0[i] = *reinterpret_cast<const float4*>(p0 + 16 * i);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) A1[i] = *reinterpret_cast<const float4*>(p1 + 16 * i);
-    }
+    float4 (&A0)[8] = S.A0;
+    float4 (&A1)[8] = S.A1;
+    RdUnit c0 = S.c0, c1 = S.c1;
     uint4 a[3], F[2][3][2];
     rd_split8(A0[0], A0[1], a[0], a[1], a[2]);
     {
@@ -220,4 +229,11 @@ __device__ __forceinline__ float rd_run_rows(const RgArgs& g, const unsigned cha
         }
     }
     return om;
+}
+template <int MODE>
+__device__ __forceinline__ float rd_run_rows(const RgArgs& g, const unsigned char* sB, const float* ap, int ald, int rs, int re, int n0,
+                                             int wave, int lane) {
+    RdStart S;
+    rd_rows_begin(ap, ald, rs, re, wave, lane, S);
+    return rd_rows_run<MODE>(g, sB, ap, ald, rs, re, n0, lane, S);
 }

@@ -120,12 +120,13 @@ def run_chain_vs_unfused(device, sizes=(300, 140), K=128, C=128, N_block=2, drop
     mb = pack(meshes, device, chunk_rows=64)
     got = {}
     from diffusion_net import _hip
-    saved = {k: _hip.get_option(k) for k in ("chain", "chain_min_rows")}
+    saved = {k: _hip.get_option(k) for k in ("chain", "chain_min_rows", "chain_small_rows")}
     try:
-        # "mixed" = the SHIPPED dispatch below 100k rows: unfused training forward + chained backward (every single-mesh training loop)
+        # "mixed" = the SHIPPED dispatch between chain_small_rows (16k) and chain_min_rows (100k) rows: unfused training forward + chained backward
         for mode in ("chain", "unfused", "mixed"):
             _hip.set_option("chain", 0 if mode == "unfused" else 1)
             _hip.set_option("chain_min_rows", 100000 if mode == "mixed" else 0)
+            _hip.set_option("chain_small_rows", 0 if mode == "mixed" else saved["chain_small_rows"])
             torch.manual_seed(seed)
             model = diffusion_net.layers.DiffusionNet(3, 5, C_width=C, N_block=N_block, outputs_at=outputs_at, dropout=dropout,
                                                       with_gradient_features=with_grad, with_gradient_rotations=with_rot)
@@ -141,7 +142,7 @@ def run_chain_vs_unfused(device, sizes=(300, 140), K=128, C=128, N_block=2, drop
         for k, v in saved.items():
             _hip.set_option(k, v)
     (om, gm), (ou0, gu0) = got["mixed"], got["unfused"]
-    assert torch.equal(om, ou0), "mixed mode: the training forward below chain_min_rows must be the unfused launches bit for bit"
+    assert torch.equal(om, ou0), "mixed mode: the training forward between chain_small_rows and chain_min_rows must be the unfused launches bit for bit"
     bad_m = {k: helpers.rel_l2(gm[k], gu0[k]) for k in gm if not helpers.rel_l2(gm[k], gu0[k]) < grad_tol}
     assert not bad_m, ("mixed mode (unfused forward + chained backward) vs unfused gradients", bad_m)
     (oc, gc), (ou, gu) = got["chain"], got["unfused"]

@@ -67,14 +67,17 @@ def test_train_mode_dropout_masks_headline_width(dev):
 
 
 def test_chain_probes_against_the_oracle(dev):
-    """The chained row kernels against the ORACLE at the shapes the round-4 judge probed by hand (see the emulator tier's twin)."""
+    """The chained row kernels against the ORACLE at the shapes the round-4 judge probed by hand (see the emulator tier's twin).  Judged by the
+    fp64 bracket -- the only fallback of the 2e-5 gradient tolerance: at 2 200 vertices the multi-threaded fp32 CPU oracle is itself 1-2e-4
+    from fp64 on first_lin.weight (measured: 1.8e-4 on the C = 64 case)."""
     import parity_cases
-    parity_cases.run_ragged_net(dev, sizes=(1500, 700), K=128, C=128, N_block=2, mlp_hidden_dims=[128])
-    parity_cases.run_ragged_net(dev, sizes=(1500, 700), K=128, C=128, N_block=2, mlp_hidden_dims=[128, 128, 128])
-    parity_cases.run_ragged_net(dev, sizes=(1500, 700), K=128, C=128, N_block=2, empty_grad_rows=3)
-    parity_cases.run_ragged_net(dev, sizes=(33, 40), K=16, C=128, N_block=2)
-    parity_cases.run_ragged_net(dev, sizes=(1500, 700), K=64, C=64, N_block=2, mlp_hidden_dims=[64])
-    parity_cases.run_ragged_net(dev, sizes=(1500, 700), K=128, C=128, N_block=2, equal_rows=True, fp64_bracket=True)
+    kw = dict(sizes=(1500, 700), N_block=2, fp64_bracket=True)
+    parity_cases.run_ragged_net(dev, K=128, C=128, mlp_hidden_dims=[128], **kw)
+    parity_cases.run_ragged_net(dev, K=128, C=128, mlp_hidden_dims=[128, 128, 128], **kw)
+    parity_cases.run_ragged_net(dev, K=128, C=128, empty_grad_rows=3, **kw)
+    parity_cases.run_ragged_net(dev, sizes=(33, 40), K=16, C=128, N_block=2, fp64_bracket=True)
+    parity_cases.run_ragged_net(dev, K=64, C=64, mlp_hidden_dims=[64], **kw)
+    parity_cases.run_ragged_net(dev, K=128, C=128, equal_rows=True, **kw)
 
 
 def test_rna_like_wide_head(dev):
