@@ -239,7 +239,9 @@ def test_graph_captured_train_step(dev):
         model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=4))
         model.to(dev).train()
         flat = FlatParams(model)
-        opt = torch.optim.Adam([flat.master], lr=1e-3, capturable=True)
+        # (the graphs keep the learning rate in a float32 DEVICE tensor -- graphs.py -- so the eager arm gets the same tensor: a Python float is a
+        # double and rounds the update differently from the fourth step on)
+        opt = torch.optim.Adam([flat.master], lr=(1e-3 if mode == "graph" else torch.tensor(1e-3, dtype=torch.float32, device=dev)), capturable=True)
         losses = []
         if mode == "graph":
             gs = GraphedTrainStep(model, flat, opt, mb, gather, x, labels, warmup=1)   # one eager update (creates the Adam state), then capture
@@ -360,7 +362,7 @@ def test_graph_captures_the_rccl_gradient_all_reduce(dev):
             model.to(dev).train()
             flat = FlatParams(model)
             flat._force_collectives = True
-            opt = torch.optim.Adam([flat.master], lr=1e-3, capturable=True)
+            opt = torch.optim.Adam([flat.master], lr=(torch.tensor(1e-3, dtype=torch.float32, device=dev) if mode == "eager" else 1e-3), capturable=True)
             losses = []
             if mode != "eager":   # the collectives captured with the step, or one flat all-reduce + the update issued after the replay
                 gs = GraphedTrainStep(model, flat, opt, mb, gather, x, labels, warmup=1, all_reduce=True if mode == "graph" else "eager")

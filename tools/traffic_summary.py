@@ -25,8 +25,16 @@ def family(name):
     m = re.match(r"void rowgemm_kernel<\d+, \d+, \d+, (\d)", name)
     if m:
         return "rowgemm_kernel<*,%s>" % m.group(1)
-    if "tngemm_kernel" in name or "tngemm_x3_kernel" in name or "tngemm_da_kernel" in name:
+    if "tngemm_x3_multi_kernel" in name:           # (one key per kernel since round 5: bench.py's brackets are per kernel)
+        return "tngemm_x3_multi_kernel"
+    if "tngemm_da_kernel" in name:
+        return "tngemm_da_kernel"
+    if "tngemm_kernel" in name or "tngemm_x3_kernel" in name:
         return "tngemm_kernel"
+    if "backproject_kernel" in name:
+        return "backproject_kernel"
+    if "diffuse_kernel" in name:
+        return "diffuse_kernel"
     if "spmm_kernel" in name:
         return "spmm_kernel"
     if "chain_fwd_kernel" in name:
