@@ -42,6 +42,9 @@
 #if defined(DN_DF_TRACE) && !defined(DN_EMULATE)   // development build only: s_memtime stamps of the first 16 workgroups (thread 0)
 __device__ unsigned long long dn_df_trace_buf[16 * 32];
 extern "C" int dn_debug_df_trace_read(unsigned long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dn_df_trace_buf), sizeof(unsigned long long) * n); }
+__device__ unsigned long long dn_df_wg_times[512 * 2];   // s_memrealtime (100 MHz, chip-wide) at the start / end of every workgroup of backproject_kernel
+extern "C" int dn_debug_df_wg_times_read(unsigned long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dn_df_wg_times), sizeof(unsigned long long) * n); }
+#define DF_WG(i_) do { if (threadIdx.x == 0 && blockIdx.x < 512) dn_df_wg_times[blockIdx.x * 2 + (i_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define DF_T(i_)                                                                                                  \
     do {                                                                                                          \
         const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                               \
@@ -49,6 +52,7 @@ extern "C" int dn_debug_df_trace_read(unsigned long long* out, int n) { return (
     } while (0)
 #else
 #define DF_T(i_) do {} while (0)
+#define DF_WG(i_) do {} while (0)
 #endif
 
 struct DfArgs {
@@ -366,6 +370,7 @@ __global__ __launch_bounds__(DN_TX_THREADS) DN_WAVES_PER_EU(2) void backproject_
     const DnTile me = a.plan[blockIdx.x];
     float om = 0.f;
     DF_T(0);
+    DF_WG(0);
     if (me.mesh >= 0 && me.nrows > 0) {
         // the wave's first two 16-row units of Phi are requested BEFORE the planes are staged (they do not depend on them): 98.3 vs 100.1 us
         // for the forward operator, 115.7 vs 116.7 backward (profiles/r05_backproject_ab.txt; streaming stores / loads measured too: slower)
@@ -379,6 +384,8 @@ __global__ __launch_bounds__(DN_TX_THREADS) DN_WAVES_PER_EU(2) void backproject_
         rg.scale = 1.f;
         om = rd_rows_run<MODE>(rg, smem, a.evecs, K, me.row0, me.row0 + me.nrows, 0, lane, st);
         DF_T(2);
+        __syncthreads();
+        DF_WG(1);
     }
     if (a.out_amax) {      // one check-first atomic per workgroup
 #pragma unroll

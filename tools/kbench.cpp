@@ -211,6 +211,19 @@ int main(int argc, char** argv) {
     hipStream_t st; HC(hipStreamCreate(&st));
     hipEvent_t e0, e1; HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
     printf("# lib=%s V=%lld meshes=%d K=%d C=%d tiles=%d chunks=%d (rows %d) nnz=%lld ws=%.0f MB diffusion-plan groups=%d wgs=%d\n", libpath.c_str(), V, n_mesh, K, C, mb.n_tiles, mb.n_chunks, chunk_rows, nnz, wsb / 1e6, df_used, mb.df_n_wg);
+    auto df_wg_times = [&]() {   // -DDN_DF_TRACE builds: when did every workgroup of the last backproject_kernel start / end (10 ns ticks, chip-wide clock)
+        auto rd = (int (*)(unsigned long long*, int))dlsym(L.h, "dn_debug_df_wg_times_read");
+        if (!rd) return;
+        std::vector<unsigned long long> tb(512 * 2); rd(tb.data(), 512 * 2);
+        const int n = mb.df_n_wg; unsigned long long t0 = ~0ull;
+        for (int w = 0; w < n; ++w) if (tb[2 * w]) t0 = std::min(t0, tb[2 * w]);
+        std::vector<double> st, en, life;
+        for (int w = 0; w < n; ++w) if (tb[2 * w] && tb[2 * w + 1] >= tb[2 * w]) { st.push_back((tb[2 * w] - t0) * 0.01); en.push_back((tb[2 * w + 1] - t0) * 0.01); life.push_back((tb[2 * w + 1] - tb[2 * w]) * 0.01); }
+        if (st.empty()) return;
+        auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
+        printf("  backproject workgroups (us from the first start): start min/median/max %.2f %.2f %.2f | end min/median/max %.2f %.2f %.2f | lifetime min/median/max %.2f %.2f %.2f\n",
+               pct(st, 0), pct(st, .5), pct(st, 1), pct(en, 0), pct(en, .5), pct(en, 1), pct(life, 0), pct(life, .5), pct(life, 1));
+    };
     auto df_trace = [&]() {   // libraries built with -DDN_DF_TRACE: s_memtime stamps of the first 16 workgroups of the one-launch diffusion kernel
         auto rd = (int (*)(unsigned long long*, int))dlsym(L.h, "dn_debug_df_trace_read");
         if (!rd) return;
@@ -324,7 +337,7 @@ int main(int argc, char** argv) {
             report(errs, refs); report(err, ref);
         }
         endl_();
-        if (trace) { DC(f(&mb, xr[0], tm, C, sv.xs, o0r[0], ws, wsb, st)); HC(hipStreamSynchronize(st)); df_trace(); }
+        if (trace) { DC(f(&mb, xr[0], tm, C, sv.xs, o0r[0], ws, wsb, st)); HC(hipStreamSynchronize(st)); df_trace(); df_wg_times(); }
     }
     if (want("diffusion_bwd")) {   // needs sv.xs of the forward above (run --ops diffusion,diffusion_bwd for the check)
         auto f = L.sym<int (*)(const dn_mesh_batch_t*, const float*, const float*, const float*, int, const float*, float*, float*, void*, size_t, void*)>("dn_diffusion_bwd_f32");
