@@ -133,8 +133,9 @@ int to_basis_partials(const dn_mesh_batch_t* mb, const float* x, int C, bool use
 }
 int from_basis(const dn_mesh_batch_t* mb, const float* spec, int C, float* out, const float* add, bool mass_epi, hipStream_t st,
                const F16& f = F16()) {
-    if (bp_ok(mb, C) && al16(spec) && al16(out) && al16(add) && al16(mb->evecs))       // direct row product (3-term engine whatever f asks for)
-        return dn_launch_backproject(T(mb->df_plan), mb->df_n_wg, mb->evecs, spec, out, add, mass_epi ? mb->mass : nullptr, f.o, mb->v_total, st);
+    if (bp_ok(mb, C) && al16(spec) && al16(out) && al16(add) && al16(mb->evecs))       // direct row product, on the engine f asks for
+        return dn_launch_backproject(T(mb->df_plan), mb->df_n_wg, mb->evecs, spec, out, add, mass_epi ? mb->mass : nullptr, f.o, mb->v_total, st,
+                                     f.on ? 1 : 0, &f.a, &f.b);
     RgArgs g = rg_new(mb);
     rg_f16(g, f);
     rg_seg(g, mb->evecs, nullptr, mb->k_eig, mb->k_eig);

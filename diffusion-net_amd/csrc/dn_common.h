@@ -571,7 +571,7 @@ int dn_diffuse_schedule(int G, int order, int* sched);
 int dn_diffuse_plan_host(const int* sizes, int n_mesh, int n_wg, int n_groups, DnTile* plan);
 int dn_launch_diffuse(const DfLaunch& L, hipStream_t stream);
 int dn_launch_backproject(const DnTile* plan, int n_wg, const float* evecs, const float* ys, float* out, const float* add, const float* mass,
-                          float* out_amax, double acct_rows, hipStream_t stream);
+                          float* out_amax, double acct_rows, hipStream_t stream, int f16 = 0, const DnAmax* a_amax = nullptr, const DnAmax* b_amax = nullptr);
 int dn_opt_chain_nw(void);   // option "chain_nw" (dn_api.hip): development override of the chained kernels' workgroup width
 
 // ---------------------------------------------------------------------------------------

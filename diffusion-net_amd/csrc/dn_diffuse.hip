@@ -321,8 +321,8 @@ __global__ __launch_bounds__(DN_TX_THREADS) DN_WAVES_PER_EU(2) void diffuse_kern
                 __syncthreads();
                 ysrc = S;
             }
-            if (have) rd_stage_b_nn<DN_TX_THREADS, true>(ysrc, C, smem, tid);
-            else rd_stage_b_nn<DN_TX_THREADS, false>(ysrc, C, smem, tid);
+            if (have) rd_stage_b_nn<DN_TX_THREADS, true, 3>(ysrc, C, smem, tid);
+            else rd_stage_b_nn<DN_TX_THREADS, false, 3>(ysrc, C, smem, tid);
             __syncthreads();
             RgArgs rg;
             rg.o0 = a.out; rg.ldo = C; rg.ldr = C; rg.N = C; rg.r0 = a.add; rg.rowv = a.rowv; rg.bias = nullptr; rg.mask = nullptr; rg.rng_seed = 0ull;
@@ -359,8 +359,12 @@ __global__ __launch_bounds__(DN_TX_THREADS) DN_WAVES_PER_EU(2) void diffuse_kern
 struct BpArgs {
     const DnTile* plan; int n_wg;
     const float* evecs; const float* ys; float* out; const float* add; const float* rowv; float* out_amax;
+    DnAmax a_amax, b_amax;       // NP = 2 (split-fp16 engine): magnitude bounds of Phi and of the spectrum (power-of-two operand scales)
 };
-template <int MODE>
+// NP = 3: 3-term split-bf16 (the forward: its output is what the gradient operators difference); NP = 2: 2-term split-fp16 with
+// power-of-two operand scales from the producers' magnitude words (the backward of the fused block, as in rounds 3-4): half the MFMAs,
+// 6 instead of 11 split instructions per operand pair, 64 instead of 96 KiB of planes.
+template <int MODE, int NP>
 __global__ __launch_bounds__(DN_TX_THREADS) DN_WAVES_PER_EU(2) void backproject_kernel(BpArgs a) {
     constexpr int K = 128, C = 128;
     DN_DYN_SMEM(smem_raw);
@@ -369,6 +373,12 @@ __global__ __launch_bounds__(DN_TX_THREADS) DN_WAVES_PER_EU(2) void backproject_
     const int tid = threadIdx.x, lane = tid & 63, wave = DN_UNIFORM(tid >> 6);
     const DnTile me = a.plan[blockIdx.x];
     float om = 0.f;
+    float sa = 1.f, sb = 1.f, so = 1.f;
+    if constexpr (NP == 2) {
+        sa = dn_pow2_scale(dn_amax_eval(a.a_amax));
+        sb = dn_pow2_scale(dn_amax_eval(a.b_amax));
+        so = (1.f / sa) * (1.f / sb);
+    }
     DF_T(0);
     DF_WG(0);
     if (me.mesh >= 0 && me.nrows > 0) {
@@ -376,13 +386,13 @@ __global__ __launch_bounds__(DN_TX_THREADS) DN_WAVES_PER_EU(2) void backproject_
         // for the forward operator, 115.7 vs 116.7 backward (profiles/r05_backproject_ab.txt; streaming stores / loads measured too: slower)
         RdStart st;
         rd_rows_begin(a.evecs, K, me.row0, me.row0 + me.nrows, wave, lane, st);
-        rd_stage_b_nn<DN_TX_THREADS, false>(a.ys + (long long)me.mesh * K * C, C, smem, tid);
+        rd_stage_b_nn<DN_TX_THREADS, false, NP>(a.ys + (long long)me.mesh * K * C, C, smem, tid, sb);
         __syncthreads();
         DF_T(1);
         RgArgs rg;
         rg.o0 = a.out; rg.ldo = C; rg.ldr = C; rg.N = C; rg.r0 = a.add; rg.rowv = a.rowv; rg.bias = nullptr; rg.mask = nullptr; rg.rng_seed = 0ull;
         rg.scale = 1.f;
-        om = rd_rows_run<MODE>(rg, smem, a.evecs, K, me.row0, me.row0 + me.nrows, 0, lane, st);
+        om = rd_rows_run<MODE, NP>(rg, smem, a.evecs, K, me.row0, me.row0 + me.nrows, 0, lane, st, sa, so);
         DF_T(2);
         __syncthreads();
         DF_WG(1);
@@ -400,24 +410,28 @@ __global__ __launch_bounds__(DN_TX_THREADS) DN_WAVES_PER_EU(2) void backproject_
         }
     }
 }
-template <int MODE>
+template <int MODE, int NP>
 static int bp_launch(const BpArgs& a, hipStream_t stream) {
     const size_t smem = (size_t)DN_RD_LDS_B + 64;
 #ifndef DN_EMULATE
     static unsigned long long lds_opt_in = 0;
-    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&backproject_kernel<MODE>), smem, &lds_opt_in); if (oe_) return oe_; }
+    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&backproject_kernel<MODE, NP>), smem, &lds_opt_in); if (oe_) return oe_; }
 #endif
-    DN_LAUNCH(backproject_kernel<MODE>, dim3(a.n_wg, 1, 1), dim3(DN_TX_THREADS, 1, 1), smem, stream, a);
+    DN_LAUNCH((backproject_kernel<MODE, NP>), dim3(a.n_wg, 1, 1), dim3(DN_TX_THREADS, 1, 1), smem, stream, a);
     return (int)hipGetLastError();
 }
 // out = evecs ys (mass == null) or add + mass * (evecs ys); plan: the FIRST group of a dn_diffuse_plan_host() plan made with ONE group
+// f16: run on the split-fp16 engine with operand magnitudes a_amax (Phi) / b_amax (the spectrum)
 int dn_launch_backproject(const DnTile* plan, int n_wg, const float* evecs, const float* ys, float* out, const float* add, const float* mass,
-                          float* out_amax, double acct_rows, hipStream_t stream) {
-    if (!plan || n_wg <= 0) return DN_ERR_BAD_MODE;
+                          float* out_amax, double acct_rows, hipStream_t stream, int f16, const DnAmax* a_amax, const DnAmax* b_amax) {
+    if (!plan || n_wg <= 0 || (f16 && (!a_amax || !b_amax))) return DN_ERR_BAD_MODE;
     BpArgs a;
+    memset(&a, 0, sizeof(a));
     a.plan = plan; a.n_wg = n_wg; a.evecs = evecs; a.ys = ys; a.out = out; a.add = add; a.rowv = mass; a.out_amax = out_amax;
+    if (f16) { a.a_amax = *a_amax; a.b_amax = *b_amax; }
     dn_prof_begin(DN_K_BACKPROJECT, stream);
-    const int err = mass ? bp_launch<DN_EPI_MASS_ADD>(a, stream) : bp_launch<DN_EPI_STORE>(a, stream);
+    const int err = f16 ? (mass ? bp_launch<DN_EPI_MASS_ADD, 2>(a, stream) : bp_launch<DN_EPI_STORE, 2>(a, stream))
+                        : (mass ? bp_launch<DN_EPI_MASS_ADD, 3>(a, stream) : bp_launch<DN_EPI_STORE, 3>(a, stream));
     dn_prof_end(DN_K_BACKPROJECT, stream, 2.0 * acct_rows * 128 * 128, 4.0 * acct_rows * ((mass ? (add ? 3 : 2) : 2) * 128.0 + (mass ? 1 : 0)));
     return err;
 }

@@ -27,6 +27,15 @@ __device__ __forceinline__ f32x4 dn_mfma_bf16_16(uint4 a, uint4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dn_bf16x8, a), __builtin_bit_cast(dn_bf16x8, b), c, 0, 0, 0);
 #endif
 }
+// the same step on fp16 operands (2-term split-fp16 engine)
+__device__ __forceinline__ f32x4 dn_mfma_f16_16(uint4 a, uint4 b, f32x4 c) {
+#ifdef DN_EMULATE
+    return dnemu_mfma_f32_16x16x32_f16(a, b, c);
+#else
+    typedef _Float16 dn_f16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dn_f16x8, a), __builtin_bit_cast(dn_f16x8, b), c, 0, 0, 0);
+#endif
+}
 #ifdef DN_EMULATE
 #define DN_SCHED_FENCE() do {} while (0)
 #define DN_UNIFORM(x) (x)
@@ -35,11 +44,16 @@ __device__ __forceinline__ f32x4 dn_mfma_bf16_16(uint4 a, uint4 b, f32x4 c) {
 #define DN_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)   // wave-uniform value the compiler cannot prove uniform -> SGPR
 #endif
 
-__device__ __forceinline__ void rd_split8(const float4& u, const float4& v, uint4& hi, uint4& mid, uint4& lo) {
-    dn_split3_pair(u.x, u.y, hi.x, mid.x, lo.x);
-    dn_split3_pair(u.z, u.w, hi.y, mid.y, lo.y);
-    dn_split3_pair(v.x, v.y, hi.z, mid.z, lo.z);
-    dn_split3_pair(v.z, v.w, hi.w, mid.w, lo.w);
+// eight consecutive-k values -> NP planes of eight 16-bit terms each.  NP = 3: bf16 (hi, mid, lo), sc ignored; NP = 2: fp16 (hi, lo) of v * sc
+template <int NP>
+__device__ __forceinline__ void rd_split8(const float4& u, const float4& v, uint4 (&pl)[NP], float sc) {
+    unsigned w[4][NP];
+    dn_split_pair<NP>(u.x, u.y, sc, w[0]);
+    dn_split_pair<NP>(u.z, u.w, sc, w[1]);
+    dn_split_pair<NP>(v.x, v.y, sc, w[2]);
+    dn_split_pair<NP>(v.z, v.w, sc, w[3]);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) pl[p] = make_uint4(w[0][p], w[1][p], w[2][p], w[3][p]);
 }
 // first physical k of slot group h (0: slots 0-3, 1: slots 4-7) of lane group lg (0..3) in k32 step s
 __device__ __forceinline__ int rd_k0(int s, int lg, int h) { return 32 * s + 16 * h + 4 * lg; }
@@ -47,8 +61,8 @@ __device__ __forceinline__ int rd_k0(int s, int lg, int h) { return 32 * s + 16 
 // Split a 128 x 128 operand B[k][n] (row-major, n contiguous, leading dimension ldb) into the fragment-ordered planes: a thread
 // fetches an 8 (k) x 4 (n) block as eight float4 along n -- the eight k of four items (four consecutive lanes).  NTHR threads.
 // COH: B was written by other workgroups of the SAME launch (write-through stores): L1-bypassing loads.
-template <int NTHR, bool COH = false>
-__device__ __forceinline__ void rd_stage_b_nn(const float* bp, int ldb, unsigned char* sB, int tid) {
+template <int NTHR, bool COH = false, int NP = 3>
+__device__ __forceinline__ void rd_stage_b_nn(const float* bp, int ldb, unsigned char* sB, int tid, float sc = 1.f) {
 #pragma unroll
     for (int h = 0; h < 512 / NTHR; ++h) {                     // 4 steps x 4 lane groups x 32 column quads = 512 blocks
         const int b = tid + NTHR * h;
@@ -67,13 +81,12 @@ __device__ __forceinline__ void rd_stage_b_nn(const float* bp, int ldb, unsigned
         for (int c = 0; c < 4; ++c) {
             const float4 u = make_float4(dn_f4_get(r[0], c), dn_f4_get(r[1], c), dn_f4_get(r[2], c), dn_f4_get(r[3], c));
             const float4 v = make_float4(dn_f4_get(r[4], c), dn_f4_get(r[5], c), dn_f4_get(r[6], c), dn_f4_get(r[7], c));
-            uint4 hi, mid, lo;
-            rd_split8(u, v, hi, mid, lo);
+            uint4 pl[NP];
+            rd_split8<NP>(u, v, pl, sc);
             const int lane = 16 * lg + ((4 * nq + c) & 15);
-            unsigned char* dst = sB + (((s * 8 + t) * 3) * 64 + lane) * 16;
-            *reinterpret_cast<uint4*>(dst) = hi;
-            *reinterpret_cast<uint4*>(dst + 1024) = mid;
-            *reinterpret_cast<uint4*>(dst + 2048) = lo;
+            unsigned char* dst = sB + (((s * 8 + t) * NP) * 64 + lane) * 16;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<uint4*>(dst + 1024 * p) = pl[p];
         }
     }
 }
@@ -93,20 +106,21 @@ __device__ __forceinline__ const float* rd_row_ptr(const float* ap, int ald, con
     return ap + (long long)(un.row0 + (li < un.nrows ? li : 0)) * ald + 4 * lg;
 }
 // B fragments of plane p of group G = 4 s + pr of a unit (k32 step s, column tiles 2 pr and 2 pr + 1): two ds_read_b128
-__device__ __forceinline__ void rd_read_plane(const unsigned char* sB, int lane, int G, int p, uint4 (&F)[3][2]) {
+template <int NP>
+__device__ __forceinline__ void rd_read_plane(const unsigned char* sB, int lane, int G, int p, uint4 (&F)[NP][2]) {
     const int s = (G & 15) >> 2, pr = G & 3;
 #pragma unroll
     for (int e = 0; e < 2; ++e)
-        F[p][e] = *reinterpret_cast<const uint4*>(sB + (((s * 8 + 2 * pr + e) * 3 + p) * 64 + lane) * 16);
+        F[p][e] = *reinterpret_cast<const uint4*>(sB + (((s * 8 + 2 * pr + e) * NP + p) * 64 + lane) * 16);
 }
 
 // One unit.  MODE: DN_EPI_STORE (out = acc) or DN_EPI_MASS_ADD (out = r0 + rowv[row] * acc, r0 optional) through pt_piece_store.
 // X: this unit's A registers, Y: the next unit's (their first pair is split here, for the next call); np_x / np_y: this lane's row of
 // the units two ahead of X's / Y's owner.  `a`: planes of the current k32 step (carried across units), F: the B-fragment ring.
-template <int MODE>
+template <int MODE, int NP>
 __device__ __forceinline__ void rd_unit_body(const RgArgs& g, const unsigned char* sB, const RdUnit& cur, const float* np_x,
-                                             const float* np_y, int n0, int lane, float4 (&X)[8], float4 (&Y)[8], uint4 (&a)[3],
-                                             uint4 (&F)[2][3][2], float& om) {
+                                             const float* np_y, int n0, int lane, float4 (&X)[8], float4 (&Y)[8], uint4 (&a)[NP],
+                                             uint4 (&F)[2][NP][2], float sa, float so, float& om) {
     const int li = lane & 15, lg = lane >> 4;
     // auxiliary operands of the epilogue: requested first (vmcnt is an in-order counter: waiting for them later must not drain the
     // prefetch loads issued during the MFMA steps)
@@ -128,28 +142,32 @@ __device__ __forceinline__ void rd_unit_body(const RgArgs& g, const unsigned cha
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
     DN_SCHED_FENCE();
+    // (A plane, B plane) per product, smallest terms first.  NP = 3: B's lo (2) is used by product 0 only, mid (1) by 1-2, hi (0) by 3-5;
+    // NP = 2 (split-fp16): hi*lo, lo*hi, hi*hi -- B's lo (1) by product 0, hi (0) by 1-2.  A plane's registers are refilled right after its last use.
+    constexpr int NPROD = NP == 3 ? 6 : 3;
+    constexpr int PA[6] = {0, 1, NP == 3 ? 0 : 0, 2, 1, 0}, PB[6] = {NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, NP == 3 ? 1 : 0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        uint4 an[3];
+        uint4 an[NP];
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr) {
             const int G = 4 * s + pr;
-            uint4 (&Fg)[3][2] = F[G & 1];
-            // (A plane, B plane) per product; B's lo (2) is used by product 0 only, mid (1) by 1-2, hi (0) by 3-5
-            constexpr int PA[6] = {0, 1, 0, 2, 1, 0}, PB[6] = {2, 1, 1, 0, 0, 0};
+            uint4 (&Fg)[NP][2] = F[G & 1];
 #define RD_MMA(p_)                                                                                                      \
-    _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                                       \
-        acc[2 * pr + e] = dn_mfma_bf16_16(Fg[PB[p_]][e], a[PA[p_]], acc[2 * pr + e]);   /* operands swapped: D[n][row] */
+    _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                                     \
+        if constexpr (NP == 3) acc[2 * pr + e] = dn_mfma_bf16_16(Fg[PB[p_]][e], a[PA[p_]], acc[2 * pr + e]);            \
+        else acc[2 * pr + e] = dn_mfma_f16_16(Fg[PB[p_]][e], a[PA[p_]], acc[2 * pr + e]);   /* operands swapped: D[n][row] */ \
+    }
             RD_MMA(0)
             DN_SCHED_FENCE();
-            rd_read_plane(sB, lane, G + 2, 2, Fg);
+            rd_read_plane<NP>(sB, lane, G + 2, NP - 1, Fg);
             if (pr == 2) {                                     // next step's planes, and the consumed registers' refill
                 if (s < 3) {
-                    rd_split8(X[2 * s + 2], X[2 * s + 3], an[0], an[1], an[2]);
+                    rd_split8<NP>(X[2 * s + 2], X[2 * s + 3], an, sa);
                     X[2 * s + 2] = *reinterpret_cast<const float4*>(np_x + 32 * (s + 1));
                     X[2 * s + 3] = *reinterpret_cast<const float4*>(np_x + 32 * (s + 1) + 16);
                 } else {
-                    rd_split8(Y[0], Y[1], an[0], an[1], an[2]);
+                    rd_split8<NP>(Y[0], Y[1], an, sa);
                     Y[0] = *reinterpret_cast<const float4*>(np_y);
                     Y[1] = *reinterpret_cast<const float4*>(np_y + 16);
                 }
@@ -157,20 +175,24 @@ __device__ __forceinline__ void rd_unit_body(const RgArgs& g, const unsigned cha
             RD_MMA(1)
             RD_MMA(2)
             DN_SCHED_FENCE();
-            rd_read_plane(sB, lane, G + 2, 1, Fg);
-            RD_MMA(3)
-            RD_MMA(4)
-            RD_MMA(5)
-            DN_SCHED_FENCE();
-            rd_read_plane(sB, lane, G + 2, 0, Fg);
+            if constexpr (NP == 3) {
+                rd_read_plane<NP>(sB, lane, G + 2, 1, Fg);
+                RD_MMA(3)
+                RD_MMA(4)
+                RD_MMA(5)
+                DN_SCHED_FENCE();
+            }
+            rd_read_plane<NP>(sB, lane, G + 2, 0, Fg);
 #undef RD_MMA
         }
 #pragma unroll
-        for (int p = 0; p < 3; ++p) a[p] = an[p];
+        for (int p = 0; p < NP; ++p) a[p] = an[p];
     }
+    (void)NPROD;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         P[t].v = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        if (NP == 2) P[t].v = dn_f4_scale(P[t].v, so);                 // exact power-of-two rescale of the split-fp16 product
         om = dn_f4_amax(om, pt_piece_store<MODE, false>(g, P[t]));     // om: running max |stored value| of this lane
     }
 }
@@ -193,9 +215,9 @@ __device__ __forceinline__ void rd_rows_begin(const float* ap, int ald, int rs, 
 #pragma unroll
     for (int i = 0; i < 8; ++i) S.A1[i] = *reinterpret_cast<const float4*>(p1 + 16 * i);
 }
-template <int MODE>
+template <int MODE, int NP = 3>
 __device__ __forceinline__ float rd_rows_run(const RgArgs& g, const unsigned char* sB, const float* ap, int ald, int rs, int re, int n0,
-                                             int lane, RdStart& S) {
+                                             int lane, RdStart& S, float sa = 1.f, float so = 1.f) {
     const int li = lane & 15, lg = lane >> 4;
     const int nu = S.nu;
     int j = S.j;
@@ -204,27 +226,27 @@ __device__ __forceinline__ float rd_rows_run(const RgArgs& g, const unsigned cha
     float4 (&A0)[8] = S.A0;
     float4 (&A1)[8] = S.A1;
     RdUnit c0 = S.c0, c1 = S.c1;
-    uint4 a[3], F[2][3][2];
-    rd_split8(A0[0], A0[1], a[0], a[1], a[2]);
+    uint4 a[NP], F[2][NP][2];
+    rd_split8<NP>(A0[0], A0[1], a, sa);
     {
         const float* p2 = rd_row_ptr(ap, ald, rd_unit(rs, re, j + 2 * DN_RD_WAVES), li, lg);
         A0[0] = *reinterpret_cast<const float4*>(p2);
         A0[1] = *reinterpret_cast<const float4*>(p2 + 16);
     }
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        rd_read_plane(sB, lane, 0, p, F[0]);
-        rd_read_plane(sB, lane, 1, p, F[1]);
+    for (int p = 0; p < NP; ++p) {
+        rd_read_plane<NP>(sB, lane, 0, p, F[0]);
+        rd_read_plane<NP>(sB, lane, 1, p, F[1]);
     }
     for (; j < nu; j += 2 * DN_RD_WAVES) {
         {
             const RdUnit n2 = rd_unit(rs, re, j + 2 * DN_RD_WAVES), n3 = rd_unit(rs, re, j + 3 * DN_RD_WAVES);
-            rd_unit_body<MODE>(g, sB, c0, rd_row_ptr(ap, ald, n2, li, lg), rd_row_ptr(ap, ald, n3, li, lg), n0, lane, A0, A1, a, F, om);
+            rd_unit_body<MODE, NP>(g, sB, c0, rd_row_ptr(ap, ald, n2, li, lg), rd_row_ptr(ap, ald, n3, li, lg), n0, lane, A0, A1, a, F, sa, so, om);
             c0 = n2;
         }
         if (j + DN_RD_WAVES < nu) {                            // wave-uniform
             const RdUnit n3 = rd_unit(rs, re, j + 3 * DN_RD_WAVES), n4 = rd_unit(rs, re, j + 4 * DN_RD_WAVES);
-            rd_unit_body<MODE>(g, sB, c1, rd_row_ptr(ap, ald, n3, li, lg), rd_row_ptr(ap, ald, n4, li, lg), n0, lane, A1, A0, a, F, om);
+            rd_unit_body<MODE, NP>(g, sB, c1, rd_row_ptr(ap, ald, n3, li, lg), rd_row_ptr(ap, ald, n4, li, lg), n0, lane, A1, A0, a, F, sa, so, om);
             c1 = n3;
         }
     }
