@@ -17,9 +17,9 @@ static_assert(sizeof(dn_tile_t) == sizeof(DnTile), "tile layout");
 enum { F16_TOB = 1, F16_FROMB = 2, F16_GF = 4, F16_MLP = 8, F16_LBI = 16, F16_GFB = 32, F16_TOB_B = 64, F16_FROMB_B = 128 };
 namespace {
 struct Opt { const char* name; int value; };
-enum { O_CHAIN, O_CHAIN_MIN_ROWS, O_CHAIN_SMALL_ROWS, O_CHAIN_NW, O_F16, O_F16_MASK, O_F16_WGRAD, O_DIFFUSE, O_DIFFUSE_GROUPS, O_DIFFUSE_ORDER, O_DIFFUSE_FLAGS, O_DIFFUSE_SPLIT, O_COUNT };
+enum { O_CHAIN, O_CHAIN_MIN_ROWS, O_CHAIN_SMALL_ROWS, O_CHAIN_NW, O_CHAIN_HH, O_F16, O_F16_MASK, O_F16_WGRAD, O_DIFFUSE, O_DIFFUSE_GROUPS, O_DIFFUSE_ORDER, O_DIFFUSE_FLAGS, O_DIFFUSE_SPLIT, O_COUNT };
 Opt g_opt[O_COUNT] = {
-    {"chain", 1}, {"chain_min_rows", 100000}, {"chain_small_rows", 16384}, {"chain_nw", 0}, {"f16", 1},
+    {"chain", 1}, {"chain_min_rows", 100000}, {"chain_small_rows", 16384}, {"chain_nw", 0}, {"chain_hh", 0}, {"f16", 1},
     {"f16_mask", F16_GF | F16_MLP | F16_LBI | F16_GFB | F16_FROMB_B}, {"f16_wgrad", 0},
     {"diffuse", 2}, {"diffuse_groups", 1}, {"diffuse_order", 0}, {"diffuse_flags", DN_DF_FLAG_DEFER}, {"diffuse_split", 0},
 };
@@ -626,6 +626,14 @@ static bool chain_aligned(const dn_block_params_t* p, const dn_block_saved_t* sv
     }
     return ok;
 }
+// 16-row halves per wave of the chained kernels: 2 (a weight fragment read feeds two MFMAs) for batches that fill the device, 1 for small ones
+// (twice the waves, half the serial product chain each): one ~7k-vertex mesh per step is 219 32-row waves on 1024 SIMDs.  Option "chain_hh"
+// forces either (tests, A/B).
+static int chain_hh(const dn_mesh_batch_t* mb) {
+    const int f = opt(O_CHAIN_HH);
+    if (f == 1 || f == 2) return f;
+    return mb->v_total <= 16384 ? 1 : 2;
+}
 static bool block_chain_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int kind) {
     if (!opt(O_CHAIN) || !opt(O_F16) || (p->with_grad && !mb->grad_norm)) return false;      // "f16" = 0: split-bf16 engine everywhere (A/B runs)
     if (kind == 1 && mb->v_total < opt(O_CHAIN_MIN_ROWS) && mb->v_total > opt(O_CHAIN_SMALL_ROWS)) return false;
@@ -719,7 +727,7 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
             auto piece = [&](const float* Wm, const float* Wm2, float* word, int ld, int col0) {
                 ChainPrepPiece& q = pa.pc[chain_np++]; q.W = Wm; q.W2 = Wm2; q.amax = word; q.ld = ld; q.col0 = col0; };
             if (p->with_grad)
-                for (int rep = 0; rep < 2; ++rep)
+                for (int rep = 0; rep < chain_hh(mb); ++rep)      // (the gradient-feature stage runs once per 16-row half of a wave)
                     for (int T = 0; T < NK; ++T) {
                         piece(p->A_re, p->with_rot ? p->A_im : nullptr, aw + AW_WA, C, 32 * T);
                         if (p->with_rot) piece(p->A_im, p->A_re, aw + AW_WA, C, 32 * T);
@@ -793,7 +801,7 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
         ca.out = out;
         ca.x_amax = x_amax; ca.xd_amax = sw + SW_XD; ca.grad_norm = mb->grad_norm;
         ca.g_amax = sw + SW_G; ca.out_amax = p->out_amax;
-        return dn_launch_chain_fwd(chain_np, ca, C, st);
+        return dn_launch_chain_fwd(chain_np, ca, C, st, chain_hh(mb));
     }
     // gradient features (layers.py:213-226)
     if (p->with_grad) {
@@ -901,7 +909,7 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
             for (int sg = 0; sg < (p->with_grad ? 3 : 2); ++sg)
                 for (int T = 0; T < NK; ++T) piece(p->W[0], nullptr, aw + AW_W0, p->widths[0], sg * C, T);
             if (p->with_grad)
-                for (int rep = 0; rep < 2; ++rep)
+                for (int rep = 0; rep < chain_hh(mb); ++rep)
                     for (int T = 0; T < NK; ++T) {
                         piece(p->A_re, p->with_rot ? p->A_im : nullptr, aw + AW_WA, C, 0, T);
                         if (p->with_rot) piece(p->A_im, p->A_re, aw + AW_WA, C, 0, T);
@@ -942,7 +950,7 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
         for (int j = 0; j < p->n_mlp; ++j) cb.w_amax[j] = aw + AW_W0 + j;
         cb.d_out_amax = dout_amax;
         cb.d_xacc = d_xacc; cb.d_xd = d_xd; cb.d_dots = d_dots; cb.d_gx = d_gx; cb.d_gy = d_gy;
-        DN_CHECK(dn_launch_chain_bwd(chain_np, cb, C, st));
+        DN_CHECK(dn_launch_chain_bwd(chain_np, cb, C, st, chain_hh(mb)));
         // every d_a exists now: the (up to three) weight-gradient products of the MiniMLP go out as ONE launch
         TnBatch tb;
         const float* d_a = d_out;

@@ -107,7 +107,7 @@ extern "C" int dn_debug_ch_trace_read(unsigned long long* out, int n) {
 #define CH_TR() do {} while (0)
 #endif
 
-template <int C, int NW>
+template <int C, int NW, int HH>
 __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(ChainArgs a) {
     constexpr int NT = C / 16;            // 16-channel output tiles
     constexpr int NK = C / 32;            // 32-channel contraction steps (= pieces per matrix)
@@ -210,11 +210,11 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
     for (int pass = 0; pass < npass; ++pass) {
         CH_TR();
         const int unit = xcd * per_x + slot0 + pass * GX;
-        const int rb = unit * (32 * NW) + 32 * wave;     // first of this wave's 32 rows (row * C fits 32 bits for every batch the library takes)
-        int rowh[2]; bool liveh[2]; int rch[2];
-        int begh[2], endh[2];
+        const int rb = unit * (16 * HH * NW) + 16 * HH * wave;     // first of this wave's 32 rows (row * C fits 32 bits for every batch the library takes)
+        int rowh[HH]; bool liveh[HH]; int rch[HH];
+        int begh[HH], endh[HH];
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
+        for (int hh = 0; hh < HH; ++hh) {
             rowh[hh] = rb + 16 * hh + m;
             liveh[hh] = rowh[hh] < a.V;
             rch[hh] = liveh[hh] ? rowh[hh] : a.V - 1;          // dead rows repeat the last row (computed, never stored)
@@ -222,23 +222,23 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
         }
 
         // =================================================== gradient features, one 16-row half at a time
-        uint4 gfh[2][NK], gfl[2][NK];     // tanh features of the two halves as operand fragments (hi / lo planes) for layer 0
+        uint4 gfh[HH][NK], gfl[HH][NK];     // tanh features of the two halves as operand fragments (hi / lo planes) for layer 0
         if (a.with_grad) {
 #pragma unroll 1
-            for (int hh = 0; hh < 2; ++hh) {
+            for (int hh = 0; hh < HH; ++hh) {
                 if (hh == 1) {
 #pragma unroll
-                    for (int T = 0; T < NK; ++T) { gfh[0][T] = gfh[1][T]; gfl[0][T] = gfl[1][T]; }
+                    for (int T = 0; T < NK; ++T) { gfh[0][T] = gfh[HH - 1][T]; gfl[0][T] = gfl[HH - 1][T]; }
                 }
-                const long long row = hh ? rowh[1] : rowh[0];
-                const bool live = hh ? liveh[1] : liveh[0];
+                const long long row = hh ? rowh[HH - 1] : rowh[0];
+                const bool live = hh ? liveh[HH - 1] : liveh[0];
                 // ---- CSR gather of the row: gx = sum_j vx_j xd[col_j], gy likewise (entry order, fmaf: bit for bit spmm_kernel's sums)
                 float gxv[NT][4], gyv[NT][4];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { gxv[nt][e] = 0.f; gyv[nt][e] = 0.f; }
-                const int beg = hh ? begh[1] : begh[0], end = hh ? endh[1] : endh[0];
+                const int beg = hh ? begh[HH - 1] : begh[0], end = hh ? endh[HH - 1] : endh[0];
                 const int nmax = (int)ch_wave_max((float)(end - beg));
                 int cj[GCH]; float wx[GCH], wy[GCH];
                 auto entries = [&](int j0) {      // pattern entries j0 .. j0 + GCH - 1 of the row (past its end: entry 0 with weight 0)
@@ -334,24 +334,24 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
                     }
                 }
 #pragma unroll
-                for (int T = 0; T < NK; ++T) ch_split8(gv[2 * T], gv[2 * T + 1], s_in, gfh[1][T], gfl[1][T]);
+                for (int T = 0; T < NK; ++T) ch_split8(gv[2 * T], gv[2 * T + 1], s_in, gfh[HH - 1][T], gfl[HH - 1][T]);
                 CH_TR();
             }
         }
 
         // =================================================== MiniMLP layer 0 on [g | x | xd] (the tanh features first: their fragments die here)
-        dn_f32x4 acc[2][NT];
+        dn_f32x4 acc[HH][NT];
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
+        for (int hh = 0; hh < HH; ++hh)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[hh][nt] = dn_f32x4{0.f, 0.f, 0.f, 0.f};
         {
             // operands of the 2 NK pieces of the x and xd segments, fetched two pieces ahead
-            float4 nx[3][2][2];
-            auto fetch = [&](int pi, float4 (&d)[2][2]) {
+            float4 nx[3][HH][2];
+            auto fetch = [&](int pi, float4 (&d)[HH][2]) {
                 const float* p = (pi < NK ? a.x : a.xd) + 32 * (pi < NK ? pi : pi - NK) + 4 * q;
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
+                for (int hh = 0; hh < HH; ++hh) {
                     d[hh][0] = *reinterpret_cast<const float4*>(p + (long long)rch[hh] * C);
                     d[hh][1] = *reinterpret_cast<const float4*>(p + (long long)rch[hh] * C + 16);
                 }
@@ -362,18 +362,18 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
 #pragma unroll
                 for (int T = 0; T < NK; ++T) {
                     CH_PIECE_BEGIN();
-                    CH_MMA2(acc, gfh[0][T], gfl[0][T], gfh[1][T], gfl[1][T]);
+                    CH_MMA2(acc, gfh[0][T], gfl[0][T], gfh[HH - 1][T], gfl[HH - 1][T]);
                     CH_PIECE_END();
                 }
             }
 #pragma unroll
             for (int pi = 0; pi < 2 * NK; ++pi) {
-                uint4 fh[2], fl[2];
+                uint4 fh[HH], fl[HH];
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) ch_split8(nx[pi % 3][hh][0], nx[pi % 3][hh][1], s_in, fh[hh], fl[hh]);
+                for (int hh = 0; hh < HH; ++hh) ch_split8(nx[pi % 3][hh][0], nx[pi % 3][hh][1], s_in, fh[hh], fl[hh]);
                 if (pi + 2 < 2 * NK) fetch(pi + 2, nx[(pi + 2) % 3]);
                 CH_PIECE_BEGIN();
-                CH_MMA2(acc, fh[0], fl[0], fh[1], fl[1]);
+                CH_MMA2(acc, fh[0], fl[0], fh[HH - 1], fl[HH - 1]);
                 CH_PIECE_END();
             }
         }
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
         // =================================================== hidden layers: h_j = dropout(relu(acc + b_j)) -> operand fragments -> next product
         //      (layers.py:143-160: the dropout in front of linear layer j + 1 is applied where h_j is produced)
         float s_act = s_in;               // scale the operand of the product just finished was split with
-        uint4 hfh[2][NK], hfl[2][NK];     // hidden activations as operand fragments
+        uint4 hfh[HH][NK], hfl[HH][NK];     // hidden activations as operand fragments
 #pragma unroll 1
         for (int j = 0; j + 1 < a.n_mlp; ++j) {
             const float so = ch_pow2_inv(s_act) * (j == 0 ? sw_inv[0] : (j == 1 ? sw_inv[1] : sw_inv[2]));
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
             float* hj = a.h[j];
             float wm = 0.f;
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
+            for (int hh = 0; hh < HH; ++hh)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const float4 b4 = *reinterpret_cast<const float4*>(bj + 16 * nt);
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
                 }
             if (hj) {
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh)
+                for (int hh = 0; hh < HH; ++hh)
                     if (liveh[hh]) {
                         float* oh = hj + (long long)rowh[hh] * C + 4 * q;
 #pragma unroll
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
             for (int jj = 0; jj < DN_CH_LAYERS; ++jj) hmax[jj] = (jj == j && wm > hmax[jj]) ? wm : hmax[jj];   // (no dynamic register index)
             s_act = ch_uniform(dn_pow2_scale(wm));
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
+            for (int hh = 0; hh < HH; ++hh)
 #pragma unroll
                 for (int T = 0; T < NK; ++T) {
                     const float va[4] = {acc[hh][2 * T][0], acc[hh][2 * T][1], acc[hh][2 * T][2], acc[hh][2 * T][3]};
@@ -434,13 +434,13 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
             CH_TR();
             // ---- product of layer j + 1
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
+            for (int hh = 0; hh < HH; ++hh)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[hh][nt] = dn_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int T = 0; T < NK; ++T) {
                 CH_PIECE_BEGIN();
-                CH_MMA2(acc, hfh[0][T], hfl[0][T], hfh[1][T], hfl[1][T]);
+                CH_MMA2(acc, hfh[0][T], hfl[0][T], hfh[HH - 1][T], hfl[HH - 1][T]);
                 CH_PIECE_END();
             }
             CH_TR();
@@ -450,15 +450,15 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
             const int jl = a.n_mlp - 1;
             const float so = ch_pow2_inv(s_act) * (jl == 1 ? sw_inv[1] : (jl == 2 ? sw_inv[2] : sw_inv[3]));
             const float* bj = sbias + jl * C + 4 * q;
-            float4 r4[2][NT];
+            float4 r4[HH][NT];
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
+            for (int hh = 0; hh < HH; ++hh) {
                 const float* px = a.x + (long long)rch[hh] * C + 4 * q;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) r4[hh][nt] = *reinterpret_cast<const float4*>(px + 16 * nt);   // (x: second read, out of L2)
             }
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
+            for (int hh = 0; hh < HH; ++hh)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const float4 b4 = *reinterpret_cast<const float4*>(bj + 16 * nt);
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
                     omax = dn_f4_amax(omax, y);
                 }
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
+            for (int hh = 0; hh < HH; ++hh)
                 if (liveh[hh]) {
                     float* oo = a.out + (long long)rowh[hh] * C + 4 * q;
 #pragma unroll
@@ -530,39 +530,44 @@ bool dn_chain_eligible(int C, int n_mlp, const int* widths, int with_grad, long 
     return V > 0;
 }
 
-template <int C, int NW>
+template <int C, int NW, int HH>
 static int chain_launch_nw(ChainArgs a, hipStream_t stream) {
-    a.units = (a.V + 32 * NW - 1) / (32 * NW);
+    a.units = (a.V + 16 * HH * NW - 1) / (16 * HH * NW);
     int g = (8 / NW) * dn_num_cus();      // eight waves per CU (256 registers per lane each): two 4-wave workgroups or one 8-wave workgroup
     if (g > a.units) g = a.units;
     g = (g + 7) / 8 * 8;
     const size_t smem = (size_t)DN_CH_RING * (2 * (C / 16) * 64) * sizeof(uint4) + (size_t)DN_CH_LAYERS * C * sizeof(float);
 #ifndef DN_EMULATE
     static unsigned long long lds_opt_in = 0;   // per-device bitmap
-    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&chain_fwd_kernel<C, NW>), smem, &lds_opt_in); if (oe_) return oe_; }
+    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&chain_fwd_kernel<C, NW, HH>), smem, &lds_opt_in); if (oe_) return oe_; }
 #endif
-    DN_LAUNCH((chain_fwd_kernel<C, NW>), dim3(g, 1, 1), dim3(64 * NW, 1, 1), smem, stream, a);
+    DN_LAUNCH((chain_fwd_kernel<C, NW, HH>), dim3(g, 1, 1), dim3(64 * NW, 1, 1), smem, stream, a);
     return (int)hipGetLastError();
 }
 template <int C>
-static int chain_launch(int npieces, const ChainArgs& a_in, hipStream_t stream) {
-    // Waves per workgroup: every workgroup streams the whole weight set once per 32 * NW rows, so large batches take four (two
+static int chain_launch(int npieces, const ChainArgs& a_in, hipStream_t stream, int hh) {
+    // Waves per workgroup: every workgroup streams the whole weight set once per 16 * HH * NW rows, so large batches take four (two
     // workgroups per CU share its matrix pipes out of phase); only batches that would leave most CUs without a workgroup are cut finer
     // (measured, block forward at 7k / 20k / 160k vertices: NW = 1: 102 / 179 / 658 us, 2: 104 / 140 / 486, 4: 113 / 129 / 388).
+    // HH = 16-row halves per wave: 2 for batches that fill the device (a weight fragment read from LDS feeds two MFMAs); 1 for small ones,
+    // where a wave's serial chain of 18 C x C products over 32 rows IS the kernel's duration (one 7k-vertex mesh: 219 waves on 1024 SIMDs):
+    // twice the waves, half the chain each.
     const int nw_env = dn_opt_chain_nw();   // (development override)
     int nw = nw_env;
     if (nw != 1 && nw != 2 && nw != 4 && nw != 8) {
         const int half = dn_num_cus() / 2;
         nw = 4;
-        while (nw > 1 && (a_in.V + 32 * nw - 1) / (32 * nw) < half) nw >>= 1;
+        while (nw > 1 && (a_in.V + 16 * hh * nw - 1) / (16 * hh * nw) < half) nw >>= 1;
     }
+    if (hh == 1 && nw > 2) nw = 2;          // (instantiated for the small-batch shapes only)
     ChainArgs a = a_in;
     a.n_pieces = npieces;
+    if (hh == 1) return nw == 2 ? chain_launch_nw<C, 2, 1>(a, stream) : chain_launch_nw<C, 1, 1>(a, stream);
     switch (nw) {
-        case 8: return chain_launch_nw<C, 8>(a, stream);
-        case 2: return chain_launch_nw<C, 2>(a, stream);
-        case 1: return chain_launch_nw<C, 1>(a, stream);
-        default: return chain_launch_nw<C, 4>(a, stream);
+        case 8: return chain_launch_nw<C, 8, 2>(a, stream);
+        case 2: return chain_launch_nw<C, 2, 2>(a, stream);
+        case 1: return chain_launch_nw<C, 1, 2>(a, stream);
+        default: return chain_launch_nw<C, 4, 2>(a, stream);
     }
 }
 
@@ -577,12 +582,12 @@ int dn_launch_chain_prep(const ChainPrepArgs& pa, int npieces, int C, hipStream_
     dn_prof_end(DN_K_SMALL, stream, 0.0, 0.0);
     return (int)hipGetLastError();
 }
-int dn_launch_chain_fwd(int npieces, const ChainArgs& a, int C, hipStream_t stream) {
-    if (npieces > DN_CH_MAX_PIECES) return 1;
+int dn_launch_chain_fwd(int npieces, const ChainArgs& a, int C, hipStream_t stream, int hh) {
+    if (npieces > DN_CH_MAX_PIECES || (hh != 1 && hh != 2)) return 1;
     dn_prof_begin(DN_K_CHAIN, stream);
     int err;
-    if (C == 128) err = chain_launch<128>(npieces, a, stream);
-    else if (C == 64) err = chain_launch<64>(npieces, a, stream);
+    if (C == 128) err = chain_launch<128>(npieces, a, stream, hh);
+    else if (C == 64) err = chain_launch<64>(npieces, a, stream, hh);
     else err = 1;
     {
         // algorithmic traffic: xd gathered once + x read once (+ once more for the residual: L2), every saved tensor written once

@@ -16,7 +16,7 @@
 #include "dn_chain_tiles.h"
 #include <stdlib.h>
 
-template <int C, int NW>
+template <int C, int NW, int HH>
 __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(ChainBwdArgs a) {
     constexpr int NT = C / 16;
     constexpr int NK = C / 32;
@@ -89,11 +89,11 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
     issue()
 #define CH_PIECE_END() do { CH_WAIT_PIECES(RING - 2); CH_BARRIER(); ++gp; } while (0)
 #define CH_ZERO(ACC)                                                                                                    \
-    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                                    \
+    _Pragma("unroll") for (int h_ = 0; h_ < HH; ++h_)                                                                   \
         _Pragma("unroll") for (int n_ = 0; n_ < NT; ++n_) ACC[h_][n_] = dn_f32x4{0.f, 0.f, 0.f, 0.f}
     // accumulator tiles (now holding fp32 values) -> operand fragments of the next product, split with scale S_
 #define CH_PACK(ACC, S_, FH, FL)                                                                                        \
-    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                                    \
+    _Pragma("unroll") for (int h_ = 0; h_ < HH; ++h_)                                                                   \
         _Pragma("unroll") for (int T_ = 0; T_ < NK; ++T_) {                                                             \
             const float va_[4] = {ACC[h_][2 * T_][0], ACC[h_][2 * T_][1], ACC[h_][2 * T_][2], ACC[h_][2 * T_][3]};       \
             const float vb_[4] = {ACC[h_][2 * T_ + 1][0], ACC[h_][2 * T_ + 1][1], ACC[h_][2 * T_ + 1][2], ACC[h_][2 * T_ + 1][3]}; \
@@ -102,31 +102,31 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
 
     for (int pass = 0; pass < npass; ++pass) {
         const int unit = xcd * per_x + slot0 + pass * GX;
-        const int rb = unit * (32 * NW) + 32 * wave;
-        int rowh[2]; bool liveh[2]; int rch[2];
+        const int rb = unit * (16 * HH * NW) + 16 * HH * wave;
+        int rowh[HH]; bool liveh[HH]; int rch[HH];
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
+        for (int hh = 0; hh < HH; ++hh) {
             rowh[hh] = rb + 16 * hh + m;
             liveh[hh] = rowh[hh] < a.V;
             rch[hh] = liveh[hh] ? rowh[hh] : a.V - 1;
         }
         // ---- d_out -> operand fragments
-        uint4 fh[2][NK], fl[2][NK];
+        uint4 fh[HH][NK], fl[HH][NK];
         {
-            float4 v[2][NT];
+            float4 v[HH][NT];
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
+            for (int hh = 0; hh < HH; ++hh) {
                 const float* p = a.d_out + (long long)rch[hh] * C + 4 * q;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) v[hh][nt] = *reinterpret_cast<const float4*>(p + 16 * nt);   // (d_out is read again for the residual)
             }
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
+            for (int hh = 0; hh < HH; ++hh)
 #pragma unroll
                 for (int T = 0; T < NK; ++T) ch_split8(v[hh][2 * T], v[hh][2 * T + 1], s_do, fh[hh][T], fl[hh][T]);
         }
         float s_act = s_do;
-        dn_f32x4 acc[2][NT];
+        dn_f32x4 acc[HH][NT];
         // ---- hidden layers, last to first: d_a[j-1] = (d_a[j] W_j) * relu'(h_{j-1}) * dropout scale   (h > 0 <=> kept and active)
 #pragma unroll 1
         for (int j = a.n_mlp - 1; j >= 1; --j) {
@@ -134,22 +134,22 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
 #pragma unroll
             for (int T = 0; T < NK; ++T) {
                 CH_PIECE_BEGIN();
-                CH_MMA2(acc, fh[0][T], fl[0][T], fh[1][T], fl[1][T]);
+                CH_MMA2(acc, fh[0][T], fl[0][T], fh[HH - 1][T], fl[HH - 1][T]);
                 CH_PIECE_END();
             }
             const float so = ch_pow2_inv(s_act) * (j == 1 ? sw_inv[1] : (j == 2 ? sw_inv[2] : sw_inv[3]));
             const float* hp = a.h[j - 1];
             const float ds = j == 1 ? a.dscale[0] : (j == 2 ? a.dscale[1] : a.dscale[2]);
-            float4 hv[2][NT];
+            float4 hv[HH][NT];
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
+            for (int hh = 0; hh < HH; ++hh) {
                 const float* p = hp + (long long)rch[hh] * C + 4 * q;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) hv[hh][nt] = *reinterpret_cast<const float4*>(p + 16 * nt);   // (d_out is read again for the residual)
             }
             float wm = 0.f;
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
+            for (int hh = 0; hh < HH; ++hh)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const float hq[4] = {hv[hh][nt].x, hv[hh][nt].y, hv[hh][nt].z, hv[hh][nt].w};
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
                 }
             float* dj = a.d_a[j - 1];
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
+            for (int hh = 0; hh < HH; ++hh)
                 if (liveh[hh]) {
                     float* o = dj + (long long)rowh[hh] * C + 4 * q;
 #pragma unroll
@@ -178,18 +178,18 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
 #pragma unroll
             for (int T = 0; T < NK; ++T) {
                 CH_PIECE_BEGIN();
-                CH_MMA2(acc, fh[0][T], fl[0][T], fh[1][T], fl[1][T]);
+                CH_MMA2(acc, fh[0][T], fl[0][T], fh[HH - 1][T], fl[HH - 1][T]);
                 CH_PIECE_END();
             }
-            float4 r4[2][NT];
+            float4 r4[HH][NT];
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
+            for (int hh = 0; hh < HH; ++hh) {
                 const float* p = a.d_out + (long long)rch[hh] * C + 4 * q;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) r4[hh][nt] = *reinterpret_cast<const float4*>(p + 16 * nt);
             }
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
+            for (int hh = 0; hh < HH; ++hh)
                 if (liveh[hh]) {
                     float* o = a.d_xacc + (long long)rowh[hh] * C + 4 * q;
 #pragma unroll
@@ -203,11 +203,11 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
 #pragma unroll
             for (int T = 0; T < NK; ++T) {
                 CH_PIECE_BEGIN();
-                CH_MMA2(acc, fh[0][T], fl[0][T], fh[1][T], fl[1][T]);
+                CH_MMA2(acc, fh[0][T], fl[0][T], fh[HH - 1][T], fl[HH - 1][T]);
                 CH_PIECE_END();
             }
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
+            for (int hh = 0; hh < HH; ++hh)
                 if (liveh[hh]) {
                     float* o = a.d_xd + (long long)rowh[hh] * C + 4 * q;
 #pragma unroll
@@ -221,19 +221,19 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
 #pragma unroll
             for (int T = 0; T < NK; ++T) {
                 CH_PIECE_BEGIN();
-                CH_MMA2(acc, fh[0][T], fl[0][T], fh[1][T], fl[1][T]);
+                CH_MMA2(acc, fh[0][T], fl[0][T], fh[HH - 1][T], fl[HH - 1][T]);
                 CH_PIECE_END();
             }
             {
-                float4 gq[2][NT];
+                float4 gq[HH][NT];
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
+                for (int hh = 0; hh < HH; ++hh) {
                     const float* p = a.g + (long long)rch[hh] * C + 4 * q;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) gq[hh][nt] = ch_ld4(p + 16 * nt);
                 }
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh)
+                for (int hh = 0; hh < HH; ++hh)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         acc[hh][nt][0] = acc[hh][nt][0] * so0 * (1.f - gq[hh][nt].x * gq[hh][nt].x);
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
                         acc[hh][nt][3] = acc[hh][nt][3] * so0 * (1.f - gq[hh][nt].w * gq[hh][nt].w);
                     }
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh)
+                for (int hh = 0; hh < HH; ++hh)
                     if (liveh[hh]) {
                         float* o = a.d_dots + (long long)rowh[hh] * C + 4 * q;
 #pragma unroll
@@ -253,15 +253,15 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
             //      d_gx = d_dots * Bre + (d_dots gx) A_re + (d_dots gy) A_im ;  d_gy = d_dots * Bim - (d_dots gx) A_im + (d_dots gy) A_re
             //      (without rotations: d_gx = d_dots * Bre + (d_dots gx) A, d_gy = d_dots * Bim + (d_dots gy) A)
 #pragma unroll 1
-            for (int hh = 0; hh < 2; ++hh) {
-                const int row = hh ? rowh[1] : rowh[0];
-                const int rc = hh ? rch[1] : rch[0];
-                const bool live = hh ? liveh[1] : liveh[0];
+            for (int hh = 0; hh < HH; ++hh) {
+                const int row = hh ? rowh[HH - 1] : rowh[0];
+                const int rc = hh ? rch[HH - 1] : rch[0];
+                const bool live = hh ? liveh[HH - 1] : liveh[0];
                 float dd[NT][4];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dd[nt][e] = hh ? acc[1][nt][e] : acc[0][nt][e];
+                    for (int e = 0; e < 4; ++e) dd[nt][e] = hh ? acc[HH - 1][nt][e] : acc[0][nt][e];
                 float u[NT][4], v[NT][4];
                 float wm = 0.f;
                 {
@@ -343,44 +343,46 @@ int dn_chain_bwd_pieces(int C, int with_grad, int with_rot, int n_mlp) {
     return (n_mlp - 1) * NK + (with_grad ? 3 : 2) * NK + (with_grad ? 2 * NK * (with_rot ? 2 : 1) : 0);
 }
 
-template <int C, int NW>
+template <int C, int NW, int HH>
 static int chain_bwd_launch_nw(ChainBwdArgs a, hipStream_t stream) {
-    a.units = (a.V + 32 * NW - 1) / (32 * NW);
+    a.units = (a.V + 16 * HH * NW - 1) / (16 * HH * NW);
     int g = (8 / NW) * dn_num_cus();
     if (g > a.units) g = a.units;
     g = (g + 7) / 8 * 8;
     const size_t smem = (size_t)DN_CH_RING * (2 * (C / 16) * 64) * sizeof(uint4);
 #ifndef DN_EMULATE
     static unsigned long long lds_opt_in = 0;   // per-device bitmap
-    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&chain_bwd_kernel<C, NW>), smem, &lds_opt_in); if (oe_) return oe_; }
+    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&chain_bwd_kernel<C, NW, HH>), smem, &lds_opt_in); if (oe_) return oe_; }
 #endif
-    DN_LAUNCH((chain_bwd_kernel<C, NW>), dim3(g, 1, 1), dim3(64 * NW, 1, 1), smem, stream, a);
+    DN_LAUNCH((chain_bwd_kernel<C, NW, HH>), dim3(g, 1, 1), dim3(64 * NW, 1, 1), smem, stream, a);
     return (int)hipGetLastError();
 }
 template <int C>
-static int chain_bwd_launch(int npieces, const ChainBwdArgs& a_in, hipStream_t stream) {
-    const int nw_env = dn_opt_chain_nw();   // (development override; see dn_chain.hip for the choice)
+static int chain_bwd_launch(int npieces, const ChainBwdArgs& a_in, hipStream_t stream, int hh) {
+    const int nw_env = dn_opt_chain_nw();   // (development override; see dn_chain.hip for the choice of NW and HH)
     int nw = nw_env;
     if (nw != 1 && nw != 2 && nw != 4) {
         const int half = dn_num_cus() / 2;
         nw = 4;
-        while (nw > 1 && (a_in.V + 32 * nw - 1) / (32 * nw) < half) nw >>= 1;
+        while (nw > 1 && (a_in.V + 16 * hh * nw - 1) / (16 * hh * nw) < half) nw >>= 1;
     }
+    if (hh == 1 && nw > 2) nw = 2;
     ChainBwdArgs a = a_in;
     a.n_pieces = npieces;
+    if (hh == 1) return nw == 2 ? chain_bwd_launch_nw<C, 2, 1>(a, stream) : chain_bwd_launch_nw<C, 1, 1>(a, stream);
     switch (nw) {
-        case 2: return chain_bwd_launch_nw<C, 2>(a, stream);
-        case 1: return chain_bwd_launch_nw<C, 1>(a, stream);
-        default: return chain_bwd_launch_nw<C, 4>(a, stream);
+        case 2: return chain_bwd_launch_nw<C, 2, 2>(a, stream);
+        case 1: return chain_bwd_launch_nw<C, 1, 2>(a, stream);
+        default: return chain_bwd_launch_nw<C, 4, 2>(a, stream);
     }
 }
 
-int dn_launch_chain_bwd(int npieces, const ChainBwdArgs& a, int C, hipStream_t stream) {
-    if (npieces > DN_CH_MAX_PIECES || npieces <= 0) return 1;
+int dn_launch_chain_bwd(int npieces, const ChainBwdArgs& a, int C, hipStream_t stream, int hh) {
+    if (npieces > DN_CH_MAX_PIECES || npieces <= 0 || (hh != 1 && hh != 2)) return 1;
     dn_prof_begin(DN_K_CHAIN_BWD, stream);
     int err;
-    if (C == 128) err = chain_bwd_launch<128>(npieces, a, stream);
-    else if (C == 64) err = chain_bwd_launch<64>(npieces, a, stream);
+    if (C == 128) err = chain_bwd_launch<128>(npieces, a, stream, hh);
+    else if (C == 64) err = chain_bwd_launch<64>(npieces, a, stream, hh);
     else err = 1;
     {
         // algorithmic traffic: d_out read once (+ once more for the residual: L2), every saved activation read once, every gradient written once

@@ -114,6 +114,7 @@ __device__ __forceinline__ void ch_dma16(const uint4* gsrc, uint4* lds_generic, 
 // next one into the same accumulator are four issues apart
 #define CH_WLOAD(W_, np_) do { W_[0] = ws_[(np_) * 64 + lane]; W_[1] = ws_[(NT + (np_)) * 64 + lane];                       \
                            W_[2] = ws_[((np_) + 1) * 64 + lane]; W_[3] = ws_[(NT + (np_) + 1) * 64 + lane]; } while (0)
+// (HH = 16-row halves per wave, a template parameter of the kernel that expands the macro: with HH = 1 the second half's MFMAs are discarded)
 #define CH_MMA2(ACC, FH0, FL0, FH1, FL1)                                                                                \
 do {                                                                                                                \
     uint4 wq_[2][4];   /* weight fragments of two output tiles (hi a, lo a, hi b, lo b), fetched one pair ahead of their MFMAs */ \
@@ -122,17 +123,17 @@ do {                                                                            
         const int cb_ = (np_ >> 1) & 1;                                                                             \
         if (np_ + 2 < NT) CH_WLOAD(wq_[cb_ ^ 1], np_ + 2);                                                          \
         ACC[0][np_] = dn_mfma16_f16(wq_[cb_][0], FL0, ACC[0][np_]);                                                 \
-        ACC[1][np_] = dn_mfma16_f16(wq_[cb_][0], FL1, ACC[1][np_]);                                                 \
+        if constexpr (HH > 1) ACC[HH - 1][np_] = dn_mfma16_f16(wq_[cb_][0], FL1, ACC[HH - 1][np_]);                 \
         ACC[0][np_ + 1] = dn_mfma16_f16(wq_[cb_][2], FL0, ACC[0][np_ + 1]);                                         \
-        ACC[1][np_ + 1] = dn_mfma16_f16(wq_[cb_][2], FL1, ACC[1][np_ + 1]);                                         \
+        if constexpr (HH > 1) ACC[HH - 1][np_ + 1] = dn_mfma16_f16(wq_[cb_][2], FL1, ACC[HH - 1][np_ + 1]);         \
         ACC[0][np_] = dn_mfma16_f16(wq_[cb_][1], FH0, ACC[0][np_]);                                                 \
-        ACC[1][np_] = dn_mfma16_f16(wq_[cb_][1], FH1, ACC[1][np_]);                                                 \
+        if constexpr (HH > 1) ACC[HH - 1][np_] = dn_mfma16_f16(wq_[cb_][1], FH1, ACC[HH - 1][np_]);                 \
         ACC[0][np_ + 1] = dn_mfma16_f16(wq_[cb_][3], FH0, ACC[0][np_ + 1]);                                         \
-        ACC[1][np_ + 1] = dn_mfma16_f16(wq_[cb_][3], FH1, ACC[1][np_ + 1]);                                         \
+        if constexpr (HH > 1) ACC[HH - 1][np_ + 1] = dn_mfma16_f16(wq_[cb_][3], FH1, ACC[HH - 1][np_ + 1]);         \
         ACC[0][np_] = dn_mfma16_f16(wq_[cb_][0], FH0, ACC[0][np_]);                                                 \
-        ACC[1][np_] = dn_mfma16_f16(wq_[cb_][0], FH1, ACC[1][np_]);                                                 \
+        if constexpr (HH > 1) ACC[HH - 1][np_] = dn_mfma16_f16(wq_[cb_][0], FH1, ACC[HH - 1][np_]);                 \
         ACC[0][np_ + 1] = dn_mfma16_f16(wq_[cb_][2], FH0, ACC[0][np_ + 1]);                                         \
-        ACC[1][np_ + 1] = dn_mfma16_f16(wq_[cb_][2], FH1, ACC[1][np_ + 1]);                                         \
+        if constexpr (HH > 1) ACC[HH - 1][np_ + 1] = dn_mfma16_f16(wq_[cb_][2], FH1, ACC[HH - 1][np_ + 1]);         \
     }                                                                                                               \
 } while (0)
 

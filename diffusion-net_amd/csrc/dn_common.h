@@ -513,7 +513,7 @@ struct ChainArgs {
     float* g_amax;                        // receives the bound ||G||_inf max|xd| (the backward's split-fp16 products scale by it)
     float* h_amax[DN_CH_LAYERS];          // accumulate max |h_j|
     float* out_amax;                      // accumulates max |out|
-    int units;                            // workgroup passes: ceil(V / (32 waves-per-workgroup))
+    int units;                            // workgroup passes: ceil(V / (16 halves-per-wave waves-per-workgroup))
 };
 // backward of the same stages: d_out -> d(pre-activations) of every layer -> [d_x | d_xd | d_dots] -> d_gx, d_gy (dn_chain_bwd.hip)
 struct ChainBwdArgs {
@@ -536,12 +536,12 @@ struct ChainBwdArgs {
     int units;
 };
 int dn_chain_bwd_pieces(int C, int with_grad, int with_rot, int n_mlp);
-int dn_launch_chain_bwd(int npieces, const ChainBwdArgs& a, int C, hipStream_t stream);
+int dn_launch_chain_bwd(int npieces, const ChainBwdArgs& a, int C, hipStream_t stream, int hh = 2);   // hh: 16-row halves per wave (the piece list repeats the gradient-feature pieces hh times)
 int dn_chain_pieces(int C, int with_grad, int with_rot, int n_mlp);
 size_t dn_chain_ws_bytes(int C, int with_grad, int with_rot, int n_mlp);
 bool dn_chain_eligible(int C, int n_mlp, const int* widths, int with_grad, long long g_nnz, int V);
 int dn_launch_chain_prep(const ChainPrepArgs& pa, int npieces, int C, hipStream_t stream);
-int dn_launch_chain_fwd(int npieces, const ChainArgs& a, int C, hipStream_t stream);
+int dn_launch_chain_fwd(int npieces, const ChainArgs& a, int C, hipStream_t stream, int hh = 2);
 
 // ---------------------------------------------------------------------------------------
 // one-launch learned-time diffusion, forward and backward (dn_diffuse.hip; K = C = 128)

@@ -125,6 +125,7 @@ int dn_tn_target_chunks(void);  /* how many entries dn_mesh_batch_t.chunks shoul
  *        "chain" (1)            chained row kernels of the fused block (0: unfused launches)
  *        "chain_min_rows" (100000)   smallest batch the TRAINING forward takes the chained kernel for
  *        "chain_small_rows" (16384)  ... and the largest small batch it takes it for (level in time, four launches fewer per block)
+ *        "chain_hh" (0)         16-row halves per wave of the chained kernels (0: 1 for batches up to 16 384 rows, else 2)
  *        "chain_nw" (0)         waves per workgroup of the chained kernels (0: chosen by batch size)
  *        "f16" (1)              split-fp16 matrix engine for the row products of the fused block (0: split-bf16 everywhere)
  *        "f16_mask" (188)       product classes on the split-fp16 engine (diagnostic bit mask, dn_api.hip)

@@ -78,6 +78,13 @@ def test_chain_probes_against_the_oracle(dev):
     parity_cases.run_ragged_net(dev, sizes=(33, 40), K=16, C=128, N_block=2, fp64_bracket=True)
     parity_cases.run_ragged_net(dev, K=64, C=64, mlp_hidden_dims=[64], **kw)
     parity_cases.run_ragged_net(dev, K=128, C=128, equal_rows=True, **kw)
+    from diffusion_net import _hip
+    old = _hip.set_option("chain_hh", 2)              # (2 200 rows take one 16-row half per wave by default: once more with two)
+    try:
+        parity_cases.run_ragged_net(dev, K=128, C=128, mlp_hidden_dims=[128, 128, 128], empty_grad_rows=3, **kw)
+        parity_cases.run_ragged_net(dev, sizes=(33, 40), K=16, C=128, N_block=2, fp64_bracket=True)
+    finally:
+        _hip.set_option("chain_hh", old)
 
 
 def test_rna_like_wide_head(dev):
@@ -144,7 +151,13 @@ def test_chained_forward_kernel_vs_unfused(dev, kw):
     """dn_chain.hip against the unfused launches of the same block (see parity_cases.run_chain_vs_unfused); the last case is large enough for
     several passes per workgroup and the four-wave workgroups of the benchmark shape"""
     import parity_cases
-    parity_cases.run_chain_vs_unfused(dev, **kw)
+    from diffusion_net import _hip
+    for hh in (0, 1, 2):                 # the library's choice by batch size, then both wave shapes forced (option chain_hh)
+        old = _hip.set_option("chain_hh", hh)
+        try:
+            parity_cases.run_chain_vs_unfused(dev, **kw)
+        finally:
+            _hip.set_option("chain_hh", old)
 
 
 def test_mismatched_patterns(dev):
