@@ -19,7 +19,7 @@ namespace {
 struct Opt { const char* name; int value; };
 enum { O_CHAIN, O_CHAIN_MIN_ROWS, O_CHAIN_SMALL_ROWS, O_CHAIN_NW, O_CHAIN_HH, O_F16, O_F16_MASK, O_F16_WGRAD, O_DIFFUSE, O_DIFFUSE_GROUPS, O_DIFFUSE_ORDER, O_DIFFUSE_FLAGS, O_DIFFUSE_SPLIT, O_COUNT };
 Opt g_opt[O_COUNT] = {
-    {"chain", 1}, {"chain_min_rows", 100000}, {"chain_small_rows", 16384}, {"chain_nw", 0}, {"chain_hh", 0}, {"f16", 1},
+    {"chain", 1}, {"chain_min_rows", 0}, {"chain_small_rows", 0}, {"chain_nw", 0}, {"chain_hh", 0}, {"f16", 1},
     {"f16_mask", F16_GF | F16_MLP | F16_LBI | F16_GFB | F16_FROMB_B}, {"f16_wgrad", 0},
     {"diffuse", 2}, {"diffuse_groups", 1}, {"diffuse_order", 0}, {"diffuse_flags", DN_DF_FLAG_DEFER}, {"diffuse_split", 0},
 };
@@ -605,18 +605,15 @@ static size_t amax_ws(void) { return pad256(AW_COUNT + DN_BLOCK_AMAX_WORDS + 2);
 // MiniMLP and their gradients -- when the shapes are the ones they are written for and the magnitude words exist.  Option "chain" = 0
 // keeps the unfused launches (dn_set_option: the tests flip it at run time).
 // kind: 0 = forward without saved activations (inference), 1 = forward saving activations (training), 2 = backward.
-// Measured on MI355X (tools/kbench, block at C = K = 128, chain / unfused, us; profiles/r04_chain_size_sweep.txt):
-//     vertices      3k        7k        14k       20k       40k       80k       160k
-//     inference   92/99    103/107   115/119   131/131   175/196   251/299   402/515
-//     training   102/102   109/110   120/120   140/129   216/205   319/315   480/512
-//     backward   162/198   169/207   186/222   229/253   349/383   555/588   869/950
-// The backward and the inference forward win at every size.  The training forward (it also writes the seven saved tensors) is level up to
-// ~15k vertices, behind between 20k and 80k -- one long pass per workgroup and too few workgroups to hide its latencies -- and ahead from
-// ~100k: it is taken from "chain_min_rows" rows on (default 100000; the tests run it at every size with 0) AND up to "chain_small_rows"
-// (default 16384: level in time, four launches fewer per block -- at the sizes the reference trains on, one ~7k-12k-vertex mesh per step,
-// launches are the time: human_segmentation_original.py:105-148).
-// The chained kernels use 16-byte vector accesses throughout and have no scalar fallback: every tensor they touch must be 16-byte aligned
-// (a plain-C caller, or a torch view with an odd storage offset, takes the unfused launches, which check per operand).  ADVICE r4.
+// Measured on MI355X (tools/kbench, block at C = K = 128, chained / unfused, us; round 5, profiles/r05_chain_hh_sweep.txt -- the chained kernels
+// with one 16-row half per wave where that is faster, see chain_hh below):
+//     vertices        7k        20k       40k       80k       160k
+//     inference     64/86     88/121   122/188   203/299   365/509
+//     training      66/90     99/120   145/194   230/307   447/507
+//     backward     114/139   185/243   290/376   471/574   822/933
+// The chained kernels win at every size in every role since the one-half-per-wave form exists (round 4: the training forward lost between
+// 20k and 80k rows and was only taken from 100k); "chain_min_rows" / "chain_small_rows" (both 0 now) can still carve a window for the
+// unfused training forward: the tests' "mixed" mode uses them.
 static bool chain_aligned(const dn_block_params_t* p, const dn_block_saved_t* sv, const float* a, const float* b_, const float* c = nullptr, const float* d = nullptr) {
     bool ok = al16(a) && al16(b_) && al16(c) && al16(d) && al16(p->A_re) && al16(p->A_im) && al16(p->time);
     for (int j = 0; j < p->n_mlp; ++j) ok = ok && al16(p->W[j]) && al16(p->b[j]) && al16(p->mask[j]);
@@ -629,10 +626,13 @@ static bool chain_aligned(const dn_block_params_t* p, const dn_block_saved_t* sv
 // 16-row halves per wave of the chained kernels: 2 (a weight fragment read feeds two MFMAs) for batches that fill the device, 1 for small ones
 // (twice the waves, half the serial product chain each): one ~7k-vertex mesh per step is 219 32-row waves on 1024 SIMDs.  Option "chain_hh"
 // forces either (tests, A/B).
-static int chain_hh(const dn_mesh_batch_t* mb) {
+// Measured (tools/kbench, block forward / backward, us, HH = 2 -> 1; profiles/r05_chain_hh_sweep.txt): 7k rows 90 -> 66 / 134 -> 114,
+// 20k 117 -> 99 / 198 -> 185, 40k 168 -> 145 / 319 -> 290, 80k 267 -> 230 / 502 -> 471, 160k 457 -> 447 / 822 -> 833: the forward takes one
+// half per wave at every size measured, the backward up to ~100k rows.
+static int chain_hh(const dn_mesh_batch_t* mb, bool backward = false) {
     const int f = opt(O_CHAIN_HH);
     if (f == 1 || f == 2) return f;
-    return mb->v_total <= 16384 ? 1 : 2;
+    return mb->v_total <= (backward ? 100000 : 262144) ? 1 : 2;
 }
 static bool block_chain_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int kind) {
     if (!opt(O_CHAIN) || !opt(O_F16) || (p->with_grad && !mb->grad_norm)) return false;      // "f16" = 0: split-bf16 engine everywhere (A/B runs)
@@ -909,7 +909,7 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
             for (int sg = 0; sg < (p->with_grad ? 3 : 2); ++sg)
                 for (int T = 0; T < NK; ++T) piece(p->W[0], nullptr, aw + AW_W0, p->widths[0], sg * C, T);
             if (p->with_grad)
-                for (int rep = 0; rep < chain_hh(mb); ++rep)
+                for (int rep = 0; rep < chain_hh(mb, true); ++rep)
                     for (int T = 0; T < NK; ++T) {
                         piece(p->A_re, p->with_rot ? p->A_im : nullptr, aw + AW_WA, C, 0, T);
                         if (p->with_rot) piece(p->A_im, p->A_re, aw + AW_WA, C, 0, T);
@@ -950,7 +950,7 @@ int dn_block_bwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
         for (int j = 0; j < p->n_mlp; ++j) cb.w_amax[j] = aw + AW_W0 + j;
         cb.d_out_amax = dout_amax;
         cb.d_xacc = d_xacc; cb.d_xd = d_xd; cb.d_dots = d_dots; cb.d_gx = d_gx; cb.d_gy = d_gy;
-        DN_CHECK(dn_launch_chain_bwd(chain_np, cb, C, st, chain_hh(mb)));
+        DN_CHECK(dn_launch_chain_bwd(chain_np, cb, C, st, chain_hh(mb, true)));
         // every d_a exists now: the (up to three) weight-gradient products of the MiniMLP go out as ONE launch
         TnBatch tb;
         const float* d_a = d_out;

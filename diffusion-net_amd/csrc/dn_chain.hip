@@ -29,6 +29,13 @@
 
 #include "dn_chain_tiles.h"
 
+#ifndef DN_CH_GCR
+#define DN_CH_GCR 1      // (1: 393.9 us block forward at 16 x 10k, 2: 408.1, 3: 431.5 -- registers, not bytes in flight; profiles/r05_rcg_ab.txt)
+#endif
+#ifndef DN_CH_RCG
+#define DN_CH_RCG 1      // row-contiguous gather in the one-half-per-wave form of the chained forward (0: operand-layout gather everywhere; A/B)
+#endif
+
 template <int C>
 __global__ __launch_bounds__(1024) void chain_prep_kernel(ChainPrepArgs a) {
     constexpr int NT = C / 16;
@@ -122,6 +129,15 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
     DN_DYN_SMEM(smem_raw);
     uint4* ring = reinterpret_cast<uint4*>(smem_raw);                      // RING slots of PIECE uint4
     float* sbias = reinterpret_cast<float*>(ring + RING * PIECE);          // [DN_CH_LAYERS][C]
+    // row-contiguous gather (RCG; one-half-per-wave form only: it needs the registers the second half's features occupy otherwise)
+    constexpr bool RCG = HH == 1 && DN_CH_RCG != 0;
+    constexpr int LPR = C / 4;            // gather: lanes that cover one row (16 bytes each)
+    constexpr int RPI = 64 / LPR;         // rows one gather instruction covers
+    constexpr int NI = 16 / RPI;          // row groups of a 16-row half
+    constexpr int SROWS = 4;              // rows per transposition slice
+    constexpr int GCR = DN_CH_GCR;        // pattern entries per gather step of the row-contiguous form (NI x GCR KiB in flight per wave)
+    static_assert(SROWS % RPI == 0 && 16 % SROWS == 0, "gather slices");
+    float4* slice = reinterpret_cast<float4*>(sbias + DN_CH_LAYERS * C) + (threadIdx.x >> 6) * (SROWS * LPR);   // wave-private, SROWS rows (RCG)
 #ifdef DN_EMULATE
     const unsigned lds0 = 0;
 #else
@@ -133,6 +149,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, q = lane >> 4;
+    const int rsub = lane / LPR, cc = lane % LPR;
 
     // XCD-contiguous unit ranges: workgroup b runs on XCD b % 8 and walks units of the b % 8-th eighth of the row axis, so that the
     // ~7 neighbour rows a row gathers are mostly rows the same L2 has just served
@@ -234,54 +251,148 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
                 const bool live = hh ? liveh[HH - 1] : liveh[0];
                 // ---- CSR gather of the row: gx = sum_j vx_j xd[col_j], gy likewise (entry order, fmaf: bit for bit spmm_kernel's sums)
                 float gxv[NT][4], gyv[NT][4];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { gxv[nt][e] = 0.f; gyv[nt][e] = 0.f; }
                 const int beg = hh ? begh[HH - 1] : begh[0], end = hh ? endh[HH - 1] : endh[0];
                 const int nmax = (int)ch_wave_max((float)(end - beg));
-                int cj[GCH]; float wx[GCH], wy[GCH];
-                auto entries = [&](int j0) {      // pattern entries j0 .. j0 + GCH - 1 of the row (past its end: entry 0 with weight 0)
+                if constexpr (!RCG) {
 #pragma unroll
-                    for (int u = 0; u < GCH; ++u) {
-                        const int idx = beg + j0 + u;
-                        const bool in = idx < end;
-                        const int ii = in ? idx : 0;
-                        cj[u] = a.col[ii];
-                        wx[u] = in ? a.vx[ii] : 0.f;
-                        wy[u] = in ? a.vy[ii] : 0.f;
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { gxv[nt][e] = 0.f; gyv[nt][e] = 0.f; }
+                    int cj[GCH]; float wx[GCH], wy[GCH];
+                    auto entries = [&](int j0) {      // pattern entries j0 .. j0 + GCH - 1 of the row (past its end: entry 0 with weight 0)
+#pragma unroll
+                        for (int u = 0; u < GCH; ++u) {
+                            const int idx = beg + j0 + u;
+                            const bool in = idx < end;
+                            const int ii = in ? idx : 0;
+                            cj[u] = a.col[ii];
+                            wx[u] = in ? a.vx[ii] : 0.f;
+                            wy[u] = in ? a.vy[ii] : 0.f;
+                        }
+                    };
+                    entries(0);
+                    for (int j0 = 0; j0 < nmax; j0 += GCH) {
+                        float4 v[GCH][NT];
+                        float cx[GCH], cy[GCH];
+#pragma unroll
+                        for (int u = 0; u < GCH; ++u) {
+                            const float* src = a.xd + (long long)cj[u] * C + 4 * q;
+                            cx[u] = wx[u]; cy[u] = wy[u];
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) v[u][nt] = *reinterpret_cast<const float4*>(src + 16 * nt);
+                        }
+                        entries(j0 + GCH);            // the next step's entries travel under this step's row pieces
+#pragma unroll
+                        for (int u = 0; u < GCH; ++u)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                gxv[nt][0] = fmaf(cx[u], v[u][nt].x, gxv[nt][0]); gyv[nt][0] = fmaf(cy[u], v[u][nt].x, gyv[nt][0]);
+                                gxv[nt][1] = fmaf(cx[u], v[u][nt].y, gxv[nt][1]); gyv[nt][1] = fmaf(cy[u], v[u][nt].y, gyv[nt][1]);
+                                gxv[nt][2] = fmaf(cx[u], v[u][nt].z, gxv[nt][2]); gyv[nt][2] = fmaf(cy[u], v[u][nt].z, gyv[nt][2]);
+                                gxv[nt][3] = fmaf(cx[u], v[u][nt].w, gxv[nt][3]); gyv[nt][3] = fmaf(cy[u], v[u][nt].w, gyv[nt][3]);
+                            }
                     }
-                };
-                entries(0);
-                for (int j0 = 0; j0 < nmax; j0 += GCH) {
-                    float4 v[GCH][NT];
-                    float cx[GCH], cy[GCH];
-#pragma unroll
-                    for (int u = 0; u < GCH; ++u) {
-                        const float* src = a.xd + (long long)cj[u] * C + 4 * q;
-                        cx[u] = wx[u]; cy[u] = wy[u];
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) v[u][nt] = *reinterpret_cast<const float4*>(src + 16 * nt);
-                    }
-                    entries(j0 + GCH);            // the next step's entries travel under this step's row pieces
-#pragma unroll
-                    for (int u = 0; u < GCH; ++u)
+                    if (a.gx && live) {
+                        float* ox = a.gx + row * C + 4 * q;
+                        float* oy = a.gy + row * C + 4 * q;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
-                            gxv[nt][0] = fmaf(cx[u], v[u][nt].x, gxv[nt][0]); gyv[nt][0] = fmaf(cy[u], v[u][nt].x, gyv[nt][0]);
-                            gxv[nt][1] = fmaf(cx[u], v[u][nt].y, gxv[nt][1]); gyv[nt][1] = fmaf(cy[u], v[u][nt].y, gyv[nt][1]);
-                            gxv[nt][2] = fmaf(cx[u], v[u][nt].z, gxv[nt][2]); gyv[nt][2] = fmaf(cy[u], v[u][nt].z, gyv[nt][2]);
-                            gxv[nt][3] = fmaf(cx[u], v[u][nt].w, gxv[nt][3]); gyv[nt][3] = fmaf(cy[u], v[u][nt].w, gyv[nt][3]);
+                            ch_st4(ox + 16 * nt, make_float4(gxv[nt][0], gxv[nt][1], gxv[nt][2], gxv[nt][3]));
+                            ch_st4(oy + 16 * nt, make_float4(gyv[nt][0], gyv[nt][1], gyv[nt][2], gyv[nt][3]));
                         }
-                }
-                if (a.gx && live) {
-                    float* ox = a.gx + row * C + 4 * q;
-                    float* oy = a.gy + row * C + 4 * q;
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        ch_st4(ox + 16 * nt, make_float4(gxv[nt][0], gxv[nt][1], gxv[nt][2], gxv[nt][3]));
-                        ch_st4(oy + 16 * nt, make_float4(gyv[nt][0], gyv[nt][1], gyv[nt][2], gyv[nt][3]));
                     }
+                } else {
+                    // The loads run in the ROW-CONTIGUOUS lane mapping (LPR lanes x 16 bytes = one row, RPI rows per instruction): the texture path
+                    // serves ~13 B/clk/CU when every lane of a quarter-wave sits on a different row -- the operand layout -- and twice that when a
+                    // quarter-wave reads 256 contiguous bytes (tools/experiments/gather_rate).  The sums -- the same fmaf chains in entry order,
+                    // bit for bit -- are then transposed into the operand layout (lane (m, q): row m, channels 16 nt + 4 q ..) through a
+                    // wave-private 4-row LDS slice.  All NI row groups of a step are in flight together (NI x GCH requests of 1 KiB per wave: the
+                    // form that did not fit the register file with two halves per wave, round 4).
+                    float4 bx[NI], by[NI];            // sums of row RPI * i + rsub of the half, channels 4 cc .. 4 cc + 3
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) { bx[i] = make_float4(0.f, 0.f, 0.f, 0.f); by[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+                    auto entries = [&](int j0, int (&cjv)[GCR], float (&wxv)[GCR], float (&wyv)[GCR]) {   // entries j0 .. j0 + GCR - 1 of this lane's row (past its end: entry 0, weight 0)
+#pragma unroll
+                        for (int u = 0; u < GCR; ++u) {
+                            const int idx = beg + j0 + u;
+                            const bool in = idx < end;
+                            const int ii = in ? idx : 0;
+                            cjv[u] = a.col[ii];
+                            wxv[u] = in ? a.vx[ii] : 0.f;
+                            wyv[u] = in ? a.vy[ii] : 0.f;
+                        }
+                    };
+                    auto request = [&](const int (&cjv)[GCR], float4 (&v)[NI][GCR]) {
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) {
+                            const int sl = RPI * i + rsub;          // lane (m = that row, q = 0) holds the row's entries
+#pragma unroll
+                            for (int u = 0; u < GCR; ++u) {
+                                const int c = ch_shfl_i(cjv[u], sl);
+                                v[i][u] = *reinterpret_cast<const float4*>(a.xd + (long long)c * C + 4 * cc);
+                            }
+                        }
+                    };
+                    auto add = [&](const float (&wxv)[GCR], const float (&wyv)[GCR], const float4 (&v)[NI][GCR]) {
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) {
+                            const int sl = RPI * i + rsub;
+#pragma unroll
+                            for (int u = 0; u < GCR; ++u) {
+                                const float cx = __shfl(wxv[u], sl, 64), cy = __shfl(wyv[u], sl, 64);
+                                const float4 t = v[i][u];
+                                bx[i].x = fmaf(cx, t.x, bx[i].x); by[i].x = fmaf(cy, t.x, by[i].x);
+                                bx[i].y = fmaf(cx, t.y, bx[i].y); by[i].y = fmaf(cy, t.y, by[i].y);
+                                bx[i].z = fmaf(cx, t.z, bx[i].z); by[i].z = fmaf(cy, t.z, by[i].z);
+                                bx[i].w = fmaf(cx, t.w, bx[i].w); by[i].w = fmaf(cy, t.w, by[i].w);
+                            }
+                        }
+                    };
+                    // (two row buffers -- the rows of step k + 1 requested before the sums of step k are formed -- were measured: 85 spilled
+                    // registers, block forward 471 vs 410 us; profiles/r05_rcg_ab.txt)
+                    int cj[GCR], cjn[GCR]; float wx[GCR], wy[GCR], wxn[GCR], wyn[GCR];
+                    entries(0, cjn, wxn, wyn);
+                    for (int j0 = 0; j0 < nmax; j0 += GCR) {
+#pragma unroll
+                        for (int u = 0; u < GCR; ++u) { cj[u] = cjn[u]; wx[u] = wxn[u]; wy[u] = wyn[u]; }
+                        float4 v[NI][GCR];
+                        request(cj, v);
+                        entries(j0 + GCR, cjn, wxn, wyn);       // the next step's entries travel under this step's rows
+                        add(wx, wy, v);
+                    }
+                    if (a.gx) {                       // saved for the backward: whole rows per half-wave
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) {
+                            const int rr = rb + 16 * hh + RPI * i + rsub;
+                            if (rr < a.V) {
+                                ch_st4(a.gx + (long long)rr * C + 4 * cc, bx[i]);
+                                ch_st4(a.gy + (long long)rr * C + 4 * cc, by[i]);
+                            }
+                        }
+                    }
+                    // row-contiguous -> operand layout, SROWS rows at a time (chunk c of slice row r sits at c ^ 4 r: the 16 lanes of a read land
+                    // on 16 different 16-byte bank groups)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int sq = 0; sq < 16 / SROWS; ++sq) {
+#pragma unroll
+                            for (int k = 0; k < SROWS / RPI; ++k) {
+                                const int r = RPI * k + rsub;
+                                slice[r * LPR + (cc ^ (4 * r))] = t ? by[sq * (SROWS / RPI) + k] : bx[sq * (SROWS / RPI) + k];
+                            }
+                            ch_wave_sync();
+                            if ((m >> 2) == sq) {
+                                const int r = m & 3;
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt) {
+                                    const float4 f = slice[r * LPR + ((4 * nt + q) ^ (4 * r))];
+                                    if (t) { gyv[nt][0] = f.x; gyv[nt][1] = f.y; gyv[nt][2] = f.z; gyv[nt][3] = f.w; }
+                                    else   { gxv[nt][0] = f.x; gxv[nt][1] = f.y; gxv[nt][2] = f.z; gxv[nt][3] = f.w; }
+                                }
+                            }
+                            ch_wave_sync();
+                        }
                 }
                 CH_TR();
                 // ---- Bre = gx A_re^T - gy A_im^T, Bim = gy A_re^T + gx A_im^T  (layers.py:122-123; without rotations Bre = gx A^T, Bim = gy A^T)
@@ -536,7 +647,8 @@ static int chain_launch_nw(ChainArgs a, hipStream_t stream) {
     int g = (8 / NW) * dn_num_cus();      // eight waves per CU (256 registers per lane each): two 4-wave workgroups or one 8-wave workgroup
     if (g > a.units) g = a.units;
     g = (g + 7) / 8 * 8;
-    const size_t smem = (size_t)DN_CH_RING * (2 * (C / 16) * 64) * sizeof(uint4) + (size_t)DN_CH_LAYERS * C * sizeof(float);
+    const size_t smem = (size_t)DN_CH_RING * (2 * (C / 16) * 64) * sizeof(uint4) + (size_t)DN_CH_LAYERS * C * sizeof(float) +
+                        (size_t)NW * 4 * C * sizeof(float);      // piece ring + biases + one 4-row gather slice per wave
 #ifndef DN_EMULATE
     static unsigned long long lds_opt_in = 0;   // per-device bitmap
     { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&chain_fwd_kernel<C, NW, HH>), smem, &lds_opt_in); if (oe_) return oe_; }
@@ -559,10 +671,10 @@ static int chain_launch(int npieces, const ChainArgs& a_in, hipStream_t stream, 
         nw = 4;
         while (nw > 1 && (a_in.V + 16 * hh * nw - 1) / (16 * hh * nw) < half) nw >>= 1;
     }
-    if (hh == 1 && nw > 2) nw = 2;          // (instantiated for the small-batch shapes only)
+    if (hh == 1 && nw > 4) nw = 4;
     ChainArgs a = a_in;
     a.n_pieces = npieces;
-    if (hh == 1) return nw == 2 ? chain_launch_nw<C, 2, 1>(a, stream) : chain_launch_nw<C, 1, 1>(a, stream);
+    if (hh == 1) return nw == 4 ? chain_launch_nw<C, 4, 1>(a, stream) : (nw == 2 ? chain_launch_nw<C, 2, 1>(a, stream) : chain_launch_nw<C, 1, 1>(a, stream));
     switch (nw) {
         case 8: return chain_launch_nw<C, 8, 2>(a, stream);
         case 2: return chain_launch_nw<C, 2, 2>(a, stream);

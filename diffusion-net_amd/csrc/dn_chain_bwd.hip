@@ -366,10 +366,9 @@ static int chain_bwd_launch(int npieces, const ChainBwdArgs& a_in, hipStream_t s
         nw = 4;
         while (nw > 1 && (a_in.V + 16 * hh * nw - 1) / (16 * hh * nw) < half) nw >>= 1;
     }
-    if (hh == 1 && nw > 2) nw = 2;
     ChainBwdArgs a = a_in;
     a.n_pieces = npieces;
-    if (hh == 1) return nw == 2 ? chain_bwd_launch_nw<C, 2, 1>(a, stream) : chain_bwd_launch_nw<C, 1, 1>(a, stream);
+    if (hh == 1) return nw == 4 ? chain_bwd_launch_nw<C, 4, 1>(a, stream) : (nw == 2 ? chain_bwd_launch_nw<C, 2, 1>(a, stream) : chain_bwd_launch_nw<C, 1, 1>(a, stream));
     switch (nw) {
         case 2: return chain_bwd_launch_nw<C, 2, 2>(a, stream);
         case 1: return chain_bwd_launch_nw<C, 1, 2>(a, stream);

@@ -80,6 +80,25 @@ __device__ __forceinline__ float4 ch_ld4(const float* p) {
     return *reinterpret_cast<const float4*>(p);
 #endif
 }
+// int shuffle (the emulator's shuffles carry floats: row indices of its test meshes are exact in fp32)
+__device__ __forceinline__ int ch_shfl_i(int v, int src_lane) {
+#ifdef DN_EMULATE
+    return (int)__shfl((float)v, src_lane, 64);
+#else
+    return __shfl(v, src_lane, 64);
+#endif
+}
+// Orders this wave's LDS traffic: what its lanes wrote before is what its lanes read after (LDS operations of a wave execute in order;
+// this keeps the compiler from moving them across).  No hardware barrier: the waves of a workgroup are at different places here.
+__device__ __forceinline__ void ch_wave_sync() {
+#ifdef DN_EMULATE
+    dnemu::wave_barrier();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
 __device__ __forceinline__ float ch_wave_max(float m) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { const float o = __shfl_xor(m, d, 64); m = o > m ? o : m; }

@@ -7,7 +7,7 @@ for p in (os.path.join(ROOT, "diffusion-net_amd"), ROOT, os.path.join(ROOT, "tes
         sys.path.insert(0, p)
 
 
-# the chained TRAINING forward takes only large batches by default (dn_api.hip, option "chain_min_rows"); the tests run it at every eligible
+# (round 4: the chained TRAINING forward took only large batches by default; since round 5 "chain_min_rows" defaults to 0 as well)  every eligible
 # size -- selected through the library's own option table (dn_set_option), applied to whichever build of it a test binds.  The shipped default
 # (unfused training forward + chained backward below 100k rows) is covered by parity_cases.run_chain_vs_unfused's "mixed" mode.
 from diffusion_net import _hip as _dn_hip  # noqa: E402

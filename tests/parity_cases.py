@@ -122,7 +122,7 @@ def run_chain_vs_unfused(device, sizes=(300, 140), K=128, C=128, N_block=2, drop
     from diffusion_net import _hip
     saved = {k: _hip.get_option(k) for k in ("chain", "chain_min_rows", "chain_small_rows")}
     try:
-        # "mixed" = the SHIPPED dispatch between chain_small_rows (16k) and chain_min_rows (100k) rows: unfused training forward + chained backward
+        # "mixed" = unfused training forward + chained backward: the shipped dispatch of round 4 below 100k rows, still selectable through chain_min_rows
         for mode in ("chain", "unfused", "mixed"):
             _hip.set_option("chain", 0 if mode == "unfused" else 1)
             _hip.set_option("chain_min_rows", 100000 if mode == "mixed" else 0)
