@@ -457,8 +457,10 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[hh][nt] = dn_f32x4{0.f, 0.f, 0.f, 0.f};
         {
-            // operands of the 2 NK pieces of the x and xd segments, fetched two pieces ahead
-            float4 nx[3][HH][2];
+            // operands of the 2 NK pieces of the x and xd segments, fetched two pieces ahead (requesting all of them up front in the
+            // one-half form -- the registers would allow it -- measured no gain: 410 vs 400 us block forward, profiles/r05_rcg_ab.txt)
+            constexpr int NXR = 3;
+            float4 nx[NXR][HH][2];
             auto fetch = [&](int pi, float4 (&d)[HH][2]) {
                 const float* p = (pi < NK ? a.x : a.xd) + 32 * (pi < NK ? pi : pi - NK) + 4 * q;
 #pragma unroll
@@ -481,8 +483,8 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
             for (int pi = 0; pi < 2 * NK; ++pi) {
                 uint4 fh[HH], fl[HH];
 #pragma unroll
-                for (int hh = 0; hh < HH; ++hh) ch_split8(nx[pi % 3][hh][0], nx[pi % 3][hh][1], s_in, fh[hh], fl[hh]);
-                if (pi + 2 < 2 * NK) fetch(pi + 2, nx[(pi + 2) % 3]);
+                for (int hh = 0; hh < HH; ++hh) ch_split8(nx[pi % NXR][hh][0], nx[pi % NXR][hh][1], s_in, fh[hh], fl[hh]);
+                if (pi + 2 < 2 * NK) fetch(pi + 2, nx[(pi + 2) % NXR]);
                 CH_PIECE_BEGIN();
                 CH_MMA2(acc, fh[0], fl[0], fh[HH - 1], fl[HH - 1]);
                 CH_PIECE_END();

@@ -99,10 +99,31 @@ __device__ __forceinline__ void ch_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #endif
 }
+// Maximum over the wave, the same value in every lane.  Data-parallel-primitive moves inside the rows of 16 lanes, row broadcasts across them,
+// one v_readlane: ~10 dependent VALU instructions.  The shuffle form (six ds_bpermute round trips through the LDS crossbar, each behind an
+// lgkmcnt(0)) cost ~700 cycles per reduction, three to five times per pass of a wave (profiles/r05_chain_trace_hh.txt).
 __device__ __forceinline__ float ch_wave_max(float m) {
+#ifdef DN_EMULATE
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { const float o = __shfl_xor(m, d, 64); m = o > m ? o : m; }
     return m;
+#else
+    int v = (int)__float_as_uint(m);
+#define CH_DPP_MAX_(ctrl_, rows_)                                                                        \
+    do {                                                                                                 \
+        const int t_ = __builtin_amdgcn_update_dpp(v, v, (ctrl_), (rows_), 0xf, false);                  \
+        const float a_ = __uint_as_float((unsigned)t_), b_ = __uint_as_float((unsigned)v);               \
+        v = (int)__float_as_uint(a_ > b_ ? a_ : b_);                                                     \
+    } while (0)
+    CH_DPP_MAX_(0xB1, 0xf);     // quad_perm [1, 0, 3, 2]
+    CH_DPP_MAX_(0x4E, 0xf);     // quad_perm [2, 3, 0, 1]
+    CH_DPP_MAX_(0x141, 0xf);    // row_half_mirror
+    CH_DPP_MAX_(0x140, 0xf);    // row_mirror: every lane of a row holds the row's maximum
+    CH_DPP_MAX_(0x142, 0xa);    // row_bcast15 into rows 1, 3
+    CH_DPP_MAX_(0x143, 0xc);    // row_bcast31 into rows 2, 3: lane 63 holds the wave's maximum
+#undef CH_DPP_MAX_
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane(v, 63));
+#endif
 }
 
 #ifndef DN_CH_RING
