@@ -629,7 +629,8 @@ static bool chain_aligned(const dn_block_params_t* p, const dn_block_saved_t* sv
 // Measured (tools/kbench, block forward / backward, us, HH = 2 -> 1; profiles/r05_chain_hh_sweep.txt): 7k rows 90 -> 66 / 134 -> 114,
 // 20k 117 -> 99 / 198 -> 185, 40k 168 -> 145 / 319 -> 290, 80k 267 -> 230 / 502 -> 471, 160k 457 -> 447 / 822 -> 833: the forward takes one
 // half per wave at every size measured, the backward up to ~100k rows.
-static int chain_hh(const dn_mesh_batch_t* mb, bool backward = false) {
+static int chain_hh(const dn_mesh_batch_t* mb, bool backward = false, int C = 128) {
+    if (C >= 256) return 2;       // (the one form of the C = 256 forward)
     const int f = opt(O_CHAIN_HH);
     if (f == 1 || f == 2) return f;
     return mb->v_total <= (backward ? 100000 : 262144) ? 1 : 2;
@@ -637,7 +638,7 @@ static int chain_hh(const dn_mesh_batch_t* mb, bool backward = false) {
 static bool block_chain_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int kind) {
     if (!opt(O_CHAIN) || !opt(O_F16) || (p->with_grad && !mb->grad_norm)) return false;      // "f16" = 0: split-bf16 engine everywhere (A/B runs)
     if (kind == 1 && mb->v_total < opt(O_CHAIN_MIN_ROWS) && mb->v_total > opt(O_CHAIN_SMALL_ROWS)) return false;
-    return dn_chain_eligible(p->C, p->n_mlp, p->widths, p->with_grad, mb->g_nnz, mb->v_total);
+    return dn_chain_eligible(p->C, p->n_mlp, p->widths, p->with_grad, mb->g_nnz, mb->v_total, kind == 2);
 }
 // Product classes of the block; option "f16_mask" (diagnostic) selects which of them run on the split-fp16 engine.
 // Default: the row products (gradient features, MLP, input gradients, backward back-projection).  Not the split-V projections
@@ -698,7 +699,7 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     float* sw = sv ? sv->amax : aw + AW_COUNT;                 // magnitudes of the saved activations (kept for the backward)
     const float *x_amax = nullptr, *ev_amax = nullptr, *ms_amax = nullptr;
     ChainPrepArgs pa; memset(&pa, 0, sizeof(pa));
-    int chain_np = 0;
+    int chain_np = 0, chain_ngf = 0;
     const bool use_chain = chain;
     if (!words && p->clamp_time) {           // no bookkeeping launch on this path: the clamp is the launch
         AmaxInit in; memset(&in, 0, sizeof(in));
@@ -727,11 +728,11 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
             auto piece = [&](const float* Wm, const float* Wm2, float* word, int ld, int col0) {
                 ChainPrepPiece& q = pa.pc[chain_np++]; q.W = Wm; q.W2 = Wm2; q.amax = word; q.ld = ld; q.col0 = col0; };
             if (p->with_grad)
-                for (int rep = 0; rep < chain_hh(mb); ++rep)      // (the gradient-feature stage runs once per 16-row half of a wave)
-                    for (int T = 0; T < NK; ++T) {
-                        piece(p->A_re, p->with_rot ? p->A_im : nullptr, aw + AW_WA, C, 32 * T);
-                        if (p->with_rot) piece(p->A_im, p->A_re, aw + AW_WA, C, 32 * T);
-                    }
+                for (int T = 0; T < NK; ++T) {      // (streamed once per 16-row half of a wave by the kernel)
+                    piece(p->A_re, p->with_rot ? p->A_im : nullptr, aw + AW_WA, C, 32 * T);
+                    if (p->with_rot) piece(p->A_im, p->A_re, aw + AW_WA, C, 32 * T);
+                }
+            chain_ngf = chain_np;
             for (int sg = 0; sg < (p->with_grad ? 3 : 2); ++sg) {      // layer 0: the g segment first (columns 2C..), then x, xd
                 const int seg = p->with_grad ? (sg + 2) % 3 : sg;
                 for (int T = 0; T < NK; ++T) piece(p->W[0], nullptr, aw + AW_W0, p->widths[0], seg * C + 32 * T);
@@ -784,6 +785,8 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
         ca.x = x; ca.xd = xd; ca.V = mb->v_total;
         ca.with_grad = p->with_grad; ca.with_rot = p->with_rot; ca.n_mlp = p->n_mlp;
         ca.wp = reinterpret_cast<const uint4*>(chain_ws);
+        // pieces the kernel streams once per 16-row half: the gradient-feature ones, and at C = 256 layer 0's g segment behind them (dn_chain.hip, G0)
+        ca.n_gf = chain_ngf + ((C >= 256 && p->with_grad) ? C / 32 : 0);
         ca.wa_amax = aw + AW_WA;
         for (int j = 0; j < p->n_mlp; ++j) {
             ca.w_amax[j] = aw + AW_W0 + j; ca.bias[j] = p->b[j];
@@ -801,7 +804,7 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
         ca.out = out;
         ca.x_amax = x_amax; ca.xd_amax = sw + SW_XD; ca.grad_norm = mb->grad_norm;
         ca.g_amax = sw + SW_G; ca.out_amax = p->out_amax;
-        return dn_launch_chain_fwd(chain_np, ca, C, st, chain_hh(mb));
+        return dn_launch_chain_fwd(chain_np, ca, C, st, chain_hh(mb, false, C));
     }
     // gradient features (layers.py:213-226)
     if (p->with_grad) {

@@ -32,6 +32,13 @@
 #ifndef DN_CH_GCR
 #define DN_CH_GCR 1      // (1: 393.9 us block forward at 16 x 10k, 2: 408.1, 3: 431.5 -- registers, not bytes in flight; profiles/r05_rcg_ab.txt)
 #endif
+#ifndef DN_CH_GCR_WIDE
+#define DN_CH_GCR_WIDE 2 // the same in the C = 256 form (one wave per SIMD: 16 KiB in flight per wave)
+#endif
+#ifndef DN_CH_ROLL
+#define DN_CH_ROLL 1     // rolling row requests in the row-contiguous gather: 1 = in the C = 256 form (latency-bound there: one wave per SIMD), 2 = everywhere
+                         // (C = 128: 28 spilled registers in the benchmark's kernel), 0 = all rows of a step requested, then all summed
+#endif
 #ifndef DN_CH_RCG
 #define DN_CH_RCG 1      // row-contiguous gather in the one-half-per-wave form of the chained forward (0: operand-layout gather everywhere; A/B)
 #endif
@@ -115,29 +122,36 @@ extern "C" int dn_debug_ch_trace_read(unsigned long long* out, int n) {
 #endif
 
 template <int C, int NW, int HH>
-__global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(ChainArgs a) {
+__global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void chain_fwd_kernel(ChainArgs a) {
     constexpr int NT = C / 16;            // 16-channel output tiles
     constexpr int NK = C / 32;            // 32-channel contraction steps (= pieces per matrix)
     constexpr int NTHR = 64 * NW;
     constexpr int PIECE = 2 * NT * 64;    // uint4 per piece
     constexpr int LPT = PIECE / NTHR;     // DMA requests per thread and piece
-    constexpr int RING = DN_CH_RING;
+    constexpr bool G0 = C >= 256;         // the one-wave-per-SIMD form of C = 256 (see the gradient-feature stage)
+    constexpr int RING = DN_CH_RING;      // (C = 256: 32 KiB pieces; 128 KiB of ring + 32 KiB of gather slices are the CU's 160 KiB)
     constexpr int GCH = DN_CH_GCHUNK;
     static_assert(PIECE % NTHR == 0, "piece staging");
     static_assert(RING >= 2 && RING <= 8 && (RING - 1) * LPT < 60, "ring depth vs the vmcnt range");
 
     DN_DYN_SMEM(smem_raw);
     uint4* ring = reinterpret_cast<uint4*>(smem_raw);                      // RING slots of PIECE uint4
-    float* sbias = reinterpret_cast<float*>(ring + RING * PIECE);          // [DN_CH_LAYERS][C]
-    // row-contiguous gather (RCG; one-half-per-wave form only: it needs the registers the second half's features occupy otherwise)
-    constexpr bool RCG = HH == 1 && DN_CH_RCG != 0;
-    constexpr int LPR = C / 4;            // gather: lanes that cover one row (16 bytes each)
+    float* sbias = reinterpret_cast<float*>(ring + RING * PIECE);          // [DN_CH_LAYERS][C]  (G0: not staged, the epilogues read the biases from memory)
+    // row-contiguous gather (RCG; at C = 128 in the one-half-per-wave form only: it needs the registers the second half's features occupy
+    // otherwise.  The C = 256 form runs one wave per SIMD with 512 registers and takes it with both halves)
+    constexpr bool RCG = (HH == 1 || C >= 256) && DN_CH_RCG != 0;
+    constexpr int GC = G0 ? 128 : C;      // channels per gather sweep (G0: the row in two column halves -- sums, request buffers and the slice are
+                                          // those of C = 128, the half gathered first is in its final registers while the second one runs)
+    constexpr int NSW = C / GC;           // sweeps
+    constexpr int GNT = GC / 16;          // 16-channel tiles per sweep
+    constexpr int LPR = GC / 4;           // gather: lanes that cover one row (segment) of a sweep (16 bytes each)
     constexpr int RPI = 64 / LPR;         // rows one gather instruction covers
     constexpr int NI = 16 / RPI;          // row groups of a 16-row half
-    constexpr int SROWS = 4;              // rows per transposition slice
-    constexpr int GCR = DN_CH_GCR;        // pattern entries per gather step of the row-contiguous form (NI x GCR KiB in flight per wave)
+    constexpr int SROWS = G0 ? 16 : 4;    // rows per transposition slice (G0: the whole half at once -- every lane reads its row unconditionally, and
+                                          // gx / gy become registers one after the other instead of as 128 conditionally merged ones)
+    constexpr int GCR = G0 ? DN_CH_GCR_WIDE : DN_CH_GCR;        // pattern entries per gather step of the row-contiguous form (NI x GCR KiB in flight per wave)
     static_assert(SROWS % RPI == 0 && 16 % SROWS == 0, "gather slices");
-    float4* slice = reinterpret_cast<float4*>(sbias + DN_CH_LAYERS * C) + (threadIdx.x >> 6) * (SROWS * LPR);   // wave-private, SROWS rows (RCG)
+    float4* slice = reinterpret_cast<float4*>(sbias + (G0 ? 0 : DN_CH_LAYERS * C)) + (threadIdx.x >> 6) * (SROWS * LPR);   // wave-private, SROWS rows (RCG)
 #ifdef DN_EMULATE
     const unsigned lds0 = 0;
 #else
@@ -178,13 +192,18 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
     for (int j = 0; j < DN_CH_LAYERS; ++j) sw_inv[j] = j < a.n_mlp ? ch_uniform(ch_pow2_inv(dn_pow2_scale(dn_amax_word(a.w_amax[j])))) : 1.f;
     unsigned long long seed_add = 0ull;
     if (a.seed_dev) seed_add = *a.seed_dev;
-    for (int i = tid; i < a.n_mlp * C; i += NTHR) sbias[i] = a.bias[i / C][i % C];   // (published by the first barrier below)
+    if constexpr (!G0)
+        for (int i = tid; i < a.n_mlp * C; i += NTHR) sbias[i] = a.bias[i / C][i % C];   // (published by the first barrier below)
 
     // ---- the piece stream: LDS-DMA fills slot p % RING with piece p, RING - 1 pieces ahead of the one being multiplied.  Every wave
     //      requests its share of a piece, waits for its share of the NEXT piece at the end of a piece (counted: the younger requests stay in
     //      flight) and the barrier there publishes it -- and tells everybody that the slot read in this piece may be overwritten.
-    const uint4* src_piece = a.wp;        // piece the NEXT request fetches (wraps at n_pieces: the stream of the next pass)
-    const uint4* const src_end = a.wp + (size_t)a.n_pieces * PIECE;
+    // The stream of a pass: the gradient-feature pieces once per 16-row half (the stage runs half by half), then every other piece once;
+    // position sq of that sequence fetches piece sq (first round of the gradient-feature pieces), sq - n_gf (second round) or
+    // sq - (HH - 1) n_gf (the layers).  It wraps at the end of a pass: the requests run ahead into the next one.
+    const int n_gf = a.with_grad ? a.n_gf : 0;
+    const int n_seq = a.n_pieces + (HH - 1) * n_gf;
+    int sq = 0;                           // position the NEXT request fetches
 #ifdef DN_EMULATE
     const int wave_u = wave;
 #else
@@ -192,12 +211,14 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
 #endif
     int rq = 0;                           // slot the next request fills
     auto issue = [&]() {
+        const int pidx = sq < HH * n_gf ? (sq >= n_gf ? sq - n_gf : sq) : sq - (HH - 1) * n_gf;
+        const uint4* src_piece = a.wp + (size_t)pidx * PIECE;
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const int e0 = rq * PIECE + i * NTHR + wave_u * 64;
             ch_dma16(src_piece + i * NTHR + tid, ring + e0, lds0 + 16u * (unsigned)e0);
         }
-        src_piece = src_piece + PIECE == src_end ? a.wp : src_piece + PIECE;
+        sq = sq + 1 == n_seq ? 0 : sq + 1;
         rq = rq + 1 == RING ? 0 : rq + 1;
     };
 #ifdef DN_EMULATE
@@ -239,14 +260,34 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
         }
 
         // =================================================== gradient features, one 16-row half at a time
-        uint4 gfh[HH][NK], gfl[HH][NK];     // tanh features of the two halves as operand fragments (hi / lo planes) for layer 0
-        if (a.with_grad) {
-#pragma unroll 1
-            for (int hh = 0; hh < HH; ++hh) {
-                if (hh == 1) {
+        // G0 (the C = 256 form): the layer-0 product of a half's tanh features follows them at once, inside the half loop -- their operand
+        // fragments then live for eight pieces instead of across the other half's whole stage (64 registers of a stage that holds gx, gy and
+        // four accumulators; the general registers of a wave end at 256 whatever the SIMD has free, the accumulators live in the other 256)
+        dn_f32x4 acc[HH][NT];               // MiniMLP accumulators of the two halves
+        // G0: an accumulator row STARTS at its layer's bias in the units of the product (b / so, exact: so is a power of two) -- one batch of
+        // bias requests per product, one latency, and epilogues that are register arithmetic only (the biases have no LDS there)
+        auto bias_init = [&](dn_f32x4 (&row)[NT], const float* bp, const float sc) {
+            float4 bq[NT];
 #pragma unroll
-                    for (int T = 0; T < NK; ++T) { gfh[0][T] = gfh[HH - 1][T]; gfl[0][T] = gfl[HH - 1][T]; }
-                }
+            for (int nt = 0; nt < NT; ++nt) bq[nt] = *reinterpret_cast<const float4*>(bp + 16 * nt);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) row[nt] = dn_f32x4{bq[nt].x * sc, bq[nt].y * sc, bq[nt].z * sc, bq[nt].w * sc};
+        };
+        const float sc0 = s_in * ch_pow2_inv(sw_inv[0]);      // 1 / (output scale of layer 0)
+        if constexpr (G0) {
+            if (!a.with_grad) {       // (with gradient features each half's row starts where its g-segment product does)
+#pragma unroll
+                for (int hh = 0; hh < HH; ++hh) bias_init(acc[hh], a.bias[0] + 4 * q, sc0);
+            }
+        } else {
+#pragma unroll
+            for (int hh = 0; hh < HH; ++hh)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[hh][nt] = dn_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        uint4 gfh[G0 ? 1 : HH][NK], gfl[G0 ? 1 : HH][NK];     // tanh features (of the two halves) as operand fragments (hi / lo planes) for layer 0
+        if (a.with_grad) {
+            auto half = [&](const int hh) __attribute__((always_inline)) {
                 const long long row = hh ? rowh[HH - 1] : rowh[0];
                 const bool live = hh ? liveh[HH - 1] : liveh[0];
                 // ---- CSR gather of the row: gx = sum_j vx_j xd[col_j], gy likewise (entry order, fmaf: bit for bit spmm_kernel's sums)
@@ -308,99 +349,141 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
                     // bit for bit -- are then transposed into the operand layout (lane (m, q): row m, channels 16 nt + 4 q ..) through a
                     // wave-private 4-row LDS slice.  All NI row groups of a step are in flight together (NI x GCH requests of 1 KiB per wave: the
                     // form that did not fit the register file with two halves per wave, round 4).
-                    float4 bx[NI], by[NI];            // sums of row RPI * i + rsub of the half, channels 4 cc .. 4 cc + 3
 #pragma unroll
-                    for (int i = 0; i < NI; ++i) { bx[i] = make_float4(0.f, 0.f, 0.f, 0.f); by[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
-                    auto entries = [&](int j0, int (&cjv)[GCR], float (&wxv)[GCR], float (&wyv)[GCR]) {   // entries j0 .. j0 + GCR - 1 of this lane's row (past its end: entry 0, weight 0)
+                    for (int sw = 0; sw < NSW; ++sw) {
+                        float4 bx[NI], by[NI];            // sums of row RPI * i + rsub of the half, channels 4 cc .. 4 cc + 3
 #pragma unroll
-                        for (int u = 0; u < GCR; ++u) {
-                            const int idx = beg + j0 + u;
-                            const bool in = idx < end;
-                            const int ii = in ? idx : 0;
-                            cjv[u] = a.col[ii];
-                            wxv[u] = in ? a.vx[ii] : 0.f;
-                            wyv[u] = in ? a.vy[ii] : 0.f;
-                        }
-                    };
-                    auto request = [&](const int (&cjv)[GCR], float4 (&v)[NI][GCR]) {
-#pragma unroll
-                        for (int i = 0; i < NI; ++i) {
-                            const int sl = RPI * i + rsub;          // lane (m = that row, q = 0) holds the row's entries
+                        for (int i = 0; i < NI; ++i) { bx[i] = make_float4(0.f, 0.f, 0.f, 0.f); by[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+                        auto entries = [&](int j0, int (&cjv)[GCR], float (&wxv)[GCR], float (&wyv)[GCR]) {   // entries j0 .. j0 + GCR - 1 of this lane's row (past its end: entry 0, weight 0)
 #pragma unroll
                             for (int u = 0; u < GCR; ++u) {
-                                const int c = ch_shfl_i(cjv[u], sl);
-                                v[i][u] = *reinterpret_cast<const float4*>(a.xd + (long long)c * C + 4 * cc);
+                                const int idx = beg + j0 + u;
+                                const bool in = idx < end;
+                                const int ii = in ? idx : 0;
+                                cjv[u] = a.col[ii];
+                                wxv[u] = in ? a.vx[ii] : 0.f;
+                                wyv[u] = in ? a.vy[ii] : 0.f;
                             }
-                        }
-                    };
-                    auto add = [&](const float (&wxv)[GCR], const float (&wyv)[GCR], const float4 (&v)[NI][GCR]) {
+                        };
+                        auto request = [&](const int (&cjv)[GCR], float4 (&v)[NI][GCR]) {
 #pragma unroll
-                        for (int i = 0; i < NI; ++i) {
-                            const int sl = RPI * i + rsub;
+                            for (int i = 0; i < NI; ++i) {
+                                const int sl = RPI * i + rsub;          // lane (m = that row, q = 0) holds the row's entries
 #pragma unroll
-                            for (int u = 0; u < GCR; ++u) {
-                                const float cx = __shfl(wxv[u], sl, 64), cy = __shfl(wyv[u], sl, 64);
-                                const float4 t = v[i][u];
-                                bx[i].x = fmaf(cx, t.x, bx[i].x); by[i].x = fmaf(cy, t.x, by[i].x);
-                                bx[i].y = fmaf(cx, t.y, bx[i].y); by[i].y = fmaf(cy, t.y, by[i].y);
-                                bx[i].z = fmaf(cx, t.z, bx[i].z); by[i].z = fmaf(cy, t.z, by[i].z);
-                                bx[i].w = fmaf(cx, t.w, bx[i].w); by[i].w = fmaf(cy, t.w, by[i].w);
-                            }
-                        }
-                    };
-                    // (two row buffers -- the rows of step k + 1 requested before the sums of step k are formed -- were measured: 85 spilled
-                    // registers, block forward 471 vs 410 us; profiles/r05_rcg_ab.txt)
-                    int cj[GCR], cjn[GCR]; float wx[GCR], wy[GCR], wxn[GCR], wyn[GCR];
-                    entries(0, cjn, wxn, wyn);
-                    for (int j0 = 0; j0 < nmax; j0 += GCR) {
-#pragma unroll
-                        for (int u = 0; u < GCR; ++u) { cj[u] = cjn[u]; wx[u] = wxn[u]; wy[u] = wyn[u]; }
-                        float4 v[NI][GCR];
-                        request(cj, v);
-                        entries(j0 + GCR, cjn, wxn, wyn);       // the next step's entries travel under this step's rows
-                        add(wx, wy, v);
-                    }
-                    if (a.gx) {                       // saved for the backward: whole rows per half-wave
-#pragma unroll
-                        for (int i = 0; i < NI; ++i) {
-                            const int rr = rb + 16 * hh + RPI * i + rsub;
-                            if (rr < a.V) {
-                                ch_st4(a.gx + (long long)rr * C + 4 * cc, bx[i]);
-                                ch_st4(a.gy + (long long)rr * C + 4 * cc, by[i]);
-                            }
-                        }
-                    }
-                    // row-contiguous -> operand layout, SROWS rows at a time (chunk c of slice row r sits at c ^ 4 r: the 16 lanes of a read land
-                    // on 16 different 16-byte bank groups)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int sq = 0; sq < 16 / SROWS; ++sq) {
-#pragma unroll
-                            for (int k = 0; k < SROWS / RPI; ++k) {
-                                const int r = RPI * k + rsub;
-                                slice[r * LPR + (cc ^ (4 * r))] = t ? by[sq * (SROWS / RPI) + k] : bx[sq * (SROWS / RPI) + k];
-                            }
-                            ch_wave_sync();
-                            if ((m >> 2) == sq) {
-                                const int r = m & 3;
-#pragma unroll
-                                for (int nt = 0; nt < NT; ++nt) {
-                                    const float4 f = slice[r * LPR + ((4 * nt + q) ^ (4 * r))];
-                                    if (t) { gyv[nt][0] = f.x; gyv[nt][1] = f.y; gyv[nt][2] = f.z; gyv[nt][3] = f.w; }
-                                    else   { gxv[nt][0] = f.x; gxv[nt][1] = f.y; gxv[nt][2] = f.z; gxv[nt][3] = f.w; }
+                                for (int u = 0; u < GCR; ++u) {
+                                    const int c = ch_shfl_i(cjv[u], sl);
+                                    v[i][u] = *reinterpret_cast<const float4*>(a.xd + (long long)c * C + GC * sw + 4 * cc);
                                 }
                             }
-                            ch_wave_sync();
+                        };
+                        auto add = [&](const float (&wxv)[GCR], const float (&wyv)[GCR], const float4 (&v)[NI][GCR]) {
+#pragma unroll
+                            for (int i = 0; i < NI; ++i) {
+                                const int sl = RPI * i + rsub;
+#pragma unroll
+                                for (int u = 0; u < GCR; ++u) {
+                                    const float cx = __shfl(wxv[u], sl, 64), cy = __shfl(wyv[u], sl, 64);
+                                    const float4 t = v[i][u];
+                                    bx[i].x = fmaf(cx, t.x, bx[i].x); by[i].x = fmaf(cy, t.x, by[i].x);
+                                    bx[i].y = fmaf(cx, t.y, bx[i].y); by[i].y = fmaf(cy, t.y, by[i].y);
+                                    bx[i].z = fmaf(cx, t.z, bx[i].z); by[i].z = fmaf(cy, t.z, by[i].z);
+                                    bx[i].w = fmaf(cx, t.w, bx[i].w); by[i].w = fmaf(cy, t.w, by[i].w);
+                                }
+                            }
+                        };
+                        // (two row buffers -- the rows of step k + 1 requested before the sums of step k are formed -- were measured: 85 spilled
+                        // registers, block forward 471 vs 410 us; profiles/r05_rcg_ab.txt)
+                        if constexpr (DN_CH_ROLL == 2 || (DN_CH_ROLL == 1 && G0)) {
+                            // Rolling form, same registers: row group i of step k is summed as soon as ITS request has landed (requests return in
+                            // order: the other NI - 1 stay in flight) and its buffer is re-requested for step k + 1 at once -- NI requests in flight
+                            // all the time instead of a sawtooth between NI and none.  The pattern entries run two steps ahead.
+                            int cj[GCR], cjn[GCR]; float wx[GCR], wy[GCR], wxn[GCR], wyn[GCR];
+                            float4 v[NI][GCR];
+                            entries(0, cj, wx, wy);
+                            entries(GCR, cjn, wxn, wyn);
+                            request(cj, v);
+                            for (int j0 = 0; j0 < nmax; j0 += GCR) {
+                                int cj2[GCR]; float wx2[GCR], wy2[GCR];
+                                entries(j0 + 2 * GCR, cj2, wx2, wy2);
+                                const bool more = j0 + GCR < nmax;      // (wave-uniform)
+#pragma unroll
+                                for (int i = 0; i < NI; ++i) {
+                                    const int sl = RPI * i + rsub;
+#pragma unroll
+                                    for (int u = 0; u < GCR; ++u) {
+                                        const float cx = __shfl(wx[u], sl, 64), cy = __shfl(wy[u], sl, 64);
+                                        const float4 t = v[i][u];
+                                        bx[i].x = fmaf(cx, t.x, bx[i].x); by[i].x = fmaf(cy, t.x, by[i].x);
+                                        bx[i].y = fmaf(cx, t.y, bx[i].y); by[i].y = fmaf(cy, t.y, by[i].y);
+                                        bx[i].z = fmaf(cx, t.z, bx[i].z); by[i].z = fmaf(cy, t.z, by[i].z);
+                                        bx[i].w = fmaf(cx, t.w, bx[i].w); by[i].w = fmaf(cy, t.w, by[i].w);
+                                    }
+                                    if (more) {
+#pragma unroll
+                                        for (int u = 0; u < GCR; ++u) {
+                                            const int c = ch_shfl_i(cjn[u], sl);
+                                            v[i][u] = *reinterpret_cast<const float4*>(a.xd + (long long)c * C + GC * sw + 4 * cc);
+                                        }
+                                    }
+                                }
+#pragma unroll
+                                for (int u = 0; u < GCR; ++u) { cj[u] = cjn[u]; wx[u] = wxn[u]; wy[u] = wyn[u]; cjn[u] = cj2[u]; wxn[u] = wx2[u]; wyn[u] = wy2[u]; }
+                            }
+                        } else {
+                            int cj[GCR], cjn[GCR]; float wx[GCR], wy[GCR], wxn[GCR], wyn[GCR];
+                            entries(0, cjn, wxn, wyn);
+                            for (int j0 = 0; j0 < nmax; j0 += GCR) {
+#pragma unroll
+                                for (int u = 0; u < GCR; ++u) { cj[u] = cjn[u]; wx[u] = wxn[u]; wy[u] = wyn[u]; }
+                                float4 v[NI][GCR];
+                                request(cj, v);
+                                entries(j0 + GCR, cjn, wxn, wyn);       // the next step's entries travel under this step's rows
+                                add(wx, wy, v);
+                            }
                         }
-                }
+                        if (a.gx) {                       // saved for the backward: whole rows per half-wave
+#pragma unroll
+                            for (int i = 0; i < NI; ++i) {
+                                const int rr = rb + 16 * hh + RPI * i + rsub;
+                                if (rr < a.V) {
+                                    ch_st4(a.gx + (long long)rr * C + GC * sw + 4 * cc, bx[i]);
+                                    ch_st4(a.gy + (long long)rr * C + GC * sw + 4 * cc, by[i]);
+                                }
+                            }
+                        }
+                        // row-contiguous -> operand layout, SROWS rows at a time (chunk c of slice row r sits at c ^ 4 r -- c ^ r in the 16-row slice: the
+                        // 16 lanes of a read land on 16 different 16-byte bank groups)
+                        constexpr int SWZ = SROWS == 16 ? 1 : 4;
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int sq = 0; sq < 16 / SROWS; ++sq) {
+#pragma unroll
+                                for (int k = 0; k < SROWS / RPI; ++k) {
+                                    const int r = RPI * k + rsub;
+                                    slice[r * LPR + (cc ^ (SWZ * r))] = t ? by[sq * (SROWS / RPI) + k] : bx[sq * (SROWS / RPI) + k];
+                                }
+                                ch_wave_sync();
+                                if (SROWS == 16 || (m / SROWS) == sq) {
+                                    const int r = m % SROWS;
+#pragma unroll
+                                    for (int nt = 0; nt < GNT; ++nt) {
+                                        const float4 f = slice[r * LPR + ((4 * nt + q) ^ (SWZ * r))];
+                                        if (t) { gyv[GNT * sw + nt][0] = f.x; gyv[GNT * sw + nt][1] = f.y; gyv[GNT * sw + nt][2] = f.z; gyv[GNT * sw + nt][3] = f.w; }
+                                        else   { gxv[GNT * sw + nt][0] = f.x; gxv[GNT * sw + nt][1] = f.y; gxv[GNT * sw + nt][2] = f.z; gxv[GNT * sw + nt][3] = f.w; }
+                                    }
+                                }
+                                ch_wave_sync();
+                            }
+                    }
+                    }
                 CH_TR();
                 // ---- Bre = gx A_re^T - gy A_im^T, Bim = gy A_re^T + gx A_im^T  (layers.py:122-123; without rotations Bre = gx A^T, Bim = gy A^T)
-                dn_f32x4 acc[2][NT];      // [0] = Bre, [1] = Bim of this half
+                dn_f32x4 ga[2][NT];       // [0] = Bre, [1] = Bim of this half
 #pragma unroll
                 for (int o = 0; o < 2; ++o)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[o][nt] = dn_f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int nt = 0; nt < NT; ++nt) ga[o][nt] = dn_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int T = 0; T < NK; ++T) {
                     uint4 fxh, fxl, fyh, fyl;
@@ -408,54 +491,86 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
                     ch_split8(gyv[2 * T], gyv[2 * T + 1], s_gf, fyh, fyl);
                     {   // A_re (or A): Bre += A gx, Bim += A gy
                         CH_PIECE_BEGIN();
-                        CH_MMA2_LEAN(acc, fxh, fxl, fyh, fyl);
+                        if constexpr (C >= 256) CH_MMA2_PAIR(ga, fxh, fxl, fyh, fyl); else CH_MMA2_LEAN(ga, fxh, fxl, fyh, fyl);
                         CH_PIECE_END();
                     }
                     if (a.with_rot) {   // A_im: Bre -= A_im gy, Bim += A_im gx
                         const uint4 nyh = make_uint4(fyh.x ^ 0x80008000u, fyh.y ^ 0x80008000u, fyh.z ^ 0x80008000u, fyh.w ^ 0x80008000u);
                         const uint4 nyl = make_uint4(fyl.x ^ 0x80008000u, fyl.y ^ 0x80008000u, fyl.z ^ 0x80008000u, fyl.w ^ 0x80008000u);
                         CH_PIECE_BEGIN();
-                        CH_MMA2_LEAN(acc, nyh, nyl, fxh, fxl);
+                        if constexpr (C >= 256) CH_MMA2_PAIR(ga, nyh, nyl, fxh, fxl); else CH_MMA2_LEAN(ga, nyh, nyl, fxh, fxl);
                         CH_PIECE_END();
                     }
                 }
                 CH_TR();
                 // ---- g = tanh(gx * Bre + gy * Bim)   (layers.py:128-130), saved tensors, operand fragments for layer 0
-                float gv[NT][4];
+                if constexpr (G0) {
+                    // tile pair by tile pair, every value stored where it is produced: the scaled accumulators (general registers once they are
+                    // multiplied) never exist all at once
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+                    for (int T = 0; T < NK; ++T) {
+                        float gv2[2][4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc[0][nt][e] *= so_gf;                   // Bre, Bim (the accumulator registers keep them for the stores below)
-                        acc[1][nt][e] *= so_gf;
-                        gv[nt][e] = ch_tanh(gxv[nt][e] * acc[0][nt][e] + gyv[nt][e] * acc[1][nt][e]);
+                        for (int u = 0; u < 2; ++u) {
+                            const int nt = 2 * T + u;
+                            float br[4], bi[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                br[e] = ga[0][nt][e] * so_gf;
+                                bi[e] = ga[1][nt][e] * so_gf;
+                                gv2[u][e] = ch_tanh(gxv[nt][e] * br[e] + gyv[nt][e] * bi[e]);
+                            }
+                            if (live && a.g) ch_st4(a.g + row * C + 4 * q + 16 * nt, make_float4(gv2[u][0], gv2[u][1], gv2[u][2], gv2[u][3]));
+                            if (live && a.bre) {
+                                ch_st4(a.bre + row * C + 4 * q + 16 * nt, make_float4(br[0], br[1], br[2], br[3]));
+                                ch_st4(a.bim + row * C + 4 * q + 16 * nt, make_float4(bi[0], bi[1], bi[2], bi[3]));
+                            }
+                        }
+                        ch_split8(gv2[0], gv2[1], s_in, gfh[0][T], gfl[0][T]);
                     }
-                if (live && a.g) {
-                    float* og = a.g + row * C + 4 * q;
+                } else {
+                    float gv[NT][4];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) ch_st4(og + 16 * nt, make_float4(gv[nt][0], gv[nt][1], gv[nt][2], gv[nt][3]));
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            ga[0][nt][e] *= so_gf;                   // Bre, Bim (the accumulator registers keep them for the stores below)
+                            ga[1][nt][e] *= so_gf;
+                            gv[nt][e] = ch_tanh(gxv[nt][e] * ga[0][nt][e] + gyv[nt][e] * ga[1][nt][e]);
+                        }
+                    if (live && a.g) {
+                        float* og = a.g + row * C + 4 * q;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) ch_st4(og + 16 * nt, make_float4(gv[nt][0], gv[nt][1], gv[nt][2], gv[nt][3]));
+                    }
+                    if (live && a.bre) {
+                        float* o0 = a.bre + row * C + 4 * q;
+                        float* o1 = a.bim + row * C + 4 * q;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            ch_st4(o0 + 16 * nt, make_float4(ga[0][nt][0], ga[0][nt][1], ga[0][nt][2], ga[0][nt][3]));
+                            ch_st4(o1 + 16 * nt, make_float4(ga[1][nt][0], ga[1][nt][1], ga[1][nt][2], ga[1][nt][3]));
+                        }
+                    }
+#pragma unroll
+                    for (int T = 0; T < NK; ++T) ch_split8(gv[2 * T], gv[2 * T + 1], s_in, gfh[hh][T], gfl[hh][T]);
                 }
-                if (live && a.bre) {
-                    float* o0 = a.bre + row * C + 4 * q;
-                    float* o1 = a.bim + row * C + 4 * q;
+                if constexpr (G0) {       // layer 0, g segment, this half (hh is a literal here: the G0 form calls this body once per half)
+                    bias_init(acc[hh], a.bias[0] + 4 * q, sc0);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        ch_st4(o0 + 16 * nt, make_float4(acc[0][nt][0], acc[0][nt][1], acc[0][nt][2], acc[0][nt][3]));
-                        ch_st4(o1 + 16 * nt, make_float4(acc[1][nt][0], acc[1][nt][1], acc[1][nt][2], acc[1][nt][3]));
+                    for (int T = 0; T < NK; ++T) {
+                        CH_PIECE_BEGIN();
+                        CH_MMA1(acc[hh], gfh[0][T], gfl[0][T]);
+                        CH_PIECE_END();
                     }
                 }
-#pragma unroll
-                for (int T = 0; T < NK; ++T) ch_split8(gv[2 * T], gv[2 * T + 1], s_in, gfh[HH - 1][T], gfl[HH - 1][T]);
                 CH_TR();
-            }
+            };
+            half(0);                  // both halves spelled out (hh a literal in each copy): every accumulator row and fragment set has its own registers
+            if constexpr (HH > 1) half(HH - 1);
         }
 
         // =================================================== MiniMLP layer 0 on [g | x | xd] (the tanh features first: their fragments die here)
-        dn_f32x4 acc[HH][NT];
-#pragma unroll
-        for (int hh = 0; hh < HH; ++hh)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[hh][nt] = dn_f32x4{0.f, 0.f, 0.f, 0.f};
         {
             // operands of the 2 NK pieces of the x and xd segments, fetched two pieces ahead (requesting all of them up front in the
             // one-half form -- the registers would allow it -- measured no gain: 410 vs 400 us block forward, profiles/r05_rcg_ab.txt)
@@ -471,12 +586,14 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
             };
             fetch(0, nx[0]);
             fetch(1, nx[1]);
-            if (a.with_grad) {
+            if constexpr (!G0) {
+                if (a.with_grad) {
 #pragma unroll
-                for (int T = 0; T < NK; ++T) {
-                    CH_PIECE_BEGIN();
-                    CH_MMA2(acc, gfh[0][T], gfl[0][T], gfh[HH - 1][T], gfl[HH - 1][T]);
-                    CH_PIECE_END();
+                    for (int T = 0; T < NK; ++T) {
+                        CH_PIECE_BEGIN();
+                        CH_MMA2(acc, gfh[0][T], gfl[0][T], gfh[G0 ? 0 : HH - 1][T], gfl[G0 ? 0 : HH - 1][T]);
+                        CH_PIECE_END();
+                    }
                 }
             }
 #pragma unroll
@@ -498,58 +615,109 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
 #pragma unroll 1
         for (int j = 0; j + 1 < a.n_mlp; ++j) {
             const float so = ch_pow2_inv(s_act) * (j == 0 ? sw_inv[0] : (j == 1 ? sw_inv[1] : sw_inv[2]));
-            const float* bj = sbias + j * C + 4 * q;
+            const float* bj = G0 ? (j == 0 ? a.bias[0] : (j == 1 ? a.bias[1] : a.bias[2])) + 4 * q : sbias + j * C + 4 * q;
             const uint8_t* mk = a.mask[j];
             const unsigned long long sd = a.seed[j] ? a.seed[j] + seed_add : 0ull;
             const float dscale = (mk || sd) ? 2.f : 1.f;
             float* hj = a.h[j];
             float wm = 0.f;
-#pragma unroll
-            for (int hh = 0; hh < HH; ++hh)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(bj + 16 * nt);
-                    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+            if constexpr (G0) {
+                // two sweeps over the accumulators -- the largest magnitude first (the split's scale), then tile pair by tile pair: value,
+                // store, operand fragment -- so that h_j never exists as 128 general registers next to its 128 registers of fragments
+                auto tile = [&](const int hh, const int nt, float (&t)[4]) {
                     unsigned kb = 0x01010101u;
                     if (mk) kb = *reinterpret_cast<const uint32_t*>(mk + (long long)rch[hh] * C + 16 * nt + 4 * q);
                     else if (sd) kb = dn_keep_bytes(dn_keep_bits(sd, rch[hh], 4 * nt + q, C / 4));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float t = acc[hh][nt][e] * so + bb[e];
-                        t = t > 0.f ? t : 0.f;
-                        t = ((kb >> (8 * e)) & 0xffu) ? t * dscale : 0.f;
-                        acc[hh][nt][e] = t;                       // (the accumulator registers now hold h_j)
-                        wm = t > wm ? t : wm;
+                        float v = acc[hh][nt][e] * so;               // (the bias is in the accumulator)
+                        v = v > 0.f ? v : 0.f;
+                        t[e] = ((kb >> (8 * e)) & 0xffu) ? v * dscale : 0.f;
                     }
-                }
-            if (hj) {
+                };
 #pragma unroll
                 for (int hh = 0; hh < HH; ++hh)
-                    if (liveh[hh]) {
-                        float* oh = hj + (long long)rowh[hh] * C + 4 * q;
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            ch_st4(oh + 16 * nt, make_float4(acc[hh][nt][0], acc[hh][nt][1], acc[hh][nt][2], acc[hh][nt][3]));
+                    for (int nt = 0; nt < NT; ++nt) {
+                        float t[4];
+                        tile(hh, nt, t);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) wm = t[e] > wm ? t[e] : wm;
+                    }
+                wm = ch_wave_max(wm);
+#pragma unroll
+                for (int jj = 0; jj < DN_CH_LAYERS; ++jj) hmax[jj] = (jj == j && wm > hmax[jj]) ? wm : hmax[jj];
+                s_act = ch_uniform(dn_pow2_scale(wm));
+#pragma unroll
+                for (int hh = 0; hh < HH; ++hh)
+#pragma unroll
+                    for (int T = 0; T < NK; ++T) {
+                        float va[4], vb[4];
+                        tile(hh, 2 * T, va);
+                        tile(hh, 2 * T + 1, vb);
+                        if (hj && liveh[hh]) {
+                            float* oh = hj + (long long)rowh[hh] * C + 4 * q + 32 * T;
+                            ch_st4(oh, make_float4(va[0], va[1], va[2], va[3]));
+                            ch_st4(oh + 16, make_float4(vb[0], vb[1], vb[2], vb[3]));
+                        }
+                        ch_split8(va, vb, s_act, hfh[hh][T], hfl[hh][T]);
+                    }
+                {   // the next product's accumulators start at its bias
+                    const float scn = s_act * ch_pow2_inv(j == 0 ? sw_inv[1] : (j == 1 ? sw_inv[2] : sw_inv[3]));
+                    const float* bn = (j == 0 ? a.bias[1] : (j == 1 ? a.bias[2] : a.bias[3])) + 4 * q;
+#pragma unroll
+                    for (int hh = 0; hh < HH; ++hh) bias_init(acc[hh], bn, scn);
+                }
+            } else {
+#pragma unroll
+                for (int hh = 0; hh < HH; ++hh)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(bj + 16 * nt);
+                        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+                        unsigned kb = 0x01010101u;
+                        if (mk) kb = *reinterpret_cast<const uint32_t*>(mk + (long long)rch[hh] * C + 16 * nt + 4 * q);
+                        else if (sd) kb = dn_keep_bytes(dn_keep_bits(sd, rch[hh], 4 * nt + q, C / 4));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float t = acc[hh][nt][e] * so + bb[e];
+                            t = t > 0.f ? t : 0.f;
+                            t = ((kb >> (8 * e)) & 0xffu) ? t * dscale : 0.f;
+                            acc[hh][nt][e] = t;                       // (the accumulator registers now hold h_j)
+                            wm = t > wm ? t : wm;
+                        }
+                    }
+                if (hj) {
+#pragma unroll
+                    for (int hh = 0; hh < HH; ++hh)
+                        if (liveh[hh]) {
+                            float* oh = hj + (long long)rowh[hh] * C + 4 * q;
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                ch_st4(oh + 16 * nt, make_float4(acc[hh][nt][0], acc[hh][nt][1], acc[hh][nt][2], acc[hh][nt][3]));
+                        }
+                }
+                wm = ch_wave_max(wm);
+#pragma unroll
+                for (int jj = 0; jj < DN_CH_LAYERS; ++jj) hmax[jj] = (jj == j && wm > hmax[jj]) ? wm : hmax[jj];   // (no dynamic register index)
+                s_act = ch_uniform(dn_pow2_scale(wm));
+#pragma unroll
+                for (int hh = 0; hh < HH; ++hh)
+#pragma unroll
+                    for (int T = 0; T < NK; ++T) {
+                        const float va[4] = {acc[hh][2 * T][0], acc[hh][2 * T][1], acc[hh][2 * T][2], acc[hh][2 * T][3]};
+                        const float vb[4] = {acc[hh][2 * T + 1][0], acc[hh][2 * T + 1][1], acc[hh][2 * T + 1][2], acc[hh][2 * T + 1][3]};
+                        ch_split8(va, vb, s_act, hfh[hh][T], hfl[hh][T]);
                     }
             }
-            wm = ch_wave_max(wm);
-#pragma unroll
-            for (int jj = 0; jj < DN_CH_LAYERS; ++jj) hmax[jj] = (jj == j && wm > hmax[jj]) ? wm : hmax[jj];   // (no dynamic register index)
-            s_act = ch_uniform(dn_pow2_scale(wm));
-#pragma unroll
-            for (int hh = 0; hh < HH; ++hh)
-#pragma unroll
-                for (int T = 0; T < NK; ++T) {
-                    const float va[4] = {acc[hh][2 * T][0], acc[hh][2 * T][1], acc[hh][2 * T][2], acc[hh][2 * T][3]};
-                    const float vb[4] = {acc[hh][2 * T + 1][0], acc[hh][2 * T + 1][1], acc[hh][2 * T + 1][2], acc[hh][2 * T + 1][3]};
-                    ch_split8(va, vb, s_act, hfh[hh][T], hfl[hh][T]);
-                }
             CH_TR();
             // ---- product of layer j + 1
+            if constexpr (!G0) {
 #pragma unroll
-            for (int hh = 0; hh < HH; ++hh)
+                for (int hh = 0; hh < HH; ++hh)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[hh][nt] = dn_f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int nt = 0; nt < NT; ++nt) acc[hh][nt] = dn_f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int T = 0; T < NK; ++T) {
                 CH_PIECE_BEGIN();
@@ -562,34 +730,57 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
         {
             const int jl = a.n_mlp - 1;
             const float so = ch_pow2_inv(s_act) * (jl == 1 ? sw_inv[1] : (jl == 2 ? sw_inv[2] : sw_inv[3]));
-            const float* bj = sbias + jl * C + 4 * q;
-            float4 r4[HH][NT];
+            const float* bj = G0 ? (jl == 1 ? a.bias[1] : (jl == 2 ? a.bias[2] : a.bias[3])) + 4 * q : sbias + jl * C + 4 * q;
+            if constexpr (G0) {
+                // one half at a time: its x row requested whole (16 requests, one latency), result formed and stored (the bias is in the
+                // accumulator)
 #pragma unroll
-            for (int hh = 0; hh < HH; ++hh) {
-                const float* px = a.x + (long long)rch[hh] * C + 4 * q;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) r4[hh][nt] = *reinterpret_cast<const float4*>(px + 16 * nt);   // (x: second read, out of L2)
-            }
-#pragma unroll
-            for (int hh = 0; hh < HH; ++hh)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(bj + 16 * nt);
-                    float4 y;
-                    y.x = (acc[hh][nt][0] * so + b4.x) + r4[hh][nt].x;
-                    y.y = (acc[hh][nt][1] * so + b4.y) + r4[hh][nt].y;
-                    y.z = (acc[hh][nt][2] * so + b4.z) + r4[hh][nt].z;
-                    y.w = (acc[hh][nt][3] * so + b4.w) + r4[hh][nt].w;
-                    r4[hh][nt] = y;
-                    omax = dn_f4_amax(omax, y);
-                }
-#pragma unroll
-            for (int hh = 0; hh < HH; ++hh)
-                if (liveh[hh]) {
+                for (int hh = 0; hh < HH; ++hh) {
+                    const float* px = a.x + (long long)rch[hh] * C + 4 * q;
                     float* oo = a.out + (long long)rowh[hh] * C + 4 * q;
+                    float4 r[NT];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) ch_st4(oo + 16 * nt, r4[hh][nt]);
+                    for (int nt = 0; nt < NT; ++nt) r[nt] = *reinterpret_cast<const float4*>(px + 16 * nt);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        float4 y;
+                        y.x = acc[hh][nt][0] * so + r[nt].x;
+                        y.y = acc[hh][nt][1] * so + r[nt].y;
+                        y.z = acc[hh][nt][2] * so + r[nt].z;
+                        y.w = acc[hh][nt][3] * so + r[nt].w;
+                        omax = dn_f4_amax(omax, y);
+                        if (liveh[hh]) ch_st4(oo + 16 * nt, y);
+                    }
                 }
+            } else {
+                float4 r4[HH][NT];
+#pragma unroll
+                for (int hh = 0; hh < HH; ++hh) {
+                    const float* px = a.x + (long long)rch[hh] * C + 4 * q;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) r4[hh][nt] = *reinterpret_cast<const float4*>(px + 16 * nt);   // (x: second read, out of L2)
+                }
+#pragma unroll
+                for (int hh = 0; hh < HH; ++hh)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(bj + 16 * nt);
+                        float4 y;
+                        y.x = (acc[hh][nt][0] * so + b4.x) + r4[hh][nt].x;
+                        y.y = (acc[hh][nt][1] * so + b4.y) + r4[hh][nt].y;
+                        y.z = (acc[hh][nt][2] * so + b4.z) + r4[hh][nt].z;
+                        y.w = (acc[hh][nt][3] * so + b4.w) + r4[hh][nt].w;
+                        r4[hh][nt] = y;
+                        omax = dn_f4_amax(omax, y);
+                    }
+#pragma unroll
+                for (int hh = 0; hh < HH; ++hh)
+                    if (liveh[hh]) {
+                        float* oo = a.out + (long long)rowh[hh] * C + 4 * q;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) ch_st4(oo + 16 * nt, r4[hh][nt]);
+                    }
+            }
             CH_TR();
         }
     }
@@ -630,13 +821,13 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_fwd_kernel(C
 // ---------------------------------------------------------------------------------------------------------------------------
 int dn_chain_pieces(int C, int with_grad, int with_rot, int n_mlp) {
     const int NK = C / 32;
-    return (with_grad ? 2 * NK * (with_rot ? 2 : 1) : 0) + (with_grad ? 3 : 2) * NK + (n_mlp - 1) * NK;
+    return (with_grad ? NK * (with_rot ? 2 : 1) : 0) + (with_grad ? 3 : 2) * NK + (n_mlp - 1) * NK;
 }
 size_t dn_chain_ws_bytes(int C, int with_grad, int with_rot, int n_mlp) {
     return (size_t)dn_chain_pieces(C, with_grad, with_rot, n_mlp) * (2 * (C / 16) * 64) * sizeof(uint4);
 }
-bool dn_chain_eligible(int C, int n_mlp, const int* widths, int with_grad, long long g_nnz, int V) {
-    if (C != 128 && C != 64) return false;
+bool dn_chain_eligible(int C, int n_mlp, const int* widths, int with_grad, long long g_nnz, int V, int backward) {
+    if (C != 128 && C != 64 && !(C == 256 && !backward)) return false;
     if (n_mlp < 2 || n_mlp > DN_CH_LAYERS) return false;
     for (int j = 1; j <= n_mlp; ++j) if (widths[j] != C) return false;
     if (with_grad && g_nnz <= 0) return false;
@@ -646,11 +837,14 @@ bool dn_chain_eligible(int C, int n_mlp, const int* widths, int with_grad, long 
 template <int C, int NW, int HH>
 static int chain_launch_nw(ChainArgs a, hipStream_t stream) {
     a.units = (a.V + 16 * HH * NW - 1) / (16 * HH * NW);
-    int g = (8 / NW) * dn_num_cus();      // eight waves per CU (256 registers per lane each): two 4-wave workgroups or one 8-wave workgroup
+    // eight waves per CU (256 registers per lane each): two 4-wave workgroups or one 8-wave workgroup.  C = 256: one 4-wave workgroup per CU,
+    // one wave per SIMD with the whole register file (the gradient-feature stage alone holds gx, gy and both accumulators: 256 registers)
+    int g = (C >= 256 ? 1 : 8 / NW) * dn_num_cus();
     if (g > a.units) g = a.units;
     g = (g + 7) / 8 * 8;
-    const size_t smem = (size_t)DN_CH_RING * (2 * (C / 16) * 64) * sizeof(uint4) + (size_t)DN_CH_LAYERS * C * sizeof(float) +
-                        (size_t)NW * 4 * C * sizeof(float);      // piece ring + biases + one 4-row gather slice per wave
+    const size_t smem = C >= 256 ? (size_t)DN_CH_RING * (2 * (C / 16) * 64) * sizeof(uint4) + (size_t)NW * 16 * 128 * sizeof(float)    // piece ring + one 16-row, 128-channel slice per wave
+                                 : (size_t)DN_CH_RING * (2 * (C / 16) * 64) * sizeof(uint4) + (size_t)DN_CH_LAYERS * C * sizeof(float) +
+                                       (size_t)NW * 4 * C * sizeof(float);      // piece ring + biases + one 4-row gather slice per wave
 #ifndef DN_EMULATE
     static unsigned long long lds_opt_in = 0;   // per-device bitmap
     { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&chain_fwd_kernel<C, NW, HH>), smem, &lds_opt_in); if (oe_) return oe_; }
@@ -676,12 +870,15 @@ static int chain_launch(int npieces, const ChainArgs& a_in, hipStream_t stream, 
     if (hh == 1 && nw > 4) nw = 4;
     ChainArgs a = a_in;
     a.n_pieces = npieces;
+    if constexpr (C >= 256) return chain_launch_nw<C, 4, 2>(a, stream);      // (one form: BASELINE config 4 is a 200k-vertex mesh)
+    else {
     if (hh == 1) return nw == 4 ? chain_launch_nw<C, 4, 1>(a, stream) : (nw == 2 ? chain_launch_nw<C, 2, 1>(a, stream) : chain_launch_nw<C, 1, 1>(a, stream));
     switch (nw) {
         case 8: return chain_launch_nw<C, 8, 2>(a, stream);
         case 2: return chain_launch_nw<C, 2, 2>(a, stream);
         case 1: return chain_launch_nw<C, 1, 2>(a, stream);
         default: return chain_launch_nw<C, 4, 2>(a, stream);
+    }
     }
 }
 
@@ -691,6 +888,7 @@ int dn_launch_chain_prep(const ChainPrepArgs& pa, int npieces, int C, hipStream_
     pb.npieces = npieces;
     dn_prof_begin(DN_K_SMALL, stream);
     if (C == 128) DN_LAUNCH((chain_prep_kernel<128>), dim3(npieces + 1, 1, 1), dim3(1024, 1, 1), 0, stream, pb);
+    else if (C == 256) DN_LAUNCH((chain_prep_kernel<256>), dim3(npieces + 1, 1, 1), dim3(1024, 1, 1), 0, stream, pb);
     else if (C == 64) DN_LAUNCH((chain_prep_kernel<64>), dim3(npieces + 1, 1, 1), dim3(1024, 1, 1), 0, stream, pb);
     else return 1;
     dn_prof_end(DN_K_SMALL, stream, 0.0, 0.0);
@@ -701,6 +899,7 @@ int dn_launch_chain_fwd(int npieces, const ChainArgs& a, int C, hipStream_t stre
     dn_prof_begin(DN_K_CHAIN, stream);
     int err;
     if (C == 128) err = chain_launch<128>(npieces, a, stream, hh);
+    else if (C == 256) err = chain_launch<256>(npieces, a, stream, hh);
     else if (C == 64) err = chain_launch<64>(npieces, a, stream, hh);
     else err = 1;
     {

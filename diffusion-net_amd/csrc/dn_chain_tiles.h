@@ -177,6 +177,47 @@ do {                                                                            
     }                                                                                                               \
 } while (0)
 
+// one product, ACCROW[nt] += W(piece) * frag, weight fragments fetched one tile pair ahead
+#define CH_MMA1(ACCROW, FH, FL)                                                                                         \
+do {                                                                                                                \
+    uint4 wq_[2][4];                                                                                                \
+    CH_WLOAD(wq_[0], 0);                                                                                            \
+    _Pragma("unroll") for (int np_ = 0; np_ < NT; np_ += 2) {                                                       \
+        const int cb_ = (np_ >> 1) & 1;                                                                             \
+        if (np_ + 2 < NT) CH_WLOAD(wq_[cb_ ^ 1], np_ + 2);                                                          \
+        ACCROW[np_] = dn_mfma16_f16(wq_[cb_][0], FL, ACCROW[np_]);                                                  \
+        ACCROW[np_ + 1] = dn_mfma16_f16(wq_[cb_][2], FL, ACCROW[np_ + 1]);                                          \
+        ACCROW[np_] = dn_mfma16_f16(wq_[cb_][1], FH, ACCROW[np_]);                                                  \
+        ACCROW[np_ + 1] = dn_mfma16_f16(wq_[cb_][3], FH, ACCROW[np_ + 1]);                                          \
+        ACCROW[np_] = dn_mfma16_f16(wq_[cb_][0], FH, ACCROW[np_]);                                                  \
+        ACCROW[np_ + 1] = dn_mfma16_f16(wq_[cb_][2], FH, ACCROW[np_ + 1]);                                          \
+    }                                                                                                               \
+} while (0)
+
+// two products sharing the weights, ACC[0] += W frag0 and ACC[1] += W frag1, with the weight fragments fetched one tile pair ahead (the
+// gradient-feature stage of the one-wave-per-SIMD form: nobody else covers the LDS latency there, and the registers are not the limit)
+#define CH_MMA2_PAIR(ACC, FH0, FL0, FH1, FL1)                                                                           \
+do {                                                                                                                \
+    uint4 wq_[2][4];                                                                                                \
+    CH_WLOAD(wq_[0], 0);                                                                                            \
+    _Pragma("unroll") for (int np_ = 0; np_ < NT; np_ += 2) {                                                       \
+        const int cb_ = (np_ >> 1) & 1;                                                                             \
+        if (np_ + 2 < NT) CH_WLOAD(wq_[cb_ ^ 1], np_ + 2);                                                          \
+        ACC[0][np_] = dn_mfma16_f16(wq_[cb_][0], FL0, ACC[0][np_]);                                                 \
+        ACC[1][np_] = dn_mfma16_f16(wq_[cb_][0], FL1, ACC[1][np_]);                                                 \
+        ACC[0][np_ + 1] = dn_mfma16_f16(wq_[cb_][2], FL0, ACC[0][np_ + 1]);                                         \
+        ACC[1][np_ + 1] = dn_mfma16_f16(wq_[cb_][2], FL1, ACC[1][np_ + 1]);                                         \
+        ACC[0][np_] = dn_mfma16_f16(wq_[cb_][1], FH0, ACC[0][np_]);                                                 \
+        ACC[1][np_] = dn_mfma16_f16(wq_[cb_][1], FH1, ACC[1][np_]);                                                 \
+        ACC[0][np_ + 1] = dn_mfma16_f16(wq_[cb_][3], FH0, ACC[0][np_ + 1]);                                         \
+        ACC[1][np_ + 1] = dn_mfma16_f16(wq_[cb_][3], FH1, ACC[1][np_ + 1]);                                         \
+        ACC[0][np_] = dn_mfma16_f16(wq_[cb_][0], FH0, ACC[0][np_]);                                                 \
+        ACC[1][np_] = dn_mfma16_f16(wq_[cb_][0], FH1, ACC[1][np_]);                                                 \
+        ACC[0][np_ + 1] = dn_mfma16_f16(wq_[cb_][2], FH0, ACC[0][np_ + 1]);                                         \
+        ACC[1][np_ + 1] = dn_mfma16_f16(wq_[cb_][2], FH1, ACC[1][np_ + 1]);                                         \
+    }                                                                                                               \
+} while (0)
+
 // the same product with the weight fragments fetched tile pair by tile pair (16 registers less): for the gradient-feature stage, whose
 // live set (gx, gy, both accumulators, the other half's tanh features) is the kernel's peak
 #define CH_MMA2_LEAN(ACC, FH0, FL0, FH1, FL1)                                                                           \

@@ -477,7 +477,7 @@ struct ChainPrepPiece {
     int transposed, row0;   // transposed (backward products d_in = d_out W): the piece's rows are W's COLUMNS row0 .. row0 + C - 1 and its
                             // contraction slots W's ROWS col0 .. col0 + 31: element (r, slot) = W[(col0 + slot) * ld + row0 + r]
 };
-#define DN_CH_MAX_PIECES 48
+#define DN_CH_MAX_PIECES 72   // C = 256 with rotations and a three-layer MiniMLP: 16 + 24 + 16 + 16
 struct ChainPrepArgs {
     ChainPrepPiece pc[DN_CH_MAX_PIECES];
     uint4* out;          // [npieces][2 * (C / 16) * 64]
@@ -494,10 +494,10 @@ struct ChainArgs {
     const float* x; const float* xd;
     int V;
     int with_grad, with_rot, n_mlp;
-    // weight pieces in stream order: [gradient-feature pieces (T-major: A_re T, A_im T)] x 2, layer 0 ([x | xd | g] segments, T-major
-    // inside a segment), layer 1, ...
+    // weight pieces: the n_gf gradient-feature pieces (T-major: A_re T, A_im T; the kernel streams them once per 16-row half), layer 0
+    // ([g | x | xd] segments, T-major inside a segment), layer 1, ...
     const uint4* wp;
-    int n_pieces;
+    int n_pieces, n_gf;
     const float* wa_amax;                 // magnitude word of A_re / A_im (joint)
     const float* w_amax[DN_CH_LAYERS];    // of W_j
     const float* bias[DN_CH_LAYERS];
@@ -539,7 +539,7 @@ int dn_chain_bwd_pieces(int C, int with_grad, int with_rot, int n_mlp);
 int dn_launch_chain_bwd(int npieces, const ChainBwdArgs& a, int C, hipStream_t stream, int hh = 2);   // hh: 16-row halves per wave (the piece list repeats the gradient-feature pieces hh times)
 int dn_chain_pieces(int C, int with_grad, int with_rot, int n_mlp);
 size_t dn_chain_ws_bytes(int C, int with_grad, int with_rot, int n_mlp);
-bool dn_chain_eligible(int C, int n_mlp, const int* widths, int with_grad, long long g_nnz, int V);
+bool dn_chain_eligible(int C, int n_mlp, const int* widths, int with_grad, long long g_nnz, int V, int backward = 0);   // (the backward kernel exists at C = 64, 128)
 int dn_launch_chain_prep(const ChainPrepArgs& pa, int npieces, int C, hipStream_t stream);
 int dn_launch_chain_fwd(int npieces, const ChainArgs& a, int C, hipStream_t stream, int hh = 2);
 

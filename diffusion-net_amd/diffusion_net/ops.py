@@ -443,7 +443,7 @@ class BlockFn(torch.autograd.Function):
             ctx.save_for_backward(x, time, xs, xd, words, *feats, *hs, *Ws, *bs,
                                   *([A_re] if A_re is not None else []), *([A_im] if A_im is not None else []))
             if debug_saved is not None:
-                debug_saved.append({"xs": xs, "xd": xd, **dict(zip(("gx", "gy", "g", "bre", "bim"), feats)), "h": list(hs)})
+                debug_saved.append({"xs": xs, "xd": xd, **dict(zip(("gx", "gy", "g", "bre", "bim"), feats)), "h": list(hs), "words": words})
         if L.dn_block_tracks_amax(mb.ref(), C.byref(p), 1 if need_grad else 0):
             _tag_amax(out, out_amax)  # the next block reads it off its input (a call that does not track magnitudes leaves the word alone: no tag)
         return out

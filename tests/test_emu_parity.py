@@ -75,6 +75,7 @@ def test_chain_probes_against_the_oracle_on_emulator(emu):
     parity_cases.run_ragged_net(emu, sizes=(33, 40), K=16, C=128, N_block=2, chunk_rows=32)
     parity_cases.run_ragged_net(emu, sizes=(150, 70), K=32, C=64, N_block=2, mlp_hidden_dims=[64], chunk_rows=64)
     parity_cases.run_ragged_net(emu, sizes=(150, 130), K=128, C=128, N_block=1, equal_rows=True, fp64_bracket=True, chunk_rows=64)
+    parity_cases.run_ragged_net(emu, sizes=(70, 45), K=32, C=256, N_block=1, empty_grad_rows=3, chunk_rows=64)      # BASELINE config 4's width (forward kernel)
     from diffusion_net import _hip
     old = _hip.set_option("chain_hh", 2)              # (the cases above took the small-batch wave shape: once more in the large-batch one)
     try:
@@ -157,14 +158,16 @@ def test_autograph_on_emulator(emu):
 
 
 @pytest.mark.parametrize("kw", [dict(sizes=(150, 135)), dict(with_rot=False, dropout=False, sizes=(133,), N_block=1), dict(with_grad=False, sizes=(150,), N_block=1),
-                                dict(C=64, K=128, sizes=(160, 140), dropout=False, N_block=1)])
+                                dict(C=64, K=128, sizes=(160, 140), dropout=False, N_block=1),
+                                dict(C=256, K=32, sizes=(150, 135), N_block=1)])
 def test_chained_forward_kernel_vs_unfused_on_emulator(emu, kw):
     """dn_chain.hip (gather -> gradient features -> MiniMLP in one launch) against the unfused launches: with / without rotations and
     gradient features, in-kernel dropout, partial last units, C = 128 and 64 -- in both wave shapes (option chain_hh: one 16-row half per
     wave, the small-batch form these sizes take by default, and two, the form of batches that fill the device)."""
     import parity_cases
     from diffusion_net import _hip
-    for hh in ((1, 2) if (kw.get("dropout", True) or kw.get("C") == 64) else (1,)):      # (both shapes for the full block and for C = 64; the GPU tier runs all)
+    # C = 256 (BASELINE config 4's width): the forward kernel only, in its one wave shape; the backward of that width is the unfused launches
+    for hh in ((0,) if kw.get("C") == 256 else (1, 2) if (kw.get("dropout", True) or kw.get("C") == 64) else (1,)):      # (both shapes for the full block and for C = 64; the GPU tier runs all)
         old = _hip.set_option("chain_hh", hh)
         try:
             parity_cases.run_chain_vs_unfused(emu, **kw)

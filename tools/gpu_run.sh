@@ -5,6 +5,7 @@
 #                immediate arrivals; forward + backward, fp64 spot checks
 #   df_trace     s_memtime phase timeline of the one-launch kernel (libdiffnet_hip_dftrace.so = make variant TAG=dftrace EXTRA=-DDN_DF_TRACE=1)
 #   df_small     the same comparison on one 7k-vertex mesh (BASELINE config 2) and on 64 x 2k meshes
+#   c256         BASELINE config 4's width: kbench block tables chained / unfused at C = 256, the C = 256 parity cases, bench.py --config cfg4
 #   kbench       block_inf / block_fwd / block_bwd / diffusion tables (tools/kbench --check)
 #   tests [k]    GPU parity tier (optionally -k <expr>)
 #   bench [args] bench.py (default flags) -> gpurun_out/bench.json
@@ -38,6 +39,12 @@ df_small)
       echo "== $shape: three launches"; $KB $shape --ops diffusion,diffusion_bwd --check --reps 50 --no-plan | grep -v "^#" | cut -c1-170
       for g in 1 2 3; do echo "== $shape: one launch, groups $g"; $KB $shape --ops diffusion,diffusion_bwd --check --reps 50 --groups $g | grep -v "^#" | cut -c1-170; done
     done; } 2>&1 | tee gpurun_out/df_small.txt ;;
+c256)
+  { for c in 1 0; do echo "== 1 x 200k, C = K = 256, chain=$c"; $KB --meshes 1 --verts 200000 --C 256 --K 256 --ops block_inf,block_fwd --check --reps 10 --opt chain=$c | grep -v "^#" | cut -c1-170; done
+    for c in 1 0; do echo "== 16 x 10k, C = 256, K = 128, chain=$c"; $KB --C 256 --ops block_inf,block_fwd --reps 10 --opt chain=$c | grep -v "^#" | cut -c1-170; done
+  } 2>&1 | tee gpurun_out/c256_kbench.txt
+  if [ -z "$NO_TESTS" ]; then timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=short -x -k "chained_forward_kernel_vs_unfused or chain_probes or large_inference" 2>&1 | tail -15 | tee gpurun_out/c256_tests.txt; fi
+  timeout 300 python bench.py --config cfg4 --no-cpu-baseline --no-other-configs > gpurun_out/c256_bench_cfg4.json 2> gpurun_out/c256_bench.err; cat gpurun_out/c256_bench_cfg4.json | cut -c1-600; tail -3 gpurun_out/c256_bench.err ;;
 kbench)
   $KB --check "$@" 2>&1 | cut -c1-200 | tee gpurun_out/kbench.txt ;;
 tests)
