@@ -32,6 +32,15 @@
 #ifndef DN_CH_GCR
 #define DN_CH_GCR 1      // (1: 393.9 us block forward at 16 x 10k, 2: 408.1, 3: 431.5 -- registers, not bytes in flight; profiles/r05_rcg_ab.txt)
 #endif
+#ifndef DN_CH_L0_EXACT
+#define DN_CH_L0_EXACT 1  // layer 0's x / xd row requests behind the piece request and counted exactly in the end-of-piece wait (0: the round-4 order; A/B)
+#endif
+#ifndef DN_CH_PF_WIDE
+#define DN_CH_PF_WIDE 2
+#endif
+#ifndef DN_CH_NXR_WIDE
+#define DN_CH_NXR_WIDE 5  // x / xd operand rows of layer 0 in flight, in pieces + 1, in the C = 256 form (3 at C <= 128)
+#endif
 #ifndef DN_CH_GCR_WIDE
 #define DN_CH_GCR_WIDE 2 // the same in the C = 256 form (one wave per SIMD: 16 KiB in flight per wave)
 #endif
@@ -131,8 +140,9 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
     constexpr bool G0 = C >= 256;         // the one-wave-per-SIMD form of C = 256 (see the gradient-feature stage)
     constexpr int RING = DN_CH_RING;      // (C = 256: 32 KiB pieces; 128 KiB of ring + 32 KiB of gather slices are the CU's 160 KiB)
     constexpr int GCH = DN_CH_GCHUNK;
+    constexpr int CH_PF = G0 ? DN_CH_PF_WIDE : 1;      // weight-fragment prefetch distance in tile pairs (one wave per SIMD: nobody else covers the LDS latency)
     static_assert(PIECE % NTHR == 0, "piece staging");
-    static_assert(RING >= 2 && RING <= 8 && (RING - 1) * LPT < 60, "ring depth vs the vmcnt range");
+    static_assert(RING >= 2 && RING <= 8 && (RING - 1) * LPT < 60 && (RING - 2) * LPT + 6 * HH < 64, "ring depth vs the vmcnt range");
 
     DN_DYN_SMEM(smem_raw);
     uint4* ring = reinterpret_cast<uint4*>(smem_raw);                      // RING slots of PIECE uint4
@@ -223,11 +233,13 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
     };
 #ifdef DN_EMULATE
 #define CH_WAIT_PIECES(n) do {} while (0)
+#define CH_WAIT_OPS(n) do {} while (0)
 #define CH_BARRIER() __syncthreads()
 #else
     // wait until at most n * LPT of this wave's vector-memory operations are outstanding (loads return in order: everything older than
     // the n youngest pieces has landed), and for every LDS read issued so far (the slot just read may be overwritten after the barrier)
 #define CH_WAIT_PIECES(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((n) * LPT) : "memory")
+#define CH_WAIT_OPS(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(n) : "memory")      // the same, counted in operations
 #define CH_BARRIER() do { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 #endif
     int gp = 0;
@@ -574,7 +586,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
         {
             // operands of the 2 NK pieces of the x and xd segments, fetched two pieces ahead (requesting all of them up front in the
             // one-half form -- the registers would allow it -- measured no gain: 410 vs 400 us block forward, profiles/r05_rcg_ab.txt)
-            constexpr int NXR = 3;
+            constexpr int NXR = G0 ? DN_CH_NXR_WIDE : 3;   // (the requests share the in-order return queue with the piece stream: a row still on its way from HBM holds the pieces behind it)
             float4 nx[NXR][HH][2];
             auto fetch = [&](int pi, float4 (&d)[HH][2]) {
                 const float* p = (pi < NK ? a.x : a.xd) + 32 * (pi < NK ? pi : pi - NK) + 4 * q;
@@ -584,8 +596,8 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
                     d[hh][1] = *reinterpret_cast<const float4*>(p + (long long)rch[hh] * C + 16);
                 }
             };
-            fetch(0, nx[0]);
-            fetch(1, nx[1]);
+#pragma unroll
+            for (int pi = 0; pi < NXR - 1; ++pi) fetch(pi, nx[pi]);
             if constexpr (!G0) {
                 if (a.with_grad) {
 #pragma unroll
@@ -601,10 +613,32 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
                 uint4 fh[HH], fl[HH];
 #pragma unroll
                 for (int hh = 0; hh < HH; ++hh) ch_split8(nx[pi % NXR][hh][0], nx[pi % NXR][hh][1], s_in, fh[hh], fl[hh]);
-                if (pi + 2 < 2 * NK) fetch(pi + 2, nx[(pi + 2) % NXR]);
-                CH_PIECE_BEGIN();
-                CH_MMA2(acc, fh[0], fl[0], fh[HH - 1], fl[HH - 1]);
-                CH_PIECE_END();
+                if constexpr (DN_CH_L0_EXACT == 0) {
+                    if (pi + NXR - 1 < 2 * NK) fetch(pi + NXR - 1, nx[(pi + NXR - 1) % NXR]);
+                    CH_PIECE_BEGIN();
+                    CH_MMA2(acc, fh[0], fl[0], fh[HH - 1], fl[HH - 1]);
+                    CH_PIECE_END();
+                } else {
+                    // The row requests go out BEHIND the piece request of their piece, and the wait at the end of the piece counts them: the
+                    // operations younger than the piece it needs are two piece requests and the row requests of this piece and the two before
+                    // it (2 HH each) -- none of them has to land.  (With the rows requested first and a wait of two pieces flat, every piece
+                    // of this stage waited for a row request one piece old: HBM latency against a piece time of a fraction of it.  The
+                    // compiler's own wait before the split above still asks for everything but the youngest row requests -- pieces requested
+                    // one piece ago included --: that one is not ours to count.)
+                    CH_PIECE_BEGIN();
+                    const bool f0 = pi + NXR - 1 < 2 * NK;
+                    if (f0) fetch(pi + NXR - 1, nx[(pi + NXR - 1) % NXR]);
+                    CH_MMA2(acc, fh[0], fl[0], fh[HH - 1], fl[HH - 1]);
+                    // row requests younger than the piece waited for: issued in pieces pi - 2, pi - 1, pi (the first two pieces of the stage
+                    // count none: what precedes them differs by configuration, and fewer is the safe side)
+                    const int kf = pi < 2 ? 0 : (int)f0 + (int)(pi - 1 + NXR - 1 < 2 * NK) + (int)(pi - 2 + NXR - 1 < 2 * NK);
+                    if (kf == 3) CH_WAIT_OPS((RING - 2) * LPT + 3 * 2 * HH);
+                    else if (kf == 2) CH_WAIT_OPS((RING - 2) * LPT + 2 * 2 * HH);
+                    else if (kf == 1) CH_WAIT_OPS((RING - 2) * LPT + 1 * 2 * HH);
+                    else CH_WAIT_OPS((RING - 2) * LPT);
+                    CH_BARRIER();
+                    ++gp;
+                }
             }
         }
         CH_TR();
@@ -790,6 +824,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the requests that ran past the end of the stream
 #endif
 #undef CH_BARRIER
+#undef CH_WAIT_OPS
 #undef CH_WAIT_PIECES
     // ---- magnitude words of what was produced: one check-first atomic per WORKGROUP and word.  The persistent workgroups finish within a few
     //      microseconds of each other, most of them read the words before anybody has raised them, and atomics on one cache line retire at

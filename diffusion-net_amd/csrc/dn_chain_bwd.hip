@@ -24,6 +24,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
     constexpr int PIECE = 2 * NT * 64;
     constexpr int LPT = PIECE / NTHR;
     constexpr int RING = DN_CH_RING;
+    constexpr int CH_PF = 1;              // (weight-fragment prefetch distance of the product macros, in tile pairs)
     static_assert(PIECE % NTHR == 0, "piece staging");
     static_assert(RING >= 2 && RING <= 8 && (RING - 1) * LPT < 60, "ring depth vs the vmcnt range");
 

@@ -150,6 +150,7 @@ __device__ __forceinline__ void ch_dma16(const uint4* gsrc, uint4* lds_generic, 
 
 
 // ---- piece x fragment products (inside a kernel that defines NT, lane and ws_ = the ring slot being read) --------------------------
+// (CH_PF, a constexpr of the kernel that expands the macros: how many tile pairs ahead of their MFMAs the weight fragments are read from LDS)
 // acc[h][nt] += W(piece) * frag[h]   (hi*lo, lo*hi, hi*hi: smallest terms first); two output tiles at a time, so that an MFMA and the
 // next one into the same accumulator are four issues apart
 #define CH_WLOAD(W_, np_) do { W_[0] = ws_[(np_) * 64 + lane]; W_[1] = ws_[(NT + (np_)) * 64 + lane];                       \
@@ -157,11 +158,11 @@ __device__ __forceinline__ void ch_dma16(const uint4* gsrc, uint4* lds_generic, 
 // (HH = 16-row halves per wave, a template parameter of the kernel that expands the macro: with HH = 1 the second half's MFMAs are discarded)
 #define CH_MMA2(ACC, FH0, FL0, FH1, FL1)                                                                                \
 do {                                                                                                                \
-    uint4 wq_[2][4];   /* weight fragments of two output tiles (hi a, lo a, hi b, lo b), fetched one pair ahead of their MFMAs */ \
-    CH_WLOAD(wq_[0], 0);                                                                                            \
+    uint4 wq_[CH_PF + 1][4];   /* weight fragments of two output tiles (hi a, lo a, hi b, lo b), fetched CH_PF pairs ahead of their MFMAs */ \
+    _Pragma("unroll") for (int pf_ = 0; pf_ < CH_PF; ++pf_) if (2 * pf_ < NT) CH_WLOAD(wq_[pf_], 2 * pf_);                                                                                            \
     _Pragma("unroll") for (int np_ = 0; np_ < NT; np_ += 2) {                                                       \
-        const int cb_ = (np_ >> 1) & 1;                                                                             \
-        if (np_ + 2 < NT) CH_WLOAD(wq_[cb_ ^ 1], np_ + 2);                                                          \
+        const int cb_ = (np_ >> 1) % (CH_PF + 1);                                                                   \
+        if (np_ + 2 * CH_PF < NT) CH_WLOAD(wq_[((np_ >> 1) + CH_PF) % (CH_PF + 1)], np_ + 2 * CH_PF);                                                          \
         ACC[0][np_] = dn_mfma16_f16(wq_[cb_][0], FL0, ACC[0][np_]);                                                 \
         if constexpr (HH > 1) ACC[HH - 1][np_] = dn_mfma16_f16(wq_[cb_][0], FL1, ACC[HH - 1][np_]);                 \
         ACC[0][np_ + 1] = dn_mfma16_f16(wq_[cb_][2], FL0, ACC[0][np_ + 1]);                                         \
@@ -180,11 +181,11 @@ do {                                                                            
 // one product, ACCROW[nt] += W(piece) * frag, weight fragments fetched one tile pair ahead
 #define CH_MMA1(ACCROW, FH, FL)                                                                                         \
 do {                                                                                                                \
-    uint4 wq_[2][4];                                                                                                \
-    CH_WLOAD(wq_[0], 0);                                                                                            \
+    uint4 wq_[CH_PF + 1][4];                                                                                        \
+    _Pragma("unroll") for (int pf_ = 0; pf_ < CH_PF; ++pf_) if (2 * pf_ < NT) CH_WLOAD(wq_[pf_], 2 * pf_);                                                                                            \
     _Pragma("unroll") for (int np_ = 0; np_ < NT; np_ += 2) {                                                       \
-        const int cb_ = (np_ >> 1) & 1;                                                                             \
-        if (np_ + 2 < NT) CH_WLOAD(wq_[cb_ ^ 1], np_ + 2);                                                          \
+        const int cb_ = (np_ >> 1) % (CH_PF + 1);                                                                   \
+        if (np_ + 2 * CH_PF < NT) CH_WLOAD(wq_[((np_ >> 1) + CH_PF) % (CH_PF + 1)], np_ + 2 * CH_PF);                                                          \
         ACCROW[np_] = dn_mfma16_f16(wq_[cb_][0], FL, ACCROW[np_]);                                                  \
         ACCROW[np_ + 1] = dn_mfma16_f16(wq_[cb_][2], FL, ACCROW[np_ + 1]);                                          \
         ACCROW[np_] = dn_mfma16_f16(wq_[cb_][1], FH, ACCROW[np_]);                                                  \
@@ -198,11 +199,11 @@ do {                                                                            
 // gradient-feature stage of the one-wave-per-SIMD form: nobody else covers the LDS latency there, and the registers are not the limit)
 #define CH_MMA2_PAIR(ACC, FH0, FL0, FH1, FL1)                                                                           \
 do {                                                                                                                \
-    uint4 wq_[2][4];                                                                                                \
-    CH_WLOAD(wq_[0], 0);                                                                                            \
+    uint4 wq_[CH_PF + 1][4];                                                                                        \
+    _Pragma("unroll") for (int pf_ = 0; pf_ < CH_PF; ++pf_) if (2 * pf_ < NT) CH_WLOAD(wq_[pf_], 2 * pf_);                                                                                            \
     _Pragma("unroll") for (int np_ = 0; np_ < NT; np_ += 2) {                                                       \
-        const int cb_ = (np_ >> 1) & 1;                                                                             \
-        if (np_ + 2 < NT) CH_WLOAD(wq_[cb_ ^ 1], np_ + 2);                                                          \
+        const int cb_ = (np_ >> 1) % (CH_PF + 1);                                                                   \
+        if (np_ + 2 * CH_PF < NT) CH_WLOAD(wq_[((np_ >> 1) + CH_PF) % (CH_PF + 1)], np_ + 2 * CH_PF);                                                          \
         ACC[0][np_] = dn_mfma16_f16(wq_[cb_][0], FL0, ACC[0][np_]);                                                 \
         ACC[1][np_] = dn_mfma16_f16(wq_[cb_][0], FL1, ACC[1][np_]);                                                 \
         ACC[0][np_ + 1] = dn_mfma16_f16(wq_[cb_][2], FL0, ACC[0][np_ + 1]);                                         \
