@@ -69,7 +69,10 @@ evidence)
   f=$(find /tmp/prof_b -name "*kernel_trace.csv" 2>/dev/null | head -1); [ -n "$f" ] && python tools/step_kernels.py "$f" > gpurun_out/step_kernels.txt 2>&1
   (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_c2 && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c2 -o trace -- python "$R/bench.py" --config cfg2 --steps 40 > /dev/null 2>&1 < /dev/null)
   f=$(find /tmp/prof_c2 -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" gpurun_out/cfg2_kernel_stats.csv
+  (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_c4 && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c4 -o trace -- python "$R/bench.py" --config cfg4 --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > /dev/null 2>&1 < /dev/null)
+  f=$(find /tmp/prof_c4 -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" gpurun_out/cfg4_kernel_stats.csv
   timeout 300 ./tools/kbench --check > gpurun_out/kbench.txt 2>&1 < /dev/null
+  { for c in 1 0; do echo "== 1 x 200k, C = K = 256, chain=$c"; timeout 120 ./tools/kbench --meshes 1 --verts 200000 --C 256 --K 256 --ops block_inf,block_fwd --check --reps 10 --opt chain=$c | grep -v "^#" | cut -c1-170; done; } > gpurun_out/kbench_c256.txt 2>&1 < /dev/null
   timeout 300 ./tools/kbench --opt chain=0 --opt diffuse=0 --ops diffusion,diffusion_bwd,block_inf,block_fwd,block_bwd > gpurun_out/kbench_unfused.txt 2>&1 < /dev/null
   if [ -z "$NO_PMC" ]; then
     ONLY_TRAFFIC=1 timeout 600 bash tools/pmc_run.sh > gpurun_out/pmc_traffic.log 2>&1 < /dev/null
