@@ -80,6 +80,7 @@ def test_chain_probes_against_the_oracle(dev):
     parity_cases.run_ragged_net(dev, K=128, C=128, equal_rows=True, **kw)
     parity_cases.run_ragged_net(dev, K=64, C=256, empty_grad_rows=3, **kw)          # BASELINE config 4's width: the chained forward of C = 256
     parity_cases.run_ragged_net(dev, K=16, C=256, mlp_hidden_dims=[256], sizes=(33, 40), N_block=1, fp64_bracket=True)
+    parity_cases.run_ragged_net(dev, K=64, C=256, mlp_hidden_dims=[256, 256, 256], **kw)                      # depth 4 at that width
     from diffusion_net import _hip
     old = _hip.set_option("chain_hh", 2)              # (2 200 rows take one 16-row half per wave by default: once more with two)
     try:
@@ -149,7 +150,8 @@ def test_autograph_reference_loop(dev):
 
 @pytest.mark.parametrize("kw", [dict(), dict(with_rot=False, dropout=False, sizes=(700, 333)), dict(with_grad=False, sizes=(1290,), N_block=1),
                                 dict(C=64, K=128, sizes=(1000, 600), dropout=False), dict(sizes=(21000, 19500), N_block=1),
-                                dict(C=256, K=64, sizes=(700, 333)), dict(C=256, K=128, sizes=(40100, 30000), N_block=1, dropout=False, grad_tol=2e-3)])
+                                dict(C=256, K=64, sizes=(700, 333)), dict(C=256, K=128, sizes=(40100, 30000), N_block=1, dropout=False, grad_tol=2e-3),
+                                dict(C=256, K=64, sizes=(1290,), with_grad=False, N_block=1)])
 def test_chained_forward_kernel_vs_unfused(dev, kw):
     """dn_chain.hip against the unfused launches of the same block (see parity_cases.run_chain_vs_unfused); the fifth case is large enough for
     several passes per workgroup and the four-wave workgroups of the benchmark shape; the last two are BASELINE config 4's width (C = 256: the
