@@ -253,8 +253,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
             // ---- gradient features backward, one 16-row half at a time:
             //      d_gx = d_dots * Bre + (d_dots gx) A_re + (d_dots gy) A_im ;  d_gy = d_dots * Bim - (d_dots gx) A_im + (d_dots gy) A_re
             //      (without rotations: d_gx = d_dots * Bre + (d_dots gx) A, d_gy = d_dots * Bim + (d_dots gy) A)
-#pragma unroll 1
-            for (int hh = 0; hh < HH; ++hh) {
+            auto half = [&](const int hh) __attribute__((always_inline)) {      // (hh is a literal in each of the two copies below: no row is selected or moved)
                 const int row = hh ? rowh[HH - 1] : rowh[0];
                 const int rc = hh ? rch[HH - 1] : rch[0];
                 const bool live = hh ? liveh[HH - 1] : liveh[0];
@@ -322,7 +321,9 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
                         }
                     }
                 }
-            }
+            };
+            half(0);
+            if constexpr (HH > 1) half(HH - 1);
         }
     }
 #ifndef DN_EMULATE
