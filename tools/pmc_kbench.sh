@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counter passes (counters only + kernel trace, separate rocprofv3 runs) over tools/kbench ops; summaries -> gpurun_out/pmck_*.txt
-#   OPS=from_basis,linear LIB=path.so bash tools/pmc_kbench.sh
+#   OPS=from_basis,linear LIB=path.so [KARGS="--meshes 1 --verts 200000 --C 256 --K 256"] bash tools/pmc_kbench.sh
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OPS=${OPS:-from_basis}
 LIB=${LIB:-$R/diffusion-net_amd/diffusion_net/libdiffnet_hip.so}
@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 run_pass() {  # name, counters...
   name=$1; shift
   rm -rf /tmp/pmck_$name
-  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmck_$name -o p -- "$R/tools/kbench" --lib "$LIB" --reps 3 --ops "$OPS" > /tmp/pmck_$name.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmck_$name -o p -- "$R/tools/kbench" --lib "$LIB" --reps 3 --ops "$OPS" $KARGS > /tmp/pmck_$name.log 2>&1
   f=$(find /tmp/pmck_$name -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then
     python3 - "$f" > "$R/gpurun_out/pmck_${TAG}_$name.txt" <<'PY'
