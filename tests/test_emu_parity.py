@@ -159,7 +159,7 @@ def test_autograph_on_emulator(emu):
 
 @pytest.mark.parametrize("kw", [dict(sizes=(150, 135)), dict(with_rot=False, dropout=False, sizes=(133,), N_block=1), dict(with_grad=False, sizes=(150,), N_block=1),
                                 dict(C=64, K=128, sizes=(160, 140), dropout=False, N_block=1),
-                                dict(C=256, K=32, sizes=(150, 135), N_block=1), dict(C=256, K=32, sizes=(140,), with_grad=False, dropout=False, N_block=1)])
+                                dict(C=256, K=32, sizes=(90, 60), N_block=1), dict(C=256, K=32, sizes=(100,), with_grad=False, dropout=False, N_block=1)])
 def test_chained_forward_kernel_vs_unfused_on_emulator(emu, kw):
     """dn_chain.hip (gather -> gradient features -> MiniMLP in one launch) against the unfused launches: with / without rotations and
     gradient features, in-kernel dropout, partial last units, C = 128 and 64 -- in both wave shapes (option chain_hh: one 16-row half per
