@@ -530,7 +530,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
                             for (int e = 0; e < 4; ++e) {
                                 br[e] = ga[0][nt][e] * so_gf;
                                 bi[e] = ga[1][nt][e] * so_gf;
-                                gv2[u][e] = ch_tanh(gxv[nt][e] * br[e] + gyv[nt][e] * bi[e]);
+                                gv2[u][e] = ch_tanh(ch_dot2(gxv[nt][e], br[e], gyv[nt][e], bi[e]));
                             }
                             if (live && a.g) ch_st4(a.g + row * C + 4 * q + 16 * nt, make_float4(gv2[u][0], gv2[u][1], gv2[u][2], gv2[u][3]));
                             if (live && a.bre) {
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
                         for (int e = 0; e < 4; ++e) {
                             ga[0][nt][e] *= so_gf;                   // Bre, Bim (the accumulator registers keep them for the stores below)
                             ga[1][nt][e] *= so_gf;
-                            gv[nt][e] = ch_tanh(gxv[nt][e] * ga[0][nt][e] + gyv[nt][e] * ga[1][nt][e]);
+                            gv[nt][e] = ch_tanh(ch_dot2(gxv[nt][e], ga[0][nt][e], gyv[nt][e], ga[1][nt][e]));
                         }
                     if (live && a.g) {
                         float* og = a.g + row * C + 4 * q;

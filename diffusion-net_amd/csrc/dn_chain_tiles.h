@@ -48,6 +48,19 @@ __device__ __forceinline__ float ch_tanh(float x) {
     const float big = copysignf((1.f - t) * r, x);
     return ax < 0.25f ? p : big;
 }
+// a b + c d with the roundings spelled out: one product rounded, the other fused into the sum.  Left to the compiler's contraction the choice of
+// WHICH product is fused follows the surrounding code (a restructure of the kernel flipped it and moved the tanh features by one ulp in a
+// quarter of the elements -- 4.6e-6 -> 6.3e-6 from fp64 on the trained-checkpoint golden after four blocks); written out, it stays put.
+#ifndef DN_CH_DOT_ORDER
+#define DN_CH_DOT_ORDER 0
+#endif
+__device__ __forceinline__ float ch_dot2(float a, float b, float c, float d) {
+#ifdef DN_EMULATE
+    return a * b + c * d;
+#else
+    return DN_CH_DOT_ORDER ? __builtin_fmaf(c, d, __fmul_rn(a, b)) : __builtin_fmaf(a, b, __fmul_rn(c, d));
+#endif
+}
 // 1 / s for a power of two s = 2^k, -126 <= k <= 126 (what dn_pow2_scale returns but for its two clamped extremes): exponent arithmetic, exact
 __device__ __forceinline__ float ch_pow2_inv(float s) {
     const unsigned e = (__float_as_uint(s) >> 23) & 0xffu;

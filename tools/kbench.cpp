@@ -435,9 +435,10 @@ int main(int argc, char** argv) {
         DC(blk_f(&mb, &bp, x, o0, &sv, ws, wsb, st));
         timeit("block_bwd", 40 * VC, 0, [&](int it) { DC(f(&mb, &bp, x, &sv, yr[it % NROT], &gr, ws, wsb, st)); });
         if (check) {
-            auto got = host(o4, (size_t)V * C); double ma = 0; for (float v : got) ma += fabs(v);
+            auto got = host(o4, (size_t)V * C); double ma = 0, mx = 0; size_t nbad = 0, imx = 0;
+            for (size_t i = 0; i < got.size(); ++i) { const float v = got[i]; if (!(fabs(v) < 1e30f)) { ++nbad; continue; } ma += fabs(v); if (fabs(v) > mx) { mx = fabs(v); imx = i; } }
             auto gw = host(dW, (size_t)3 * C * C); double mw = 0; for (float v : gw) mw += fabs(v);
-            printf("  mean|d_x| %.9e  d_x[V/2] %.7e  mean|dW0| %.9e", ma / got.size(), got[(size_t)(V / 2) * C + 5], mw / gw.size());
+            printf("  mean|d_x| %.9e  d_x[V/2] %.7e  mean|dW0| %.9e  max|d_x| %.4e at row %zu  non-finite %zu", ma / got.size(), got[(size_t)(V / 2) * C + 5], mw / gw.size(), mx, imx / C, nbad);
         }
         endl_();
     }
