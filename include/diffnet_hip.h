@@ -125,7 +125,8 @@ int dn_tn_target_chunks(void);  /* how many entries dn_mesh_batch_t.chunks shoul
  *        "chain" (1)            chained row kernels of the fused block (0: unfused launches)
  *        "chain_min_rows" (0)   smallest batch the TRAINING forward takes the chained kernel for ...
  *        "chain_small_rows" (0)      ... and the largest small batch below that which takes it all the same (a window for the unfused launches: tests)
- *        "chain_hh" (0)         16-row halves per wave of the chained kernels (0: by batch size and direction, dn_api.hip)
+ *        "chain_hh" (0)         16-row halves per wave of the chained kernels (0: by batch size and direction, dn_api.hip; the forward
+ *                               kernel of C = 256 has one shape -- two halves, four waves -- and ignores this option and the next)
  *        "chain_nw" (0)         waves per workgroup of the chained kernels (0: chosen by batch size)
  *        "f16" (1)              split-fp16 matrix engine for the row products of the fused block (0: split-bf16 everywhere)
  *        "f16_mask" (188)       product classes on the split-fp16 engine (diagnostic bit mask, dn_api.hip)
