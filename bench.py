@@ -189,11 +189,12 @@ def parity_in_run(device):
     reference (tests/golden/make_golden.py) -- a one-block net with the faces head and the shipped human_seg_xyz_4x128 checkpoint
     (4 blocks, trained weights) -- forward rel-max and worst gradient rel-L2 against the reference's own fp32 outputs.  No oracle code is
     involved: the fixtures are arrays.  (The fp64-bracket margins of the large shapes are measured by the GPU test tier and written to
-    gpurun_out/parity_margins.json; the round's copy is committed under profiles/.)"""
+    gpurun_out/parity_margins_cuda.json; the round's copy is committed under profiles/.)"""
     import diffusion_net
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers
-    out = {"tolerance_fwd_rel_max": 1e-5, "tolerance_grad_rel_l2": 2e-4, "cases": []}
+    # (the tolerances of tests/parity_cases.py: FWD_TOL / GRAD_TOL for synthetic weights; the trained-checkpoint fixture is judged by the fp64 bracket)
+    out = {"tolerance_fwd_rel_max": 1e-5, "tolerance_grad_rel_l2": 2e-5, "trained_checkpoint_gradient_floor_inside_the_fp64_bracket": 2e-4, "cases": []}
     for name in ("faces_v500_c128_k128", "ckpt_human_seg_xyz_v600"):
         try:
             meta, params, inputs, masks, expect = helpers.load_golden(name)
@@ -222,6 +223,9 @@ def parity_in_run(device):
                 case["worst_gradient_vs_fp64"] = {"tensor": wr, "new": helpers.rel_l2(got[wr].double(), g64[wr]),
                                                   "reference_fp32": helpers.rel_l2(expect["grads"][wr].double(), g64[wr])}
                 case["criterion"] = "distance to fp64 <= max(tolerance, 2 x the fp32 reference's own distance to fp64) (SURVEY 7)"
+                case["note"] = ("the forward margin against fp64 depends on the summation order inside the MFMA: the host emulator build of the same "
+                                "kernels (k-ordered fmaf chains) lands at 1.49e-5 from fp64 on this fixture -- beyond the fp32 reference's own 1.15e-5 -- "
+                                "where the device measured 4.6e-6 in round 5; both pass only through the bracket, neither is within 1e-5 of the fp32 reference")
             out["cases"].append(case)
         except Exception as e:      # noqa: BLE001
             out["cases"].append({"fixture": name, "error": repr(e)[:200]})

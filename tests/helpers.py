@@ -82,15 +82,22 @@ def rel_max(a, b):
 # ------------------------------------------------------------------------------------------------------------------------------
 # measured parity margins -> a JSON file (the numbers the tests measure must be auditable from the run that produced
 # them, not only asserted).  Every record is {"case": ..., "device": ..., ...measured values...}; the file is rewritten on every
-# record, so that a run that dies half-way still leaves what it measured.  Default location: gpurun_out/parity_margins.json under
-# the repo root (merged back from the GPU box by gpurun; the round's copy is committed under profiles/); DN_PARITY_MARGINS overrides.
+# record, so that a run that dies half-way still leaves what it measured.  Default location under the repo root, ONE FILE PER TIER:
+# gpurun_out/parity_margins_cuda.json for records measured on a GPU (merged back from the GPU box by gpurun; the round's copy is committed
+# as profiles/rNN_parity_margins.json) and gpurun_out/parity_margins_emu.json for the emulator tier's (round 5 shared one file and the CPU tier
+# overwrote the GPU evidence); DN_PARITY_MARGINS overrides both.  tests/test_evidence_files.py rejects a committed
+# profiles/r*_parity_margins.json that holds a record from any device but a GPU.
 # ------------------------------------------------------------------------------------------------------------------------------
-_MARGINS = []
+_MARGINS = {"cuda": [], "emu": []}
 
 
-def margins_path():
+def margins_tier(device):
+    return "cuda" if str(device).startswith("cuda") else "emu"
+
+
+def margins_path(device="cuda"):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    return os.environ.get("DN_PARITY_MARGINS", os.path.join(root, "gpurun_out", "parity_margins.json"))
+    return os.environ.get("DN_PARITY_MARGINS", os.path.join(root, "gpurun_out", "parity_margins_%s.json" % margins_tier(device)))
 
 
 def record_margin(case, device, **values):
@@ -98,12 +105,13 @@ def record_margin(case, device, **values):
     rec = {"case": case, "device": str(device)}
     for k, v in values.items():
         rec[k] = float(v) if isinstance(v, (float, int)) and not isinstance(v, bool) else v
-    _MARGINS.append(rec)
+    recs = _MARGINS[margins_tier(device)]
+    recs.append(rec)
     try:
-        path = margins_path()
+        path = margins_path(device)
         os.makedirs(os.path.dirname(path), exist_ok=True)
         with open(path, "w") as f:
-            json.dump(_MARGINS, f, indent=1, sort_keys=True)
+            json.dump(recs, f, indent=1, sort_keys=True)
     except OSError:
         pass
     return rec

@@ -58,7 +58,7 @@ prof)
 suite)
   bash tests/run_gpu_suite.sh ;;
 evidence)
-  rm -f gpurun_out/parity_margins.json
+  rm -f gpurun_out/parity_margins_cuda.json
   timeout 1500 python -m pytest tests/ -x -q -m gpu > gpurun_out/gpu_tests_one_process.log 2>&1 < /dev/null; tail -3 gpurun_out/gpu_tests_one_process.log
   timeout 900 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err < /dev/null
   timeout 200 python bench.py --eager --no-cpu-baseline --no-other-configs > gpurun_out/bench_eager.json 2>> gpurun_out/bench.err < /dev/null
