@@ -17,11 +17,11 @@ static_assert(sizeof(dn_tile_t) == sizeof(DnTile), "tile layout");
 enum { F16_TOB = 1, F16_FROMB = 2, F16_GF = 4, F16_MLP = 8, F16_LBI = 16, F16_GFB = 32, F16_TOB_B = 64, F16_FROMB_B = 128 };
 namespace {
 struct Opt { const char* name; int value; };
-enum { O_CHAIN, O_CHAIN_MIN_ROWS, O_CHAIN_SMALL_ROWS, O_CHAIN_NW, O_CHAIN_HH, O_F16, O_F16_MASK, O_F16_WGRAD, O_DIFFUSE, O_DIFFUSE_GROUPS, O_DIFFUSE_ORDER, O_DIFFUSE_FLAGS, O_DIFFUSE_SPLIT, O_COUNT };
+enum { O_CHAIN, O_CHAIN_MIN_ROWS, O_CHAIN_SMALL_ROWS, O_CHAIN_NW, O_CHAIN_HH, O_F16, O_F16_MASK, O_F16_WGRAD, O_DIFFUSE, O_DIFFUSE_GROUPS, O_DIFFUSE_ORDER, O_DIFFUSE_FLAGS, O_DIFFUSE_SPLIT, O_SPECTRAL_GRAD, O_COUNT };
 Opt g_opt[O_COUNT] = {
     {"chain", 1}, {"chain_min_rows", 0}, {"chain_small_rows", 0}, {"chain_nw", 0}, {"chain_hh", 0}, {"f16", 1},
     {"f16_mask", F16_GF | F16_MLP | F16_LBI | F16_GFB | F16_FROMB_B}, {"f16_wgrad", 0},
-    {"diffuse", 2}, {"diffuse_groups", 1}, {"diffuse_order", 0}, {"diffuse_flags", DN_DF_FLAG_DEFER}, {"diffuse_split", 0},
+    {"diffuse", 2}, {"diffuse_groups", 1}, {"diffuse_order", 0}, {"diffuse_flags", DN_DF_FLAG_DEFER}, {"diffuse_split", 0}, {"spectral_grad", 1},
 };
 inline int opt(int i) { return g_opt[i].value; }
 }  // namespace
@@ -395,7 +395,7 @@ int dn_get_option(const char* name, int* value) {
     return DN_ERR_INVALID;
 }
 
-int dn_version(void) { return 500; }
+int dn_version(void) { return 600; }
 int dn_tile_rows(void) { return DN_TM; }
 int dn_tn_target_chunks(void) { return 2 * dn_num_cus(); }
 int dn_diffusion_plan_wgs(void) { return dn_num_cus(); }
@@ -471,6 +471,27 @@ int dn_diffusion_bwd_f32(const dn_mesh_batch_t* mb, const float* d_xd, const flo
         DN_CHECK(dn_launch_reduce(dtp, d_time, mb->n_mesh, C, C, S(stream)));
     }
     return from_basis(mb, dxs, C, d_x, d_x_add, true, S(stream));   // d_x_add may be NULL
+}
+
+// ------------------------------------------------------------------ spectral-gradient operands (dn_spectral.hip)
+int dn_spectral_grad_supported(int k_eig, int C) { return dn_chain_sg_eligible(C, k_eig, 1, 1) ? 1 : 0; }
+int dn_spectral_units(const int32_t* sizes, int n_mesh, dn_tile_t* units) {
+    if (!sizes || n_mesh <= 0) return 0;
+    return dn_sg_units_host(sizes, n_mesh, reinterpret_cast<DnTile*>(units));
+}
+size_t dn_spectral_pack_bytes(int n_units, int k_eig) { return dn_sg_pack_elems(n_units, k_eig) * sizeof(uint4); }
+size_t dn_spectral_pack_workspace_bytes(const dn_mesh_batch_t* mb) { return 2 * pad256((size_t)mb->v_total * mb->k_eig) + 512; }
+int dn_spectral_pack_f32(const dn_mesh_batch_t* mb, const dn_tile_t* units, int n_units, void* sg_pack, float* sg_amax, void* ws, size_t ws_bytes,
+                         void* stream) {
+    if (!mb || !units || n_units <= 0 || !sg_pack || !sg_amax || !mb->evecs || !mb->g_rowptr || !mb->g_col || !mb->g_vx || !mb->g_vy ||
+        mb->k_eig % 32 != 0 || mb->k_eig > 256 || !al16(mb->evecs) || !al16(sg_pack))
+        return DN_ERR_INVALID;
+    Bump b(ws, ws_bytes);
+    float* gpx = b.f((size_t)mb->v_total * mb->k_eig);
+    float* gpy = b.f((size_t)mb->v_total * mb->k_eig);
+    if (!b.ok) return DN_ERR_INVALID;
+    return dn_launch_sg_pack(T(units), n_units, mb->n_mesh, mb->k_eig, mb->evecs, mb->g_rowptr, mb->g_col, mb->g_vx, mb->g_vy, gpx, gpy, sg_amax,
+                             reinterpret_cast<uint4*>(sg_pack), S(stream));
 }
 
 // ------------------------------------------------------------------ gradient apply
@@ -640,6 +661,13 @@ static bool block_chain_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p
     if (kind == 1 && mb->v_total < opt(O_CHAIN_MIN_ROWS) && mb->v_total > opt(O_CHAIN_SMALL_ROWS)) return false;
     return dn_chain_eligible(p->C, p->n_mlp, p->widths, p->with_grad, mb->g_nnz, mb->v_total, kind == 2);
 }
+// The spectral-gradient form of the chained forward (dn_spectral.hip, dn_chain.hip KE > 0): batches that carry the packed operands, shapes the
+// kernel is instantiated for, one 16-row half per wave (the forward's form up to 262144 rows); not with the one-launch diffusion operator.
+static bool block_sg_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int kind) {
+    return opt(O_SPECTRAL_GRAD) && kind < 2 && mb->sg_pack && mb->sg_units && mb->sg_amax && mb->sg_n_units > 0 && al16(mb->sg_pack) &&
+           block_chain_ok(mb, p, kind) && dn_chain_sg_eligible(p->C, mb->k_eig, p->with_grad, chain_hh(mb, false, p->C)) && !diffuse_ok(mb, p->C);
+}
+static size_t sg_piece_floats(const dn_mesh_batch_t* mb, int C) { return (size_t)mb->n_mesh * (mb->k_eig / 32) * (2 * (C / 16) * 64) * 4; }
 // Product classes of the block; option "f16_mask" (diagnostic) selects which of them run on the split-fp16 engine.
 // Default: the row products (gradient features, MLP, input gradients, backward back-projection).  Not the split-V projections
 // evecs^T x (their lock-step kernel gains nothing: 55 -> 54.6 us, and leaving them out spares the transposed gather a magnitude
@@ -661,6 +689,7 @@ size_t dn_block_fwd_workspace_bytes(const dn_mesh_batch_t* mb, const dn_block_pa
     const size_t VC = (size_t)mb->v_total * p->C;
     size_t n = pad256((size_t)mb->n_chunks * mb->k_eig * p->C) + pad256((size_t)mb->n_mesh * mb->k_eig * p->C) + amax_ws() + 512;
     if (block_chain_ok(mb, p, with_saved ? 1 : 0)) n += pad256(dn_chain_ws_bytes(p->C, p->with_grad, p->with_rot, p->n_mlp) / sizeof(float));
+    if (block_sg_ok(mb, p, with_saved ? 1 : 0)) n += pad256(sg_piece_floats(mb, p->C)) + pad256((size_t)mb->n_mesh);
     if (diffuse_ok(mb, p->C)) n += pad256(diffuse_ws_floats(mb));
     if (!with_saved) {
         n += pad256((size_t)mb->n_mesh * mb->k_eig * p->C) + 4 * pad256(VC);          // xs, xd, gx, gy, g
@@ -680,6 +709,10 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     float* aw = b.f(AW_COUNT + DN_BLOCK_AMAX_WORDS + 2);
     const bool chain = block_chain_ok(mb, p, sv ? 1 : 0) && (!sv || sv->amax) && chain_aligned(p, sv, x, out);
     float* chain_ws = block_chain_ok(mb, p, sv ? 1 : 0) ? b.f(dn_chain_ws_bytes(p->C, p->with_grad, p->with_rot, p->n_mlp) / sizeof(float)) : nullptr;
+    const bool sg_ws = block_sg_ok(mb, p, sv ? 1 : 0);
+    float* ysp = sg_ws ? b.f(sg_piece_floats(mb, C)) : nullptr;          // the scaled spectrum as weight pieces + its per-mesh magnitudes
+    float* ysa = sg_ws ? b.f((size_t)mb->n_mesh) : nullptr;
+    const bool sg = chain && sg_ws;                                       // xd, gx, gy computed inside the chained kernel (dn_spectral.hip)
     float* diffuse_ws = diffuse_ok(mb, C) ? b.f(diffuse_ws_floats(mb)) : nullptr;
     float *xs, *xd, *gx = nullptr, *gy = nullptr, *gf = nullptr, *bre = nullptr, *bim = nullptr;
     float* hbuf[2] = {nullptr, nullptr};
@@ -774,10 +807,15 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
         }
         DN_CHECK(dn_launch_spec_fwd(partial, mb->mesh_chunk_off, mb->evals, p->time, xs, ys, mb->n_mesh, K, C, st,
                                     (f16 && (f16_mask() & F16_FROMB)) ? aw + AW_YS : nullptr));   // only the split-fp16 back-projection needs max |ys|
-        F16 fb;
-        if (f16) fb = f16_if(F16_FROMB, f16_of(ev_amax, aw + AW_YS, sw + SW_XD));
-        else if (words) fb.o = sw + SW_XD;                                  // (the chained kernel scales xd by its magnitude)
-        DN_CHECK(from_basis(mb, ys, C, xd, nullptr, false, st, fb));
+        if (sg) {
+            // no back-projection launch: the chained kernel multiplies [evecs | gradX evecs | gradY evecs] by the spectrum itself
+            DN_CHECK(dn_launch_spec_pieces(ys, mb->n_mesh, K, C, reinterpret_cast<uint4*>(ysp), ysa, st));
+        } else {
+            F16 fb;
+            if (f16) fb = f16_if(F16_FROMB, f16_of(ev_amax, aw + AW_YS, sw + SW_XD));
+            else if (words) fb.o = sw + SW_XD;                                  // (the chained kernel scales xd by its magnitude)
+            DN_CHECK(from_basis(mb, ys, C, xd, nullptr, false, st, fb));
+        }
     }
     if (use_chain) {   // gather -> gradient features -> MiniMLP + residual in one launch (layers.py:213-239)
         ChainArgs ca; memset(&ca, 0, sizeof(ca));
@@ -804,6 +842,12 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
         ca.out = out;
         ca.x_amax = x_amax; ca.xd_amax = sw + SW_XD; ca.grad_norm = mb->grad_norm;
         ca.g_amax = sw + SW_G; ca.out_amax = p->out_amax;
+        if (sg) {
+            ca.xd = nullptr;
+            ca.sg_pack = reinterpret_cast<const uint4*>(mb->sg_pack); ca.sg_units = T(mb->sg_units); ca.sg_n_units = mb->sg_n_units; ca.sg_amax = mb->sg_amax;
+            ca.ysp = reinterpret_cast<const uint4*>(ysp); ca.ys_amax = ysa;
+            ca.xd_out = sv ? xd : nullptr; ca.xd_amax_out = sw + SW_XD;
+        }
         return dn_launch_chain_fwd(chain_np, ca, C, st, chain_hh(mb, false, C));
     }
     // gradient features (layers.py:213-226)

@@ -130,8 +130,13 @@ extern "C" int dn_debug_ch_trace_read(unsigned long long* out, int n) {
 #define CH_TR() do {} while (0)
 #endif
 
-template <int C, int NW, int HH>
+// KE > 0: the spectral-gradient form (dn_spectral.hip) for k_eig = 32 KE -- no CSR gather, no xd read: the pass starts with the three products
+// [Phi | G_X Phi | G_Y Phi][rows] * ys[mesh] (operand fragments streamed pre-split from the packed batch operand, the scaled spectrum's pieces
+// through the same LDS ring as the weights) and xd, gx, gy are born in the accumulator layout the following stages consume.
+template <int C, int NW, int HH, int KE = 0>
 __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void chain_fwd_kernel(ChainArgs a) {
+    constexpr bool SG = KE > 0;
+    static_assert(!SG || (HH == 1 && C < 256), "spectral-gradient form: one 16-row half per wave, two waves per SIMD");
     constexpr int NT = C / 16;            // 16-channel output tiles
     constexpr int NK = C / 32;            // 32-channel contraction steps (= pieces per matrix)
     constexpr int NTHR = 64 * NW;
@@ -143,13 +148,14 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
     constexpr int CH_PF = G0 ? DN_CH_PF_WIDE : 1;      // weight-fragment prefetch distance in tile pairs (one wave per SIMD: nobody else covers the LDS latency)
     static_assert(PIECE % NTHR == 0, "piece staging");
     static_assert(RING >= 2 && RING <= 8 && (RING - 1) * LPT < 60 && (RING - 2) * LPT + 6 * HH < 64, "ring depth vs the vmcnt range");
+    static_assert(!SG || (RING - 2) * LPT + 6 * (KE - 1) < 64, "operand-fragment requests of the spectral stage vs the vmcnt range");
 
     DN_DYN_SMEM(smem_raw);
     uint4* ring = reinterpret_cast<uint4*>(smem_raw);                      // RING slots of PIECE uint4
     float* sbias = reinterpret_cast<float*>(ring + RING * PIECE);          // [DN_CH_LAYERS][C]  (G0: not staged, the epilogues read the biases from memory)
     // row-contiguous gather (RCG; at C = 128 in the one-half-per-wave form only: it needs the registers the second half's features occupy
     // otherwise.  The C = 256 form runs one wave per SIMD with 512 registers and takes it with both halves)
-    constexpr bool RCG = (HH == 1 || C >= 256) && DN_CH_RCG != 0;
+    constexpr bool RCG = !SG && (HH == 1 || C >= 256) && DN_CH_RCG != 0;
     constexpr int GC = G0 ? 128 : C;      // channels per gather sweep (G0: the row in two column halves -- sums, request buffers and the slice are
                                           // those of C = 128, the half gathered first is in its final registers while the second one runs)
     constexpr int NSW = C / GC;           // sweeps
@@ -177,6 +183,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
 
     // XCD-contiguous unit ranges: workgroup b runs on XCD b % 8 and walks units of the b % 8-th eighth of the row axis, so that the
     // ~7 neighbour rows a row gathers are mostly rows the same L2 has just served
+    // (SG: a.units counts 16 NW-row sub-units of the batch's 64-row units -- rows of ONE mesh, padded: the pass's spectrum is that mesh's)
     const int GX = gridDim.x >> 3;        // workgroups per XCD (the host launches a multiple of 8)
     const int per_x = (a.units + 7) >> 3;
     const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
@@ -189,9 +196,13 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
     if (npass == 0) return;
 
     // ---- operand scales known up front
-    const float s_in = ch_uniform(dn_pow2_scale(fmaxf(fmaxf(dn_amax_word(a.x_amax), dn_amax_word(a.xd_amax)), a.with_grad ? 1.f : 0.f)));   // [x | xd | g]
+    // (SG: xd, gx, gy are produced by this kernel -- their scales are per pass, from the wave's own 16 rows, as the hidden activations')
+    const float x_mag = SG ? dn_amax_word(a.x_amax) : 0.f;
+    float s_in = SG ? 1.f : ch_uniform(dn_pow2_scale(fmaxf(fmaxf(dn_amax_word(a.x_amax), dn_amax_word(a.xd_amax)), a.with_grad ? 1.f : 0.f)));   // [x | xd | g]
     float s_gf = 1.f, so_gf = 1.f;
-    if (a.with_grad) {
+    const float swa_inv = (SG && a.with_grad) ? ch_uniform(ch_pow2_inv(dn_pow2_scale(dn_amax_word(a.wa_amax)))) : 1.f;
+    float xdmax = 0.f, gmax = 0.f;        // SG: largest |xd|, |gx|, |gy| this wave produced
+    if (!SG && a.with_grad) {
         const float gb = dn_amax_word(a.xd_amax) * dn_amax_word(a.grad_norm);
         if (blockIdx.x == 0 && tid == 0 && a.g_amax) atomicMax(reinterpret_cast<unsigned*>(a.g_amax), __float_as_uint(gb));
         s_gf = ch_uniform(dn_pow2_scale(gb));
@@ -211,9 +222,15 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
     // The stream of a pass: the gradient-feature pieces once per 16-row half (the stage runs half by half), then every other piece once;
     // position sq of that sequence fetches piece sq (first round of the gradient-feature pieces), sq - n_gf (second round) or
     // sq - (HH - 1) n_gf (the layers).  It wraps at the end of a pass: the requests run ahead into the next one.
+    // SG: the pass's KE spectrum pieces come first, from the pass's mesh (the requests run ahead into the next pass: imesh follows the stream)
     const int n_gf = a.with_grad ? a.n_gf : 0;
-    const int n_seq = a.n_pieces + (HH - 1) * n_gf;
+    const int n_seq = a.n_pieces + (HH - 1) * n_gf + KE;
     int sq = 0;                           // position the NEXT request fetches
+    constexpr int SUB = SG ? 4 / NW : 1;  // workgroup passes per 64-row unit
+    auto unit_of = [&](int pass_) { return xcd * per_x + slot0 + pass_ * GX; };
+    DnTile tl_nx = DnTile{0, 0, 0, 0};    // SG: the unit of the NEXT pass (loaded a pass ahead of its use)
+    int imesh = 0;
+    if constexpr (SG) { tl_nx = a.sg_units[unit_of(0) / SUB]; imesh = tl_nx.mesh; }
 #ifdef DN_EMULATE
     const int wave_u = wave;
 #else
@@ -221,14 +238,20 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
 #endif
     int rq = 0;                           // slot the next request fills
     auto issue = [&]() {
-        const int pidx = sq < HH * n_gf ? (sq >= n_gf ? sq - n_gf : sq) : sq - (HH - 1) * n_gf;
-        const uint4* src_piece = a.wp + (size_t)pidx * PIECE;
+        const uint4* src_piece;
+        if constexpr (SG) {
+            src_piece = sq < KE ? a.ysp + ((size_t)imesh * KE + sq) * PIECE : a.wp + (size_t)(sq - KE) * PIECE;
+        } else {
+            const int pidx = sq < HH * n_gf ? (sq >= n_gf ? sq - n_gf : sq) : sq - (HH - 1) * n_gf;
+            src_piece = a.wp + (size_t)pidx * PIECE;
+        }
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const int e0 = rq * PIECE + i * NTHR + wave_u * 64;
             ch_dma16(src_piece + i * NTHR + tid, ring + e0, lds0 + 16u * (unsigned)e0);
         }
-        sq = sq + 1 == n_seq ? 0 : sq + 1;
+        if (sq + 1 == n_seq) { sq = 0; if constexpr (SG) imesh = tl_nx.mesh; }      // (tl_nx: the unit after the one being multiplied, or the last one again)
+        else ++sq;
         rq = rq + 1 == RING ? 0 : rq + 1;
     };
 #ifdef DN_EMULATE
@@ -259,16 +282,30 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
 
     for (int pass = 0; pass < npass; ++pass) {
         CH_TR();
-        const int unit = xcd * per_x + slot0 + pass * GX;
-        const int rb = unit * (16 * HH * NW) + 16 * HH * wave;     // first of this wave's 32 rows (row * C fits 32 bits for every batch the library takes)
+        const int unit = unit_of(pass);
+        int rb = unit * (16 * HH * NW) + 16 * HH * wave;     // first of this wave's 32 rows (row * C fits 32 bits for every batch the library takes)
+        int row_end = a.V;
+        [[maybe_unused]] int sg_mesh = 0;
+        [[maybe_unused]] long long sg_group = 0;
+        if constexpr (SG) {
+            // this pass's 64-row unit (rows of one mesh; past the mesh's end the packed operands hold zeros) and the next pass's, whose mesh the
+            // piece requests that run ahead need
+            const DnTile tl = tl_nx;
+            if (pass + 1 < npass) tl_nx = a.sg_units[unit_of(pass + 1) / SUB];
+            const int sub = unit % SUB;
+            rb = tl.row0 + 16 * (NW * sub + wave);
+            row_end = tl.row0 + tl.nrows;
+            sg_mesh = tl.mesh;
+            sg_group = 4LL * (unit / SUB) + NW * sub + wave;
+        }
         int rowh[HH]; bool liveh[HH]; int rch[HH];
         int begh[HH], endh[HH];
 #pragma unroll
         for (int hh = 0; hh < HH; ++hh) {
             rowh[hh] = rb + 16 * hh + m;
-            liveh[hh] = rowh[hh] < a.V;
-            rch[hh] = liveh[hh] ? rowh[hh] : a.V - 1;          // dead rows repeat the last row (computed, never stored)
-            if (a.with_grad) { begh[hh] = a.rowptr[rch[hh]]; endh[hh] = a.rowptr[rch[hh] + 1]; }
+            liveh[hh] = rowh[hh] < row_end;
+            rch[hh] = liveh[hh] ? rowh[hh] : row_end - 1;      // dead rows repeat the last row (computed, never stored)
+            if (!SG && a.with_grad) { begh[hh] = a.rowptr[rch[hh]]; endh[hh] = a.rowptr[rch[hh] + 1]; }
         }
 
         // =================================================== gradient features, one 16-row half at a time
@@ -298,15 +335,87 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
                 for (int nt = 0; nt < NT; ++nt) acc[hh][nt] = dn_f32x4{0.f, 0.f, 0.f, 0.f};
         }
         uint4 gfh[G0 ? 1 : HH][NK], gfl[G0 ? 1 : HH][NK];     // tanh features (of the two halves) as operand fragments (hi / lo planes) for layer 0
+        [[maybe_unused]] float xdv[SG ? NT : 1][4];            // SG: this wave's xd rows (accumulator layout), layer 0's third operand segment
         if (a.with_grad) {
             auto half = [&](const int hh) __attribute__((always_inline)) {
                 const long long row = hh ? rowh[HH - 1] : rowh[0];
                 const bool live = hh ? liveh[HH - 1] : liveh[0];
                 // ---- CSR gather of the row: gx = sum_j vx_j xd[col_j], gy likewise (entry order, fmaf: bit for bit spmm_kernel's sums)
                 float gxv[NT][4], gyv[NT][4];
-                const int beg = hh ? begh[HH - 1] : begh[0], end = hh ? endh[HH - 1] : endh[0];
-                const int nmax = (int)ch_wave_max((float)(end - beg));
-                if constexpr (!RCG) {
+                [[maybe_unused]] int beg = 0, end = 0, nmax = 0;
+                if constexpr (!SG) {
+                    beg = hh ? begh[HH - 1] : begh[0]; end = hh ? endh[HH - 1] : endh[0];
+                    nmax = (int)ch_wave_max((float)(end - beg));
+                }
+                if constexpr (SG) {
+                    // ---- [xd | gx | gy] = [Phi | G_X Phi | G_Y Phi][16 rows] ys[mesh]: the operand fragments arrive pre-split (fp16 hi / lo, this
+                    // lane's eight contraction slots of step T as one uint4 per plane: every request of the wave is 1 KiB contiguous), all of a pass's
+                    // requested up front; the spectrum's pieces come through the ring.  One piece read from LDS feeds all three products.
+                    const uint4* fp = a.sg_pack + (size_t)sg_group * (3 * KE * 128) + lane;
+                    uint4 fr[KE][3][2];
+#pragma unroll
+                    for (int T = 0; T < KE; ++T)
+#pragma unroll
+                        for (int op = 0; op < 3; ++op) {
+                            fr[T][op][0] = fp[(size_t)(op * KE + T) * 128];
+                            fr[T][op][1] = fp[(size_t)(op * KE + T) * 128 + 64];
+                        }
+                    const float* am = a.sg_amax + 4 * sg_mesh;
+                    const float ys_inv = ch_pow2_inv(dn_pow2_scale(a.ys_amax[sg_mesh]));
+                    const float u_xd = ch_uniform(ys_inv * ch_pow2_inv(dn_pow2_scale(am[0])));
+                    const float u_gx = ch_uniform(ys_inv * ch_pow2_inv(dn_pow2_scale(am[1])));
+                    const float u_gy = ch_uniform(ys_inv * ch_pow2_inv(dn_pow2_scale(am[2])));
+                    dn_f32x4 sa[3][NT];
+#pragma unroll
+                    for (int op = 0; op < 3; ++op)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) sa[op][nt] = dn_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int T = 0; T < KE; ++T) {
+                        CH_PIECE_BEGIN();
+                        CH_MMA3(sa, fr[T]);
+                        // the piece waited for is older than every fragment request: the ones still in flight (and the ring's two youngest pieces) may stay
+                        // (loads only are counted -- requests younger than the piece waited for, DMA(gp + 1), which went out RING - 2 pieces ago: the
+                        // fragment requests of this pass are younger than it during the first RING - 2 pieces only)
+                        if (T == 0 && RING > 2) CH_WAIT_OPS((RING - 2) * LPT + 6 * (KE - 1));
+                        else if (T == 1 && RING > 3) CH_WAIT_OPS((RING - 2) * LPT + 6 * (KE > 1 ? KE - 2 : 0));
+                        else CH_WAIT_OPS((RING - 2) * LPT);
+                        CH_BARRIER();
+                        ++gp;
+                    }
+                    float wx = 0.f, wg = 0.f;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float vd = sa[0][nt][e] * u_xd, vx_ = sa[1][nt][e] * u_gx, vy_ = sa[2][nt][e] * u_gy;
+                            xdv[nt][e] = vd; gxv[nt][e] = vx_; gyv[nt][e] = vy_;
+                            wx = fabsf(vd) > wx ? fabsf(vd) : wx;
+                            wg = fabsf(vx_) > wg ? fabsf(vx_) : wg;
+                            wg = fabsf(vy_) > wg ? fabsf(vy_) : wg;
+                        }
+                    wx = ch_wave_max(wx); wg = ch_wave_max(wg);
+                    xdmax = wx > xdmax ? wx : xdmax; gmax = wg > gmax ? wg : gmax;
+                    s_in = ch_uniform(dn_pow2_scale(fmaxf(fmaxf(x_mag, wx), 1.f)));        // [g | x | xd] of this pass
+                    s_gf = ch_uniform(dn_pow2_scale(wg));
+                    so_gf = ch_uniform(ch_pow2_inv(s_gf) * swa_inv);
+                    if (live) {
+                        if (a.xd_out) {
+                            float* od = a.xd_out + row * C + 4 * q;
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) ch_st4(od + 16 * nt, make_float4(xdv[nt][0], xdv[nt][1], xdv[nt][2], xdv[nt][3]));
+                        }
+                        if (a.gx) {
+                            float* ox = a.gx + row * C + 4 * q;
+                            float* oy = a.gy + row * C + 4 * q;
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                ch_st4(ox + 16 * nt, make_float4(gxv[nt][0], gxv[nt][1], gxv[nt][2], gxv[nt][3]));
+                                ch_st4(oy + 16 * nt, make_float4(gyv[nt][0], gyv[nt][1], gyv[nt][2], gyv[nt][3]));
+                            }
+                        }
+                    }
+                } else if constexpr (!RCG) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -587,6 +696,8 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
             // operands of the 2 NK pieces of the x and xd segments, fetched two pieces ahead (requesting all of them up front in the
             // one-half form -- the registers would allow it -- measured no gain: 410 vs 400 us block forward, profiles/r05_rcg_ab.txt)
             constexpr int NXR = G0 ? DN_CH_NXR_WIDE : 3;   // (the requests share the in-order return queue with the piece stream: a row still on its way from HBM holds the pieces behind it)
+            constexpr int NFETCH = SG ? NK : 2 * NK;       // pieces whose operand rows come from memory (SG: the xd segment is in registers)
+            static_assert(NXR - 1 <= NFETCH, "operand prefetch depth");
             float4 nx[NXR][HH][2];
             auto fetch = [&](int pi, float4 (&d)[HH][2]) {
                 const float* p = (pi < NK ? a.x : a.xd) + 32 * (pi < NK ? pi : pi - NK) + 4 * q;
@@ -612,9 +723,12 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
             for (int pi = 0; pi < 2 * NK; ++pi) {
                 uint4 fh[HH], fl[HH];
 #pragma unroll
-                for (int hh = 0; hh < HH; ++hh) ch_split8(nx[pi % NXR][hh][0], nx[pi % NXR][hh][1], s_in, fh[hh], fl[hh]);
+                for (int hh = 0; hh < HH; ++hh) {
+                    if (SG && pi >= NK) ch_split8(xdv[(2 * (pi - NK)) % NT], xdv[(2 * (pi - NK) + 1) % NT], s_in, fh[hh], fl[hh]);
+                    else ch_split8(nx[pi % NXR][hh][0], nx[pi % NXR][hh][1], s_in, fh[hh], fl[hh]);
+                }
                 if constexpr (DN_CH_L0_EXACT == 0) {
-                    if (pi + NXR - 1 < 2 * NK) fetch(pi + NXR - 1, nx[(pi + NXR - 1) % NXR]);
+                    if (pi + NXR - 1 < NFETCH) fetch(pi + NXR - 1, nx[(pi + NXR - 1) % NXR]);
                     CH_PIECE_BEGIN();
                     CH_MMA2(acc, fh[0], fl[0], fh[HH - 1], fl[HH - 1]);
                     CH_PIECE_END();
@@ -626,12 +740,12 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
                     // compiler's own wait before the split above still asks for everything but the youngest row requests -- pieces requested
                     // one piece ago included --: that one is not ours to count.)
                     CH_PIECE_BEGIN();
-                    const bool f0 = pi + NXR - 1 < 2 * NK;
+                    const bool f0 = pi + NXR - 1 < NFETCH;
                     if (f0) fetch(pi + NXR - 1, nx[(pi + NXR - 1) % NXR]);
                     CH_MMA2(acc, fh[0], fl[0], fh[HH - 1], fl[HH - 1]);
                     // row requests younger than the piece waited for: issued in pieces pi - 2, pi - 1, pi (the first two pieces of the stage
                     // count none: what precedes them differs by configuration, and fewer is the safe side)
-                    const int kf = pi < 2 ? 0 : (int)f0 + (int)(pi - 1 + NXR - 1 < 2 * NK) + (int)(pi - 2 + NXR - 1 < 2 * NK);
+                    const int kf = pi < 2 ? 0 : (int)f0 + (int)(pi - 1 + NXR - 1 < NFETCH) + (int)(pi - 2 + NXR - 1 < NFETCH);
                     if (kf == 3) CH_WAIT_OPS((RING - 2) * LPT + 3 * 2 * HH);
                     else if (kf == 2) CH_WAIT_OPS((RING - 2) * LPT + 2 * 2 * HH);
                     else if (kf == 1) CH_WAIT_OPS((RING - 2) * LPT + 1 * 2 * HH);
@@ -831,21 +945,26 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
     //      ~8 ns each: one per wave (2048 x 3) cost 13 us of a 345 us kernel, one per workgroup 5-6 us (measured against a build that leaves the words unwritten).  The waves of a workgroup arrive here together (same pass count,
     //      a barrier per piece); the piece ring is idle by now and lends its first words.
     {
-        float* wmax = reinterpret_cast<float*>(ring);          // [NW][DN_CH_LAYERS + 1]
-        float vals[DN_CH_LAYERS + 1];
+        constexpr int NWORD = DN_CH_LAYERS + 3;                 // hidden layers, out, and (SG) xd, gx / gy
+        float* wmax = reinterpret_cast<float*>(ring);          // [NW][NWORD]
+        float vals[NWORD];
 #pragma unroll
         for (int j = 0; j < DN_CH_LAYERS; ++j) vals[j] = ch_wave_max(hmax[j]);
         vals[DN_CH_LAYERS] = ch_wave_max(omax);
+        vals[DN_CH_LAYERS + 1] = xdmax;                         // (already wave-uniform)
+        vals[DN_CH_LAYERS + 2] = gmax;
         __syncthreads();          // every wave has waited for its last DMA requests (above): nothing lands in the ring any more
         if (lane == 0) {
 #pragma unroll
-            for (int j = 0; j <= DN_CH_LAYERS; ++j) wmax[wave * (DN_CH_LAYERS + 1) + j] = vals[j];
+            for (int j = 0; j < NWORD; ++j) wmax[wave * NWORD + j] = vals[j];
         }
         __syncthreads();
-        if (tid <= DN_CH_LAYERS) {
+        if (tid < NWORD) {
             float mm = 0.f;
-            for (int w = 0; w < NW; ++w) { const float t = wmax[w * (DN_CH_LAYERS + 1) + tid]; mm = t > mm ? t : mm; }
+            for (int w = 0; w < NW; ++w) { const float t = wmax[w * NWORD + tid]; mm = t > mm ? t : mm; }
             float* word = tid == DN_CH_LAYERS ? a.out_amax : (tid < a.n_mlp - 1 ? a.h_amax[tid] : nullptr);
+            if (tid == DN_CH_LAYERS + 1) word = SG ? a.xd_amax_out : nullptr;
+            if (tid == DN_CH_LAYERS + 2) word = SG ? a.g_amax : nullptr;
             if (word && mm > 0.f && mm > *reinterpret_cast<volatile float*>(word)) atomicMax(reinterpret_cast<unsigned*>(word), __float_as_uint(mm));
         }
     }
@@ -861,6 +980,7 @@ int dn_chain_pieces(int C, int with_grad, int with_rot, int n_mlp) {
 size_t dn_chain_ws_bytes(int C, int with_grad, int with_rot, int n_mlp) {
     return (size_t)dn_chain_pieces(C, with_grad, with_rot, n_mlp) * (2 * (C / 16) * 64) * sizeof(uint4);
 }
+bool dn_chain_sg_eligible(int C, int K, int with_grad, int hh) { return (C == 128 || C == 64) && K == 128 && with_grad && hh == 1; }
 bool dn_chain_eligible(int C, int n_mlp, const int* widths, int with_grad, long long g_nnz, int V, int backward) {
     if (C != 128 && C != 64 && !(C == 256 && !backward)) return false;
     if (n_mlp < 2 || n_mlp > DN_CH_LAYERS) return false;
@@ -869,9 +989,9 @@ bool dn_chain_eligible(int C, int n_mlp, const int* widths, int with_grad, long 
     return V > 0;
 }
 
-template <int C, int NW, int HH>
+template <int C, int NW, int HH, int KE = 0>
 static int chain_launch_nw(ChainArgs a, hipStream_t stream) {
-    a.units = (a.V + 16 * HH * NW - 1) / (16 * HH * NW);
+    a.units = KE > 0 ? a.sg_n_units * (DN_SG_UNIT_ROWS / (16 * NW)) : (a.V + 16 * HH * NW - 1) / (16 * HH * NW);
     // eight waves per CU (256 registers per lane each): two 4-wave workgroups or one 8-wave workgroup.  C = 256: one 4-wave workgroup per CU,
     // one wave per SIMD with the whole register file (the gradient-feature stage alone holds gx, gy and both accumulators: 256 registers)
     int g = (C >= 256 ? 1 : 8 / NW) * dn_num_cus();
@@ -882,9 +1002,9 @@ static int chain_launch_nw(ChainArgs a, hipStream_t stream) {
                                        (size_t)NW * 4 * C * sizeof(float);      // piece ring + biases + one 4-row gather slice per wave
 #ifndef DN_EMULATE
     static unsigned long long lds_opt_in = 0;   // per-device bitmap
-    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&chain_fwd_kernel<C, NW, HH>), smem, &lds_opt_in); if (oe_) return oe_; }
+    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&chain_fwd_kernel<C, NW, HH, KE>), smem, &lds_opt_in); if (oe_) return oe_; }
 #endif
-    DN_LAUNCH((chain_fwd_kernel<C, NW, HH>), dim3(g, 1, 1), dim3(64 * NW, 1, 1), smem, stream, a);
+    DN_LAUNCH((chain_fwd_kernel<C, NW, HH, KE>), dim3(g, 1, 1), dim3(64 * NW, 1, 1), smem, stream, a);
     return (int)hipGetLastError();
 }
 template <int C>
@@ -907,6 +1027,10 @@ static int chain_launch(int npieces, const ChainArgs& a_in, hipStream_t stream, 
     a.n_pieces = npieces;
     if constexpr (C >= 256) return chain_launch_nw<C, 4, 2>(a, stream);      // (one form: BASELINE config 4 is a 200k-vertex mesh)
     else {
+    if (a.sg_pack) {       // spectral-gradient form (dn_chain_sg_eligible: hh == 1, k_eig == 128)
+        if (hh != 1) return 1;
+        return nw == 4 ? chain_launch_nw<C, 4, 1, 4>(a, stream) : (nw == 2 ? chain_launch_nw<C, 2, 1, 4>(a, stream) : chain_launch_nw<C, 1, 1, 4>(a, stream));
+    }
     if (hh == 1) return nw == 4 ? chain_launch_nw<C, 4, 1>(a, stream) : (nw == 2 ? chain_launch_nw<C, 2, 1>(a, stream) : chain_launch_nw<C, 1, 1>(a, stream));
     switch (nw) {
         case 8: return chain_launch_nw<C, 8, 2>(a, stream);
@@ -939,12 +1063,15 @@ int dn_launch_chain_fwd(int npieces, const ChainArgs& a, int C, hipStream_t stre
     else err = 1;
     {
         // algorithmic traffic: xd gathered once + x read once (+ once more for the residual: L2), every saved tensor written once
+        // (spectral-gradient form: the three packed operands [V, 128] instead of xd, which becomes one more saved tensor; three more products)
         const double VC = 4.0 * (double)a.V * C;
         double nw = 1.0;                                     // out
         if (a.gx) nw += 2.0; if (a.bre) nw += 2.0; if (a.g) nw += 1.0;
+        if (a.sg_pack && a.xd_out) nw += 1.0;
         for (int j = 0; j < DN_CH_LAYERS; ++j) if (j < a.n_mlp - 1 && a.h[j]) nw += 1.0;
         const double prod = (a.with_grad ? (a.with_rot ? 4.0 : 2.0) : 0.0) + (a.with_grad ? 3.0 : 2.0) + (a.n_mlp - 1);
-        dn_prof_end(DN_K_CHAIN, stream, 2.0 * (double)a.V * C * C * prod, VC * (2.0 + nw));
+        const double rd = a.sg_pack ? VC + 3.0 * 4.0 * (double)a.V * 128.0 : 2.0 * VC;
+        dn_prof_end(DN_K_CHAIN, stream, 2.0 * (double)a.V * C * C * prod + (a.sg_pack ? 3.0 * 2.0 * (double)a.V * 128.0 * C : 0.0), rd + VC * nw);
     }
     return err;
 }

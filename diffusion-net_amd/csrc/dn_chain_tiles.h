@@ -252,3 +252,23 @@ _Pragma("unroll") for (int np_ = 0; np_ < NT; np_ += 2) {                       
     ACC[1][np_ + 1] = dn_mfma16_f16(w_[2], FH1, ACC[1][np_ + 1]);                                                   \
 }
 
+// three products sharing the piece: ACC[op][nt] += W(piece) * FR[op] (FR[op][0] = hi, [1] = lo plane of the operand fragment), op = xd, gx, gy of
+// the spectral-gradient stage.  One weight-fragment read from LDS feeds three MFMAs; consecutive MFMAs go to different accumulators (the same
+// accumulator comes round every sixth issue).  Lean form (the stage holds 24 operand fragments and three accumulator rows: the register peak).
+#define CH_MMA3(ACC, FR)                                                                                                \
+_Pragma("unroll") for (int np_ = 0; np_ < NT; np_ += 2) {                                                           \
+    uint4 w_[4];                                                                                                    \
+    CH_WLOAD(w_, np_);                                                                                              \
+    _Pragma("unroll") for (int op_ = 0; op_ < 3; ++op_) {                                                           \
+        ACC[op_][np_] = dn_mfma16_f16(w_[0], FR[op_][1], ACC[op_][np_]);                                            \
+        ACC[op_][np_ + 1] = dn_mfma16_f16(w_[2], FR[op_][1], ACC[op_][np_ + 1]);                                    \
+    }                                                                                                               \
+    _Pragma("unroll") for (int op_ = 0; op_ < 3; ++op_) {                                                           \
+        ACC[op_][np_] = dn_mfma16_f16(w_[1], FR[op_][0], ACC[op_][np_]);                                            \
+        ACC[op_][np_ + 1] = dn_mfma16_f16(w_[3], FR[op_][0], ACC[op_][np_ + 1]);                                    \
+    }                                                                                                               \
+    _Pragma("unroll") for (int op_ = 0; op_ < 3; ++op_) {                                                           \
+        ACC[op_][np_] = dn_mfma16_f16(w_[0], FR[op_][0], ACC[op_][np_]);                                            \
+        ACC[op_][np_ + 1] = dn_mfma16_f16(w_[2], FR[op_][0], ACC[op_][np_ + 1]);                                    \
+    }                                                                                                               \
+}

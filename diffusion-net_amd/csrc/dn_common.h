@@ -514,6 +514,17 @@ struct ChainArgs {
     float* h_amax[DN_CH_LAYERS];          // accumulate max |h_j|
     float* out_amax;                      // accumulates max |out|
     int units;                            // workgroup passes: ceil(V / (16 halves-per-wave waves-per-workgroup))
+    // ---- spectral-gradient form (dn_spectral.hip; kernel template parameter KE = k_eig / 32 > 0): xd, gx, gy are NOT read / gathered but
+    // computed in the kernel as [Phi | G_X Phi | G_Y Phi][rows] * ys[mesh] from the packed operands of the batch (sg_pack) and the scaled
+    // spectrum's pieces (ysp); xd / rowptr / col / vx / vy / xd_amax / grad_norm above are unused
+    const uint4* sg_pack;                 // [groups][3][KE][2][64] fragment-ordered fp16 (hi, lo) planes, 16 rows per group, 4 groups per unit
+    const DnTile* sg_units;               // [sg_n_units] runs of <= 64 rows of one mesh; unit u owns groups 4 u .. 4 u + 3
+    int sg_n_units;
+    const float* sg_amax;                 // [n_mesh][4]: largest magnitudes of Phi, G_X Phi, G_Y Phi per mesh (their power-of-two scales)
+    const uint4* ysp;                     // [n_mesh][KE][piece] the scaled spectrum as transposed weight pieces (dn_launch_spec_pieces)
+    const float* ys_amax;                 // [n_mesh] largest magnitude of every mesh's scaled spectrum
+    float* xd_out;                        // [V, C] receives xd (saved for the backward), or null
+    float* xd_amax_out;                   // accumulates max |xd| (g_amax accumulates max |gx|, |gy| in this form)
 };
 // backward of the same stages: d_out -> d(pre-activations) of every layer -> [d_x | d_xd | d_dots] -> d_gx, d_gy (dn_chain_bwd.hip)
 struct ChainBwdArgs {
@@ -542,6 +553,18 @@ size_t dn_chain_ws_bytes(int C, int with_grad, int with_rot, int n_mlp);
 bool dn_chain_eligible(int C, int n_mlp, const int* widths, int with_grad, long long g_nnz, int V, int backward = 0);   // (the backward kernel exists at C = 64, 128)
 int dn_launch_chain_prep(const ChainPrepArgs& pa, int npieces, int C, hipStream_t stream);
 int dn_launch_chain_fwd(int npieces, const ChainArgs& a, int C, hipStream_t stream, int hh = 2);
+// ---- spectral-gradient operands (dn_spectral.hip): the gradient apply re-associated, gx = G_X (Phi ys) = (G_X Phi) ys.  Built once per
+// mesh batch: G_X Phi, G_Y Phi by a CSR gather accumulated in fp64, then [Phi | G_X Phi | G_Y Phi] split into fp16 (hi, lo) planes in the
+// operand-fragment order of the chained forward kernel, 16 rows per group, every mesh padded to whole 64-row units.
+#define DN_SG_UNIT_ROWS 64
+bool dn_chain_sg_eligible(int C, int K, int with_grad, int hh);     // shapes chain_fwd_kernel<C, NW, 1, K / 32> is instantiated for
+int dn_sg_units_host(const int* sizes, int n_mesh, DnTile* out);    // out may be null: returns the unit count
+size_t dn_sg_pack_elems(int n_units, int K);                        // uint4 elements of the packed operand
+int dn_launch_sg_pack(const DnTile* units, int n_units, int n_mesh, int K, const float* evecs, const int* rowptr, const int* col, const float* vx,
+                      const float* vy, float* gpx, float* gpy, float* amax4, uint4* out, hipStream_t stream);
+// ys [n_mesh, K, C] -> transposed weight pieces [n_mesh][K / 32][2 (C / 16) 64] uint4 (fp16 hi / lo planes scaled by the power of two of the
+// mesh's largest |ys|), ys_amax[n_mesh] receives those magnitudes
+int dn_launch_spec_pieces(const float* ys, int n_mesh, int K, int C, uint4* out, float* ys_amax, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------
 // one-launch learned-time diffusion, forward and backward (dn_diffuse.hip; K = C = 128)

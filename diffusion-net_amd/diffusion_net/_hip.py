@@ -35,6 +35,7 @@ class MeshBatchStruct(C.Structure):
         ("gt_rowptr", _vp), ("gt_col", _vp), ("gt_vx", _vp), ("gt_vy", _vp),
         ("evecs_amax", _vp), ("mass_amax", _vp), ("grad_norm", _vp),
         ("df_plan", _vp), ("df_n_wg", C.c_int32), ("df_n_groups", C.c_int32),
+        ("sg_pack", _vp), ("sg_units", _vp), ("sg_amax", _vp), ("sg_n_units", C.c_int32),
     ]
 
 
@@ -82,6 +83,11 @@ _SIGNATURES = {
     "dn_diffusion_workspace_bytes": (C.c_size_t, [_P(MeshBatchStruct), C.c_int]),
     "dn_diffusion_fwd_f32": (C.c_int, [_P(MeshBatchStruct), _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]),
     "dn_diffusion_bwd_f32": (C.c_int, [_P(MeshBatchStruct), _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "dn_spectral_grad_supported": (C.c_int, [C.c_int, C.c_int]),
+    "dn_spectral_units": (C.c_int, [_vp, C.c_int, _vp]),
+    "dn_spectral_pack_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "dn_spectral_pack_workspace_bytes": (C.c_size_t, [_P(MeshBatchStruct)]),
+    "dn_spectral_pack_f32": (C.c_int, [_P(MeshBatchStruct), _vp, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]),
     "dn_grad_apply_fwd_f32": (C.c_int, [_P(MeshBatchStruct), _vp, C.c_int, _vp, _vp, _vp]),
     "dn_grad_apply_bwd_f32": (C.c_int, [_P(MeshBatchStruct), _vp, _vp, _vp, C.c_int, _vp, _vp]),
     "dn_gradfeat_workspace_bytes": (C.c_size_t, [_P(MeshBatchStruct), C.c_int]),

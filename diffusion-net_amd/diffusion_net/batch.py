@@ -139,6 +139,28 @@ def _plan_on(device, sizes, n_groups):
     return hit
 
 
+def _sg_units_on(device, sizes):
+    """Unit table of the spectral-gradient operands (``dn_spectral_units``, host arithmetic in the library): runs of <= 64 rows of one mesh."""
+    key = ("sg_units", str(device), tuple(sizes))
+    hit = _table_cache.get(key)
+    if hit is None:
+        if len(_table_cache) > 256:
+            _table_cache.clear()
+        L = _hip.lib()
+        arr = np.ascontiguousarray(np.asarray(sizes, dtype=np.int32))
+        n = int(L.dn_spectral_units(arr.ctypes.data, len(arr), None))
+        units = np.zeros((max(n, 1), 4), dtype=np.int32)
+        L.dn_spectral_units(arr.ctypes.data, len(arr), units.ctypes.data)
+        hit = (torch.from_numpy(units[:n].copy()).to(device), n)
+        _table_cache[key] = hit
+    return hit
+
+
+# False: batches are packed without the spectral-gradient operands (3 x 4 V K bytes per mesh) and the block forward keeps the back-projection
+# launch + CSR gather (the library option "spectral_grad" = 0 selects that at run time for batches that do carry them)
+spectral_grad = True
+
+
 def _tables_on(device, sizes, chunk_rows):
     tile_rows = _hip.lib().dn_tile_rows()
     key = (str(device), tuple(sizes), tuple(chunk_rows) if isinstance(chunk_rows, (list, tuple)) else chunk_rows, tile_rows)
@@ -291,6 +313,19 @@ class MeshBatch:
             s.evecs_amax, s.mass_amax = self.amax.data_ptr(), self.amax.data_ptr() + 4
             if self.g_rowptr is not None:
                 s.grad_norm = self.amax.data_ptr() + 8
+        # spectral-gradient operands (dn_spectral.hip): [evecs | gradX evecs | gradY evecs] as pre-split operand fragments -- with them the block
+        # forward computes xd, gx, gy inside its chained row kernel.  Once per packed batch: two launches, no host synchronisation.
+        self.sg_pack = self.sg_units = self.sg_amax = None
+        L = _hip.lib()
+        if spectral_grad and self.g_rowptr is not None and self.evecs is not None and vt > 0 and s.g_nnz > 0 \
+                and L.dn_spectral_grad_supported(self.k_eig, 128):
+            self.sg_units, n_units = _sg_units_on(self.device, self.sizes)
+            self.sg_pack = torch.empty(int(L.dn_spectral_pack_bytes(n_units, self.k_eig)), dtype=torch.uint8, device=self.device)
+            self.sg_amax = torch.empty(4 * len(self.sizes), dtype=torch.float32, device=self.device)
+            ws = _hip.workspace(self.device, L.dn_spectral_pack_workspace_bytes(C.byref(s)))
+            _hip.check(L.dn_spectral_pack_f32(C.byref(s), self.sg_units.data_ptr(), n_units, self.sg_pack.data_ptr(), self.sg_amax.data_ptr(),
+                                              ws.data_ptr(), ws.numel(), _hip.stream_of(self.evecs)), "dn_spectral_pack_f32")
+            s.sg_pack, s.sg_units, s.sg_amax, s.sg_n_units = self.sg_pack.data_ptr(), self.sg_units.data_ptr(), self.sg_amax.data_ptr(), n_units
         self._struct = s
 
     # ------------------------------------------------------------------ accessors

@@ -65,6 +65,13 @@ typedef struct dn_mesh_batch {
     /* Optional (round 5): the work plan of the one-launch diffusion operator (dn_diffusion_plan()): device array of df_n_groups * df_n_wg
      * entries.  NULL / 0: the diffusion runs as three launches (projection, spectral step, back-projection). */
     const dn_tile_t* df_plan; int32_t df_n_wg, df_n_groups;
+    /* Optional (round 6): the spectral-gradient operands of the batch (dn_spectral_pack_f32): the spatial gradient apply re-associated
+     * through the eigenbasis, gradX (evecs ys) = (gradX evecs) ys.  sg_pack: [evecs | gradX evecs | gradY evecs] as fp16 (hi, lo) operand
+     * fragments, 16 rows per group, every mesh padded to whole 64-row units; sg_units: [sg_n_units] the units ({row0, nrows <= 64, mesh, 0},
+     * dn_spectral_units()); sg_amax: [n_mesh][4] floats, the per-mesh magnitudes the fragments were scaled by.  With them the block forward
+     * computes xd, gx, gy inside its chained row kernel (no back-projection launch, no CSR gather) for the shapes
+     * dn_spectral_grad_supported() names.  NULL / 0: back-projection + gather, as before. */
+    const void* sg_pack; const dn_tile_t* sg_units; const float* sg_amax; int32_t sg_n_units;
 } dn_mesh_batch_t;
 
 /* Weights of one DiffusionNetBlock (layers.py:167-198), nn.Linear layout: W[out][in]. */
@@ -115,7 +122,7 @@ typedef struct dn_block_grads {
     float* d_x_amax;                   /* optional: device float that receives max |d_x| */
 } dn_block_grads_t;
 
-int dn_version(void);         /* 500: round-5 layout (dn_mesh_batch_t.df_plan ..., dn_set_option) */
+int dn_version(void);         /* 600: round-6 layout (dn_mesh_batch_t.sg_pack ...); 500: round 5 (dn_mesh_batch_t.df_plan ..., dn_set_option) */
 int dn_tile_rows(void);      /* rows per entry of dn_mesh_batch_t.tiles (128) */
 int dn_tn_target_chunks(void);  /* how many entries dn_mesh_batch_t.chunks should have on the current device for the split-V products to fill it in
                                    whole rounds: one workgroup slot per CU (wave-specialised kernel).  Any chunk list is CORRECT; this one is fastest. */
@@ -137,7 +144,9 @@ int dn_tn_target_chunks(void);  /* how many entries dn_mesh_batch_t.chunks shoul
  *        "diffuse_groups" (1)   mesh groups dn_diffusion_plan() deals the batch into when asked for 0 (the direct back-projection needs 1)
  *        "diffuse_order" (0)    schedule of the one-launch operator (0: interleaved groups, 1: projections first)
  *        "diffuse_flags" (1)    one-launch kernel: bit 0 = arrivals posted from inside the next projection loop; bits 1, 2 = tests (forced solo path)
- *        "diffuse_split" (0)    one-launch kernel: bit i = a kernel boundary after schedule step i (measurements) */
+ *        "diffuse_split" (0)    one-launch kernel: bit i = a kernel boundary after schedule step i (measurements)
+ *        "spectral_grad" (1)    batches that carry spectral-gradient operands (dn_spectral_pack_f32): 1 = the chained forward kernel computes
+ *                               xd, gx, gy from them (no back-projection launch, no CSR gather); 0 = back-projection + gather */
 int dn_set_option(const char* name, int value);
 int dn_get_option(const char* name, int* value);
 
@@ -175,6 +184,21 @@ int dn_diffusion_fwd_f32(const dn_mesh_batch_t* mb, const float* x, const float*
                          float* xs, float* xd, void* ws, size_t ws_bytes, void* stream);
 int dn_diffusion_bwd_f32(const dn_mesh_batch_t* mb, const float* d_xd, const float* xs, const float* time, int C,
                          const float* d_x_add, float* d_x, float* d_time, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- spectral-gradient operands (dn_spectral.hip; no reference counterpart: layers.py:213-223 applies gradX / gradY to x_diffuse = evecs ys,
+ *      which lies in the span of evecs -- gradX x_diffuse = (gradX evecs) ys exactly).  Built ONCE per mesh batch:
+ *      dn_spectral_grad_supported(k_eig, C): 1 if the block forward takes the operands at this shape (k_eig = 128, C in {64, 128}).
+ *      dn_spectral_units(): HOST arithmetic -- sizes[n_mesh] = vertices per mesh in row order -> units[] (NULL: count only); returns the count.
+ *      dn_spectral_pack_bytes(n_units, k_eig): bytes of the packed operand.  dn_spectral_pack_workspace_bytes(): scratch of the pack call.
+ *      dn_spectral_pack_f32(): mb needs evecs, the gradient CSR and k_eig % 32 == 0; units = DEVICE copy of the unit table; writes
+ *      sg_pack[dn_spectral_pack_bytes] and sg_amax[4 n_mesh]; gradX evecs / gradY evecs are accumulated in fp64 in entry order (deterministic).
+ *      The caller then sets mb->sg_pack / sg_units / sg_amax / sg_n_units. */
+int dn_spectral_grad_supported(int k_eig, int C);
+int dn_spectral_units(const int32_t* sizes, int n_mesh, dn_tile_t* units);
+size_t dn_spectral_pack_bytes(int n_units, int k_eig);
+size_t dn_spectral_pack_workspace_bytes(const dn_mesh_batch_t* mb);
+int dn_spectral_pack_f32(const dn_mesh_batch_t* mb, const dn_tile_t* units, int n_units, void* sg_pack, float* sg_amax,
+                         void* ws, size_t ws_bytes, void* stream);
 
 /* ---- spatial gradient apply, layers.py:217-223 (gx = gradX x, gy = gradY x) and its transpose
  *      d_x = add + gradX^T d_gx + gradY^T d_gy (add may be NULL). */

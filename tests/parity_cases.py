@@ -158,6 +158,75 @@ def run_chain_vs_unfused(device, sizes=(300, 140), K=128, C=128, N_block=2, drop
 
 
 # ------------------------------------------------------------------------------------------
+# spectral-gradient form of the chained forward (dn_spectral.hip, chain_fwd_kernel<.., KE>) vs the back-projection + gather form
+# ------------------------------------------------------------------------------------------
+def run_spectral_grad(device, sizes=(300, 140, 131), C=128, N_block=2, dropout=True, seed=7, chain_nw=0, fwd_tol=4e-6, grad_tol=2e-5):
+    """K = 128.  Same model, batch and dropout seed with the library option "spectral_grad" on and off: the chained forward kernel computes
+    xd = evecs ys, gx = (gradX evecs) ys, gy = (gradY evecs) ys itself from the batch's packed operands (layers.py:213-223 re-associated), or reads
+    xd from the back-projection launch and gathers gx, gy through the CSR.  Training forward + every gradient, the saved xd / gx / gy, and the
+    inference forward; the two forms differ in rounding only and must NOT be bitwise equal.  Both are also measured against the fp64 oracle: the
+    spectral form must be at least as close as max(1e-5, 2 x the gather form)."""
+    from diffusion_net import _hip
+    K = 128
+    meshes, feats = make_ragged(sizes, K, 3, seed)
+    mb = pack(meshes, device, chunk_rows=64)
+    assert mb.sg_pack is not None, "the batch carries no spectral-gradient operands"
+    got, params = {}, None
+    saved = {k: _hip.get_option(k) for k in ("spectral_grad", "chain_nw")}
+    try:
+        _hip.set_option("chain_nw", chain_nw)
+        for mode in (1, 0):
+            _hip.set_option("spectral_grad", mode)
+            torch.manual_seed(seed)
+            model = diffusion_net.layers.DiffusionNet(3, 5, C_width=C, N_block=N_block, outputs_at="vertices", dropout=dropout)
+            model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=seed))
+            params = {k: v.clone() for k, v in model.state_dict().items()}
+            model.to(device).train(dropout)
+            x = torch.cat(feats, 0).to(device).requires_grad_(True)
+            torch.manual_seed(seed + 11)
+            ops.debug_saved = []
+            try:
+                out = model.forward_packed(x, mb, None)
+                sv = {k: ops.debug_saved[0][k].cpu() for k in ("xd", "gx", "gy")}
+            finally:
+                ops.debug_saved = None
+            w = torch.randn(out.shape, generator=torch.Generator().manual_seed(seed + 1)).to(device)
+            (out * w).sum().backward()
+            model.train(False)
+            with torch.no_grad():
+                inf = model.forward_packed(x.detach(), mb, None).cpu()
+            got[mode] = (out.detach().cpu(), {"x_in": x.grad.cpu(), **{k: p.grad.cpu() for k, p in model.named_parameters()}}, sv, inf)
+    finally:
+        for k, v in saved.items():
+            _hip.set_option(k, v)
+    (o1, g1, s1, i1), (o0, g0, s0, i0) = got[1], got[0]
+    assert not torch.equal(s1["gx"], s0["gx"]) and not torch.equal(o1, o0), "spectral-gradient and gather form bitwise equal: the new kernel did not run"
+    e_sv = {k: helpers.rel_max(s1[k], s0[k]) for k in s1}
+    e_f, e_i = helpers.rel_max(o1, o0), helpers.rel_max(i1, i0)
+    e_g = {k: helpers.rel_l2(g1[k], g0[k]) for k in g1}
+    rec = dict(sizes=list(sizes), C=C, N_block=N_block, dropout=bool(dropout), chain_nw=chain_nw, saved_rel_max=e_sv, fwd_rel_max=e_f,
+               inference_rel_max=e_i, worst_gradient_rel_l2=max(e_g.values()), fwd_tol=fwd_tol, grad_tol=grad_tol)
+    if not dropout:
+        # the inference forward of both forms against the fp64 oracle (per mesh)
+        p64 = {k: v.double() for k, v in params.items()}
+        ref = []
+        for m, f in zip(meshes, feats):
+            c64 = lambda t: t.double() if t.is_floating_point() else t
+            o, _ = orc.net_forward_backward(p64, dict(x_in=c64(f), mass=c64(m["mass"]), evals=c64(m["evals"]), evecs=c64(m["evecs"]),
+                                                      gradX=c64(m["gradX"]), gradY=c64(m["gradY"]), faces=m["faces"]),
+                                            outputs_at="vertices", loss_weights=torch.ones(f.shape[0], 5, dtype=torch.float64))
+            ref.append(o)
+        ref = torch.cat(ref, 0)
+        rec["inference_vs_fp64_spectral"], rec["inference_vs_fp64_gather"] = helpers.rel_max(i1.double(), ref), helpers.rel_max(i0.double(), ref)
+        assert rec["inference_vs_fp64_spectral"] < max(FWD_TOL, 2 * rec["inference_vs_fp64_gather"]), rec
+    helpers.record_margin("spectral_grad_vs_gather", device, **rec)
+    assert max(e_sv.values()) < fwd_tol and e_f < fwd_tol and e_i < fwd_tol, rec
+    bad = {k: v for k, v in e_g.items() if not v < grad_tol}
+    assert not bad, ("spectral-gradient vs gather gradients", bad)
+    return rec
+
+
+# ------------------------------------------------------------------------------------------
 # one-launch diffusion operator (dn_diffuse.hip) vs the oracle and vs the three-launch form
 # ------------------------------------------------------------------------------------------
 def run_diffuse_fused(device, sizes=(300, 140, 210), seed=3, configs=((1, 0, 1), (3, 0, 1), (2, 1, 0), (3, 0, 7)), reps=2,

@@ -85,6 +85,16 @@ def test_chain_probes_against_the_oracle_on_emulator(emu):
         _hip.set_option("chain_hh", old)
 
 
+def test_spectral_gradient_form_on_emulator(emu):
+    """chain_fwd_kernel<C, NW, 1, 4> (xd, gx, gy from the packed spectral operands) vs the back-projection + gather form and vs the fp64 oracle: ragged
+    meshes whose sizes are not multiples of the 64-row unit, every workgroup width (sub-units of a unit), with and without dropout, C = 128 and 64."""
+    import parity_cases
+    parity_cases.run_spectral_grad(emu, sizes=(300, 140, 131), dropout=True)
+    parity_cases.run_spectral_grad(emu, sizes=(150, 193), N_block=1, dropout=False, chain_nw=2)
+    parity_cases.run_spectral_grad(emu, sizes=(200, 129), N_block=1, dropout=False, chain_nw=1)
+    parity_cases.run_spectral_grad(emu, sizes=(150, 170), C=64, N_block=1, dropout=False)
+
+
 def test_mismatched_patterns_on_emulator(emu):
     import parity_cases
     parity_cases.run_mismatched_patterns(emu)
