@@ -664,7 +664,8 @@ static bool block_chain_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p
 // The spectral-gradient form of the chained forward (dn_spectral.hip, dn_chain.hip KE > 0): batches that carry the packed operands, shapes the
 // kernel is instantiated for, one 16-row half per wave (the forward's form up to 262144 rows); not with the one-launch diffusion operator.
 static bool block_sg_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int kind) {
-    return opt(O_SPECTRAL_GRAD) && kind < 2 && mb->sg_pack && mb->sg_units && mb->sg_amax && mb->sg_n_units > 0 && al16(mb->sg_pack) &&
+    return opt(O_SPECTRAL_GRAD) && kind < 2 && mb->sg_pack && mb->sg_units && mb->sg_amax && mb->sg_n_units > 0 && al16(mb->sg_pack) && al16(mb->sg_amax) &&
+           mb->sg_n_units <= 100 * dn_num_cus() &&      // (a workgroup's pass table lives in LDS: DN_CH_SG_MAXP = 64 passes of 2 x CUs workgroups)
            block_chain_ok(mb, p, kind) && dn_chain_sg_eligible(p->C, mb->k_eig, p->with_grad, chain_hh(mb, false, p->C)) && !diffuse_ok(mb, p->C);
 }
 static size_t sg_piece_floats(const dn_mesh_batch_t* mb, int C) { return (size_t)mb->n_mesh * (mb->k_eig / 32) * (2 * (C / 16) * 64) * 4; }

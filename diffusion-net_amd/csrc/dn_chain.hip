@@ -48,6 +48,15 @@
 #define DN_CH_ROLL 1     // rolling row requests in the row-contiguous gather: 1 = in the C = 256 form (latency-bound there: one wave per SIMD), 2 = everywhere
                          // (C = 128: 28 spilled registers in the benchmark's kernel), 0 = all rows of a step requested, then all summed
 #endif
+#ifndef DN_CH_SG_PF
+#define DN_CH_SG_PF 0    // contraction steps of the spectral stage whose operand fragments are requested a pass ahead (24 registers each: 1 / 2 / 3 / 4 steps carried cost 10 / 42 / 101 / 140 spilled registers at C = 128 wherever they are requested)
+#endif
+#ifndef DN_CH_SG_PFPOINT
+#define DN_CH_SG_PFPOINT 1
+#endif
+#ifndef DN_CH_SG_MAXP
+#define DN_CH_SG_MAXP 64 // passes per workgroup of the spectral-gradient form (their descriptors live in LDS; the launcher checks)
+#endif
 #ifndef DN_CH_RCG
 #define DN_CH_RCG 1      // row-contiguous gather in the one-half-per-wave form of the chained forward (0: operand-layout gather everywhere; A/B)
 #endif
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
     constexpr int CH_PF = G0 ? DN_CH_PF_WIDE : 1;      // weight-fragment prefetch distance in tile pairs (one wave per SIMD: nobody else covers the LDS latency)
     static_assert(PIECE % NTHR == 0, "piece staging");
     static_assert(RING >= 2 && RING <= 8 && (RING - 1) * LPT < 60 && (RING - 2) * LPT + 6 * HH < 64, "ring depth vs the vmcnt range");
-    static_assert(!SG || (RING - 2) * LPT + 6 * (KE - 1) < 64, "operand-fragment requests of the spectral stage vs the vmcnt range");
+    static_assert(!SG || (RING - 2) * LPT + 6 * KE < 64, "operand-fragment requests of the spectral stage vs the vmcnt range");
 
     DN_DYN_SMEM(smem_raw);
     uint4* ring = reinterpret_cast<uint4*>(smem_raw);                      // RING slots of PIECE uint4
@@ -168,6 +177,11 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
     constexpr int GCR = G0 ? DN_CH_GCR_WIDE : DN_CH_GCR;        // pattern entries per gather step of the row-contiguous form (NI x GCR KiB in flight per wave)
     static_assert(SROWS % RPI == 0 && 16 % SROWS == 0, "gather slices");
     float4* slice = reinterpret_cast<float4*>(sbias + (G0 ? 0 : DN_CH_LAYERS * C)) + (threadIdx.x >> 6) * (SROWS * LPR);   // wave-private, SROWS rows (RCG)
+    // SG: the workgroup's passes -- {first row, end of the mesh's rows, mesh, first 16-row group} and the three result scales -- staged once in the
+    // space of the gather slices: a per-pass descriptor read from memory compiles to a vector load behind an s_waitcnt vmcnt(0), which drains
+    // the piece ring and the operand requests in flight (seen as 8-16 k cycles at the top of every pass)
+    int4* pinfo = reinterpret_cast<int4*>(sbias + DN_CH_LAYERS * C);                     // [DN_CH_SG_MAXP]
+    float4* pscale = reinterpret_cast<float4*>(pinfo + DN_CH_SG_MAXP);                   // [DN_CH_SG_MAXP]
 #ifdef DN_EMULATE
     const unsigned lds0 = 0;
 #else
@@ -228,9 +242,21 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
     int sq = 0;                           // position the NEXT request fetches
     constexpr int SUB = SG ? 4 / NW : 1;  // workgroup passes per 64-row unit
     auto unit_of = [&](int pass_) { return xcd * per_x + slot0 + pass_ * GX; };
-    DnTile tl_nx = DnTile{0, 0, 0, 0};    // SG: the unit of the NEXT pass (loaded a pass ahead of its use)
-    int imesh = 0;
-    if constexpr (SG) { tl_nx = a.sg_units[unit_of(0) / SUB]; imesh = tl_nx.mesh; }
+    int imesh = 0, mesh_nx = 0;           // SG: mesh of the pass whose pieces are being requested / of the pass after the one being multiplied
+    if constexpr (SG) {
+        for (int pp = tid; pp < npass; pp += NTHR) {
+            const int un = unit_of(pp);
+            const DnTile tl = a.sg_units[un / SUB];
+            const int sub = un % SUB;
+            pinfo[pp] = int4{tl.row0 + 16 * NW * sub, tl.row0 + tl.nrows, tl.mesh, 4 * (un / SUB) + NW * sub};
+            const float4 am = *reinterpret_cast<const float4*>(a.sg_amax + 4 * tl.mesh);
+            const float ys_inv = ch_pow2_inv(dn_pow2_scale(a.ys_amax[tl.mesh]));
+            pscale[pp] = make_float4(ys_inv * ch_pow2_inv(dn_pow2_scale(am.x)), ys_inv * ch_pow2_inv(dn_pow2_scale(am.y)),
+                                     ys_inv * ch_pow2_inv(dn_pow2_scale(am.z)), 0.f);
+        }
+        imesh = ch_uniform_i(a.sg_units[unit_of(0) / SUB].mesh);      // (pass 0's pieces are requested before the table is published)
+        mesh_nx = imesh;
+    }
 #ifdef DN_EMULATE
     const int wave_u = wave;
 #else
@@ -250,7 +276,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
             const int e0 = rq * PIECE + i * NTHR + wave_u * 64;
             ch_dma16(src_piece + i * NTHR + tid, ring + e0, lds0 + 16u * (unsigned)e0);
         }
-        if (sq + 1 == n_seq) { sq = 0; if constexpr (SG) imesh = tl_nx.mesh; }      // (tl_nx: the unit after the one being multiplied, or the last one again)
+        if (sq + 1 == n_seq) { sq = 0; if constexpr (SG) imesh = mesh_nx; }      // (mesh_nx: of the pass after the one being multiplied, or the last one again)
         else ++sq;
         rq = rq + 1 == RING ? 0 : rq + 1;
     };
@@ -279,24 +305,47 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
 #pragma unroll
     for (int j = 0; j < DN_CH_LAYERS; ++j) hmax[j] = 0.f;
     float omax = 0.f;
+    // SG: the operand fragments of a pass -- [Phi | G_X Phi | G_Y Phi] of this wave's 16 rows, pre-split fp16 (hi, lo), this lane's eight
+    // contraction slots of step T as one uint4 per plane (every request of the wave is 1 KiB contiguous) -- are requested a pass AHEAD, inside
+    // the previous pass's layer 0, and carried in registers to the top of their pass
+    [[maybe_unused]] uint4 fr[SG ? KE : 1][3][2];
+    // (all KE steps carried across the pass cost 140 spilled registers -- the fragments went to scratch as they arrived; the first PFK steps are
+    // carried, the rest are requested at the top of their pass and arrive under the first steps' products)
+    constexpr int PFK = SG ? (DN_CH_SG_PF < KE ? DN_CH_SG_PF : KE) : 0;
+    auto load_frags = [&](const int grp, const int t0, const int t1) {
+        if constexpr (SG) {
+            const uint4* fp = a.sg_pack + (size_t)grp * (3 * KE * 128) + lane;
+#pragma unroll
+            for (int T = 0; T < KE; ++T)
+#pragma unroll
+                for (int op = 0; op < 3; ++op)
+                    if (T >= t0 && T < t1) {
+                        fr[T][op][0] = fp[(size_t)(op * KE + T) * 128];
+                        fr[T][op][1] = fp[(size_t)(op * KE + T) * 128 + 64];
+                    }
+        }
+    };
+    if constexpr (SG) load_frags(ch_uniform_i(pinfo[0].w) + wave, 0, PFK);
 
     for (int pass = 0; pass < npass; ++pass) {
         CH_TR();
         const int unit = unit_of(pass);
         int rb = unit * (16 * HH * NW) + 16 * HH * wave;     // first of this wave's 32 rows (row * C fits 32 bits for every batch the library takes)
         int row_end = a.V;
-        [[maybe_unused]] int sg_mesh = 0;
-        [[maybe_unused]] long long sg_group = 0;
+        [[maybe_unused]] float u_xd = 1.f, u_gx = 1.f, u_gy = 1.f;
+        [[maybe_unused]] int grp_nx = 0, grp_cur = 0;
         if constexpr (SG) {
-            // this pass's 64-row unit (rows of one mesh; past the mesh's end the packed operands hold zeros) and the next pass's, whose mesh the
-            // piece requests that run ahead need
-            const DnTile tl = tl_nx;
-            if (pass + 1 < npass) tl_nx = a.sg_units[unit_of(pass + 1) / SUB];
-            const int sub = unit % SUB;
-            rb = tl.row0 + 16 * (NW * sub + wave);
-            row_end = tl.row0 + tl.nrows;
-            sg_mesh = tl.mesh;
-            sg_group = 4LL * (unit / SUB) + NW * sub + wave;
+            // this pass's rows (of one mesh; past the mesh's end the packed operands hold zeros) and the next pass's mesh and group, which the piece
+            // requests and the operand requests that run ahead need
+            const int4 pi_ = pinfo[pass];
+            const float4 ps_ = pscale[pass];
+            const int4 pn_ = pinfo[pass + 1 < npass ? pass + 1 : pass];
+            rb = ch_uniform_i(pi_.x) + 16 * wave;
+            row_end = ch_uniform_i(pi_.y);
+            mesh_nx = ch_uniform_i(pn_.z);
+            grp_nx = ch_uniform_i(pn_.w) + wave;
+            grp_cur = ch_uniform_i(pi_.w) + wave;
+            u_xd = ch_uniform(ps_.x); u_gx = ch_uniform(ps_.y); u_gy = ch_uniform(ps_.z);
         }
         int rowh[HH]; bool liveh[HH]; int rch[HH];
         int begh[HH], endh[HH];
@@ -351,20 +400,9 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
                     // ---- [xd | gx | gy] = [Phi | G_X Phi | G_Y Phi][16 rows] ys[mesh]: the operand fragments arrive pre-split (fp16 hi / lo, this
                     // lane's eight contraction slots of step T as one uint4 per plane: every request of the wave is 1 KiB contiguous), all of a pass's
                     // requested up front; the spectrum's pieces come through the ring.  One piece read from LDS feeds all three products.
-                    const uint4* fp = a.sg_pack + (size_t)sg_group * (3 * KE * 128) + lane;
-                    uint4 fr[KE][3][2];
-#pragma unroll
-                    for (int T = 0; T < KE; ++T)
-#pragma unroll
-                        for (int op = 0; op < 3; ++op) {
-                            fr[T][op][0] = fp[(size_t)(op * KE + T) * 128];
-                            fr[T][op][1] = fp[(size_t)(op * KE + T) * 128 + 64];
-                        }
-                    const float* am = a.sg_amax + 4 * sg_mesh;
-                    const float ys_inv = ch_pow2_inv(dn_pow2_scale(a.ys_amax[sg_mesh]));
-                    const float u_xd = ch_uniform(ys_inv * ch_pow2_inv(dn_pow2_scale(am[0])));
-                    const float u_gx = ch_uniform(ys_inv * ch_pow2_inv(dn_pow2_scale(am[1])));
-                    const float u_gy = ch_uniform(ys_inv * ch_pow2_inv(dn_pow2_scale(am[2])));
+                    // (fr: steps 0 .. PFK - 1 requested a pass ahead, in front of the previous pass's hidden layers -- before the loop for the first pass)
+                    load_frags(grp_cur, PFK, KE);
+                    CH_TR();
                     dn_f32x4 sa[3][NT];
 #pragma unroll
                     for (int op = 0; op < 3; ++op)
@@ -374,15 +412,9 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
                     for (int T = 0; T < KE; ++T) {
                         CH_PIECE_BEGIN();
                         CH_MMA3(sa, fr[T]);
-                        // the piece waited for is older than every fragment request: the ones still in flight (and the ring's two youngest pieces) may stay
-                        // (loads only are counted -- requests younger than the piece waited for, DMA(gp + 1), which went out RING - 2 pieces ago: the
-                        // fragment requests of this pass are younger than it during the first RING - 2 pieces only)
-                        if (T == 0 && RING > 2) CH_WAIT_OPS((RING - 2) * LPT + 6 * (KE - 1));
-                        else if (T == 1 && RING > 3) CH_WAIT_OPS((RING - 2) * LPT + 6 * (KE > 1 ? KE - 2 : 0));
-                        else CH_WAIT_OPS((RING - 2) * LPT);
-                        CH_BARRIER();
-                        ++gp;
+                        CH_PIECE_END();
                     }
+                    CH_TR();
                     float wx = 0.f, wg = 0.f;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
@@ -758,6 +790,10 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
         CH_TR();
         // =================================================== hidden layers: h_j = dropout(relu(acc + b_j)) -> operand fragments -> next product
         //      (layers.py:143-160: the dropout in front of linear layer j + 1 is applied where h_j is produced)
+        // SG: the next pass's operand fragments go out here -- layer 0's operands are dead, the hidden layers hold two 32-register sets -- and
+        // have the rest of the pass to arrive (requested inside layer 0 they cost 140 spilled registers)
+        const bool pf = SG && pass + 1 < npass;
+        if constexpr (SG && DN_CH_SG_PFPOINT == 0) { if (pf) load_frags(grp_nx, 0, PFK); }
         float s_act = s_in;               // scale the operand of the product just finished was split with
         uint4 hfh[HH][NK], hfl[HH][NK];     // hidden activations as operand fragments
 #pragma unroll 1
@@ -870,12 +906,17 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
             for (int T = 0; T < NK; ++T) {
                 CH_PIECE_BEGIN();
                 CH_MMA2(acc, hfh[0][T], hfl[0][T], hfh[HH - 1][T], hfl[HH - 1][T]);
-                CH_PIECE_END();
+                // (SG: the 6 KE fragment requests issued in front of this loop are younger than the piece waited for -- DMA(gp + 1), out RING - 2
+                // pieces ago -- during its first RING - 2 pieces: they may stay in flight; loads only are counted)
+                if (SG && DN_CH_SG_PFPOINT == 0 && T < RING - 2 && j == 0 && pf) { CH_WAIT_OPS((RING - 2) * LPT + 6 * PFK); CH_BARRIER(); ++gp; }
+                else CH_PIECE_END();
             }
             CH_TR();
         }
         // =================================================== last layer: out = acc + b + x   (layers.py:236-239)
         {
+            // SG, DN_CH_SG_PFPOINT = 1: the next pass's operand fragments go out in front of the last epilogue (the hidden fragments are dead)
+            if constexpr (SG && DN_CH_SG_PFPOINT == 1) { if (pf) load_frags(grp_nx, 0, PFK); }
             const int jl = a.n_mlp - 1;
             const float so = ch_pow2_inv(s_act) * (jl == 1 ? sw_inv[1] : (jl == 2 ? sw_inv[2] : sw_inv[3]));
             const float* bj = G0 ? (jl == 1 ? a.bias[1] : (jl == 2 ? a.bias[2] : a.bias[3])) + 4 * q : sbias + jl * C + 4 * q;
@@ -999,7 +1040,8 @@ static int chain_launch_nw(ChainArgs a, hipStream_t stream) {
     g = (g + 7) / 8 * 8;
     const size_t smem = C >= 256 ? (size_t)DN_CH_RING * (2 * (C / 16) * 64) * sizeof(uint4) + (size_t)NW * 16 * 128 * sizeof(float)    // piece ring + one 16-row, 128-channel slice per wave
                                  : (size_t)DN_CH_RING * (2 * (C / 16) * 64) * sizeof(uint4) + (size_t)DN_CH_LAYERS * C * sizeof(float) +
-                                       (size_t)NW * 4 * C * sizeof(float);      // piece ring + biases + one 4-row gather slice per wave
+                                       (KE > 0 ? (size_t)DN_CH_SG_MAXP * 32 : (size_t)NW * 4 * C * sizeof(float));      // piece ring + biases + one 4-row gather slice per wave (KE > 0: the pass table)
+    if (KE > 0 && ((a.units + 7) / 8 + g / 8 - 1) / (g / 8) > DN_CH_SG_MAXP) return 1;      // (never for a batch the dispatch sends here: <= 262144 rows on >= 8 workgroups)
 #ifndef DN_EMULATE
     static unsigned long long lds_opt_in = 0;   // per-device bitmap
     { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&chain_fwd_kernel<C, NW, HH, KE>), smem, &lds_opt_in); if (oe_) return oe_; }

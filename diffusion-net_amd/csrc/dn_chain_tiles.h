@@ -74,6 +74,13 @@ __device__ __forceinline__ float ch_uniform(float v) {
     return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v)));
 #endif
 }
+__device__ __forceinline__ int ch_uniform_i(int v) {
+#ifdef DN_EMULATE
+    return v;
+#else
+    return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
 // Streaming global accesses of the chained kernels (dn_common.h): every activation tile is written exactly once per launch and consumed by
 // a LATER kernel; the single-use tiles of the backward are read the same way.  Build with -DDN_CH_STREAM=0 for plain accesses (A/B).
 #ifndef DN_CH_STREAM

@@ -188,6 +188,7 @@ def run_spectral_grad(device, sizes=(300, 140, 131), C=128, N_block=2, dropout=T
             try:
                 out = model.forward_packed(x, mb, None)
                 sv = {k: ops.debug_saved[0][k].cpu() for k in ("xd", "gx", "gy")}
+                pats = [[h.cpu() > 0 for h in rec_["h"]] for rec_ in ops.debug_saved]
             finally:
                 ops.debug_saved = None
             w = torch.randn(out.shape, generator=torch.Generator().manual_seed(seed + 1)).to(device)
@@ -195,17 +196,26 @@ def run_spectral_grad(device, sizes=(300, 140, 131), C=128, N_block=2, dropout=T
             model.train(False)
             with torch.no_grad():
                 inf = model.forward_packed(x.detach(), mb, None).cpu()
-            got[mode] = (out.detach().cpu(), {"x_in": x.grad.cpu(), **{k: p.grad.cpu() for k, p in model.named_parameters()}}, sv, inf)
+            got[mode] = (out.detach().cpu(), {"x_in": x.grad.cpu(), **{k: p.grad.cpu() for k, p in model.named_parameters()}}, sv, inf, pats)
     finally:
         for k, v in saved.items():
             _hip.set_option(k, v)
-    (o1, g1, s1, i1), (o0, g0, s0, i0) = got[1], got[0]
+    (o1, g1, s1, i1, p1), (o0, g0, s0, i0, p0) = got[1], got[0]
+    # A ReLU net is piecewise linear: a hidden unit within rounding distance of zero lands on either side in the two forms, and ONE flipped
+    # (vertex, unit) pair moves the parameter gradients of its own and of every earlier block by ~1e-3 (run_ragged_net's flip-aware criterion).
+    # The gradients are therefore compared strictly from the first block BEHIND the last flip on; the flips must be rare.
+    flips = [sum(int((a != b).sum()) for a, b in zip(ba, bb)) for ba, bb in zip(p1, p0)]
+    n_units = sum(a.numel() for ba in p1 for a in ba)
+    last_flip = max([i for i, f in enumerate(flips) if f] or [-1])
+    assert sum(flips) <= max(2, n_units // 100000), ("hidden units on different sides of zero in the two forms", flips, n_units)
+    strict = lambda k: k.startswith("last_lin") or (k.startswith("block_") and int(k.split(".")[0][6:]) > last_flip) or last_flip < 0
     assert not torch.equal(s1["gx"], s0["gx"]) and not torch.equal(o1, o0), "spectral-gradient and gather form bitwise equal: the new kernel did not run"
     e_sv = {k: helpers.rel_max(s1[k], s0[k]) for k in s1}
     e_f, e_i = helpers.rel_max(o1, o0), helpers.rel_max(i1, i0)
-    e_g = {k: helpers.rel_l2(g1[k], g0[k]) for k in g1}
+    e_g = {k: helpers.rel_l2(g1[k], g0[k]) for k in g1 if strict(k)}
     rec = dict(sizes=list(sizes), C=C, N_block=N_block, dropout=bool(dropout), chain_nw=chain_nw, saved_rel_max=e_sv, fwd_rel_max=e_f,
-               inference_rel_max=e_i, worst_gradient_rel_l2=max(e_g.values()), fwd_tol=fwd_tol, grad_tol=grad_tol)
+               inference_rel_max=e_i, worst_gradient_rel_l2=max(e_g.values()), fwd_tol=fwd_tol, grad_tol=grad_tol,
+               flipped_hidden_units_per_block=flips, hidden_units=n_units, gradients_compared=len(e_g))
     if not dropout:
         # the inference forward of both forms against the fp64 oracle (per mesh)
         p64 = {k: v.double() for k, v in params.items()}

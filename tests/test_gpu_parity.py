@@ -169,6 +169,19 @@ def test_chained_forward_kernel_vs_unfused(dev, kw):
             _hip.set_option("chain_hh", old)
 
 
+def test_spectral_gradient_form_vs_gather(dev):
+    """chain_fwd_kernel<C, NW, 1, 4> (xd, gx, gy computed in the kernel from the packed spectral operands of the batch, dn_spectral.hip) against the
+    back-projection + CSR-gather form and the fp64 oracle: ragged batches off the 64-row unit grid, every workgroup width, dropout, C = 128 / 64,
+    and a batch of many passes per workgroup (40k rows)."""
+    import parity_cases
+    parity_cases.run_spectral_grad(dev, sizes=(300, 140, 131), dropout=True)
+    parity_cases.run_spectral_grad(dev, sizes=(1500, 700, 129), N_block=2, dropout=False)
+    parity_cases.run_spectral_grad(dev, sizes=(150, 193), N_block=1, dropout=False, chain_nw=2)
+    parity_cases.run_spectral_grad(dev, sizes=(200, 129), N_block=1, dropout=False, chain_nw=1)
+    parity_cases.run_spectral_grad(dev, sizes=(900, 170), C=64, N_block=2, dropout=False)
+    parity_cases.run_spectral_grad(dev, sizes=(20500, 19999), N_block=1, dropout=True)
+
+
 def test_mismatched_patterns(dev):
     import parity_cases
     parity_cases.run_mismatched_patterns(dev)

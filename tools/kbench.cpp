@@ -164,6 +164,26 @@ int main(int argc, char** argv) {
         if (!getenv("KB_NO_AMAX")) { mb.evecs_amax = d; mb.mass_amax = d + 1; mb.grad_norm = d + 2; }
     }
 
+    int sg_units_n = 0;
+    if (!getenv("KB_NO_SG") && L.sym<int (*)(int, int)>("dn_spectral_grad_supported")(K, C)) {
+        // spectral-gradient operands, as diffusion_net.batch.MeshBatch attaches them (dn_spectral.hip): built once, on the device
+        auto f_units = L.sym<int (*)(const int32_t*, int, dn_tile_t*)>("dn_spectral_units");
+        sg_units_n = f_units(sizes.data(), n_mesh, nullptr);
+        std::vector<dn_tile_t> units(sg_units_n);
+        f_units(sizes.data(), n_mesh, units.data());
+        const dn_tile_t* d_units = dev(units);
+        void* pack; HC(hipMalloc(&pack, L.sym<size_t (*)(int, int)>("dn_spectral_pack_bytes")(sg_units_n, K)));
+        float* sgam = devz((size_t)4 * n_mesh);
+        const size_t pws = L.sym<size_t (*)(const dn_mesh_batch_t*)>("dn_spectral_pack_workspace_bytes")(&mb);
+        void* pw; HC(hipMalloc(&pw, pws));
+        const int e = L.sym<int (*)(const dn_mesh_batch_t*, const dn_tile_t*, int, void*, float*, void*, size_t, void*)>("dn_spectral_pack_f32")(
+            &mb, d_units, sg_units_n, pack, sgam, pw, pws, nullptr);
+        if (e) { fprintf(stderr, "dn_spectral_pack_f32 -> %d\n", e); return 5; }
+        HC(hipDeviceSynchronize());
+        HC(hipFree(pw));
+        mb.sg_pack = pack; mb.sg_units = d_units; mb.sg_amax = sgam; mb.sg_n_units = sg_units_n;
+    }
+
     auto randv = [&](size_t n, float sc) { std::vector<float> v(n); for (auto& x : v) x = sc * Nrm(rng); return v; };
     std::vector<float> hx = randv((size_t)V * C, 1.f), hy = randv((size_t)V * C, 1.f), hW = randv((size_t)C * C, 1.f / sqrtf((float)C)),
                        hW2 = randv((size_t)C * C, 1.f / sqrtf((float)C)), hW3 = randv((size_t)3 * C * C, 1.f / sqrtf(3.f * C)), hb = randv(C, 0.1f),
@@ -210,7 +230,7 @@ int main(int argc, char** argv) {
     void* ws; HC(hipMalloc(&ws, wsb));
     hipStream_t st; HC(hipStreamCreate(&st));
     hipEvent_t e0, e1; HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
-    printf("# lib=%s V=%lld meshes=%d K=%d C=%d tiles=%d chunks=%d (rows %d) nnz=%lld ws=%.0f MB diffusion-plan groups=%d wgs=%d\n", libpath.c_str(), V, n_mesh, K, C, mb.n_tiles, mb.n_chunks, chunk_rows, nnz, wsb / 1e6, df_used, mb.df_n_wg);
+    printf("# lib=%s V=%lld meshes=%d K=%d C=%d tiles=%d chunks=%d (rows %d) nnz=%lld ws=%.0f MB diffusion-plan groups=%d wgs=%d spectral-gradient units=%d\n", libpath.c_str(), V, n_mesh, K, C, mb.n_tiles, mb.n_chunks, chunk_rows, nnz, wsb / 1e6, df_used, mb.df_n_wg, sg_units_n);
     auto df_wg_times = [&]() {   // -DDN_DF_TRACE builds: when did every workgroup of the last backproject_kernel start / end (10 ns ticks, chip-wide clock)
         auto rd = (int (*)(unsigned long long*, int))dlsym(L.h, "dn_debug_df_wg_times_read");
         if (!rd) return;
