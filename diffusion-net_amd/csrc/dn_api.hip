@@ -663,8 +663,17 @@ static bool block_chain_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p
 }
 // The spectral-gradient form of the chained forward (dn_spectral.hip, dn_chain.hip KE > 0): batches that carry the packed operands, shapes the
 // kernel is instantiated for, one 16-row half per wave (the forward's form up to 262144 rows); not with the one-launch diffusion operator.
+// Option "spectral_grad": 1 (default) = the inference forward at every size, the training forward up to 65536 rows; 2 = both at every size; 0 = never.
+// Measured (tools/kbench block_inf / block_fwd, us, spectral / gather form, same box; profiles/r06_sg_sweep.txt):
+//     vertices      7k          20k         40k         80k         160k        240k       64 x 2k
+//     inference   58.9/65.3   75.2/82.4   103/117     169/185     323/334     448/476     274/276
+//     training    60.8/66.7   88.5/92.3   122/132     212/203     389/390     545/581     326/317
+// The inference forward gains at every size (no back-projection launch, no xd round trip); the training forward also writes xd, gx, gy from the
+// kernel (13 instead of 10 arrays of [V, C] through it) and is level with back-projection + gather from ~80k rows on (bench.py headline, two
+// runs each on one box: 30.82 / 30.85 M vertices/s against 31.02 / 31.02).
 static bool block_sg_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int kind) {
-    return opt(O_SPECTRAL_GRAD) && kind < 2 && mb->sg_pack && mb->sg_units && mb->sg_amax && mb->sg_n_units > 0 && al16(mb->sg_pack) && al16(mb->sg_amax) &&
+    const int o = opt(O_SPECTRAL_GRAD);
+    return o && kind < 2 && (o >= 2 || kind == 0 || mb->v_total <= 65536) && mb->sg_pack && mb->sg_units && mb->sg_amax && mb->sg_n_units > 0 && al16(mb->sg_pack) && al16(mb->sg_amax) &&
            mb->sg_n_units <= 100 * dn_num_cus() &&      // (a workgroup's pass table lives in LDS: DN_CH_SG_MAXP = 64 passes of 2 x CUs workgroups)
            block_chain_ok(mb, p, kind) && dn_chain_sg_eligible(p->C, mb->k_eig, p->with_grad, chain_hh(mb, false, p->C)) && !diffuse_ok(mb, p->C);
 }

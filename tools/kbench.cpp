@@ -443,7 +443,9 @@ int main(int argc, char** argv) {
     auto blk_f = L.sym<int (*)(const dn_mesh_batch_t*, const dn_block_params_t*, const float*, float*, const dn_block_saved_t*, void*, size_t, void*)>("dn_block_fwd_f32");
     if (want("block_inf")) { dn_block_params_t p2 = bp; p2.drop_seed = 0; timeit("block_inf", 12 * VC, 0, [&](int it) { DC(blk_f(&mb, &p2, xr[it % NROT], o0r[it % NROT], nullptr, ws, wsb, st)); }); endl_(); }
     if (want("block_fwd")) {
-        timeit("block_fwd", 20 * VC, 0, [&](int it) { DC(blk_f(&mb, &bp, xr[it % NROT], o0r[it % NROT], &sv, ws, wsb, st)); });
+        dn_block_saved_t svf = sv;
+        if (getenv("KB_NO_BRE")) { svf.bre = nullptr; svf.bim = nullptr; }     // experiment: the training forward without the Bre / Bim stores (saved-set diet)
+        timeit("block_fwd", 20 * VC, 0, [&](int it) { DC(blk_f(&mb, &bp, xr[it % NROT], o0r[it % NROT], &svf, ws, wsb, st)); });
         if (check) {   // fingerprint of the output (compare runs with DN_F16=0 / 1 / masks): mean |out| and three entries
             auto got = host(o0r[0], (size_t)V * C); double ma = 0; for (float v : got) ma += fabs(v);
             printf("  mean|out| %.9e  out[0] %.7e out[V/2] %.7e out[-1] %.7e", ma / got.size(), got[0], got[(size_t)(V / 2) * C + 5], got.back());
