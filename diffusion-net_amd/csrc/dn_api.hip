@@ -5,6 +5,7 @@
 #include "../../include/diffnet_hip.h"
 #include <string.h>
 #include <stdlib.h>
+#include <atomic>
 #define DN_MIN_TIME 1e-8f       /* layers.py:49 */
 
 static_assert(sizeof(dn_tile_t) == sizeof(DnTile), "tile layout");
@@ -12,18 +13,20 @@ static_assert(sizeof(dn_tile_t) == sizeof(DnTile), "tile layout");
 #define DN_SMALLN_BLOCKS 2048
 #define DN_CHECK(expr) do { int _e = (expr); if (_e) return _e; } while (0)
 
-// ---- tuning options (dn_set_option / dn_get_option): plain ints read at call time; nothing on the compute path writes them or reads the
-// environment.  Kernel selection for A/B measurements and for tests that must run a particular kernel.
+// ---- tuning options (dn_set_option / dn_get_option): relaxed atomic ints read at call time; nothing on the compute path writes them or reads
+// the environment.  Kernel selection for A/B measurements and for tests that must run a particular kernel.  A value must not change between a
+// *_workspace_bytes() query and the call it sizes, nor between a graph capture's warm-up and the capture (include/diffnet_hip.h); a caller that
+// needs different engines for different models in one process uses dn_block_params_t.flags, which are per call.
 enum { F16_TOB = 1, F16_FROMB = 2, F16_GF = 4, F16_MLP = 8, F16_LBI = 16, F16_GFB = 32, F16_TOB_B = 64, F16_FROMB_B = 128 };
 namespace {
-struct Opt { const char* name; int value; };
+struct Opt { const char* name; std::atomic<int> value; };
 enum { O_CHAIN, O_CHAIN_MIN_ROWS, O_CHAIN_SMALL_ROWS, O_CHAIN_NW, O_CHAIN_HH, O_F16, O_F16_MASK, O_F16_WGRAD, O_DIFFUSE, O_DIFFUSE_GROUPS, O_DIFFUSE_ORDER, O_DIFFUSE_FLAGS, O_DIFFUSE_SPLIT, O_SPECTRAL_GRAD, O_COUNT };
 Opt g_opt[O_COUNT] = {
     {"chain", 1}, {"chain_min_rows", 0}, {"chain_small_rows", 0}, {"chain_nw", 0}, {"chain_hh", 0}, {"f16", 1},
     {"f16_mask", F16_GF | F16_MLP | F16_LBI | F16_GFB | F16_FROMB_B}, {"f16_wgrad", 0},
     {"diffuse", 2}, {"diffuse_groups", 1}, {"diffuse_order", 0}, {"diffuse_flags", DN_DF_FLAG_DEFER}, {"diffuse_split", 0}, {"spectral_grad", 1},
 };
-inline int opt(int i) { return g_opt[i].value; }
+inline int opt(int i) { return g_opt[i].value.load(std::memory_order_relaxed); }
 }  // namespace
 int dn_opt_chain_nw(void) { return opt(O_CHAIN_NW); }
 
@@ -101,10 +104,14 @@ void tn_finish(TnArgs& g) {
 //                every batch but many-small-meshes ones -- kept selectable
 //   0            the wave-specialised row GEMM of rounds 1-4
 bool diffuse_ok(const dn_mesh_batch_t* mb, int C) {
-    return opt(O_DIFFUSE) == 1 && mb->df_plan && mb->df_n_wg > 0 && mb->df_n_groups > 0 && mb->df_n_groups <= DN_DF_MAX_GROUPS && mb->k_eig == 128 && C == 128;
+    return opt(O_DIFFUSE) == 1 && mb->df_plan && mb->df_n_wg > 0 && mb->df_n_groups > 0 && mb->df_n_groups <= DN_DF_MAX_GROUPS && mb->k_eig == 128 && C == 128 &&
+           mb->df_n_wg == dn_num_cus() && mb->df_v_total == mb->v_total;
 }
+// (the plan is caller data the kernels index memory with: it must have been made for this device's workgroup count and -- the stamp
+// dn_mesh_batch_t.df_v_total, set by whoever called dn_diffusion_plan() -- for this batch's row count; anything else takes the row GEMM)
+bool plan_matches(const dn_mesh_batch_t* mb) { return mb->df_n_wg == dn_num_cus() && mb->df_v_total == mb->v_total; }
 bool bp_ok(const dn_mesh_batch_t* mb, int C) {
-    return opt(O_DIFFUSE) != 0 && mb->df_plan && mb->df_n_wg > 0 && mb->df_n_groups == 1 && mb->k_eig == 128 && C == 128;
+    return opt(O_DIFFUSE) != 0 && mb->df_plan && mb->df_n_wg > 0 && mb->df_n_groups == 1 && mb->k_eig == 128 && C == 128 && plan_matches(mb);
 }
 size_t diffuse_ws_floats(const dn_mesh_batch_t* mb) { return dn_diffuse_ws_bytes(mb->df_n_wg, mb->df_n_groups, mb->n_mesh) / sizeof(float); }
 int diffuse_dt_rows(const dn_mesh_batch_t* mb) { return dn_diffuse_dt_rows(mb->df_n_wg, mb->df_n_groups); }
@@ -386,12 +393,12 @@ const char* dn_prof_kind_name(int kind) {
 
 int dn_set_option(const char* name, int value) {
     if (!name) return DN_ERR_INVALID;
-    for (int i = 0; i < O_COUNT; ++i) if (strcmp(name, g_opt[i].name) == 0) { g_opt[i].value = value; return 0; }
+    for (int i = 0; i < O_COUNT; ++i) if (strcmp(name, g_opt[i].name) == 0) { g_opt[i].value.store(value, std::memory_order_relaxed); return 0; }
     return DN_ERR_INVALID;
 }
 int dn_get_option(const char* name, int* value) {
     if (!name || !value) return DN_ERR_INVALID;
-    for (int i = 0; i < O_COUNT; ++i) if (strcmp(name, g_opt[i].name) == 0) { *value = g_opt[i].value; return 0; }
+    for (int i = 0; i < O_COUNT; ++i) if (strcmp(name, g_opt[i].name) == 0) { *value = opt(i); return 0; }
     return DN_ERR_INVALID;
 }
 
@@ -615,7 +622,7 @@ enum { AW_IN = 0, AW_YS, AW_MISC, AW_WA, AW_W0, AW_D0 = AW_W0 + DN_MAX_MLP_LAYER
 enum { SW_X = 0, SW_XD, SW_G, SW_H0 };                                                                                          // saved words
 static_assert(SW_H0 + DN_MAX_MLP_LAYERS <= DN_BLOCK_AMAX_WORDS, "saved amax words");
 static bool block_f16_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p) {
-    if (!opt(O_F16)) return false;
+    if (!opt(O_F16) || (p->flags & DN_BLOCK_NO_F16)) return false;
     auto ok = [](int w) { return w >= 128 && w % 32 == 0; };
     if (!ok(p->C) || !ok(mb->k_eig)) return false;
     for (int j = 1; j < p->n_mlp; ++j) if (!ok(p->widths[j])) return false;
@@ -658,6 +665,7 @@ static int chain_hh(const dn_mesh_batch_t* mb, bool backward = false, int C = 12
 }
 static bool block_chain_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int kind) {
     if (!opt(O_CHAIN) || !opt(O_F16) || (p->with_grad && !mb->grad_norm)) return false;      // "f16" = 0: split-bf16 engine everywhere (A/B runs)
+    if (p->flags & (DN_BLOCK_NO_CHAIN | DN_BLOCK_NO_F16)) return false;                        // per-call engine choice (include/diffnet_hip.h)
     if (kind == 1 && mb->v_total < opt(O_CHAIN_MIN_ROWS) && mb->v_total > opt(O_CHAIN_SMALL_ROWS)) return false;
     return dn_chain_eligible(p->C, p->n_mlp, p->widths, p->with_grad, mb->g_nnz, mb->v_total, kind == 2);
 }
@@ -672,7 +680,7 @@ static bool block_chain_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p
 // kernel (13 instead of 10 arrays of [V, C] through it) and is level with back-projection + gather from ~80k rows on (bench.py headline, two
 // runs each on one box: 30.82 / 30.85 M vertices/s against 31.02 / 31.02).
 static bool block_sg_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int kind) {
-    const int o = opt(O_SPECTRAL_GRAD);
+    const int o = (p->flags & DN_BLOCK_NO_SPECTRAL_GRAD) ? 0 : ((p->flags & DN_BLOCK_SPECTRAL_GRAD_ALWAYS) ? 2 : opt(O_SPECTRAL_GRAD));
     return o && kind < 2 && (o >= 2 || kind == 0 || mb->v_total <= 65536) && mb->sg_pack && mb->sg_units && mb->sg_amax && mb->sg_n_units > 0 && al16(mb->sg_pack) && al16(mb->sg_amax) &&
            mb->sg_n_units <= 100 * dn_num_cus() &&      // (a workgroup's pass table lives in LDS: DN_CH_SG_MAXP = 64 passes of 2 x CUs workgroups)
            block_chain_ok(mb, p, kind) && dn_chain_sg_eligible(p->C, mb->k_eig, p->with_grad, chain_hh(mb, false, p->C)) && !diffuse_ok(mb, p->C);

@@ -1084,7 +1084,7 @@ static int chain_launch(int npieces, const ChainArgs& a_in, hipStream_t stream, 
 }
 
 int dn_launch_chain_prep(const ChainPrepArgs& pa, int npieces, int C, hipStream_t stream) {
-    if (npieces > DN_CH_MAX_PIECES || npieces <= 0) return 1;
+    if (npieces > DN_CH_MAX_PIECES || npieces <= 0 || (C != 128 && C != 256 && C != 64)) return 1;      // (before the timing bracket opens)
     ChainPrepArgs pb = pa;
     pb.npieces = npieces;
     dn_prof_begin(DN_K_SMALL, stream);

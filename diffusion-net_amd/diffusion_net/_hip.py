@@ -36,6 +36,7 @@ class MeshBatchStruct(C.Structure):
         ("evecs_amax", _vp), ("mass_amax", _vp), ("grad_norm", _vp),
         ("df_plan", _vp), ("df_n_wg", C.c_int32), ("df_n_groups", C.c_int32),
         ("sg_pack", _vp), ("sg_units", _vp), ("sg_amax", _vp), ("sg_n_units", C.c_int32),
+        ("df_v_total", C.c_int32),
     ]
 
 
@@ -45,7 +46,7 @@ class BlockParamsStruct(C.Structure):
         ("widths", C.c_int32 * (MAX_MLP + 1)),
         ("time", _vp), ("A_re", _vp), ("A_im", _vp),
         ("W", _vp * MAX_MLP), ("b", _vp * MAX_MLP), ("mask", _vp * MAX_MLP), ("drop_seed", C.c_uint64), ("drop_seed_dev", _vp),
-        ("x_amax", _vp), ("out_amax", _vp), ("clamp_time", C.c_int32),
+        ("x_amax", _vp), ("out_amax", _vp), ("clamp_time", C.c_int32), ("flags", C.c_uint32),
     ]
 
 

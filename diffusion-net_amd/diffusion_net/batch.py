@@ -291,6 +291,7 @@ class MeshBatch:
         if self.k_eig == 128 and self.evecs is not None and vt > 0:
             self.df_plan, s.df_n_wg, s.df_n_groups = _plan_on(self.device, self.sizes, 0)
             s.df_plan = _hip.ptr(self.df_plan)
+            s.df_v_total = vt            # the plan's stamp: the library ignores a plan made for another batch
         if self.evecs is not None and self.evecs.numel() > 0 and self.mass is not None:
             # once per packed batch (two small reductions, no host synchronisation)
             words = [self.evecs.detach().abs().amax(), self.mass.detach().abs().amax()]

@@ -312,6 +312,7 @@ class BlockConfig:
         self.grad_hook = None        # dist.FlatParams: called after the block's gradients were delivered
         self.grad_pre_hook = None    # ... and before they are written
         self.clamp_time = False      # True: the block forward clamps diffusion_time to >= 1e-8 in place inside its first launch (layers.py:48-49)
+        self.flags = 0               # per-call engine choice (include/diffnet_hip.h: DN_BLOCK_*), 0 = follow the library's option table
         if self.n_mlp > _hip.MAX_MLP:
             raise ValueError("MiniMLP deeper than %d layers is not supported by the HIP block" % _hip.MAX_MLP)
 
@@ -320,6 +321,7 @@ def _params_struct(cfg: BlockConfig, time, A_re, A_im, Ws, bs, masks, x_amax=Non
     p = _hip.BlockParamsStruct()
     p.x_amax, p.out_amax = _hip.ptr(x_amax), _hip.ptr(out_amax)
     p.C, p.n_mlp, p.with_grad, p.with_rot = cfg.C, cfg.n_mlp, int(cfg.with_grad), int(cfg.with_rot)
+    p.flags = int(getattr(cfg, "flags", 0))
     for i, w in enumerate(cfg.widths):
         p.widths[i] = w
     p.time, p.A_re, p.A_im = time.data_ptr(), _hip.ptr(A_re), _hip.ptr(A_im)

@@ -17,7 +17,9 @@
  *   - re-entrant: the compute path reads no environment variables and writes no global state.  Three process-wide pieces of
  *     bookkeeping exist: the opt-in timing of dn_prof_* (off by default), a per-device "large-LDS attribute set" bitmap per kernel
  *     instantiation (set-once, idempotent), and the table of tuning options behind dn_set_option() (kernel selection for A/B runs and
- *     tests; written only by that call, read by the entry points at call time);
+ *     tests; relaxed atomics written only by that call, read by the entry points at call time -- a value must not change between a
+ *     *_workspace_bytes() query and the call it sizes, nor between the warm-up and the capture of a HIP graph; per-call engine choices
+ *     go through dn_block_params_t.flags instead);
  *   - every struct below must be ZERO-INITIALISED by the caller before its fields are filled (memset): fields are only ever appended, and
  *     an appended field's zero value selects the behaviour of the versions before it.  dn_version() identifies the layout generation.
  *
@@ -72,6 +74,10 @@ typedef struct dn_mesh_batch {
      * computes xd, gx, gy inside its chained row kernel (no back-projection launch, no CSR gather) for the shapes
      * dn_spectral_grad_supported() names.  NULL / 0: back-projection + gather, as before. */
     const void* sg_pack; const dn_tile_t* sg_units; const float* sg_amax; int32_t sg_n_units;
+    /* Stamp of df_plan (round 6): v_total of the batch dn_diffusion_plan() was called for.  The plan names rows the kernels write: a plan whose
+     * stamp is not this batch's v_total, or whose df_n_wg is not dn_diffusion_plan_wgs() of the current device, is IGNORED (row GEMM instead) --
+     * a caller that leaves the field zero therefore never takes the planned kernels. */
+    int32_t df_v_total;
 } dn_mesh_batch_t;
 
 /* Weights of one DiffusionNetBlock (layers.py:167-198), nn.Linear layout: W[out][in]. */
@@ -98,7 +104,15 @@ typedef struct dn_block_params {
      * applies to the parameter in every forward (layers.py:48-49: the Parameter keeps the clamped values) -- as part of the call's first
      * launch, instead of a separate elementwise kernel of the caller.  `time` must then be writable.  The backward ignores the field. */
     int32_t clamp_time;
+    /* Optional (round 6): per-call engine choice, overriding the process-wide dn_set_option() table for THIS call (two models in one process may
+     * want different engines; the table is for A/B runs).  0 = follow the table.  Workspace queries take the same params, so a call and its
+     * query always agree. */
+    uint32_t flags;
 } dn_block_params_t;
+#define DN_BLOCK_NO_CHAIN 1u                 /* unfused launches instead of the chained row kernels                  */
+#define DN_BLOCK_NO_F16 2u                   /* split-bf16 engine throughout (implies the unfused launches)          */
+#define DN_BLOCK_NO_SPECTRAL_GRAD 4u         /* back-projection + CSR gather even if the batch carries sg_pack       */
+#define DN_BLOCK_SPECTRAL_GRAD_ALWAYS 8u     /* spectral-gradient forward at every size (option "spectral_grad" = 2) */
 
 /* Activations the forward saves for the backward (caller-allocated). */
 typedef struct dn_block_saved {

@@ -236,6 +236,40 @@ def run_spectral_grad(device, sizes=(300, 140, 131), C=128, N_block=2, dropout=T
     return rec
 
 
+def run_block_flags(device, sizes=(300, 140), C=128, seed=9):
+    """dn_block_params_t.flags (per-call engine choice) against the process-wide option table: a model whose blocks carry DN_BLOCK_NO_SPECTRAL_GRAD /
+    DN_BLOCK_NO_CHAIN must produce, bit for bit, what the same model produces with the option "spectral_grad" / "chain" set to 0 -- while the table
+    itself stays at its defaults (two models in one process with different engines)."""
+    from diffusion_net import _hip
+    meshes, feats = make_ragged(sizes, 128, 3, seed)
+    mb = pack(meshes, device, chunk_rows=64)
+
+    def run(flags=0, opts=()):
+        saved = {k: _hip.get_option(k) for k, _ in opts}
+        try:
+            for k, v in opts:
+                _hip.set_option(k, v)
+            torch.manual_seed(seed)
+            model = diffusion_net.layers.DiffusionNet(3, 5, C_width=C, N_block=1, outputs_at="vertices", dropout=False)
+            model.load_state_dict(synthetic.randomize_times(model.state_dict(), seed=seed))
+            model.to(device).train(False)
+            for blk in model.blocks:
+                blk._cfg.flags = flags
+            x = torch.cat(feats, 0).to(device).requires_grad_(True)
+            out = model.forward_packed(x, mb, None)
+            out.square().sum().backward()
+            return out.detach().cpu(), x.grad.cpu()
+        finally:
+            for k, v in saved.items():
+                _hip.set_option(k, v)
+    base = run()
+    for flag, name in ((4, "spectral_grad"), (1, "chain")):      # DN_BLOCK_NO_SPECTRAL_GRAD, DN_BLOCK_NO_CHAIN
+        by_flag, by_opt = run(flags=flag), run(opts=((name, 0),))
+        assert torch.equal(by_flag[0], by_opt[0]) and torch.equal(by_flag[1], by_opt[1]), "flags=%d differs from option %s=0" % (flag, name)
+        assert not torch.equal(by_flag[0], base[0]), "flags=%d changed nothing" % flag
+    assert torch.equal(run()[0], base[0])
+
+
 # ------------------------------------------------------------------------------------------
 # one-launch diffusion operator (dn_diffuse.hip) vs the oracle and vs the three-launch form
 # ------------------------------------------------------------------------------------------

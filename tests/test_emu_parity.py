@@ -95,6 +95,11 @@ def test_spectral_gradient_form_on_emulator(emu):
     parity_cases.run_spectral_grad(emu, sizes=(150, 170), C=64, N_block=1, dropout=False)
 
 
+def test_per_call_engine_flags_on_emulator(emu):
+    import parity_cases
+    parity_cases.run_block_flags(emu)
+
+
 def test_mismatched_patterns_on_emulator(emu):
     import parity_cases
     parity_cases.run_mismatched_patterns(emu)

@@ -185,6 +185,12 @@ def test_spectral_gradient_form_vs_gather(dev):
     parity_cases.run_spectral_grad(dev, sizes=(20500, 19999), N_block=1, dropout=True)
 
 
+def test_per_call_engine_flags(dev):
+    import parity_cases
+    parity_cases.run_block_flags(dev)
+    parity_cases.run_block_flags(dev, sizes=(3000, 1400), seed=3)
+
+
 def test_mismatched_patterns(dev):
     import parity_cases
     parity_cases.run_mismatched_patterns(dev)

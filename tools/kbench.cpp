@@ -152,7 +152,7 @@ int main(int argc, char** argv) {
         const int nwg = L.sym<int (*)()>("dn_diffusion_plan_wgs")();
         std::vector<dn_tile_t> plan((size_t)DN_DIFFUSION_MAX_GROUPS * nwg);
         df_used = L.sym<int (*)(const int32_t*, int, int, int, dn_tile_t*)>("dn_diffusion_plan")(sizes.data(), n_mesh, nwg, df_groups, plan.data());
-        if (df_used > 0) { plan.resize((size_t)df_used * nwg); mb.df_plan = dev(plan); mb.df_n_wg = nwg; mb.df_n_groups = df_used; }
+        if (df_used > 0) { plan.resize((size_t)df_used * nwg); mb.df_plan = dev(plan); mb.df_n_wg = nwg; mb.df_n_groups = df_used; mb.df_v_total = (int)V; }
     }
     {   // operand magnitudes for the split-fp16 engine, as diffusion_net.batch.MeshBatch provides them
         float am[2] = {0.f, 0.f};
