@@ -568,7 +568,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "--gpus %d but the launcher started %d ranks" % (args.gpus, world)
     if os.environ.get("DN_BENCH_LAUNCH_CHECK"):   # tests/test_dist_gloo.py: the launcher leg alone (runs without a GPU)
-        print(json.dumps({"rank": rank, "local": local, "world": world, "master": os.environ.get("MASTER_ADDR")}), flush=True)
+        print(json.dumps({"rank": rank, "local": local, "local_rank": local, "world": world, "master": os.environ.get("MASTER_ADDR")}), flush=True)
         return
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU path)"
     # TEST HOOK (tests/test_gpu_parity.py on the 1-GPU boxes): every rank on GPU 0, collectives over gloo -- exercises the N-rank logic
@@ -733,13 +733,32 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     lib.dn_prof_enable(0)
+    multi = None
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        mine = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                       # every rank's own clock over the same K steps: a straggler shows here, not only in the MAX
+        t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         vt = torch.tensor([v_step], device=device, dtype=torch.float64)
         dist.all_reduce(vt, op=dist.ReduceOp.SUM)
         v_all = float(vt.item())
+        # the gradient all-reduce by itself (outside the timed region): the flat bucket as the step sends it, K times between two fences --
+        # so that the first real N-GPU run says how much of its step is the collective and how much is the ranks waiting for each other
+        fence()
+        ta = time.perf_counter()
+        for _ in range(max(args.steps, 5)):
+            flat.all_reduce_mean()
+        fence()
+        ar_ms = 1e3 * (time.perf_counter() - ta) / max(args.steps, 5)
+        flat.zero_grad()
+        multi = {"per_rank_ms_per_step": [1e3 * float(e.item()) / args.steps for e in every], "max_over_ranks_ms_per_step": 1e3 * elapsed / args.steps,
+                 "all_reduce_alone_ms": ar_ms, "all_reduce_bytes": int(flat.grad.numel() * 4),
+                 "all_reduce_in_step": "host call after the replayed graph (no overlap)" if (gs is not None and not args.graph_collectives)
+                                       else ("captured with the step, per-block buckets overlapped with the backward" if gs is not None else
+                                             "per-block buckets launched from inside backward (eager)"),
+                 "backend": dist.get_backend()}
     else:
         v_all = float(v_step)
     assert torch.isfinite(loss).item()
@@ -861,6 +880,8 @@ def main():
                        **({"TEST_ONLY": "all ranks share GPU 0, gloo collectives (DN_BENCH_TEST_SHARED_GPU)"} if shared_gpu else {})},
             "roofline": roof, "kernel_families": fam, "diffusion_block": diff,
         }
+        if multi is not None:
+            res["multi_gpu"] = multi
         if world == 1:
             res["parity"] = parity_in_run(device)
         if not args.no_cpu_baseline and world == 1 and args.config == "headline":   # reported at N = 1 only (the other ranks would sit idle behind it)

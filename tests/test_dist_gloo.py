@@ -72,6 +72,32 @@ def test_gradient_accumulation_with_overlap_two_ranks():
     assert float((r0["overlap"] - ref).norm() / ref.norm()) < 1e-6       # (S1/R + g2) summed over ranks: round-off only
 
 
+def test_gradient_accumulation_with_overlap_four_ranks():
+    """The same three modes at world size 4 (two micro-batches per rank, eight meshes): every replica holds the same averaged gradient bit for
+    bit in every mode, the three modes agree up to round-off, and the four-rank average equals the two-rank average of the
+    same eight meshes up to round-off (the collective's summation tree differs with the world size)."""
+    subprocess.run(["make", "-C", CSRC, "-j8", "emu"], check=True, capture_output=True)
+    import torch.multiprocessing as mp
+    import dist_worker
+    sizes = [96, 64, 80, 72, 88, 56, 104, 48]
+    res = {}
+    for world in (4, 2):
+        with tempfile.TemporaryDirectory() as tmp:
+            mp.spawn(dist_worker.run_accumulate, args=(world, _free_port(), EMU_SO, sizes, tmp), nprocs=world, join=True)
+            res[world] = [torch.load(os.path.join(tmp, f"acc_rank{r}.pt")) for r in range(world)]
+    for mode in ("overlap", "no_sync", "flat"):
+        for r in range(1, 4):
+            assert torch.equal(res[4][0][mode], res[4][r][mode]), (mode, r)
+    ref = res[4][0]["flat"]
+    assert float(ref.norm()) > 0
+    # (at two ranks no_sync + per-range collectives equals the flat collective bit for bit; with four, a ring all-reduce sums an element's four
+    # contributions in an order that depends on where the element sits in the buffer it travels in -- round-off only)
+    assert float((res[4][0]["no_sync"] - ref).norm() / ref.norm()) < 1e-6
+    assert float((res[4][0]["overlap"] - ref).norm() / ref.norm()) < 1e-6
+    # world 2: every rank accumulates four meshes; world 4: two -- the MEAN over ranks of per-rank sums differs by the factor 2 between them
+    assert float((2.0 * ref - res[2][0]["flat"]).norm() / res[2][0]["flat"].norm()) < 1e-5
+
+
 def test_autograph_dropout_masks_differ_across_ranks():
     """Two identically seeded replicas, automatic graph replay on: the replayed forwards must draw different dropout masks on the two
     ranks (the rank is mixed into the captured seed) and fresh masks on every replay."""
@@ -102,3 +128,25 @@ def test_bench_gpus_n_launches_n_ranks():
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert sorted(l["rank"] for l in lines) == [0, 1], r.stdout
     assert all(l["world"] == 2 and l["master"] == "127.0.0.1" for l in lines), lines
+
+
+def test_bench_gpus_8_launches_8_ranks():
+    """The driver's 8-GPU command line: `python bench.py --gpus 8` must come up as eight ranks with LOCAL_RANK 0..7 on 127.0.0.1 (launcher leg only,
+    no GPU call), and the driver's own form -- already under torch.distributed.run with WORLD_SIZE = 8 -- must not re-launch itself."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DN_BENCH_LAUNCH_CHECK"] = "1"
+    import json
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert sorted(l["rank"] for l in lines) == list(range(8)), r.stdout
+    assert sorted(l["local_rank"] for l in lines) == list(range(8)), r.stdout
+    assert all(l["world"] == 8 and l["master"] == "127.0.0.1" for l in lines), lines
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert sorted(l["rank"] for l in lines) == list(range(8)), r.stdout
