@@ -139,6 +139,7 @@ extern "C" int dn_debug_ch_trace_read(unsigned long long* out, int n) {
 #define CH_TR() do {} while (0)
 #endif
 
+DN_CLK_DECLARE(chain_fwd)
 // KE > 0: the spectral-gradient form (dn_spectral.hip) for k_eig = 32 KE -- no CSR gather, no xd read: the pass starts with the three products
 // [Phi | G_X Phi | G_Y Phi][rows] * ys[mesh] (operand fragments streamed pre-split from the packed batch operand, the scaled spectrum's pieces
 // through the same LDS ring as the weights) and xd, gx, gy are born in the accumulator layout the following stages consume.
@@ -146,6 +147,7 @@ template <int C, int NW, int HH, int KE = 0>
 __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void chain_fwd_kernel(ChainArgs a) {
     constexpr bool SG = KE > 0;
     static_assert(!SG || (HH == 1 && C < 256), "spectral-gradient form: one 16-row half per wave, two waves per SIMD");
+    DN_CLK_STAMP(chain_fwd, 0);
     constexpr int NT = C / 16;            // 16-channel output tiles
     constexpr int NK = C / 32;            // 32-channel contraction steps (= pieces per matrix)
     constexpr int NTHR = 64 * NW;
@@ -1009,6 +1011,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
             if (word && mm > 0.f && mm > *reinterpret_cast<volatile float*>(word)) atomicMax(reinterpret_cast<unsigned*>(word), __float_as_uint(mm));
         }
     }
+    DN_CLK_STAMP(chain_fwd, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

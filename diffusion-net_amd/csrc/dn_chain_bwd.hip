@@ -16,8 +16,10 @@
 #include "dn_chain_tiles.h"
 #include <stdlib.h>
 
+DN_CLK_DECLARE(chain_bwd)
 template <int C, int NW, int HH>
 __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(ChainBwdArgs a) {
+    DN_CLK_STAMP(chain_bwd, 0);
     constexpr int NT = C / 16;
     constexpr int NK = C / 32;
     constexpr int NTHR = 64 * NW;
@@ -329,6 +331,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
 #ifndef DN_EMULATE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the requests that ran past the end of the stream
 #endif
+    DN_CLK_STAMP(chain_bwd, 1);
 #undef CH_PACK
 #undef CH_ZERO
 #undef CH_PIECE_END

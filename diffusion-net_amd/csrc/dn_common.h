@@ -702,6 +702,29 @@ int dn_launch_tngemm(const TnArgs& g, int nchunks, hipStream_t stream);
 int dn_launch_tngemm_multi(const TnArgs* gs, const int* nchunks, int count, hipStream_t stream);   // several products, one launch
 
 // ---------------------------------------------------------------------------------------
+// development build -DDN_CLK_TRACE (make variant TAG=clk EXTRA=-DDN_CLK_TRACE): thread 0 of the first 256 workgroups of a kernel stamps
+// s_memtime (shader clock) and s_memrealtime (constant 100 MHz) at entry and exit; the ratio of the two differences IS the shader clock the
+// kernel ran at (the "1.44 GHz under the 3-term MFMA stream" of round 5 was inferred from one trace of another kernel).
+// One buffer and one reader per translation unit that uses it (tools/kbench --clk reads them).
+// ---------------------------------------------------------------------------------------
+#if defined(DN_CLK_TRACE) && !defined(DN_EMULATE)
+#define DN_CLK_DECLARE(name_)                                                                                          \
+    __device__ unsigned long long dn_clk_buf_##name_[256 * 4];                                                         \
+    extern "C" int dn_debug_clk_read_##name_(unsigned long long* out, int n) {                                         \
+        return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dn_clk_buf_##name_), sizeof(unsigned long long) * (size_t)(n < 1024 ? n : 1024)); }
+#define DN_CLK_STAMP(name_, i_)                                                                                        \
+    do {                                                                                                               \
+        if (threadIdx.x == 0 && blockIdx.x < 256 && blockIdx.y == 0 && blockIdx.z == 0) {                              \
+            dn_clk_buf_##name_[blockIdx.x * 4 + 2 * (i_)] = __builtin_amdgcn_s_memtime();                              \
+            dn_clk_buf_##name_[blockIdx.x * 4 + 2 * (i_) + 1] = __builtin_amdgcn_s_memrealtime();                      \
+        }                                                                                                              \
+    } while (0)
+#else
+#define DN_CLK_DECLARE(name_)
+#define DN_CLK_STAMP(name_, i_) do {} while (0)
+#endif
+
+// ---------------------------------------------------------------------------------------
 // opt-in per-kernel timing (bench.py's roofline leg): when enabled, every launch is bracketed by
 // hipEvents on its own stream and summed per kernel family.  Off by default; compiled out of the
 // emulator build.

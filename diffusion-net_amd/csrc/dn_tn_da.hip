@@ -96,8 +96,10 @@ __device__ __forceinline__ void da_compute(const unsigned char* buf, int wr, int
     }
 }
 
+DN_CLK_DECLARE(tn_da)
 template <int NP>
 __global__ __launch_bounds__(DN_DA_THREADS) DN_WAVES_PER_EU(2) void tngemm_da_kernel(DaArgs g) {
+    DN_CLK_STAMP(tn_da, 0);
     float sa = 1.f, sb = 1.f, so = 1.f;
     if constexpr (NP == 2) {   // split-fp16: A = dd * g (bound: the product of the two magnitudes), B = g
         sa = dn_pow2_scale(dn_amax_eval(g.a_amax));
@@ -174,6 +176,7 @@ __global__ __launch_bounds__(DN_DA_THREADS) DN_WAVES_PER_EU(2) void tngemm_da_ke
                     out[o * 128 + c] = NP == 2 ? v * so : v;
                 }
     }
+    DN_CLK_STAMP(tn_da, 1);
 }
 
 // partial: [nwg][2][128][128] floats (dA_re part, dA_im part of every workgroup's row range)

@@ -326,8 +326,10 @@ __global__ __launch_bounds__(DN_TX_THREADS, 4) void tngemm_x3_kernel(TnArgs g) {
 // three, and a single mesh's handful of chunks share the device): workgroup blockIdx.x belongs to the problem whose range it falls into
 #define DN_TN_MULTI 3
 struct TnMulti { TnArgs p[DN_TN_MULTI]; int first[DN_TN_MULTI + 1]; int nblk[DN_TN_MULTI]; int ny[DN_TN_MULTI]; int count; };
+DN_CLK_DECLARE(tn_multi)
 template <int FLAVOR, int NP>
 __global__ __launch_bounds__(DN_TX_THREADS, 4) void tngemm_x3_multi_kernel(TnMulti mm) {
+    DN_CLK_STAMP(tn_multi, 0);
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < DN_TN_MULTI; ++i) pi = (i < mm.count && (int)blockIdx.x >= mm.first[i]) ? i : pi;
@@ -336,6 +338,7 @@ __global__ __launch_bounds__(DN_TX_THREADS, 4) void tngemm_x3_multi_kernel(TnMul
     if (pi == 0) tn_x3_body<FLAVOR, NP>(mm.p[0], local % mm.nblk[0], (local / mm.nblk[0]) % mm.ny[0], local / (mm.nblk[0] * mm.ny[0]));
     else if (pi == 1) tn_x3_body<FLAVOR, NP>(mm.p[1], local % mm.nblk[1], (local / mm.nblk[1]) % mm.ny[1], local / (mm.nblk[1] * mm.ny[1]));
     else tn_x3_body<FLAVOR, NP>(mm.p[2], local % mm.nblk[2], (local / mm.nblk[2]) % mm.ny[2], local / (mm.nblk[2] * mm.ny[2]));
+    DN_CLK_STAMP(tn_multi, 1);
 }
 
 template <int FLAVOR, int NP>

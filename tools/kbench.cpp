@@ -488,6 +488,22 @@ int main(int argc, char** argv) {
             }
         }
     }
+    if (getenv("KB_CLK")) {   // libraries built with EXTRA=-DDN_CLK_TRACE: shader clock each kernel ran at = d(s_memtime) / d(s_memrealtime at 100 MHz), last launch
+        for (const char* nm : {"chain_fwd", "chain_bwd", "tn_multi", "tn_da"}) {
+            auto rd = (int (*)(unsigned long long*, int))dlsym(L.h, (std::string("dn_debug_clk_read_") + nm).c_str());
+            if (!rd) continue;
+            std::vector<unsigned long long> b(1024, 0);
+            if (rd(b.data(), 1024)) continue;
+            double lo = 1e30, hi = 0, sum = 0, dur = 0; int n = 0;
+            for (int w = 0; w < 256; ++w) {
+                const double dt = (double)(b[4 * w + 2] - b[4 * w]), dr = (double)(b[4 * w + 3] - b[4 * w + 1]);
+                if (b[4 * w + 1] == 0 || dr <= 0 || dt <= 0) continue;
+                const double ghz = dt / (dr * 10.0);      // cycles per nanosecond
+                lo = std::min(lo, ghz); hi = std::max(hi, ghz); sum += ghz; dur += dr * 0.01; ++n;
+            }
+            if (n) printf("== clock %-10s %3d workgroups: shader clock %.3f GHz (min %.3f, max %.3f) over a workgroup life of %.1f us on average\n", nm, n, sum / n, lo, hi, dur / n);
+        }
+    }
     if (trace) {   // libraries built with EXTRA=-DDN_CH_TRACE=<block>: s_memtime stamps of wave 0 of that workgroup of the chained forward kernel (last call)
         auto rd = (int (*)(unsigned long long*, int))dlsym(L.h, "dn_debug_ch_trace_read");
         if (rd) {
