@@ -415,7 +415,11 @@ def _engine_note():
     from diffusion_net import _hip
     return ("split-bf16 MFMA only (library option f16=0)" if _hip.get_option("f16") == 0 else
             "row products (gradient features, MLP, input gradients, backward back-projection) on 2-term split-fp16 MFMA with producer-side "
-            "power-of-two scales; projections, forward back-projection and all parameter-gradient sums on 3-term split-bf16 MFMA")
+            "power-of-two scales; projections, forward back-projection and all parameter-gradient sums on 3-term split-bf16 MFMA" +
+            ("" if _hip.get_option("spectral_grad") == 0 else
+             "; spectral-gradient forward (option spectral_grad=%d: %s): xd, gx, gy = [evecs | gradX evecs | gradY evecs] ys inside the chained forward "
+             "kernel on the 2-term engine, gradX evecs / gradY evecs accumulated in fp64 once per mesh" %
+             (_hip.get_option("spectral_grad"), "inference at every size, training up to 65536 rows" if _hip.get_option("spectral_grad") == 1 else "every size")))
 
 
 def run_epoch_mode(args, device, lib, world, rank):
