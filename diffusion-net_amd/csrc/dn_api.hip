@@ -6,6 +6,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <atomic>
+#include <stdio.h>
 #define DN_MIN_TIME 1e-8f       /* layers.py:49 */
 
 static_assert(sizeof(dn_tile_t) == sizeof(DnTile), "tile layout");
@@ -481,10 +482,10 @@ int dn_diffusion_bwd_f32(const dn_mesh_batch_t* mb, const float* d_xd, const flo
 }
 
 // ------------------------------------------------------------------ spectral-gradient operands (dn_spectral.hip)
-int dn_spectral_grad_supported(int k_eig, int C) { return dn_chain_sg_eligible(C, k_eig, 1, 1) ? 1 : 0; }
-int dn_spectral_units(const int32_t* sizes, int n_mesh, dn_tile_t* units) {
+int dn_spectral_grad_supported(int k_eig, int C) { return dn_chain_sg_eligible(C, k_eig, 1, C >= 256 ? 2 : 1) ? 1 : 0; }
+int dn_spectral_units(const int32_t* sizes, int n_mesh, int k_eig, dn_tile_t* units) {
     if (!sizes || n_mesh <= 0) return 0;
-    return dn_sg_units_host(sizes, n_mesh, reinterpret_cast<DnTile*>(units));
+    return dn_sg_units_host(sizes, n_mesh, k_eig, reinterpret_cast<DnTile*>(units));
 }
 size_t dn_spectral_pack_bytes(int n_units, int k_eig) { return dn_sg_pack_elems(n_units, k_eig) * sizeof(uint4); }
 size_t dn_spectral_pack_workspace_bytes(const dn_mesh_batch_t* mb) { return 2 * pad256((size_t)mb->v_total * mb->k_eig) + 512; }
@@ -680,6 +681,11 @@ static bool block_chain_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p
 // kernel (13 instead of 10 arrays of [V, C] through it) and is level with back-projection + gather from ~80k rows on (bench.py headline, two
 // runs each on one box: 30.82 / 30.85 M vertices/s against 31.02 / 31.02).
 static bool block_sg_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int kind) {
+#ifdef DN_DEBUG_SG
+    fprintf(stderr, "[sg] kind %d opt %d flags %u v %d pack %p units %p amax %p n_units %d al %d %d cus %d chain_ok %d elig %d (C %d K %d wg %d hh %d) diffuse_ok %d\n", kind, opt(O_SPECTRAL_GRAD), p->flags, mb->v_total,
+            mb->sg_pack, (const void*)mb->sg_units, (const void*)mb->sg_amax, mb->sg_n_units, (int)al16(mb->sg_pack), (int)al16(mb->sg_amax), dn_num_cus(), (int)block_chain_ok(mb, p, kind),
+            (int)dn_chain_sg_eligible(p->C, mb->k_eig, p->with_grad, chain_hh(mb, false, p->C)), p->C, mb->k_eig, p->with_grad, chain_hh(mb, false, p->C), (int)diffuse_ok(mb, p->C));
+#endif
     const int o = (p->flags & DN_BLOCK_NO_SPECTRAL_GRAD) ? 0 : ((p->flags & DN_BLOCK_SPECTRAL_GRAD_ALWAYS) ? 2 : opt(O_SPECTRAL_GRAD));
     return o && kind < 2 && (o >= 2 || kind == 0 || mb->v_total <= 65536) && mb->sg_pack && mb->sg_units && mb->sg_amax && mb->sg_n_units > 0 && al16(mb->sg_pack) && al16(mb->sg_amax) &&
            mb->sg_n_units <= 100 * dn_num_cus() &&      // (a workgroup's pass table lives in LDS: DN_CH_SG_MAXP = 64 passes of 2 x CUs workgroups)
@@ -707,7 +713,7 @@ size_t dn_block_fwd_workspace_bytes(const dn_mesh_batch_t* mb, const dn_block_pa
     const size_t VC = (size_t)mb->v_total * p->C;
     size_t n = pad256((size_t)mb->n_chunks * mb->k_eig * p->C) + pad256((size_t)mb->n_mesh * mb->k_eig * p->C) + amax_ws() + 512;
     if (block_chain_ok(mb, p, with_saved ? 1 : 0)) n += pad256(dn_chain_ws_bytes(p->C, p->with_grad, p->with_rot, p->n_mlp) / sizeof(float));
-    if (block_sg_ok(mb, p, with_saved ? 1 : 0)) n += pad256(sg_piece_floats(mb, p->C)) + pad256((size_t)mb->n_mesh);
+    if (block_sg_ok(mb, p, with_saved ? 1 : 0)) n += pad256(sg_piece_floats(mb, p->C)) + pad256((size_t)2 * mb->n_mesh);
     if (diffuse_ok(mb, p->C)) n += pad256(diffuse_ws_floats(mb));
     if (!with_saved) {
         n += pad256((size_t)mb->n_mesh * mb->k_eig * p->C) + 4 * pad256(VC);          // xs, xd, gx, gy, g
@@ -729,7 +735,7 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     float* chain_ws = block_chain_ok(mb, p, sv ? 1 : 0) ? b.f(dn_chain_ws_bytes(p->C, p->with_grad, p->with_rot, p->n_mlp) / sizeof(float)) : nullptr;
     const bool sg_ws = block_sg_ok(mb, p, sv ? 1 : 0);
     float* ysp = sg_ws ? b.f(sg_piece_floats(mb, C)) : nullptr;          // the scaled spectrum as weight pieces + its per-mesh magnitudes
-    float* ysa = sg_ws ? b.f((size_t)mb->n_mesh) : nullptr;
+    float* ysa = sg_ws ? b.f((size_t)2 * mb->n_mesh) : nullptr;
     const bool sg = chain && sg_ws;                                       // xd, gx, gy computed inside the chained kernel (dn_spectral.hip)
     float* diffuse_ws = diffuse_ok(mb, C) ? b.f(diffuse_ws_floats(mb)) : nullptr;
     float *xs, *xd, *gx = nullptr, *gy = nullptr, *gf = nullptr, *bre = nullptr, *bim = nullptr;
@@ -855,16 +861,19 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
         }
         ca.seed_dev = (const unsigned long long*)p->drop_seed_dev;
         if (p->with_grad && sv) { ca.gx = gx; ca.gy = gy; ca.g = gf; ca.bre = bre; ca.bim = bim; }
+        if (sg && C >= 256) { ca.gx = gx; ca.gy = gy; }      // (the C = 256 spectral form hands gx, gy from its spectral phase to its gradient-feature stage through memory)
         // (Measured and rejected: gathering gx, gy with the stand-alone CSR kernel first and letting the training chain read them -- the chained
         // kernel drops from 357 to 293 us, but the 87 us gather launch more than eats it: block forward 480 vs 465 us, profiles/r04_pregather.txt.)
         ca.out = out;
         ca.x_amax = x_amax; ca.xd_amax = sw + SW_XD; ca.grad_norm = mb->grad_norm;
         ca.g_amax = sw + SW_G; ca.out_amax = p->out_amax;
         if (sg) {
-            ca.xd = nullptr;
+            // (C = 256: the kernel writes xd to the buffer and reads it back in layer 0; C <= 128: xd stays in registers, written only when saved)
+            ca.xd = C >= 256 ? xd : nullptr;
             ca.sg_pack = reinterpret_cast<const uint4*>(mb->sg_pack); ca.sg_units = T(mb->sg_units); ca.sg_n_units = mb->sg_n_units; ca.sg_amax = mb->sg_amax;
+            ca.sg_unit_rows = dn_sg_unit_rows(K); ca.sg_n_mesh = mb->n_mesh;
             ca.ysp = reinterpret_cast<const uint4*>(ysp); ca.ys_amax = ysa;
-            ca.xd_out = sv ? xd : nullptr; ca.xd_amax_out = sw + SW_XD;
+            ca.xd_out = (sv || C >= 256) ? xd : nullptr; ca.xd_amax_out = sw + SW_XD;
         }
         return dn_launch_chain_fwd(chain_np, ca, C, st, chain_hh(mb, false, C));
     }

@@ -143,11 +143,22 @@ DN_CLK_DECLARE(chain_fwd)
 // KE > 0: the spectral-gradient form (dn_spectral.hip) for k_eig = 32 KE -- no CSR gather, no xd read: the pass starts with the three products
 // [Phi | G_X Phi | G_Y Phi][rows] * ys[mesh] (operand fragments streamed pre-split from the packed batch operand, the scaled spectrum's pieces
 // through the same LDS ring as the weights) and xd, gx, gy are born in the accumulator layout the following stages consume.
-template <int C, int NW, int HH, int KE = 0>
+// MODE (C = K = 256 only): the spectral-gradient form there is TWO launches of this kernel -- MODE 1 = the spectral phase alone (xd, gx, gy of every
+// pass written to memory), MODE 2 = the chain reading gx, gy where the gather form gathers them (KE = 0: plain piece stream, plain row mapping).
+// Fused into one launch (rounds of this file's history) the phase's 192 accumulators + operand buffers sat inside a kernel whose other stages are
+// at the register limit: values spilled THERE were reloaded in the phase's piece loop, and a scratch reload is followed by a compiler-made
+// s_waitcnt vmcnt(0) that drains the ring and the operand requests in flight (8-9 k cycles per piece instead of ~3 k).
+template <int C, int NW, int HH, int KE = 0, int MODE = 0>
 __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void chain_fwd_kernel(ChainArgs a) {
     constexpr bool SG = KE > 0;
-    static_assert(!SG || (HH == 1 && C < 256), "spectral-gradient form: one 16-row half per wave, two waves per SIMD");
+    constexpr bool PRE = MODE == 2;       // gx, gy come from memory (written by the MODE 1 launch)
+    static_assert(MODE == 0 || (C >= 256 && ((MODE == 1 && KE > 0) || (MODE == 2 && KE == 0))), "two-launch spectral form: C = 256");
+    static_assert(!SG || (HH == 1 && C < 256 && KE <= 4) || (C == 256 && HH == 2 && NW == 4 && KE == 8 && MODE == 1), "spectral-gradient forms: C <= 128 with one 16-row half per wave; C = K = 256: the spectral phase as its own launch");
+
     DN_CLK_STAMP(chain_fwd, 0);
+    // (the spectral-gradient forms exist with gradient features only: a compile-time fact there -- as a run-time flag it keeps the MiniMLP
+    // accumulators of the no-gradient-features path alive across the spectral phase: 128 of the 256 accumulator registers at C = 256)
+    const bool with_grad_ = SG ? true : (a.with_grad != 0);
     constexpr int NT = C / 16;            // 16-channel output tiles
     constexpr int NK = C / 32;            // 32-channel contraction steps (= pieces per matrix)
     constexpr int NTHR = 64 * NW;
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
     constexpr int CH_PF = G0 ? DN_CH_PF_WIDE : 1;      // weight-fragment prefetch distance in tile pairs (one wave per SIMD: nobody else covers the LDS latency)
     static_assert(PIECE % NTHR == 0, "piece staging");
     static_assert(RING >= 2 && RING <= 8 && (RING - 1) * LPT < 60 && (RING - 2) * LPT + 6 * HH < 64, "ring depth vs the vmcnt range");
-    static_assert(!SG || (RING - 2) * LPT + 6 * KE < 64, "operand-fragment requests of the spectral stage vs the vmcnt range");
+
 
     DN_DYN_SMEM(smem_raw);
     uint4* ring = reinterpret_cast<uint4*>(smem_raw);                      // RING slots of PIECE uint4
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
     // SG: the workgroup's passes -- {first row, end of the mesh's rows, mesh, first 16-row group} and the three result scales -- staged once in the
     // space of the gather slices: a per-pass descriptor read from memory compiles to a vector load behind an s_waitcnt vmcnt(0), which drains
     // the piece ring and the operand requests in flight (seen as 8-16 k cycles at the top of every pass)
-    int4* pinfo = reinterpret_cast<int4*>(sbias + DN_CH_LAYERS * C);                     // [DN_CH_SG_MAXP]
+    int4* pinfo = reinterpret_cast<int4*>(sbias + (G0 ? 0 : DN_CH_LAYERS * C));          // [DN_CH_SG_MAXP]
     float4* pscale = reinterpret_cast<float4*>(pinfo + DN_CH_SG_MAXP);                   // [DN_CH_SG_MAXP]
 #ifdef DN_EMULATE
     const unsigned lds0 = 0;
@@ -214,13 +225,13 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
     // ---- operand scales known up front
     // (SG: xd, gx, gy are produced by this kernel -- their scales are per pass, from the wave's own 16 rows, as the hidden activations')
     const float x_mag = SG ? dn_amax_word(a.x_amax) : 0.f;
-    float s_in = SG ? 1.f : ch_uniform(dn_pow2_scale(fmaxf(fmaxf(dn_amax_word(a.x_amax), dn_amax_word(a.xd_amax)), a.with_grad ? 1.f : 0.f)));   // [x | xd | g]
+    float s_in = SG ? 1.f : ch_uniform(dn_pow2_scale(fmaxf(fmaxf(dn_amax_word(a.x_amax), dn_amax_word(a.xd_amax)), with_grad_ ? 1.f : 0.f)));   // [x | xd | g]
     float s_gf = 1.f, so_gf = 1.f;
-    const float swa_inv = (SG && a.with_grad) ? ch_uniform(ch_pow2_inv(dn_pow2_scale(dn_amax_word(a.wa_amax)))) : 1.f;
+    const float swa_inv = (SG && with_grad_) ? ch_uniform(ch_pow2_inv(dn_pow2_scale(dn_amax_word(a.wa_amax)))) : 1.f;
     float xdmax = 0.f, gmax = 0.f;        // SG: largest |xd|, |gx|, |gy| this wave produced
-    if (!SG && a.with_grad) {
-        const float gb = dn_amax_word(a.xd_amax) * dn_amax_word(a.grad_norm);
-        if (blockIdx.x == 0 && tid == 0 && a.g_amax) atomicMax(reinterpret_cast<unsigned*>(a.g_amax), __float_as_uint(gb));
+    if (!SG && with_grad_) {
+        const float gb = PRE ? dn_amax_word(a.g_amax) : dn_amax_word(a.xd_amax) * dn_amax_word(a.grad_norm);      // (PRE: max |gx|, |gy| as measured by the spectral launch)
+        if (!PRE && blockIdx.x == 0 && tid == 0 && a.g_amax) atomicMax(reinterpret_cast<unsigned*>(a.g_amax), __float_as_uint(gb));
         s_gf = ch_uniform(dn_pow2_scale(gb));
         so_gf = ch_uniform(ch_pow2_inv(s_gf) * ch_pow2_inv(dn_pow2_scale(dn_amax_word(a.wa_amax))));
     }
@@ -239,10 +250,12 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
     // position sq of that sequence fetches piece sq (first round of the gradient-feature pieces), sq - n_gf (second round) or
     // sq - (HH - 1) n_gf (the layers).  It wraps at the end of a pass: the requests run ahead into the next one.
     // SG: the pass's KE spectrum pieces come first, from the pass's mesh (the requests run ahead into the next pass: imesh follows the stream)
-    const int n_gf = a.with_grad ? a.n_gf : 0;
-    const int n_seq = a.n_pieces + (HH - 1) * n_gf + KE;
+    const int n_gf = with_grad_ ? a.n_gf : 0;
+    // (SG: the spectrum's pieces come first, once per half -- the spectral phase runs both halves back to back)
+    const int n_seq = MODE == 1 ? HH * KE : a.n_pieces + (HH - 1) * n_gf + HH * KE;      // (MODE 1: the spectrum's pieces are the whole stream)
     int sq = 0;                           // position the NEXT request fetches
-    constexpr int SUB = SG ? 4 / NW : 1;  // workgroup passes per 64-row unit
+    const int SUB = SG ? a.sg_unit_rows / (16 * HH * NW) : 1;  // workgroup passes per unit of the packed operands (64 / 128 rows)
+    const int GPU_ = SG ? a.sg_unit_rows / 16 : 1;             // 16-row groups per unit
     auto unit_of = [&](int pass_) { return xcd * per_x + slot0 + pass_ * GX; };
     int imesh = 0, mesh_nx = 0;           // SG: mesh of the pass whose pieces are being requested / of the pass after the one being multiplied
     if constexpr (SG) {
@@ -250,11 +263,13 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
             const int un = unit_of(pp);
             const DnTile tl = a.sg_units[un / SUB];
             const int sub = un % SUB;
-            pinfo[pp] = int4{tl.row0 + 16 * NW * sub, tl.row0 + tl.nrows, tl.mesh, 4 * (un / SUB) + NW * sub};
+            pinfo[pp] = int4{tl.row0 + 16 * HH * NW * sub, tl.row0 + tl.nrows, tl.mesh, GPU_ * (un / SUB) + HH * NW * sub};
             const float4 am = *reinterpret_cast<const float4*>(a.sg_amax + 4 * tl.mesh);
             const float ys_inv = ch_pow2_inv(dn_pow2_scale(a.ys_amax[tl.mesh]));
+            // .w: a bound of |xd| over the mesh -- (largest row 2-norm of Phi) x (largest column 2-norm of ys), Cauchy-Schwarz -- for the forms whose
+            // layer-0 scale must be fixed before xd exists (C = 256)
             pscale[pp] = make_float4(ys_inv * ch_pow2_inv(dn_pow2_scale(am.x)), ys_inv * ch_pow2_inv(dn_pow2_scale(am.y)),
-                                     ys_inv * ch_pow2_inv(dn_pow2_scale(am.z)), 0.f);
+                                     ys_inv * ch_pow2_inv(dn_pow2_scale(am.z)), am.w * a.ys_amax[a.sg_n_mesh + tl.mesh]);
         }
         imesh = ch_uniform_i(a.sg_units[unit_of(0) / SUB].mesh);      // (pass 0's pieces are requested before the table is published)
         mesh_nx = imesh;
@@ -267,10 +282,11 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
     int rq = 0;                           // slot the next request fills
     auto issue = [&]() {
         const uint4* src_piece;
-        if constexpr (SG) {
-            src_piece = sq < KE ? a.ysp + ((size_t)imesh * KE + sq) * PIECE : a.wp + (size_t)(sq - KE) * PIECE;
+        if (SG && (MODE == 1 || sq < HH * KE)) {
+            src_piece = a.ysp + ((size_t)imesh * KE + (sq >= KE ? sq - KE : sq)) * PIECE;       // (HH <= 2)
         } else {
-            const int pidx = sq < HH * n_gf ? (sq >= n_gf ? sq - n_gf : sq) : sq - (HH - 1) * n_gf;
+            const int sw_ = sq - HH * KE;
+            const int pidx = sw_ < HH * n_gf ? (sw_ >= n_gf ? sw_ - n_gf : sw_) : sw_ - (HH - 1) * n_gf;
             src_piece = a.wp + (size_t)pidx * PIECE;
         }
 #pragma unroll
@@ -331,6 +347,10 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
 
     for (int pass = 0; pass < npass; ++pass) {
         CH_TR();
+        // (C = 256 spectral form: the lane index is made opaque per pass -- left visible, the compiler hoists the pass's per-lane address
+        // arithmetic (a dozen 64-bit row pointers) out of the loop, spills it at the loop head and reloads it inside the product loops)
+        const int lane_p = ch_opaque<false>(lane);
+        const int m = lane_p & 15, q = lane_p >> 4;
         const int unit = unit_of(pass);
         int rb = unit * (16 * HH * NW) + 16 * HH * wave;     // first of this wave's 32 rows (row * C fits 32 bits for every batch the library takes)
         int row_end = a.V;
@@ -342,12 +362,13 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
             const int4 pi_ = pinfo[pass];
             const float4 ps_ = pscale[pass];
             const int4 pn_ = pinfo[pass + 1 < npass ? pass + 1 : pass];
-            rb = ch_uniform_i(pi_.x) + 16 * wave;
+            rb = ch_uniform_i(pi_.x) + 16 * HH * wave;
             row_end = ch_uniform_i(pi_.y);
             mesh_nx = ch_uniform_i(pn_.z);
-            grp_nx = ch_uniform_i(pn_.w) + wave;
-            grp_cur = ch_uniform_i(pi_.w) + wave;
+            grp_nx = ch_uniform_i(pn_.w) + HH * wave;
+            grp_cur = ch_uniform_i(pi_.w) + HH * wave;
             u_xd = ch_uniform(ps_.x); u_gx = ch_uniform(ps_.y); u_gy = ch_uniform(ps_.z);
+            if constexpr (G0) s_in = ch_uniform(dn_pow2_scale(fmaxf(fmaxf(x_mag, ch_uniform(ps_.w)), 1.f)));     // [g | x | xd] of this pass, xd by its bound
         }
         int rowh[HH]; bool liveh[HH]; int rch[HH];
         int begh[HH], endh[HH];
@@ -356,7 +377,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
             rowh[hh] = rb + 16 * hh + m;
             liveh[hh] = rowh[hh] < row_end;
             rch[hh] = liveh[hh] ? rowh[hh] : row_end - 1;      // dead rows repeat the last row (computed, never stored)
-            if (!SG && a.with_grad) { begh[hh] = a.rowptr[rch[hh]]; endh[hh] = a.rowptr[rch[hh] + 1]; }
+            if (!SG && !PRE && with_grad_) { begh[hh] = a.rowptr[rch[hh]]; endh[hh] = a.rowptr[rch[hh] + 1]; }
         }
 
         // =================================================== gradient features, one 16-row half at a time
@@ -375,7 +396,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
         };
         const float sc0 = s_in * ch_pow2_inv(sw_inv[0]);      // 1 / (output scale of layer 0)
         if constexpr (G0) {
-            if (!a.with_grad) {       // (with gradient features each half's row starts where its g-segment product does)
+            if (!with_grad_) {       // (with gradient features each half's row starts where its g-segment product does)
 #pragma unroll
                 for (int hh = 0; hh < HH; ++hh) bias_init(acc[hh], a.bias[0] + 4 * q, sc0);
             }
@@ -385,20 +406,128 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[hh][nt] = dn_f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        [[maybe_unused]] float s_gf_h[HH];
+        if constexpr (SG && G0) {
+            // =================================================== C = K = 256: the spectral phase of the pass, both halves back to back --
+            // [xd | gx | gy] = [Phi | G_X Phi | G_Y Phi][16 rows] ys[mesh], three products sharing every piece (one sweep of KE pieces per half: a
+            // piece costs ~2.5 k cycles here whatever it multiplies, one wave per SIMD), 192 accumulators while the MiniMLP's are not live yet; the
+            // results go to memory (xd for layer 0, gx / gy for this pass's gradient-feature stage -- the general registers cannot hold both
+            // halves' 256).  The operand fragments stream through FOUR 1-step register buffers, refilled as they are consumed: the compiler's wait in
+            // front of a buffer's first use counts only its own requests (not the ring's), i.e. it lets "the requests of the refills issued since" stay
+            // in flight and, with the ring's requests queued in between, forces part of the NEWEST refill to land -- with two 2-step buffers that was the one
+            // issued a moment ago (its whole HBM latency exposed at every buffer: 8-9 k cycles per piece); with three it is the one before.
+            // (the lane index is recomputed here: the kernel-long `lane` is spilled at the gradient-feature stage's register peak, and a scratch
+            // reload inside this phase's piece loop is followed by a compiler-made s_waitcnt vmcnt(0) that drains the ring and the operand requests
+            // in flight -- measured 8-9 k cycles per piece instead of ~3 k)
+            const int lane_r = ch_fresh_lane();
+            constexpr int FB = 1;                        // contraction steps per fragment buffer (1 x 4 buffers: 68 spilled registers in the kernel; 2 x 3: 116)
+            constexpr int NPART = KE / FB;               // buffer loads per half
+            constexpr int NBUF = 4;
+            static_assert(KE % FB == 0 && HH * NPART > NBUF, "fragment buffers of the spectral phase");
+            uint4 fq[NBUF][FB][3][2];
+            auto load_buf = [&](const int grp, const int part, uint4 (&dst)[FB][3][2]) {
+                // uniform base + a 32-bit lane offset the compiler cannot see through: left to itself it hoists the 48 addresses of a pass's
+                // requests out of the pass loop (2 registers each, live across the whole kernel: 259 spilled registers)
+                const char* base = reinterpret_cast<const char*>(a.sg_pack) + (size_t)grp * (3 * KE * 128 * 16);
+                unsigned lo = 16u * (unsigned)lane_r;
+#ifndef DN_EMULATE
+                asm volatile("" : "+v"(lo));
+#endif
+#pragma unroll
+                for (int t = 0; t < FB; ++t)
+#pragma unroll
+                    for (int op = 0; op < 3; ++op) {
+                        dst[t][op][0] = *reinterpret_cast<const uint4*>(base + (lo + 16u * (unsigned)((op * KE + FB * part + t) * 128)));
+                        dst[t][op][1] = *reinterpret_cast<const uint4*>(base + (lo + 16u * (unsigned)((op * KE + FB * part + t) * 128 + 64)));
+                    }
+            };
+#pragma unroll
+            for (int i = 0; i < NBUF; ++i) load_buf(grp_cur + i / NPART, i % NPART, fq[i]);
+            CH_TR();
+#pragma unroll
+            for (int hh = 0; hh < HH; ++hh) {
+                dn_f32x4 sa[3][NT];
+#pragma unroll
+                for (int op = 0; op < 3; ++op)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) sa[op][nt] = dn_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int part = 0; part < NPART; ++part) {
+                    const int gpi = hh * NPART + part;           // buffer loads are numbered through both halves
+#pragma unroll
+                    for (int t = 0; t < FB; ++t) {
+                        // (the slot's address with this lane's offset folded in and hidden from the optimiser: every weight-fragment read is then
+                        // base + immediate.  Left visible, the compiler precomputes lane x 16 + slot + tile offset for all four 32 KiB slots -- 128
+                        // address registers hoisted out of the pass loop, 70 of them spilled at its head and reloaded inside the pieces)
+                        const ch_lds_p ws_ = ch_opaque_lds(ring + (gp % RING) * PIECE + lane_r);
+                        issue();
+                        constexpr int lane = 0;
+                        CH_MMA3(sa, fq[gpi % NBUF][t]);
+                        // (a refill -- 6 FB requests -- is younger than the piece waited for, DMA(gp + 1), at the ends of the two pieces after it, and
+                        // the initial fills are at the first pieces' ends: they may stay in flight; the last refill goes out after buffer load
+                        // HH NPART - NBUF - 1 was consumed.  Loads only are counted.)
+                        if (gpi + NBUF - 1 < HH * NPART) { CH_WAIT_OPS((RING - 2) * LPT + 6 * FB); CH_BARRIER(); ++gp; }
+                        else CH_PIECE_END();
+                    }
+                    // the buffer just consumed takes the steps NBUF buffer loads on -- of this half, or of the other one (fenced: hoisted above the
+                    // products that still read the buffer, a refill needs 24 MORE registers instead of reusing them)
+                    ch_sched_fence();
+                    if (gpi + NBUF < HH * NPART) load_buf(grp_cur + (gpi + NBUF) / NPART, (gpi + NBUF) % NPART, fq[gpi % NBUF]);
+                    ch_sched_fence();
+                }
+                const long long row = rowh[hh];
+                float wx = 0.f, wg = 0.f;
+                float* od = a.xd_out + row * C + 4 * q;
+                float* ox = a.gx + row * C + 4 * q;
+                float* oy = a.gy + row * C + 4 * q;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float4 vd = make_float4(sa[0][nt][0] * u_xd, sa[0][nt][1] * u_xd, sa[0][nt][2] * u_xd, sa[0][nt][3] * u_xd);
+                    const float4 vx_ = make_float4(sa[1][nt][0] * u_gx, sa[1][nt][1] * u_gx, sa[1][nt][2] * u_gx, sa[1][nt][3] * u_gx);
+                    const float4 vy_ = make_float4(sa[2][nt][0] * u_gy, sa[2][nt][1] * u_gy, sa[2][nt][2] * u_gy, sa[2][nt][3] * u_gy);
+                    wx = dn_f4_amax(wx, vd); wg = dn_f4_amax(wg, vx_); wg = dn_f4_amax(wg, vy_);
+                    if (liveh[hh]) {       // (plain stores: the chain launch behind this one reads these rows)
+                        *reinterpret_cast<float4*>(od + 16 * nt) = vd;
+                        *reinterpret_cast<float4*>(ox + 16 * nt) = vx_;
+                        *reinterpret_cast<float4*>(oy + 16 * nt) = vy_;
+                    }
+                    ch_sched_fence();      // (tile by tile: left free, the scheduler reads all 192 accumulators into general registers first -- next to
+                                           // the other half's prefetched operand buffers that is 288 live registers and 118 spilled ones)
+                }
+                wx = ch_wave_max(wx); wg = ch_wave_max(wg);
+                xdmax = wx > xdmax ? wx : xdmax; gmax = wg > gmax ? wg : gmax;
+                s_gf_h[hh] = ch_uniform(dn_pow2_scale(wg));
+            }
+            CH_TR();
+            if constexpr (MODE == 1) continue;       // (this launch is the spectral phase only; the chain is the MODE 2 launch behind it)
+        }
         uint4 gfh[G0 ? 1 : HH][NK], gfl[G0 ? 1 : HH][NK];     // tanh features (of the two halves) as operand fragments (hi / lo planes) for layer 0
-        [[maybe_unused]] float xdv[SG ? NT : 1][4];            // SG: this wave's xd rows (accumulator layout), layer 0's third operand segment
-        if (a.with_grad) {
+        [[maybe_unused]] float xdv[(SG && !G0) ? NT : 1][4];   // SG, C <= 128: this wave's xd rows (accumulator layout), layer 0's third operand segment
+        if (with_grad_) {
             auto half = [&](const int hh) __attribute__((always_inline)) {
                 const long long row = hh ? rowh[HH - 1] : rowh[0];
                 const bool live = hh ? liveh[HH - 1] : liveh[0];
                 // ---- CSR gather of the row: gx = sum_j vx_j xd[col_j], gy likewise (entry order, fmaf: bit for bit spmm_kernel's sums)
                 float gxv[NT][4], gyv[NT][4];
                 [[maybe_unused]] int beg = 0, end = 0, nmax = 0;
-                if constexpr (!SG) {
+                if constexpr (!SG && !PRE) {
                     beg = hh ? begh[HH - 1] : begh[0]; end = hh ? endh[HH - 1] : endh[0];
                     nmax = (int)ch_wave_max((float)(end - beg));
                 }
-                if constexpr (SG) {
+                if constexpr (PRE) {
+                    // ---- two-launch spectral form: gx, gy of these rows were computed by the spectral launch (MODE 1) in this very layout
+                    const long long rc_ = hh ? rch[HH - 1] : rch[0];
+                    const float* px = a.gx + rc_ * C + 4 * q;
+                    const float* py = a.gy + rc_ * C + 4 * q;
+                    float4 tx[NT], ty[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) { tx[nt] = *reinterpret_cast<const float4*>(px + 16 * nt); ty[nt] = *reinterpret_cast<const float4*>(py + 16 * nt); }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        gxv[nt][0] = tx[nt].x; gxv[nt][1] = tx[nt].y; gxv[nt][2] = tx[nt].z; gxv[nt][3] = tx[nt].w;
+                        gyv[nt][0] = ty[nt].x; gyv[nt][1] = ty[nt].y; gyv[nt][2] = ty[nt].z; gyv[nt][3] = ty[nt].w;
+                    }
+                } else if constexpr (SG && !G0) {
                     // ---- [xd | gx | gy] = [Phi | G_X Phi | G_Y Phi][16 rows] ys[mesh]: the operand fragments arrive pre-split (fp16 hi / lo, this
                     // lane's eight contraction slots of step T as one uint4 per plane: every request of the wave is 1 KiB contiguous), all of a pass's
                     // requested up front; the spectrum's pieces come through the ring.  One piece read from LDS feeds all three products.
@@ -730,7 +859,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
             // operands of the 2 NK pieces of the x and xd segments, fetched two pieces ahead (requesting all of them up front in the
             // one-half form -- the registers would allow it -- measured no gain: 410 vs 400 us block forward, profiles/r05_rcg_ab.txt)
             constexpr int NXR = G0 ? DN_CH_NXR_WIDE : 3;   // (the requests share the in-order return queue with the piece stream: a row still on its way from HBM holds the pieces behind it)
-            constexpr int NFETCH = SG ? NK : 2 * NK;       // pieces whose operand rows come from memory (SG: the xd segment is in registers)
+            constexpr int NFETCH = (SG && !G0) ? NK : 2 * NK;       // pieces whose operand rows come from memory (SG, C <= 128: the xd segment is in registers)
             static_assert(NXR - 1 <= NFETCH, "operand prefetch depth");
             float4 nx[NXR][HH][2];
             auto fetch = [&](int pi, float4 (&d)[HH][2]) {
@@ -744,7 +873,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
 #pragma unroll
             for (int pi = 0; pi < NXR - 1; ++pi) fetch(pi, nx[pi]);
             if constexpr (!G0) {
-                if (a.with_grad) {
+                if (with_grad_) {
 #pragma unroll
                     for (int T = 0; T < NK; ++T) {
                         CH_PIECE_BEGIN();
@@ -758,7 +887,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
                 uint4 fh[HH], fl[HH];
 #pragma unroll
                 for (int hh = 0; hh < HH; ++hh) {
-                    if (SG && pi >= NK) ch_split8(xdv[(2 * (pi - NK)) % NT], xdv[(2 * (pi - NK) + 1) % NT], s_in, fh[hh], fl[hh]);
+                    if (SG && !G0 && pi >= NK) ch_split8(xdv[(2 * (pi - NK)) % NT], xdv[(2 * (pi - NK) + 1) % NT], s_in, fh[hh], fl[hh]);
                     else ch_split8(nx[pi % NXR][hh][0], nx[pi % NXR][hh][1], s_in, fh[hh], fl[hh]);
                 }
                 if constexpr (DN_CH_L0_EXACT == 0) {
@@ -1024,7 +1153,9 @@ int dn_chain_pieces(int C, int with_grad, int with_rot, int n_mlp) {
 size_t dn_chain_ws_bytes(int C, int with_grad, int with_rot, int n_mlp) {
     return (size_t)dn_chain_pieces(C, with_grad, with_rot, n_mlp) * (2 * (C / 16) * 64) * sizeof(uint4);
 }
-bool dn_chain_sg_eligible(int C, int K, int with_grad, int hh) { return (C == 128 || C == 64) && K == 128 && with_grad && hh == 1; }
+bool dn_chain_sg_eligible(int C, int K, int with_grad, int hh) {
+    return with_grad && (((C == 128 || C == 64) && K == 128 && hh == 1) || (C == 256 && K == 256 && hh == 2));
+}
 bool dn_chain_eligible(int C, int n_mlp, const int* widths, int with_grad, long long g_nnz, int V, int backward) {
     if (C != 128 && C != 64 && !(C == 256 && !backward)) return false;
     if (n_mlp < 2 || n_mlp > DN_CH_LAYERS) return false;
@@ -1033,23 +1164,23 @@ bool dn_chain_eligible(int C, int n_mlp, const int* widths, int with_grad, long 
     return V > 0;
 }
 
-template <int C, int NW, int HH, int KE = 0>
+template <int C, int NW, int HH, int KE = 0, int MODE = 0>
 static int chain_launch_nw(ChainArgs a, hipStream_t stream) {
-    a.units = KE > 0 ? a.sg_n_units * (DN_SG_UNIT_ROWS / (16 * NW)) : (a.V + 16 * HH * NW - 1) / (16 * HH * NW);
+    a.units = KE > 0 ? a.sg_n_units * (a.sg_unit_rows / (16 * HH * NW)) : (a.V + 16 * HH * NW - 1) / (16 * HH * NW);
     // eight waves per CU (256 registers per lane each): two 4-wave workgroups or one 8-wave workgroup.  C = 256: one 4-wave workgroup per CU,
     // one wave per SIMD with the whole register file (the gradient-feature stage alone holds gx, gy and both accumulators: 256 registers)
     int g = (C >= 256 ? 1 : 8 / NW) * dn_num_cus();
     if (g > a.units) g = a.units;
     g = (g + 7) / 8 * 8;
-    const size_t smem = C >= 256 ? (size_t)DN_CH_RING * (2 * (C / 16) * 64) * sizeof(uint4) + (size_t)NW * 16 * 128 * sizeof(float)    // piece ring + one 16-row, 128-channel slice per wave
+    const size_t smem = C >= 256 ? (size_t)DN_CH_RING * (2 * (C / 16) * 64) * sizeof(uint4) + (KE > 0 ? (size_t)DN_CH_SG_MAXP * 32 : (size_t)NW * 16 * 128 * sizeof(float))    // piece ring + one 16-row, 128-channel slice per wave (KE > 0: the pass table)
                                  : (size_t)DN_CH_RING * (2 * (C / 16) * 64) * sizeof(uint4) + (size_t)DN_CH_LAYERS * C * sizeof(float) +
                                        (KE > 0 ? (size_t)DN_CH_SG_MAXP * 32 : (size_t)NW * 4 * C * sizeof(float));      // piece ring + biases + one 4-row gather slice per wave (KE > 0: the pass table)
     if (KE > 0 && ((a.units + 7) / 8 + g / 8 - 1) / (g / 8) > DN_CH_SG_MAXP) return 1;      // (never for a batch the dispatch sends here: <= 262144 rows on >= 8 workgroups)
 #ifndef DN_EMULATE
     static unsigned long long lds_opt_in = 0;   // per-device bitmap
-    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&chain_fwd_kernel<C, NW, HH, KE>), smem, &lds_opt_in); if (oe_) return oe_; }
+    { const int oe_ = dn_lds_opt_in(reinterpret_cast<const void*>(&chain_fwd_kernel<C, NW, HH, KE, MODE>), smem, &lds_opt_in); if (oe_) return oe_; }
 #endif
-    DN_LAUNCH((chain_fwd_kernel<C, NW, HH, KE>), dim3(g, 1, 1), dim3(64 * NW, 1, 1), smem, stream, a);
+    DN_LAUNCH((chain_fwd_kernel<C, NW, HH, KE, MODE>), dim3(g, 1, 1), dim3(64 * NW, 1, 1), smem, stream, a);
     return (int)hipGetLastError();
 }
 template <int C>
@@ -1070,7 +1201,17 @@ static int chain_launch(int npieces, const ChainArgs& a_in, hipStream_t stream, 
     if (hh == 1 && nw > 4) nw = 4;
     ChainArgs a = a_in;
     a.n_pieces = npieces;
-    if constexpr (C >= 256) return chain_launch_nw<C, 4, 2>(a, stream);      // (one form: BASELINE config 4 is a 200k-vertex mesh)
+    if constexpr (C >= 256) {      // (one wave shape: BASELINE config 4 is a 200k-vertex mesh)
+        if (!a.sg_pack) return chain_launch_nw<C, 4, 2>(a, stream);
+        // spectral-gradient form at C = K = 256: the spectral phase (xd, gx, gy -> memory, their magnitudes -> xd_amax_out / g_amax), then the chain
+        // reading them (plain rows, plain piece stream)
+        const int e1 = chain_launch_nw<C, 4, 2, 8, 1>(a, stream);
+        if (e1) return e1;
+        ChainArgs b = a;
+        b.sg_pack = nullptr; b.sg_units = nullptr; b.sg_n_units = 0; b.ysp = nullptr;
+        b.xd_amax = a.xd_amax_out;
+        return chain_launch_nw<C, 4, 2, 0, 2>(b, stream);
+    }
     else {
     if (a.sg_pack) {       // spectral-gradient form (dn_chain_sg_eligible: hh == 1, k_eig == 128)
         if (hh != 1) return 1;
@@ -1100,6 +1241,7 @@ int dn_launch_chain_prep(const ChainPrepArgs& pa, int npieces, int C, hipStream_
 }
 int dn_launch_chain_fwd(int npieces, const ChainArgs& a, int C, hipStream_t stream, int hh) {
     if (npieces > DN_CH_MAX_PIECES || (hh != 1 && hh != 2)) return 1;
+    if (a.sg_pack && C >= 256 && (!a.xd_out || a.xd != a.xd_out || !a.gx || !a.gy)) return 1;      // (the C = 256 spectral form reads xd, gx, gy back from the buffers it writes)
     dn_prof_begin(DN_K_CHAIN, stream);
     int err;
     if (C == 128) err = chain_launch<128>(npieces, a, stream, hh);
@@ -1115,8 +1257,9 @@ int dn_launch_chain_fwd(int npieces, const ChainArgs& a, int C, hipStream_t stre
         if (a.sg_pack && a.xd_out) nw += 1.0;
         for (int j = 0; j < DN_CH_LAYERS; ++j) if (j < a.n_mlp - 1 && a.h[j]) nw += 1.0;
         const double prod = (a.with_grad ? (a.with_rot ? 4.0 : 2.0) : 0.0) + (a.with_grad ? 3.0 : 2.0) + (a.n_mlp - 1);
-        const double rd = a.sg_pack ? VC + 3.0 * 4.0 * (double)a.V * 128.0 : 2.0 * VC;
-        dn_prof_end(DN_K_CHAIN, stream, 2.0 * (double)a.V * C * C * prod + (a.sg_pack ? 3.0 * 2.0 * (double)a.V * 128.0 * C : 0.0), rd + VC * nw);
+        const double Ksg = a.sg_pack ? (C >= 256 ? 256.0 : 128.0) : 0.0;
+        const double rd = a.sg_pack ? VC + 3.0 * 4.0 * (double)a.V * Ksg + (C >= 256 ? VC : 0.0) : 2.0 * VC;      // (C = 256: xd written and read back)
+        dn_prof_end(DN_K_CHAIN, stream, 2.0 * (double)a.V * C * C * prod + 3.0 * 2.0 * (double)a.V * Ksg * C, rd + VC * nw + (a.sg_pack && C >= 256 && !a.gx ? VC : 0.0));
     }
     return err;
 }

@@ -518,11 +518,11 @@ struct ChainArgs {
     // computed in the kernel as [Phi | G_X Phi | G_Y Phi][rows] * ys[mesh] from the packed operands of the batch (sg_pack) and the scaled
     // spectrum's pieces (ysp); xd / rowptr / col / vx / vy / xd_amax / grad_norm above are unused
     const uint4* sg_pack;                 // [groups][3][KE][2][64] fragment-ordered fp16 (hi, lo) planes, 16 rows per group, 4 groups per unit
-    const DnTile* sg_units;               // [sg_n_units] runs of <= 64 rows of one mesh; unit u owns groups 4 u .. 4 u + 3
-    int sg_n_units;
-    const float* sg_amax;                 // [n_mesh][4]: largest magnitudes of Phi, G_X Phi, G_Y Phi per mesh (their power-of-two scales)
+    const DnTile* sg_units;               // [sg_n_units] runs of <= dn_sg_unit_rows(K) rows of one mesh; unit u owns that many / 16 consecutive groups
+    int sg_n_units, sg_unit_rows, sg_n_mesh;
+    const float* sg_amax;                 // [n_mesh][4]: largest magnitudes of Phi, G_X Phi, G_Y Phi per mesh (their power-of-two scales), largest row 2-norm of Phi
     const uint4* ysp;                     // [n_mesh][KE][piece] the scaled spectrum as transposed weight pieces (dn_launch_spec_pieces)
-    const float* ys_amax;                 // [n_mesh] largest magnitude of every mesh's scaled spectrum
+    const float* ys_amax;                 // [2 n_mesh] largest magnitude of every mesh's scaled spectrum; behind them the largest column 2-norms
     float* xd_out;                        // [V, C] receives xd (saved for the backward), or null
     float* xd_amax_out;                   // accumulates max |xd| (g_amax accumulates max |gx|, |gy| in this form)
 };
@@ -556,14 +556,14 @@ int dn_launch_chain_fwd(int npieces, const ChainArgs& a, int C, hipStream_t stre
 // ---- spectral-gradient operands (dn_spectral.hip): the gradient apply re-associated, gx = G_X (Phi ys) = (G_X Phi) ys.  Built once per
 // mesh batch: G_X Phi, G_Y Phi by a CSR gather accumulated in fp64, then [Phi | G_X Phi | G_Y Phi] split into fp16 (hi, lo) planes in the
 // operand-fragment order of the chained forward kernel, 16 rows per group, every mesh padded to whole 64-row units.
-#define DN_SG_UNIT_ROWS 64
-bool dn_chain_sg_eligible(int C, int K, int with_grad, int hh);     // shapes chain_fwd_kernel<C, NW, 1, K / 32> is instantiated for
-int dn_sg_units_host(const int* sizes, int n_mesh, DnTile* out);    // out may be null: returns the unit count
+int dn_sg_unit_rows(int K);                                         // rows per unit: 64 (K <= 128), 128 (K = 256) = one workgroup pass of the consuming kernel
+bool dn_chain_sg_eligible(int C, int K, int with_grad, int hh);     // shapes chain_fwd_kernel<C, NW, HH, K / 32> is instantiated for
+int dn_sg_units_host(const int* sizes, int n_mesh, int K, DnTile* out);    // out may be null: returns the unit count
 size_t dn_sg_pack_elems(int n_units, int K);                        // uint4 elements of the packed operand
 int dn_launch_sg_pack(const DnTile* units, int n_units, int n_mesh, int K, const float* evecs, const int* rowptr, const int* col, const float* vx,
                       const float* vy, float* gpx, float* gpy, float* amax4, uint4* out, hipStream_t stream);
 // ys [n_mesh, K, C] -> transposed weight pieces [n_mesh][K / 32][2 (C / 16) 64] uint4 (fp16 hi / lo planes scaled by the power of two of the
-// mesh's largest |ys|), ys_amax[n_mesh] receives those magnitudes
+// mesh's largest |ys|); ys_amax[2 n_mesh] receives those magnitudes and, behind them, every mesh's largest column 2-norm of ys
 int dn_launch_spec_pieces(const float* ys, int n_mesh, int K, int C, uint4* out, float* ys_amax, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------

@@ -85,7 +85,7 @@ _SIGNATURES = {
     "dn_diffusion_fwd_f32": (C.c_int, [_P(MeshBatchStruct), _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]),
     "dn_diffusion_bwd_f32": (C.c_int, [_P(MeshBatchStruct), _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "dn_spectral_grad_supported": (C.c_int, [C.c_int, C.c_int]),
-    "dn_spectral_units": (C.c_int, [_vp, C.c_int, _vp]),
+    "dn_spectral_units": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "dn_spectral_pack_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "dn_spectral_pack_workspace_bytes": (C.c_size_t, [_P(MeshBatchStruct)]),
     "dn_spectral_pack_f32": (C.c_int, [_P(MeshBatchStruct), _vp, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]),

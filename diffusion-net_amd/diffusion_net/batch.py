@@ -139,18 +139,18 @@ def _plan_on(device, sizes, n_groups):
     return hit
 
 
-def _sg_units_on(device, sizes):
-    """Unit table of the spectral-gradient operands (``dn_spectral_units``, host arithmetic in the library): runs of <= 64 rows of one mesh."""
-    key = ("sg_units", str(device), tuple(sizes))
+def _sg_units_on(device, sizes, k_eig):
+    """Unit table of the spectral-gradient operands (``dn_spectral_units``, host arithmetic in the library): runs of <= 64 (128 at K = 256) rows of one mesh."""
+    key = ("sg_units", str(device), tuple(sizes), int(k_eig))
     hit = _table_cache.get(key)
     if hit is None:
         if len(_table_cache) > 256:
             _table_cache.clear()
         L = _hip.lib()
         arr = np.ascontiguousarray(np.asarray(sizes, dtype=np.int32))
-        n = int(L.dn_spectral_units(arr.ctypes.data, len(arr), None))
+        n = int(L.dn_spectral_units(arr.ctypes.data, len(arr), int(k_eig), None))
         units = np.zeros((max(n, 1), 4), dtype=np.int32)
-        L.dn_spectral_units(arr.ctypes.data, len(arr), units.ctypes.data)
+        L.dn_spectral_units(arr.ctypes.data, len(arr), int(k_eig), units.ctypes.data)
         hit = (torch.from_numpy(units[:n].copy()).to(device), n)
         _table_cache[key] = hit
     return hit
@@ -319,8 +319,8 @@ class MeshBatch:
         self.sg_pack = self.sg_units = self.sg_amax = None
         L = _hip.lib()
         if spectral_grad and self.g_rowptr is not None and self.evecs is not None and vt > 0 and s.g_nnz > 0 \
-                and L.dn_spectral_grad_supported(self.k_eig, 128):
-            self.sg_units, n_units = _sg_units_on(self.device, self.sizes)
+                and (L.dn_spectral_grad_supported(self.k_eig, 128) or L.dn_spectral_grad_supported(self.k_eig, 256)):
+            self.sg_units, n_units = _sg_units_on(self.device, self.sizes, self.k_eig)
             self.sg_pack = torch.empty(int(L.dn_spectral_pack_bytes(n_units, self.k_eig)), dtype=torch.uint8, device=self.device)
             self.sg_amax = torch.empty(4 * len(self.sizes), dtype=torch.float32, device=self.device)
             ws = _hip.workspace(self.device, L.dn_spectral_pack_workspace_bytes(C.byref(s)))

@@ -238,6 +238,7 @@ class DiffusionNetBlock(nn.Module):
             seed, seed_dev = (masks if isinstance(masks, tuple) else (masks or 0, None))
             return torch.ops.diffusion_net.block(x2d, self.diffusion.diffusion_time, A_re, A_im, wb, mb.handle, self._cfg.handle, seed, seed_dev,
                                                  mb.n_mesh, mb.k_eig)[0]
+        self._cfg._grad_enabled = torch.is_grad_enabled()      # (sampled here: inside the Function's forward grad mode is always off)
         return ops.BlockFn.apply(mb, self._cfg, masks, x2d, self.diffusion.diffusion_time, A_re, A_im, *wb)
 
     def forward(self, x_in, mass, L, evals, evecs, gradX, gradY):

@@ -420,7 +420,11 @@ class BlockFn(torch.autograd.Function):
         p = _params_struct(cfg, time, A_re, A_im, Ws, bs, masks, x_amax, out_amax)
         p.clamp_time = 1 if clamp_in_call else 0
         out = new(V, Cc)
-        need_grad = any(ctx.needs_input_grad)
+        # ctx.needs_input_grad is True for every Parameter even under torch.no_grad() (torch 2.10), and grad mode is always off inside a
+        # Function's forward: the caller samples torch.is_grad_enabled() and leaves it on the config (layers.forward_packed).  Until round 6
+        # every "inference" call through the package ran the TRAINING forward (eight saved arrays of [V, C] written per block: +11 % at
+        # BASELINE config 4's shape) -- and with it never took the inference-only kernel choices.
+        need_grad = any(ctx.needs_input_grad) and bool(getattr(cfg, "_grad_enabled", True))
         if need_grad:
             sv = _hip.BlockSavedStruct()
             xs, xd = new(mb.n_mesh, mb.k_eig, Cc), new(V, Cc)

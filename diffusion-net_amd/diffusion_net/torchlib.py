@@ -113,6 +113,7 @@ def block(x: Tensor, time: Tensor, A_re: Optional[Tensor], A_im: Optional[Tensor
     """-> [out, xs, xd, words, (gx, gy, g, bre, bim), h_0 ...]: the output and what the backward needs besides the inputs."""
     ctx = _Ctx([False] * 3 + [True] * (4 + len(wb)))
     ctx.no_clamp = True        # `time` is an input of a custom op that declares no mutation: the caller has clamped it (layers.forward_packed)
+    _obj(cfg)._grad_enabled = True      # (this op always returns what its backward op needs)
     out = ops.BlockFn.forward(ctx, _obj(mb), _obj(cfg), _masks(seed, seed_dev), x, time, A_re, A_im, *wb)
     return [out] + list(ctx.saved_tensors[2:5 + ctx.n_feat + ctx.n_h])
 

@@ -69,7 +69,7 @@ typedef struct dn_mesh_batch {
     const dn_tile_t* df_plan; int32_t df_n_wg, df_n_groups;
     /* Optional (round 6): the spectral-gradient operands of the batch (dn_spectral_pack_f32): the spatial gradient apply re-associated
      * through the eigenbasis, gradX (evecs ys) = (gradX evecs) ys.  sg_pack: [evecs | gradX evecs | gradY evecs] as fp16 (hi, lo) operand
-     * fragments, 16 rows per group, every mesh padded to whole 64-row units; sg_units: [sg_n_units] the units ({row0, nrows <= 64, mesh, 0},
+     * fragments, 16 rows per group, every mesh padded to whole units of 64 (k_eig <= 128) / 128 (k_eig = 256) rows; sg_units: [sg_n_units] the units ({row0, nrows, mesh, 0},
      * dn_spectral_units()); sg_amax: [n_mesh][4] floats, the per-mesh magnitudes the fragments were scaled by.  With them the block forward
      * computes xd, gx, gy inside its chained row kernel (no back-projection launch, no CSR gather) for the shapes
      * dn_spectral_grad_supported() names.  NULL / 0: back-projection + gather, as before. */
@@ -202,14 +202,16 @@ int dn_diffusion_bwd_f32(const dn_mesh_batch_t* mb, const float* d_xd, const flo
 
 /* ---- spectral-gradient operands (dn_spectral.hip; no reference counterpart: layers.py:213-223 applies gradX / gradY to x_diffuse = evecs ys,
  *      which lies in the span of evecs -- gradX x_diffuse = (gradX evecs) ys exactly).  Built ONCE per mesh batch:
- *      dn_spectral_grad_supported(k_eig, C): 1 if the block forward takes the operands at this shape (k_eig = 128, C in {64, 128}).
- *      dn_spectral_units(): HOST arithmetic -- sizes[n_mesh] = vertices per mesh in row order -> units[] (NULL: count only); returns the count.
+ *      dn_spectral_grad_supported(k_eig, C): 1 if the block forward takes the operands at this shape (k_eig = 128 with C in {64, 128};
+ *      k_eig = C = 256).
+ *      dn_spectral_units(): HOST arithmetic -- sizes[n_mesh] = vertices per mesh in row order -> units[] (NULL: count only) of <= 64 rows
+ *      (k_eig <= 128) or <= 128 rows (k_eig = 256) of one mesh each; returns the count.
  *      dn_spectral_pack_bytes(n_units, k_eig): bytes of the packed operand.  dn_spectral_pack_workspace_bytes(): scratch of the pack call.
  *      dn_spectral_pack_f32(): mb needs evecs, the gradient CSR and k_eig % 32 == 0; units = DEVICE copy of the unit table; writes
  *      sg_pack[dn_spectral_pack_bytes] and sg_amax[4 n_mesh]; gradX evecs / gradY evecs are accumulated in fp64 in entry order (deterministic).
  *      The caller then sets mb->sg_pack / sg_units / sg_amax / sg_n_units. */
 int dn_spectral_grad_supported(int k_eig, int C);
-int dn_spectral_units(const int32_t* sizes, int n_mesh, dn_tile_t* units);
+int dn_spectral_units(const int32_t* sizes, int n_mesh, int k_eig, dn_tile_t* units);
 size_t dn_spectral_pack_bytes(int n_units, int k_eig);
 size_t dn_spectral_pack_workspace_bytes(const dn_mesh_batch_t* mb);
 int dn_spectral_pack_f32(const dn_mesh_batch_t* mb, const dn_tile_t* units, int n_units, void* sg_pack, float* sg_amax,

@@ -160,14 +160,13 @@ def run_chain_vs_unfused(device, sizes=(300, 140), K=128, C=128, N_block=2, drop
 # ------------------------------------------------------------------------------------------
 # spectral-gradient form of the chained forward (dn_spectral.hip, chain_fwd_kernel<.., KE>) vs the back-projection + gather form
 # ------------------------------------------------------------------------------------------
-def run_spectral_grad(device, sizes=(300, 140, 131), C=128, N_block=2, dropout=True, seed=7, chain_nw=0, fwd_tol=4e-6, grad_tol=2e-5):
+def run_spectral_grad(device, sizes=(300, 140, 131), C=128, N_block=2, dropout=True, seed=7, chain_nw=0, fwd_tol=4e-6, grad_tol=2e-5, K=128):
     """K = 128.  Same model, batch and dropout seed with the library option "spectral_grad" on and off: the chained forward kernel computes
     xd = evecs ys, gx = (gradX evecs) ys, gy = (gradY evecs) ys itself from the batch's packed operands (layers.py:213-223 re-associated), or reads
     xd from the back-projection launch and gathers gx, gy through the CSR.  Training forward + every gradient, the saved xd / gx / gy, and the
     inference forward; the two forms differ in rounding only and must NOT be bitwise equal.  Both are also measured against the fp64 oracle: the
     spectral form must be at least as close as max(1e-5, 2 x the gather form)."""
     from diffusion_net import _hip
-    K = 128
     meshes, feats = make_ragged(sizes, K, 3, seed)
     mb = pack(meshes, device, chunk_rows=64)
     assert mb.sg_pack is not None, "the batch carries no spectral-gradient operands"
@@ -175,7 +174,7 @@ def run_spectral_grad(device, sizes=(300, 140, 131), C=128, N_block=2, dropout=T
     saved = {k: _hip.get_option(k) for k in ("spectral_grad", "chain_nw")}
     try:
         _hip.set_option("chain_nw", chain_nw)
-        for mode in (1, 0):
+        for mode in (2, 0):          # (2: the spectral form at every size, also in the training forward)
             _hip.set_option("spectral_grad", mode)
             torch.manual_seed(seed)
             model = diffusion_net.layers.DiffusionNet(3, 5, C_width=C, N_block=N_block, outputs_at="vertices", dropout=dropout)
@@ -200,7 +199,7 @@ def run_spectral_grad(device, sizes=(300, 140, 131), C=128, N_block=2, dropout=T
     finally:
         for k, v in saved.items():
             _hip.set_option(k, v)
-    (o1, g1, s1, i1, p1), (o0, g0, s0, i0, p0) = got[1], got[0]
+    (o1, g1, s1, i1, p1), (o0, g0, s0, i0, p0) = got[2], got[0]
     # A ReLU net is piecewise linear: a hidden unit within rounding distance of zero lands on either side in the two forms, and ONE flipped
     # (vertex, unit) pair moves the parameter gradients of its own and of every earlier block by ~1e-3 (run_ragged_net's flip-aware criterion).
     # The gradients are therefore compared strictly from the first block BEHIND the last flip on; the flips must be rare.

@@ -93,6 +93,7 @@ def test_spectral_gradient_form_on_emulator(emu):
     parity_cases.run_spectral_grad(emu, sizes=(150, 193), N_block=1, dropout=False, chain_nw=2)
     parity_cases.run_spectral_grad(emu, sizes=(200, 129), N_block=1, dropout=False, chain_nw=1)
     parity_cases.run_spectral_grad(emu, sizes=(150, 170), C=64, N_block=1, dropout=False)
+    parity_cases.run_spectral_grad(emu, sizes=(300, 260), C=256, K=256, N_block=1, dropout=False)      # BASELINE config 4's shape: one wave per SIMD, 128-row units
 
 
 def test_per_call_engine_flags_on_emulator(emu):

@@ -183,6 +183,8 @@ def test_spectral_gradient_form_vs_gather(dev):
     parity_cases.run_spectral_grad(dev, sizes=(200, 129), N_block=1, dropout=False, chain_nw=1)
     parity_cases.run_spectral_grad(dev, sizes=(900, 170), C=64, N_block=2, dropout=False)
     parity_cases.run_spectral_grad(dev, sizes=(20500, 19999), N_block=1, dropout=True)
+    parity_cases.run_spectral_grad(dev, sizes=(300, 260), C=256, K=256, N_block=1, dropout=False)         # BASELINE config 4's width and basis size
+    parity_cases.run_spectral_grad(dev, sizes=(5000, 3300, 700), C=256, K=256, N_block=2, dropout=True)
 
 
 def test_per_call_engine_flags(dev):

@@ -167,10 +167,10 @@ int main(int argc, char** argv) {
     int sg_units_n = 0;
     if (!getenv("KB_NO_SG") && L.sym<int (*)(int, int)>("dn_spectral_grad_supported")(K, C)) {
         // spectral-gradient operands, as diffusion_net.batch.MeshBatch attaches them (dn_spectral.hip): built once, on the device
-        auto f_units = L.sym<int (*)(const int32_t*, int, dn_tile_t*)>("dn_spectral_units");
-        sg_units_n = f_units(sizes.data(), n_mesh, nullptr);
+        auto f_units = L.sym<int (*)(const int32_t*, int, int, dn_tile_t*)>("dn_spectral_units");
+        sg_units_n = f_units(sizes.data(), n_mesh, K, nullptr);
         std::vector<dn_tile_t> units(sg_units_n);
-        f_units(sizes.data(), n_mesh, units.data());
+        f_units(sizes.data(), n_mesh, K, units.data());
         const dn_tile_t* d_units = dev(units);
         void* pack; HC(hipMalloc(&pack, L.sym<size_t (*)(int, int)>("dn_spectral_pack_bytes")(sg_units_n, K)));
         float* sgam = devz((size_t)4 * n_mesh);
