@@ -687,7 +687,9 @@ static bool block_sg_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p, i
             (int)dn_chain_sg_eligible(p->C, mb->k_eig, p->with_grad, chain_hh(mb, false, p->C)), p->C, mb->k_eig, p->with_grad, chain_hh(mb, false, p->C), (int)diffuse_ok(mb, p->C));
 #endif
     const int o = (p->flags & DN_BLOCK_NO_SPECTRAL_GRAD) ? 0 : ((p->flags & DN_BLOCK_SPECTRAL_GRAD_ALWAYS) ? 2 : opt(O_SPECTRAL_GRAD));
-    return o && kind < 2 && (o >= 2 || kind == 0 || mb->v_total <= 65536) && mb->sg_pack && mb->sg_units && mb->sg_amax && mb->sg_n_units > 0 && al16(mb->sg_pack) && al16(mb->sg_amax) &&
+    // (C = K = 256, the two-launch form: measured SLOWER than back-projection + gather -- BASELINE config 4 at 27.1 M vertices/s against 29.1 M, its
+    // spectral launch takes 404 us where ~250 would pay -- and therefore only taken when asked for: option value 2 / DN_BLOCK_SPECTRAL_GRAD_ALWAYS)
+    return o && kind < 2 && (o >= 2 || (p->C < 256 && (kind == 0 || mb->v_total <= 65536))) && mb->sg_pack && mb->sg_units && mb->sg_amax && mb->sg_n_units > 0 && al16(mb->sg_pack) && al16(mb->sg_amax) &&
            mb->sg_n_units <= 100 * dn_num_cus() &&      // (a workgroup's pass table lives in LDS: DN_CH_SG_MAXP = 64 passes of 2 x CUs workgroups)
            block_chain_ok(mb, p, kind) && dn_chain_sg_eligible(p->C, mb->k_eig, p->with_grad, chain_hh(mb, false, p->C)) && !diffuse_ok(mb, p->C);
 }

@@ -159,6 +159,10 @@ def _sg_units_on(device, sizes, k_eig):
 # False: batches are packed without the spectral-gradient operands (3 x 4 V K bytes per mesh) and the block forward keeps the back-projection
 # launch + CSR gather (the library option "spectral_grad" = 0 selects that at run time for batches that do carry them)
 spectral_grad = True
+# True: also for k_eig = 256 batches (the two-launch form of C = K = 256; 3 x 4 V K bytes = 614 MB for one 200k-vertex mesh).  Off by default: that
+# form measures slower than back-projection + gather (BASELINE config 4: 27.1 against 29.1 M vertices/s) and is only taken with the library
+# option "spectral_grad" = 2; the tests switch this on.
+spectral_grad_wide = False
 
 
 def _tables_on(device, sizes, chunk_rows):
@@ -319,7 +323,7 @@ class MeshBatch:
         self.sg_pack = self.sg_units = self.sg_amax = None
         L = _hip.lib()
         if spectral_grad and self.g_rowptr is not None and self.evecs is not None and vt > 0 and s.g_nnz > 0 \
-                and (L.dn_spectral_grad_supported(self.k_eig, 128) or L.dn_spectral_grad_supported(self.k_eig, 256)):
+                and (L.dn_spectral_grad_supported(self.k_eig, 128) or (spectral_grad_wide and L.dn_spectral_grad_supported(self.k_eig, 256))):
             self.sg_units, n_units = _sg_units_on(self.device, self.sizes, self.k_eig)
             self.sg_pack = torch.empty(int(L.dn_spectral_pack_bytes(n_units, self.k_eig)), dtype=torch.uint8, device=self.device)
             self.sg_amax = torch.empty(4 * len(self.sizes), dtype=torch.float32, device=self.device)

@@ -161,7 +161,8 @@ int dn_tn_target_chunks(void);  /* how many entries dn_mesh_batch_t.chunks shoul
  *        "diffuse_split" (0)    one-launch kernel: bit i = a kernel boundary after schedule step i (measurements)
  *        "spectral_grad" (1)    batches that carry spectral-gradient operands (dn_spectral_pack_f32): the chained forward kernel computes xd, gx, gy
  *                               from them (no back-projection launch, no CSR gather) -- 1 = in the inference forward at every size and in the training
- *                               forward up to 65536 rows (where it measures faster), 2 = always, 0 = never (back-projection + gather) */
+ *                               forward up to 65536 rows, both at C <= 128 (where it measures faster), 2 = wherever a form exists (incl. the two-launch
+ *                               form of k_eig = C = 256, which measures slower), 0 = never (back-projection + gather) */
 int dn_set_option(const char* name, int value);
 int dn_get_option(const char* name, int* value);
 

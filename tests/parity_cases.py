@@ -166,9 +166,14 @@ def run_spectral_grad(device, sizes=(300, 140, 131), C=128, N_block=2, dropout=T
     xd from the back-projection launch and gathers gx, gy through the CSR.  Training forward + every gradient, the saved xd / gx / gy, and the
     inference forward; the two forms differ in rounding only and must NOT be bitwise equal.  Both are also measured against the fp64 oracle: the
     spectral form must be at least as close as max(1e-5, 2 x the gather form)."""
-    from diffusion_net import _hip
+    from diffusion_net import _hip, batch as _batch
     meshes, feats = make_ragged(sizes, K, 3, seed)
-    mb = pack(meshes, device, chunk_rows=64)
+    wide = _batch.spectral_grad_wide
+    _batch.spectral_grad_wide = True            # (k_eig = 256 batches carry the operands only on request)
+    try:
+        mb = pack(meshes, device, chunk_rows=64)
+    finally:
+        _batch.spectral_grad_wide = wide
     assert mb.sg_pack is not None, "the batch carries no spectral-gradient operands"
     got, params = {}, None
     saved = {k: _hip.get_option(k) for k in ("spectral_grad", "chain_nw")}
