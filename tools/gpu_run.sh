@@ -64,6 +64,8 @@ evidence)
   timeout 200 python bench.py --eager --no-cpu-baseline --no-other-configs > gpurun_out/bench_eager.json 2>> gpurun_out/bench.err < /dev/null
   timeout 200 python bench.py --lib-opt chain=0 --no-cpu-baseline --no-other-configs > gpurun_out/bench_chain_off.json 2>> gpurun_out/bench.err < /dev/null
   timeout 200 python bench.py --lib-opt diffuse=0 --no-cpu-baseline --no-other-configs > gpurun_out/bench_diffuse_off.json 2>> gpurun_out/bench.err < /dev/null
+  timeout 200 python bench.py --lib-opt spectral_grad=2 --no-cpu-baseline --no-other-configs > gpurun_out/bench_spectral_always.json 2>> gpurun_out/bench.err < /dev/null
+  timeout 200 python bench.py --lib-opt spectral_grad=0 --no-cpu-baseline --no-other-configs > gpurun_out/bench_spectral_off.json 2>> gpurun_out/bench.err < /dev/null
   (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_b && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o trace -- python "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs > "$R/gpurun_out/prof_bench.json" 2> "$R/gpurun_out/prof.err" < /dev/null)
   f=$(find /tmp/prof_b -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" gpurun_out/bench_kernel_stats.csv
   f=$(find /tmp/prof_b -name "*kernel_trace.csv" 2>/dev/null | head -1); [ -n "$f" ] && python tools/step_kernels.py "$f" > gpurun_out/step_kernels.txt 2>&1
@@ -79,9 +81,9 @@ evidence)
     (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_m && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_m -o trace -- python "$R/tools/microbench.py" --reps 3 > /dev/null 2>&1 < /dev/null)
     f=$(find /tmp/prof_m -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" gpurun_out/microbench_kernel_stats.csv
     [ -f gpurun_out/pmc_fetch.txt ] && python tools/traffic_summary.py gpurun_out/pmc_fetch.txt gpurun_out/pmc_write.txt gpurun_out/microbench_kernel_stats.csv gpurun_out/traffic.json > gpurun_out/traffic_summary.log 2>&1
-    OPS=diffusion,diffusion_bwd,block_fwd,block_bwd TAG=r05 timeout 600 bash tools/pmc_kbench.sh > gpurun_out/pmc_sq.log 2>&1 < /dev/null
+    OPS=diffusion,diffusion_bwd,block_fwd,block_bwd,block_inf TAG=r06 timeout 600 bash tools/pmc_kbench.sh > gpurun_out/pmc_sq.log 2>&1 < /dev/null
   fi
-  for j in bench bench_eager bench_chain_off bench_diffuse_off; do python tools/bench_brief.py < gpurun_out/$j.json; done
+  for j in bench bench_eager bench_chain_off bench_diffuse_off bench_spectral_always bench_spectral_off; do python tools/bench_brief.py < gpurun_out/$j.json; done
   tail -3 gpurun_out/bench.err; cat gpurun_out/traffic_summary.log 2>/dev/null | tail -8 ;;
 *) echo "unknown section $sec"; exit 1 ;;
 esac
