@@ -29,7 +29,7 @@ import torch.nn.functional as F
 PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: exact-f32 MFMA = f32 vector peak
 PEAK_HBM_GBPS = 8000.0            # HBM3E spec (6.29 TB/s measured copy ceiling)
 PEAK_MFMA_BF16_TFLOPS = 2500.0    # dense bf16 MFMA (no sparsity)
-TRAFFIC_JSON = "r05_traffic.json"  # PMC FETCH/WRITE passes of the same kernels (tools/pmc_run.sh + tools/traffic_summary.py), committed under profiles/
+TRAFFIC_JSON = "r06_traffic.json"  # PMC FETCH/WRITE passes of the same kernels (tools/pmc_run.sh + tools/traffic_summary.py), committed under profiles/
 
 
 def mesh_sizes(n_meshes, v_mean, rank):
@@ -270,9 +270,12 @@ def kernel_family_report(lib):
     # HBM bytes per launch of that family from the committed FETCH_SIZE / WRITE_SIZE PMC passes (separate rocprofv3
     # --pmc runs of the same workload, gfx950 x2 read correction applied; tools/traffic_summary.py)
     try:
-        tj = TRAFFIC_JSON if os.path.exists(os.path.join(ROOT, "profiles", TRAFFIC_JSON)) else "r04_traffic.json"
+        tj = TRAFFIC_JSON if os.path.exists(os.path.join(ROOT, "profiles", TRAFFIC_JSON)) else "r05_traffic.json"
         tr = json.load(open(os.path.join(ROOT, "profiles", tj)))
-        roof["traffic"] = tr[dom["kernel"]]["hbm_bytes_per_launch"]
+        # (the PMC workload also runs the inference forward -- another instantiation of the same kernel, a fraction of the traffic: the member
+        # with the largest traffic is the training-step kernel this line is about)
+        ent = tr[dom["kernel"]]
+        roof["traffic"] = max([m["hbm_bytes_per_launch"] for m in ent.get("members", {}).values()] or [ent["hbm_bytes_per_launch"]])
         roof["traffic_source"] = ("NOT measured in this run: read from profiles/%s -- separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; "
                                   "(2*FETCH_SIZE+WRITE_SIZE)*1024 B per launch, gfx950 read correction) over tools/microbench.py at this batch shape; "
                                   "algorithmic bytes per launch = %.4g" % (tj, dom["bytes_per_launch"]))
