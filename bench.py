@@ -601,6 +601,9 @@ def main():
     for kv in args.lib_opt:                    # applied when the library is bound (and to every sub-run: they get the same flags)
         k_, v_ = kv.split("=", 1)
         _hip.default_options[k_] = int(v_)
+    if _hip.default_options.get("spectral_grad") == 2:   # "always": k_eig = 256 batches carry the packed operands too (off by default: DESIGN.md)
+        from diffusion_net import batch as _batch
+        _batch.spectral_grad_wide = True
     if not os.path.exists(_hip.LIB_PATH):      # fresh checkout: compile the HIP sources once (rank 0), never a fallback
         if rank == 0:
             import __graft_entry__

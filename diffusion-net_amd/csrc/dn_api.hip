@@ -139,8 +139,15 @@ int to_basis_partials(const dn_mesh_batch_t* mb, const float* x, int C, bool use
     tn_finish(g);
     return dn_launch_tngemm(g, mb->n_chunks, st);
 }
+// the forward back-projection at K = C = 256 as the ring kernel of dn_backproject_wide.hip (3-term engine; option "diffuse" != 0; needs a
+// workspace for the split spectrum: the block calls and dn_diffusion_f32 pass one, callers without take the row GEMM)
+bool bw_ok(const dn_mesh_batch_t* mb, int C) {
+    return opt(O_DIFFUSE) != 0 && mb->tiles && dn_backproject_wide_ok(mb->k_eig, C, mb->n_tiles) && al16(mb->evecs);
+}
 int from_basis(const dn_mesh_batch_t* mb, const float* spec, int C, float* out, const float* add, bool mass_epi, hipStream_t st,
-               const F16& f = F16()) {
+               const F16& f = F16(), float* wide_ws = nullptr) {
+    if (wide_ws && !mass_epi && !add && !f.on && bw_ok(mb, C) && al16(spec) && al16(out) && al16(wide_ws))
+        return dn_launch_backproject_wide(T(mb->tiles), mb->n_tiles, mb->n_mesh, mb->evecs, spec, wide_ws, out, f.o, mb->k_eig, C, mb->v_total, st);
     if (bp_ok(mb, C) && al16(spec) && al16(out) && al16(add) && al16(mb->evecs))       // direct row product, on the engine f asks for
         return dn_launch_backproject(T(mb->df_plan), mb->df_n_wg, mb->evecs, spec, out, add, mass_epi ? mb->mass : nullptr, f.o, mb->v_total, st,
                                      f.on ? 1 : 0, &f.a, &f.b);
@@ -388,7 +395,7 @@ int dn_prof_read(int kind, double* out) {
     return 0;
 }
 const char* dn_prof_kind_name(int kind) {
-    static const char* names[DN_K_COUNT] = {"rowgemm_kernel<*,1>", "rowgemm_kernel<*,2>", "tngemm_kernel", "spmm_kernel", "small", "chain_fwd_kernel", "chain_bwd_kernel", "diffuse_kernel", "tngemm_x3_multi_kernel", "tngemm_da_kernel", "backproject_kernel"};
+    static const char* names[DN_K_COUNT] = {"rowgemm_kernel<*,1>", "rowgemm_kernel<*,2>", "tngemm_kernel", "spmm_kernel", "small", "chain_fwd_kernel", "chain_bwd_kernel", "diffuse_kernel", "tngemm_x3_multi_kernel", "tngemm_da_kernel", "backproject_kernel", "spectral_apply_kernel"};
     return (kind >= 0 && kind < DN_K_COUNT) ? names[kind] : "";
 }
 
@@ -433,6 +440,7 @@ size_t dn_diffusion_workspace_bytes(const dn_mesh_batch_t* mb, int C) {
     size_t n = pad256((size_t)mb->n_chunks * mb->k_eig * C) + pad256((size_t)mb->n_mesh * mb->k_eig * C) +
                pad256((size_t)dn_spec_bwd_dt_rows(mb->n_mesh, mb->k_eig) * C) + 512;
     if (diffuse_ok(mb, C)) n += pad256(diffuse_ws_floats(mb)) + pad256((size_t)diffuse_dt_rows(mb) * C);      // (the hybrid form uses both sets)
+    if (bw_ok(mb, C)) n += pad256(dn_backproject_wide_ws_floats(mb->n_mesh, mb->k_eig, C));                   // (K = C = 256: the split spectrum)
     return n;
 }
 int dn_diffusion_fwd_f32(const dn_mesh_batch_t* mb, const float* x, const float* time, int C, float* xs, float* xd,
@@ -447,10 +455,11 @@ int dn_diffusion_fwd_f32(const dn_mesh_batch_t* mb, const float* x, const float*
     }
     float* partial = b.f((size_t)mb->n_chunks * mb->k_eig * C);
     float* ys = b.f((size_t)mb->n_mesh * mb->k_eig * C);
+    float* wide_ws = bw_ok(mb, C) ? b.f(dn_backproject_wide_ws_floats(mb->n_mesh, mb->k_eig, C)) : nullptr;
     if (!b.ok) return DN_ERR_INVALID;
     DN_CHECK(to_basis_partials(mb, x, C, true, partial, S(stream)));
     DN_CHECK(dn_launch_spec_fwd(partial, mb->mesh_chunk_off, mb->evals, time, xs, ys, mb->n_mesh, mb->k_eig, C, S(stream)));
-    return from_basis(mb, ys, C, xd, nullptr, false, S(stream));
+    return from_basis(mb, ys, C, xd, nullptr, false, S(stream), F16(), wide_ws);
 }
 int dn_diffusion_bwd_f32(const dn_mesh_batch_t* mb, const float* d_xd, const float* xs, const float* time, int C,
                          const float* d_x_add, float* d_x, float* d_time, void* ws, size_t ws_bytes, void* stream) {
@@ -681,14 +690,10 @@ static bool block_chain_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p
 // kernel (13 instead of 10 arrays of [V, C] through it) and is level with back-projection + gather from ~80k rows on (bench.py headline, two
 // runs each on one box: 30.82 / 30.85 M vertices/s against 31.02 / 31.02).
 static bool block_sg_ok(const dn_mesh_batch_t* mb, const dn_block_params_t* p, int kind) {
-#ifdef DN_DEBUG_SG
-    fprintf(stderr, "[sg] kind %d opt %d flags %u v %d pack %p units %p amax %p n_units %d al %d %d cus %d chain_ok %d elig %d (C %d K %d wg %d hh %d) diffuse_ok %d\n", kind, opt(O_SPECTRAL_GRAD), p->flags, mb->v_total,
-            mb->sg_pack, (const void*)mb->sg_units, (const void*)mb->sg_amax, mb->sg_n_units, (int)al16(mb->sg_pack), (int)al16(mb->sg_amax), dn_num_cus(), (int)block_chain_ok(mb, p, kind),
-            (int)dn_chain_sg_eligible(p->C, mb->k_eig, p->with_grad, chain_hh(mb, false, p->C)), p->C, mb->k_eig, p->with_grad, chain_hh(mb, false, p->C), (int)diffuse_ok(mb, p->C));
-#endif
     const int o = (p->flags & DN_BLOCK_NO_SPECTRAL_GRAD) ? 0 : ((p->flags & DN_BLOCK_SPECTRAL_GRAD_ALWAYS) ? 2 : opt(O_SPECTRAL_GRAD));
-    // (C = K = 256, the two-launch form: measured SLOWER than back-projection + gather -- BASELINE config 4 at 27.1 M vertices/s against 29.1 M, its
-    // spectral launch takes 404 us where ~250 would pay -- and therefore only taken when asked for: option value 2 / DN_BLOCK_SPECTRAL_GRAD_ALWAYS)
+    // (C = K = 256, the two-launch form: measured SLOWER than back-projection + gather -- BASELINE config 4 at 28.2 M vertices/s against 29.1 M: its
+    // spectral launch reads 0.61 GB of operands and writes 0.61 GB of xd / gx / gy that the chain reads back, 366 us where ~250 would pay -- and
+    // therefore only taken when asked for: option value 2 / DN_BLOCK_SPECTRAL_GRAD_ALWAYS)
     return o && kind < 2 && (o >= 2 || (p->C < 256 && (kind == 0 || mb->v_total <= 65536))) && mb->sg_pack && mb->sg_units && mb->sg_amax && mb->sg_n_units > 0 && al16(mb->sg_pack) && al16(mb->sg_amax) &&
            mb->sg_n_units <= 100 * dn_num_cus() &&      // (a workgroup's pass table lives in LDS: DN_CH_SG_MAXP = 64 passes of 2 x CUs workgroups)
            block_chain_ok(mb, p, kind) && dn_chain_sg_eligible(p->C, mb->k_eig, p->with_grad, chain_hh(mb, false, p->C)) && !diffuse_ok(mb, p->C);
@@ -717,6 +722,7 @@ size_t dn_block_fwd_workspace_bytes(const dn_mesh_batch_t* mb, const dn_block_pa
     if (block_chain_ok(mb, p, with_saved ? 1 : 0)) n += pad256(dn_chain_ws_bytes(p->C, p->with_grad, p->with_rot, p->n_mlp) / sizeof(float));
     if (block_sg_ok(mb, p, with_saved ? 1 : 0)) n += pad256(sg_piece_floats(mb, p->C)) + pad256((size_t)2 * mb->n_mesh);
     if (diffuse_ok(mb, p->C)) n += pad256(diffuse_ws_floats(mb));
+    if (bw_ok(mb, p->C)) n += pad256(dn_backproject_wide_ws_floats(mb->n_mesh, mb->k_eig, p->C));
     if (!with_saved) {
         n += pad256((size_t)mb->n_mesh * mb->k_eig * p->C) + 4 * pad256(VC);          // xs, xd, gx, gy, g
         n += 2 * pad256((size_t)mb->v_total * max_width(p));                            // hidden ping-pong
@@ -740,6 +746,7 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
     float* ysa = sg_ws ? b.f((size_t)2 * mb->n_mesh) : nullptr;
     const bool sg = chain && sg_ws;                                       // xd, gx, gy computed inside the chained kernel (dn_spectral.hip)
     float* diffuse_ws = diffuse_ok(mb, C) ? b.f(diffuse_ws_floats(mb)) : nullptr;
+    float* wide_ws = bw_ok(mb, C) ? b.f(dn_backproject_wide_ws_floats(mb->n_mesh, K, C)) : nullptr;   // the spectrum split into ring pieces (K = C = 256)
     float *xs, *xd, *gx = nullptr, *gy = nullptr, *gf = nullptr, *bre = nullptr, *bim = nullptr;
     float* hbuf[2] = {nullptr, nullptr};
     if (sv) {
@@ -840,7 +847,7 @@ int dn_block_fwd_f32(const dn_mesh_batch_t* mb, const dn_block_params_t* p, cons
             F16 fb;
             if (f16) fb = f16_if(F16_FROMB, f16_of(ev_amax, aw + AW_YS, sw + SW_XD));
             else if (words) fb.o = sw + SW_XD;                                  // (the chained kernel scales xd by its magnitude)
-            DN_CHECK(from_basis(mb, ys, C, xd, nullptr, false, st, fb));
+            DN_CHECK(from_basis(mb, ys, C, xd, nullptr, false, st, fb, wide_ws));
         }
     }
     if (use_chain) {   // gather -> gradient features -> MiniMLP + residual in one launch (layers.py:213-239)

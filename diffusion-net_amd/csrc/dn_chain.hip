@@ -143,17 +143,17 @@ DN_CLK_DECLARE(chain_fwd)
 // KE > 0: the spectral-gradient form (dn_spectral.hip) for k_eig = 32 KE -- no CSR gather, no xd read: the pass starts with the three products
 // [Phi | G_X Phi | G_Y Phi][rows] * ys[mesh] (operand fragments streamed pre-split from the packed batch operand, the scaled spectrum's pieces
 // through the same LDS ring as the weights) and xd, gx, gy are born in the accumulator layout the following stages consume.
-// MODE (C = K = 256 only): the spectral-gradient form there is TWO launches of this kernel -- MODE 1 = the spectral phase alone (xd, gx, gy of every
-// pass written to memory), MODE 2 = the chain reading gx, gy where the gather form gathers them (KE = 0: plain piece stream, plain row mapping).
-// Fused into one launch (rounds of this file's history) the phase's 192 accumulators + operand buffers sat inside a kernel whose other stages are
-// at the register limit: values spilled THERE were reloaded in the phase's piece loop, and a scratch reload is followed by a compiler-made
-// s_waitcnt vmcnt(0) that drains the ring and the operand requests in flight (8-9 k cycles per piece instead of ~3 k).
+// MODE 2 (C = K = 256 only): the spectral-gradient form there is TWO launches -- spectral_apply_kernel (dn_spectral.hip: xd, gx, gy of every row
+// written to memory) and this kernel reading gx, gy where the gather form gathers them (KE = 0: plain piece stream, plain row mapping).  Fused
+// into this kernel the spectral products' 192 accumulators + operand buffers sat inside a kernel whose other stages are at the register limit:
+// values spilled THERE were reloaded in the products' piece loop, and a scratch reload is followed by a compiler-made s_waitcnt vmcnt(0) that
+// drains the ring and the operand requests in flight (8-9 k cycles per piece instead of ~3 k; profiles/r06_sg256.txt).
 template <int C, int NW, int HH, int KE = 0, int MODE = 0>
 __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void chain_fwd_kernel(ChainArgs a) {
     constexpr bool SG = KE > 0;
-    constexpr bool PRE = MODE == 2;       // gx, gy come from memory (written by the MODE 1 launch)
-    static_assert(MODE == 0 || (C >= 256 && ((MODE == 1 && KE > 0) || (MODE == 2 && KE == 0))), "two-launch spectral form: C = 256");
-    static_assert(!SG || (HH == 1 && C < 256 && KE <= 4) || (C == 256 && HH == 2 && NW == 4 && KE == 8 && MODE == 1), "spectral-gradient forms: C <= 128 with one 16-row half per wave; C = K = 256: the spectral phase as its own launch");
+    constexpr bool PRE = MODE == 2;       // gx, gy come from memory (written by spectral_apply_kernel)
+    static_assert(MODE == 0 || (MODE == 2 && C >= 256 && KE == 0), "two-launch spectral form: C = 256");
+    static_assert(!SG || (HH == 1 && C < 256 && KE <= 4), "fused spectral-gradient form: C <= 128, one 16-row half per wave");
 
     DN_CLK_STAMP(chain_fwd, 0);
     // (the spectral-gradient forms exist with gradient features only: a compile-time fact there -- as a run-time flag it keeps the MiniMLP
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
     // SG: the pass's KE spectrum pieces come first, from the pass's mesh (the requests run ahead into the next pass: imesh follows the stream)
     const int n_gf = with_grad_ ? a.n_gf : 0;
     // (SG: the spectrum's pieces come first, once per half -- the spectral phase runs both halves back to back)
-    const int n_seq = MODE == 1 ? HH * KE : a.n_pieces + (HH - 1) * n_gf + HH * KE;      // (MODE 1: the spectrum's pieces are the whole stream)
+    const int n_seq = a.n_pieces + (HH - 1) * n_gf + HH * KE;
     int sq = 0;                           // position the NEXT request fetches
     const int SUB = SG ? a.sg_unit_rows / (16 * HH * NW) : 1;  // workgroup passes per unit of the packed operands (64 / 128 rows)
     const int GPU_ = SG ? a.sg_unit_rows / 16 : 1;             // 16-row groups per unit
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
     int rq = 0;                           // slot the next request fills
     auto issue = [&]() {
         const uint4* src_piece;
-        if (SG && (MODE == 1 || sq < HH * KE)) {
+        if (SG && sq < HH * KE) {
             src_piece = a.ysp + ((size_t)imesh * KE + (sq >= KE ? sq - KE : sq)) * PIECE;       // (HH <= 2)
         } else {
             const int sw_ = sq - HH * KE;
@@ -347,10 +347,6 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
 
     for (int pass = 0; pass < npass; ++pass) {
         CH_TR();
-        // (C = 256 spectral form: the lane index is made opaque per pass -- left visible, the compiler hoists the pass's per-lane address
-        // arithmetic (a dozen 64-bit row pointers) out of the loop, spills it at the loop head and reloads it inside the product loops)
-        const int lane_p = ch_opaque<false>(lane);
-        const int m = lane_p & 15, q = lane_p >> 4;
         const int unit = unit_of(pass);
         int rb = unit * (16 * HH * NW) + 16 * HH * wave;     // first of this wave's 32 rows (row * C fits 32 bits for every batch the library takes)
         int row_end = a.V;
@@ -368,7 +364,6 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
             grp_nx = ch_uniform_i(pn_.w) + HH * wave;
             grp_cur = ch_uniform_i(pi_.w) + HH * wave;
             u_xd = ch_uniform(ps_.x); u_gx = ch_uniform(ps_.y); u_gy = ch_uniform(ps_.z);
-            if constexpr (G0) s_in = ch_uniform(dn_pow2_scale(fmaxf(fmaxf(x_mag, ch_uniform(ps_.w)), 1.f)));     // [g | x | xd] of this pass, xd by its bound
         }
         int rowh[HH]; bool liveh[HH]; int rch[HH];
         int begh[HH], endh[HH];
@@ -406,101 +401,6 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[hh][nt] = dn_f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        [[maybe_unused]] float s_gf_h[HH];
-        if constexpr (SG && G0) {
-            // =================================================== C = K = 256: the spectral phase of the pass, both halves back to back --
-            // [xd | gx | gy] = [Phi | G_X Phi | G_Y Phi][16 rows] ys[mesh], three products sharing every piece (one sweep of KE pieces per half: a
-            // piece costs ~2.5 k cycles here whatever it multiplies, one wave per SIMD), 192 accumulators while the MiniMLP's are not live yet; the
-            // results go to memory (xd for layer 0, gx / gy for this pass's gradient-feature stage -- the general registers cannot hold both
-            // halves' 256).  The operand fragments stream through FOUR 1-step register buffers, refilled as they are consumed: the compiler's wait in
-            // front of a buffer's first use counts only its own requests (not the ring's), i.e. it lets "the requests of the refills issued since" stay
-            // in flight and, with the ring's requests queued in between, forces part of the NEWEST refill to land -- with two 2-step buffers that was the one
-            // issued a moment ago (its whole HBM latency exposed at every buffer: 8-9 k cycles per piece); with three it is the one before.
-            // (the lane index is recomputed here: the kernel-long `lane` is spilled at the gradient-feature stage's register peak, and a scratch
-            // reload inside this phase's piece loop is followed by a compiler-made s_waitcnt vmcnt(0) that drains the ring and the operand requests
-            // in flight -- measured 8-9 k cycles per piece instead of ~3 k)
-            const int lane_r = ch_fresh_lane();
-            constexpr int FB = 1;                        // contraction steps per fragment buffer (1 x 4 buffers: 68 spilled registers in the kernel; 2 x 3: 116)
-            constexpr int NPART = KE / FB;               // buffer loads per half
-            constexpr int NBUF = 4;
-            static_assert(KE % FB == 0 && HH * NPART > NBUF, "fragment buffers of the spectral phase");
-            uint4 fq[NBUF][FB][3][2];
-            auto load_buf = [&](const int grp, const int part, uint4 (&dst)[FB][3][2]) {
-                // uniform base + a 32-bit lane offset the compiler cannot see through: left to itself it hoists the 48 addresses of a pass's
-                // requests out of the pass loop (2 registers each, live across the whole kernel: 259 spilled registers)
-                const char* base = reinterpret_cast<const char*>(a.sg_pack) + (size_t)grp * (3 * KE * 128 * 16);
-                unsigned lo = 16u * (unsigned)lane_r;
-#ifndef DN_EMULATE
-                asm volatile("" : "+v"(lo));
-#endif
-#pragma unroll
-                for (int t = 0; t < FB; ++t)
-#pragma unroll
-                    for (int op = 0; op < 3; ++op) {
-                        dst[t][op][0] = *reinterpret_cast<const uint4*>(base + (lo + 16u * (unsigned)((op * KE + FB * part + t) * 128)));
-                        dst[t][op][1] = *reinterpret_cast<const uint4*>(base + (lo + 16u * (unsigned)((op * KE + FB * part + t) * 128 + 64)));
-                    }
-            };
-#pragma unroll
-            for (int i = 0; i < NBUF; ++i) load_buf(grp_cur + i / NPART, i % NPART, fq[i]);
-            CH_TR();
-#pragma unroll
-            for (int hh = 0; hh < HH; ++hh) {
-                dn_f32x4 sa[3][NT];
-#pragma unroll
-                for (int op = 0; op < 3; ++op)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) sa[op][nt] = dn_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int part = 0; part < NPART; ++part) {
-                    const int gpi = hh * NPART + part;           // buffer loads are numbered through both halves
-#pragma unroll
-                    for (int t = 0; t < FB; ++t) {
-                        // (the slot's address with this lane's offset folded in and hidden from the optimiser: every weight-fragment read is then
-                        // base + immediate.  Left visible, the compiler precomputes lane x 16 + slot + tile offset for all four 32 KiB slots -- 128
-                        // address registers hoisted out of the pass loop, 70 of them spilled at its head and reloaded inside the pieces)
-                        const ch_lds_p ws_ = ch_opaque_lds(ring + (gp % RING) * PIECE + lane_r);
-                        issue();
-                        constexpr int lane = 0;
-                        CH_MMA3(sa, fq[gpi % NBUF][t]);
-                        // (a refill -- 6 FB requests -- is younger than the piece waited for, DMA(gp + 1), at the ends of the two pieces after it, and
-                        // the initial fills are at the first pieces' ends: they may stay in flight; the last refill goes out after buffer load
-                        // HH NPART - NBUF - 1 was consumed.  Loads only are counted.)
-                        if (gpi + NBUF - 1 < HH * NPART) { CH_WAIT_OPS((RING - 2) * LPT + 6 * FB); CH_BARRIER(); ++gp; }
-                        else CH_PIECE_END();
-                    }
-                    // the buffer just consumed takes the steps NBUF buffer loads on -- of this half, or of the other one (fenced: hoisted above the
-                    // products that still read the buffer, a refill needs 24 MORE registers instead of reusing them)
-                    ch_sched_fence();
-                    if (gpi + NBUF < HH * NPART) load_buf(grp_cur + (gpi + NBUF) / NPART, (gpi + NBUF) % NPART, fq[gpi % NBUF]);
-                    ch_sched_fence();
-                }
-                const long long row = rowh[hh];
-                float wx = 0.f, wg = 0.f;
-                float* od = a.xd_out + row * C + 4 * q;
-                float* ox = a.gx + row * C + 4 * q;
-                float* oy = a.gy + row * C + 4 * q;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const float4 vd = make_float4(sa[0][nt][0] * u_xd, sa[0][nt][1] * u_xd, sa[0][nt][2] * u_xd, sa[0][nt][3] * u_xd);
-                    const float4 vx_ = make_float4(sa[1][nt][0] * u_gx, sa[1][nt][1] * u_gx, sa[1][nt][2] * u_gx, sa[1][nt][3] * u_gx);
-                    const float4 vy_ = make_float4(sa[2][nt][0] * u_gy, sa[2][nt][1] * u_gy, sa[2][nt][2] * u_gy, sa[2][nt][3] * u_gy);
-                    wx = dn_f4_amax(wx, vd); wg = dn_f4_amax(wg, vx_); wg = dn_f4_amax(wg, vy_);
-                    if (liveh[hh]) {       // (plain stores: the chain launch behind this one reads these rows)
-                        *reinterpret_cast<float4*>(od + 16 * nt) = vd;
-                        *reinterpret_cast<float4*>(ox + 16 * nt) = vx_;
-                        *reinterpret_cast<float4*>(oy + 16 * nt) = vy_;
-                    }
-                    ch_sched_fence();      // (tile by tile: left free, the scheduler reads all 192 accumulators into general registers first -- next to
-                                           // the other half's prefetched operand buffers that is 288 live registers and 118 spilled ones)
-                }
-                wx = ch_wave_max(wx); wg = ch_wave_max(wg);
-                xdmax = wx > xdmax ? wx : xdmax; gmax = wg > gmax ? wg : gmax;
-                s_gf_h[hh] = ch_uniform(dn_pow2_scale(wg));
-            }
-            CH_TR();
-            if constexpr (MODE == 1) continue;       // (this launch is the spectral phase only; the chain is the MODE 2 launch behind it)
-        }
         uint4 gfh[G0 ? 1 : HH][NK], gfl[G0 ? 1 : HH][NK];     // tanh features (of the two halves) as operand fragments (hi / lo planes) for layer 0
         [[maybe_unused]] float xdv[(SG && !G0) ? NT : 1][4];   // SG, C <= 128: this wave's xd rows (accumulator layout), layer 0's third operand segment
         if (with_grad_) {
@@ -515,7 +415,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
                     nmax = (int)ch_wave_max((float)(end - beg));
                 }
                 if constexpr (PRE) {
-                    // ---- two-launch spectral form: gx, gy of these rows were computed by the spectral launch (MODE 1) in this very layout
+                    // ---- two-launch spectral form: gx, gy of these rows were computed by spectral_apply_kernel in this very layout
                     const long long rc_ = hh ? rch[HH - 1] : rch[0];
                     const float* px = a.gx + rc_ * C + 4 * q;
                     const float* py = a.gy + rc_ * C + 4 * q;
@@ -1203,9 +1103,9 @@ static int chain_launch(int npieces, const ChainArgs& a_in, hipStream_t stream, 
     a.n_pieces = npieces;
     if constexpr (C >= 256) {      // (one wave shape: BASELINE config 4 is a 200k-vertex mesh)
         if (!a.sg_pack) return chain_launch_nw<C, 4, 2>(a, stream);
-        // spectral-gradient form at C = K = 256: the spectral phase (xd, gx, gy -> memory, their magnitudes -> xd_amax_out / g_amax), then the chain
-        // reading them (plain rows, plain piece stream)
-        const int e1 = chain_launch_nw<C, 4, 2, 8, 1>(a, stream);
+        // spectral-gradient form at C = K = 256: spectral_apply_kernel (xd, gx, gy -> memory, their magnitudes -> xd_amax_out / g_amax), then the
+        // chain reading them (plain rows, plain piece stream)
+        const int e1 = dn_launch_spectral_apply(a, C, stream);
         if (e1) return e1;
         ChainArgs b = a;
         b.sg_pack = nullptr; b.sg_units = nullptr; b.sg_n_units = 0; b.ysp = nullptr;

@@ -74,41 +74,6 @@ __device__ __forceinline__ float ch_uniform(float v) {
     return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v)));
 #endif
 }
-// the value, with its origin hidden from the optimiser when ON (no instruction is emitted; OFF: the value itself, same code as without the call)
-template <bool ON>
-__device__ __forceinline__ int ch_opaque(int v) {
-#ifndef DN_EMULATE
-    if constexpr (ON) asm volatile("" : "+v"(v));
-#endif
-    return v;
-}
-// this thread's lane, recomputed (two instructions) instead of carried in a register since the kernel's start
-__device__ __forceinline__ int ch_fresh_lane() {
-#ifdef DN_EMULATE
-    return (int)(threadIdx.x & 63);
-#else
-    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-#endif
-}
-// an LDS pointer with its value hidden from the optimiser (no instruction) but its address space kept: reads through it stay ds_read with
-// base + immediate addressing (through a generic pointer they would become flat loads, which count in vmcnt as well)
-#if defined(DN_EMULATE) || !defined(__HIP_DEVICE_COMPILE__)
-typedef const uint4* ch_lds_p;
-__device__ __forceinline__ ch_lds_p ch_opaque_lds(const uint4* p) { return p; }
-#else
-typedef const __attribute__((address_space(3))) uint4* ch_lds_p;
-__device__ __forceinline__ ch_lds_p ch_opaque_lds(const uint4* p) {
-    unsigned off = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint4*)p;
-    asm volatile("" : "+v"(off));
-    return (ch_lds_p)(uintptr_t)off;
-}
-#endif
-// nothing is scheduled across this point
-__device__ __forceinline__ void ch_sched_fence() {
-#ifndef DN_EMULATE
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
 __device__ __forceinline__ int ch_uniform_i(int v) {
 #ifdef DN_EMULATE
     return v;

@@ -565,6 +565,9 @@ int dn_launch_sg_pack(const DnTile* units, int n_units, int n_mesh, int K, const
 // ys [n_mesh, K, C] -> transposed weight pieces [n_mesh][K / 32][2 (C / 16) 64] uint4 (fp16 hi / lo planes scaled by the power of two of the
 // mesh's largest |ys|); ys_amax[2 n_mesh] receives those magnitudes and, behind them, every mesh's largest column 2-norm of ys
 int dn_launch_spec_pieces(const float* ys, int n_mesh, int K, int C, uint4* out, float* ys_amax, hipStream_t stream);
+// C = K = 256: xd, gx, gy = [Phi | G_X Phi | G_Y Phi] ys as a launch of its own (the fields of ChainArgs it reads: sg_*, ysp, ys_amax, xd_out, gx, gy,
+// xd_amax_out, g_amax); the chained forward then runs in its MODE 2 form (dn_chain.hip)
+int dn_launch_spectral_apply(const ChainArgs& a, int C, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------
 // one-launch learned-time diffusion, forward and backward (dn_diffuse.hip; K = C = 128)
@@ -595,6 +598,11 @@ int dn_diffuse_plan_host(const int* sizes, int n_mesh, int n_wg, int n_groups, D
 int dn_launch_diffuse(const DfLaunch& L, hipStream_t stream);
 int dn_launch_backproject(const DnTile* plan, int n_wg, const float* evecs, const float* ys, float* out, const float* add, const float* mass,
                           float* out_amax, double acct_rows, hipStream_t stream, int f16 = 0, const DnAmax* a_amax = nullptr, const DnAmax* b_amax = nullptr);
+// dn_backproject_wide.hip: the forward back-projection at K = C = 256 (3-term engine, the spectrum streamed through an LDS-DMA ring)
+bool dn_backproject_wide_ok(int K, int C, int n_tiles);
+size_t dn_backproject_wide_ws_floats(int n_mesh, int K, int C);
+int dn_launch_backproject_wide(const DnTile* tiles, int n_tiles, int n_mesh, const float* evecs, const float* ys, float* ws, float* out, float* out_amax,
+                               int K, int C, double acct_rows, hipStream_t stream);
 int dn_opt_chain_nw(void);   // option "chain_nw" (dn_api.hip): development override of the chained kernels' workgroup width
 
 // ---------------------------------------------------------------------------------------
@@ -729,7 +737,7 @@ int dn_launch_tngemm_multi(const TnArgs* gs, const int* nchunks, int count, hipS
 // hipEvents on its own stream and summed per kernel family.  Off by default; compiled out of the
 // emulator build.
 // ---------------------------------------------------------------------------------------
-enum { DN_K_ROWGEMM = 0, DN_K_ROWGEMM_DUAL = 1, DN_K_TNGEMM = 2, DN_K_SPMM = 3, DN_K_SMALL = 4, DN_K_CHAIN = 5, DN_K_CHAIN_BWD = 6, DN_K_DIFFUSE = 7, DN_K_TN_MULTI = 8, DN_K_TN_DA = 9, DN_K_BACKPROJECT = 10, DN_K_COUNT = 11 };   // one kind per KERNEL (rocprof name), except the small-kernel bucket
+enum { DN_K_ROWGEMM = 0, DN_K_ROWGEMM_DUAL = 1, DN_K_TNGEMM = 2, DN_K_SPMM = 3, DN_K_SMALL = 4, DN_K_CHAIN = 5, DN_K_CHAIN_BWD = 6, DN_K_DIFFUSE = 7, DN_K_TN_MULTI = 8, DN_K_TN_DA = 9, DN_K_BACKPROJECT = 10, DN_K_SPECTRAL = 11, DN_K_COUNT = 12 };   // one kind per KERNEL (rocprof name), except the small-kernel bucket
 #ifdef DN_EMULATE
 static inline void dn_prof_begin(int, hipStream_t) {}
 static inline void dn_prof_end(int, hipStream_t, double, double) {}

@@ -168,7 +168,7 @@ int dn_get_option(const char* name, int* value);
 
 /* ---- opt-in per-kernel timing for benchmarks (no reference counterpart; the one piece of mutable global
  *      state, off by default): every launch is bracketed by hipEvents on its stream and summed per kernel
- *      kernel kind in [0, 11) (dn_prof_kind_name(kind) is "" past the last one).  read: out[0..3] = {ms, launches, algorithmic flops, algorithmic bytes}. */
+ *      kernel kind in [0, 12) (dn_prof_kind_name(kind) is "" past the last one).  read: out[0..3] = {ms, launches, algorithmic flops, algorithmic bytes}. */
 int dn_prof_enable(int on);
 int dn_prof_reset(void);
 int dn_prof_read(int kind, double* out);

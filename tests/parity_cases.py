@@ -648,6 +648,40 @@ def run_ops(device, sizes=(200, 77), K=20, C=32, seed=5, chunk_rows=None):
     assert helpers.rel_l2(xm.grad.cpu(), xr.grad) < GRAD_TOL
 
 
+def run_backproject_wide(device, sizes=(300, 257, 290), seed=17, tol=4e-6):
+    """K = C = 256 (BASELINE config 4's shape): the forward back-projection runs as the ring kernel of dn_backproject_wide.hip (3-term engine, the
+    spectrum split once per mesh and streamed through LDS).  LearnedTimeDiffusion forward against the fp64 evaluation of layers.py:44-67 and
+    against the row GEMM the shape took before (option diffuse = 0: the same 3-term arithmetic in another summation order -- close to rounding,
+    NOT bitwise equal, which would mean the new kernel did not run).  Ragged: meshes that end inside a 128-row tile and inside a 16-row group."""
+    from diffusion_net import _hip
+    K = C = 256
+    meshes, _ = make_ragged(sizes, K, 3, seed)
+    mb = pack(meshes, device)
+    g = torch.Generator().manual_seed(seed)
+    vt = sum(sizes)
+    x = torch.randn(vt, C, generator=g)
+    time = 0.01 + 0.3 * torch.rand(C, generator=g)
+    offs = [0]
+    for v in sizes:
+        offs.append(offs[-1] + v)
+    got = {}
+    saved = _hip.get_option("diffuse")
+    try:
+        for d in (2, 0):
+            _hip.set_option("diffuse", d)
+            got[d] = ops.DiffusionFn.apply(x.to(device), time.to(device), mb).cpu()
+    finally:
+        _hip.set_option("diffuse", saved)
+    ref = torch.cat([orc.spectral_diffusion(x[offs[i]:offs[i + 1]][None].double(), m["mass"][None].double(), m["evals"][None].double(),
+                                            m["evecs"][None].double(), time.double())[0] for i, m in enumerate(meshes)], 0)
+    e = {d: helpers.rel_max(got[d].double(), ref) for d in got}
+    e_ab = helpers.rel_max(got[2], got[0])
+    helpers.record_margin("backproject_wide", device, sizes=list(sizes), ring_vs_fp64=e[2], rowgemm_vs_fp64=e[0], ring_vs_rowgemm=e_ab, tol=tol)
+    assert not torch.equal(got[2], got[0]), "ring kernel and row GEMM bitwise equal: the ring kernel did not run"
+    assert e[2] < tol and e[0] < tol and e_ab < tol, (e, e_ab)
+    return e, e_ab
+
+
 def run_mismatched_patterns(device, V=150, K=8, C=32, seed=11):
     """gradX / gradY with different sparsity patterns -> union pattern with explicit zeros."""
     m = synthetic.make_mesh_operators(V, K, seed=seed)

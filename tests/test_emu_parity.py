@@ -95,6 +95,12 @@ def test_spectral_gradient_form_on_emulator(emu):
     parity_cases.run_spectral_grad(emu, sizes=(270,), C=256, K=256, N_block=1, dropout=False)      # BASELINE config 4's shape: two launches, 128-row units (chain_nw = 1: the GPU tier)
 
 
+def test_backproject_wide_on_emulator(emu):
+    """backproject_wide_kernel (K = C = 256: spectrum pieces through the LDS ring, 3-term engine) vs fp64 and vs the row GEMM; ragged tiles."""
+    import parity_cases
+    parity_cases.run_backproject_wide(emu)
+
+
 def test_per_call_engine_flags_on_emulator(emu):
     import parity_cases
     parity_cases.run_block_flags(emu)

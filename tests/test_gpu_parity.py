@@ -187,6 +187,15 @@ def test_spectral_gradient_form_vs_gather(dev):
     parity_cases.run_spectral_grad(dev, sizes=(5000, 3300, 700), C=256, K=256, N_block=2, dropout=True)
 
 
+def test_backproject_wide(dev):
+    """backproject_wide_kernel (dn_backproject_wide.hip: the forward back-projection at K = C = 256 with the spectrum's pieces streamed through an
+    LDS-DMA ring, 3-term engine) against fp64 and the row GEMM: ragged meshes, many tiles per workgroup, one mesh larger than a round of the chip."""
+    import parity_cases
+    parity_cases.run_backproject_wide(dev)
+    parity_cases.run_backproject_wide(dev, sizes=(40000, 300, 2777), seed=4)
+    parity_cases.run_backproject_wide(dev, sizes=(70001,), seed=5)
+
+
 def test_per_call_engine_flags(dev):
     import parity_cases
     parity_cases.run_block_flags(dev)

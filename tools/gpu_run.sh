@@ -45,6 +45,23 @@ c256)
   } 2>&1 | tee gpurun_out/c256_kbench.txt
   if [ -z "$NO_TESTS" ]; then timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=short -x -k "chained_forward_kernel_vs_unfused or chain_probes or large_inference" 2>&1 | tail -15 | tee gpurun_out/c256_tests.txt; fi
   timeout 300 python bench.py --config cfg4 --no-cpu-baseline --no-other-configs > gpurun_out/c256_bench_cfg4.json 2> gpurun_out/c256_bench.err; cat gpurun_out/c256_bench_cfg4.json | cut -c1-600; tail -3 gpurun_out/c256_bench.err ;;
+sg256)
+  { for o in 2 0; do echo "== 1 x 200k, C = K = 256, spectral_grad=$o"; $KB --meshes 1 --verts 200000 --C 256 --K 256 --ops block_inf,block_fwd --check --reps 10 --opt spectral_grad=$o | grep -v "^#" | cut -c1-170; done
+    for o in 2 0; do echo "== kernel stats of block_inf, spectral_grad=$o"
+      (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_s && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s -o trace -- "$R/tools/kbench" --lib "$R/diffusion-net_amd/diffusion_net/libdiffnet_hip.so" --meshes 1 --verts 200000 --C 256 --K 256 --ops block_inf --reps 10 --opt spectral_grad=$o > /tmp/prof_s.log 2>&1 < /dev/null)
+      f=$(find /tmp/prof_s -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cut -c1-160 "$f" | grep -v "rocclr\|sg_grad\|sg_pack" | head -8; done
+    for o in 2 1 0; do echo "== bench cfg4, spectral_grad=$o"; timeout 300 python bench.py --config cfg4 --no-cpu-baseline --no-other-configs --lib-opt spectral_grad=$o 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; done
+  } 2>&1 | tee gpurun_out/sg256.txt
+  if [ -z "$NO_TESTS" ]; then timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=short -x -k "spectral_gradient or large_inference" 2>&1 | tail -15 | tee gpurun_out/sg256_tests.txt; fi ;;
+bw256)
+  { for d in 2 0; do echo "== 1 x 200k, C = K = 256, diffuse=$d (2: ring back-projection kernel, 0: row GEMM)"; $KB --meshes 1 --verts 200000 --C 256 --K 256 --ops diffusion,block_inf --check --reps 10 --opt diffuse=$d | grep -v "^#" | cut -c1-170; done
+    for shape in "--meshes 16 --verts 10000" "--meshes 3 --verts 70000"; do for d in 2 0; do echo "== $shape, C = K = 256, diffuse=$d"; $KB $shape --C 256 --K 256 --ops diffusion,block_inf --check --reps 10 --opt diffuse=$d | grep -v "^#" | cut -c1-170; done; done
+    echo "== kernel stats of block_inf, 1 x 200k"
+    (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_s && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s -o trace -- "$R/tools/kbench" --lib "$R/diffusion-net_amd/diffusion_net/libdiffnet_hip.so" --meshes 1 --verts 200000 --C 256 --K 256 --ops block_inf --reps 10 > /tmp/prof_s.log 2>&1 < /dev/null)
+    f=$(find /tmp/prof_s -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cut -c1-160 "$f" | grep -v "rocclr\|sg_grad\|sg_pack" | head -9
+    for d in 2 0; do echo "== bench cfg4, diffuse=$d"; timeout 300 python bench.py --config cfg4 --no-cpu-baseline --no-other-configs --lib-opt diffuse=$d 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; done
+  } 2>&1 | tee gpurun_out/bw256.txt
+  if [ -z "$NO_TESTS" ]; then timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=short -x -k "backproject_wide or large_inference or ops" 2>&1 | tail -15 | tee gpurun_out/bw256_tests.txt; fi ;;
 kbench)
   $KB --check "$@" 2>&1 | cut -c1-200 | tee gpurun_out/kbench.txt ;;
 tests)
