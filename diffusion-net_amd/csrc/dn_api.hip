@@ -413,6 +413,7 @@ int dn_get_option(const char* name, int* value) {
 int dn_version(void) { return 600; }
 int dn_tile_rows(void) { return DN_TM; }
 int dn_tn_target_chunks(void) { return 2 * dn_num_cus(); }
+int dn_tn_target_chunks_k(int k_eig) { return (k_eig >= 256 ? 1 : 2) * dn_num_cus(); }
 int dn_diffusion_plan_wgs(void) { return dn_num_cus(); }
 int dn_diffusion_plan(const int32_t* sizes, int n_mesh, int n_wg, int n_groups, dn_tile_t* plan) {
     if (!sizes || !plan) return 0;

@@ -70,6 +70,7 @@ _SIGNATURES = {
     "dn_version": (C.c_int, []),
     "dn_tile_rows": (C.c_int, []),
     "dn_tn_target_chunks": (C.c_int, []),
+    "dn_tn_target_chunks_k": (C.c_int, [C.c_int]),
     "dn_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "dn_get_option": (C.c_int, [C.c_char_p, _P(C.c_int)]),
     "dn_diffusion_plan_wgs": (C.c_int, []),

@@ -281,7 +281,7 @@ class MeshBatch:
             raise ValueError("more than 2^31 vertices in one batch")
         # default: as many chunks as the split-V kernels have workgroup slots, nearly equal in size (balanced_chunk_rows); an explicit
         # chunk_rows (tests) gives fixed-size chunks
-        self.chunk_rows = int(chunk_rows) if chunk_rows else balanced_chunk_rows(self.sizes, _hip.lib().dn_tn_target_chunks())
+        self.chunk_rows = int(chunk_rows) if chunk_rows else balanced_chunk_rows(self.sizes, _hip.lib().dn_tn_target_chunks_k(int(self.k_eig)))
         self.tiles, self.chunks, self.mesh_chunk_off, self.mesh_rows = _tables_on(self.device, self.sizes, self.chunk_rows)
         s = _hip.MeshBatchStruct()
         s.n_mesh, s.v_total, s.k_eig = len(self.sizes), vt, self.k_eig

@@ -140,6 +140,9 @@ int dn_version(void);         /* 600: round-6 layout (dn_mesh_batch_t.sg_pack ..
 int dn_tile_rows(void);      /* rows per entry of dn_mesh_batch_t.tiles (128) */
 int dn_tn_target_chunks(void);  /* how many entries dn_mesh_batch_t.chunks should have on the current device for the split-V products to fill it in
                                    whole rounds: one workgroup slot per CU (wave-specialised kernel).  Any chunk list is CORRECT; this one is fastest. */
+int dn_tn_target_chunks_k(int k_eig);   /* (round 6) the same for a batch of k_eig eigenvectors per mesh: from k_eig = 256 on half as many chunks -- every chunk
+                                   writes a k_eig x C partial that the spectral step reads back (one 200k-vertex mesh, K = C = 256: projection 210 -> 190 us,
+                                   block inference 1388 -> 1347 us with 240 instead of 489 chunks; profiles/r06_chunks256.txt) */
 
 /* ---- tuning options (no reference counterpart): process-wide integers the entry points read at call time, for A/B measurements and for
  *      tests that must run a particular kernel.  Unknown names return non-zero.  Defaults in parentheses.

@@ -104,11 +104,11 @@ int main(int argc, char** argv) {
     std::vector<int> sizes(n_mesh);
     for (auto& s : sizes) s = (int)(verts * (0.9 + 0.2 * U(rng)));
     long long V = 0; for (int s : sizes) V += s;
-    // chunk table: --chunk R gives fixed R-row chunks; default: as diffusion_net.batch.balanced_chunk_rows -- dn_tn_target_chunks() chunks of nearly equal size
+    // chunk table: --chunk R gives fixed R-row chunks; default: as diffusion_net.batch.balanced_chunk_rows -- dn_tn_target_chunks_k(K) chunks of nearly equal size
     std::vector<int> per_mesh(n_mesh, chunk_rows);
     if (!chunk_rows) {
-        auto tgt = (int (*)())dlsym(L.h, "dn_tn_target_chunks");
-        const int target = tgt ? tgt() : 512;
+        auto tgt = (int (*)(int))dlsym(L.h, "dn_tn_target_chunks_k");
+        const int target = tgt ? tgt(K) : 512;
         std::vector<int> cnt(n_mesh), cap(n_mesh); std::vector<double> quota(n_mesh); int sum = 0;
         for (int m = 0; m < n_mesh; ++m) { quota[m] = (double)target * sizes[m] / V; cap[m] = std::max(1, sizes[m] / 128); cnt[m] = std::min(cap[m], std::max(1, (int)quota[m])); sum += cnt[m]; }
         std::vector<int> order(n_mesh); for (int m = 0; m < n_mesh; ++m) order[m] = m;
