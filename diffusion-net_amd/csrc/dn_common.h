@@ -393,6 +393,7 @@ struct TnArgs {
     int acct_rows;              // host-side accounting only
     int f16;                    // split-fp16 engine (aligned split path only); operand magnitude bounds as in RgArgs
     DnAmax a_amax, b_amax;
+    int lin_nb, lin_ny, lin_nz; // filled by the launcher: > 0 = one-dimensional launch in the XCD-aware tile order (tngemm_x3_kernel)
 };
 // Allow more than 64 KiB of dynamic LDS for one kernel instantiation, once per DEVICE (function attributes are per device;
 // `done` is the instantiation's own 64-bit device bitmap).  Not thread-safe beyond "setting it twice is harmless".

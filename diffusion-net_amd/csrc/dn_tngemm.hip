@@ -318,9 +318,24 @@ __device__ __forceinline__ void tn_x3_body(const TnArgs& g, const int bx, const 
     }
 }
 
+#ifndef DN_TN_XCD
+#define DN_TN_XCD 1   // products with several output tiles per chunk block (K or C > 128): the tiles of a chunk block run on ONE XCD, back to back (0: the
+#endif                // three-dimensional grid, chunk-major: a chunk's tiles a whole sweep apart; A/B)
 template <int FLAVOR, int NP>
 __global__ __launch_bounds__(DN_TX_THREADS, 4) void tngemm_x3_kernel(TnArgs g) {
-    tn_x3_body<FLAVOR, NP>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (g.lin_ny > 0) {
+        // The tiles of a chunk block multiply the same rows of both operands (at K = C = 256: four tiles, every row of Phi and of x read by two
+        // of them).  Chunk-major the second read comes a whole sweep later -- from memory once the operands exceed the Infinity Cache (0.41 GB for
+        // one 200k-vertex mesh).  Here workgroups 8 s + x, s = nt c + t, take tile t of chunk block 8 c + x: round-robin dispatch (blockIdx & 7)
+        // sends a chunk block's tiles to one XCD one after the other and its rows are fetched into that XCD's L2 once.
+        const int nt = g.lin_ny * g.lin_nz, nb = g.lin_nb, local = (int)blockIdx.x, nfull = nb & ~7;
+        int tile;
+        if (local < nfull * nt) { const int seq = local >> 3; bx = 8 * (seq / nt) + (local & 7); tile = seq % nt; }
+        else { const int t = local - nfull * nt, rem = nb - nfull; bx = nfull + t % rem; tile = t / rem; }
+        by = tile % g.lin_ny; bz = tile / g.lin_ny;
+    }
+    tn_x3_body<FLAVOR, NP>(g, bx, by, bz);
 }
 // several independent products in ONE launch (the three weight-gradient products of a block's backward: one ramp and one tail instead of
 // three, and a single mesh's handful of chunks share the device): workgroup blockIdx.x belongs to the problem whose range it falls into
@@ -379,6 +394,11 @@ int dn_launch_tngemm(const TnArgs& g_in, int nchunks, hipStream_t stream) {
     dn_prof_begin(DN_K_TNGEMM, stream);
     int err;
     if (g.aligned && DN_TN_X3) {
+        g.lin_nb = g.lin_ny = g.lin_nz = 0;
+        if (DN_TN_XCD && grid.y * grid.z > 1) {
+            g.lin_nb = nblk; g.lin_ny = (int)grid.y; g.lin_nz = (int)grid.z;
+            grid = dim3(nblk * grid.y * grid.z, 1, 1);
+        }
         switch (flavor) {
             case DN_TN_QA: err = tx_launch<DN_TN_QA>(g, grid, stream); break;
             case DN_TN_COLSUM: err = tx_launch<DN_TN_COLSUM>(g, grid, stream); break;

@@ -41,6 +41,7 @@ def test_ops_on_emulator(emu):
     parity_cases.run_ops(emu)
     parity_cases.run_ops(emu, sizes=(96,), K=32, C=64, chunk_rows=32)   # aligned fast paths, several chunks
     parity_cases.run_ops(emu, sizes=(1100, 90), K=20, C=32, chunk_rows=32)   # > 32 chunks in a mesh (second pass of the fused spectral backward's chunk lanes), K % 8 != 0
+    parity_cases.run_ops(emu, sizes=(300, 277, 170), K=160, C=192, seed=3)   # 2 x 2 output tiles per chunk block: the one-dimensional XCD-ordered launch of the split-V products, ragged tile edges
 
 
 @pytest.mark.parametrize("outputs_at", ["vertices", "faces", "global_mean"])

@@ -40,6 +40,8 @@ def test_single_ops(dev):
     parity_cases.run_ops(dev)
     parity_cases.run_ops(dev, sizes=(1500, 700, 129), K=128, C=128)
     parity_cases.run_ops(dev, sizes=(3000,), K=64, C=256, chunk_rows=512)
+    parity_cases.run_ops(dev, sizes=(3000, 2777, 170), K=160, C=192, seed=3)     # 2 x 2 output tiles per chunk block (XCD-ordered one-dimensional launch), ragged tile edges, a tail of chunk blocks
+    parity_cases.run_ops(dev, sizes=(9000, 300), K=256, C=256, seed=4)
 
 
 def test_one_launch_diffusion(dev):
