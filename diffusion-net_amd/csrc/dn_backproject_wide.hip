@@ -14,6 +14,7 @@
 // Bounds (one 200k-vertex mesh): HBM 0.41 GB (~80 us at the practical rate); matrix pipe 12.5 k row groups x 768 MFMAs x 16 cycles over
 // 1024 SIMDs = ~75 us at 2.1 GHz, in 7 rounds of 8 waves per CU where 6.1 would do (a tile is the unit the ring synchronises).
 // Measured (profiles/r06_bw256.txt): 160 us against the row GEMM's 221 -- half the matrix peak, the level of every 3-term kernel here.
+// (Streaming stores of the result measured level: diffusion 391-408 vs 392-401 us, block inference 1411-1416 vs 1393-1415 us -- plain stores kept.)
 #include "dn_chain_tiles.h"
 #include "dn_direct_tiles.h"
 
