@@ -44,6 +44,9 @@
 #ifndef DN_CH_GCR_WIDE
 #define DN_CH_GCR_WIDE 2 // the same in the C = 256 form (one wave per SIMD: 16 KiB in flight per wave)
 #endif
+#ifndef DN_CH_LINES_WIDE
+#define DN_CH_LINES_WIDE 1   // C = 256: the result rows as whole-line stores too (dn_chain_tiles.h, ch_st_tiles)
+#endif
 #ifndef DN_CH_ROLL
 #define DN_CH_ROLL 1     // rolling row requests in the row-contiguous gather: 1 = in the C = 256 form (latency-bound there: one wave per SIMD), 2 = everywhere
                          // (C = 128: 28 spilled registers in the benchmark's kernel), 0 = all rows of a step requested, then all summed
@@ -462,21 +465,11 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
                     s_in = ch_uniform(dn_pow2_scale(fmaxf(fmaxf(x_mag, wx), 1.f)));        // [g | x | xd] of this pass
                     s_gf = ch_uniform(dn_pow2_scale(wg));
                     so_gf = ch_uniform(ch_pow2_inv(s_gf) * swa_inv);
-                    if (live) {
-                        if (a.xd_out) {
-                            float* od = a.xd_out + row * C + 4 * q;
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) ch_st4(od + 16 * nt, make_float4(xdv[nt][0], xdv[nt][1], xdv[nt][2], xdv[nt][3]));
-                        }
-                        if (a.gx) {
-                            float* ox = a.gx + row * C + 4 * q;
-                            float* oy = a.gy + row * C + 4 * q;
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) {
-                                ch_st4(ox + 16 * nt, make_float4(gxv[nt][0], gxv[nt][1], gxv[nt][2], gxv[nt][3]));
-                                ch_st4(oy + 16 * nt, make_float4(gyv[nt][0], gyv[nt][1], gyv[nt][2], gyv[nt][3]));
-                            }
-                        }
+                    // (whole-line stores, dn_chain_tiles.h: every lane takes part -- a lane also writes for row m +- 8 -- so no per-lane guard here)
+                    if (a.xd_out) ch_st_tiles<NT, HH == 1>(a.xd_out, C, row, row_end, m, q, [&](const int nt) { return make_float4(xdv[nt][0], xdv[nt][1], xdv[nt][2], xdv[nt][3]); });
+                    if (a.gx) {
+                        ch_st_tiles<NT, HH == 1>(a.gx, C, row, row_end, m, q, [&](const int nt) { return make_float4(gxv[nt][0], gxv[nt][1], gxv[nt][2], gxv[nt][3]); });
+                        ch_st_tiles<NT, HH == 1>(a.gy, C, row, row_end, m, q, [&](const int nt) { return make_float4(gyv[nt][0], gyv[nt][1], gyv[nt][2], gyv[nt][3]); });
                     }
                 } else if constexpr (!RCG) {
 #pragma unroll
@@ -517,14 +510,9 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
                                 gxv[nt][3] = fmaf(cx[u], v[u][nt].w, gxv[nt][3]); gyv[nt][3] = fmaf(cy[u], v[u][nt].w, gyv[nt][3]);
                             }
                     }
-                    if (a.gx && live) {
-                        float* ox = a.gx + row * C + 4 * q;
-                        float* oy = a.gy + row * C + 4 * q;
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            ch_st4(ox + 16 * nt, make_float4(gxv[nt][0], gxv[nt][1], gxv[nt][2], gxv[nt][3]));
-                            ch_st4(oy + 16 * nt, make_float4(gyv[nt][0], gyv[nt][1], gyv[nt][2], gyv[nt][3]));
-                        }
+                    if (a.gx) {
+                        ch_st_tiles<NT, HH == 1>(a.gx, C, row, row_end, m, q, [&](const int nt) { return make_float4(gxv[nt][0], gxv[nt][1], gxv[nt][2], gxv[nt][3]); });
+                        ch_st_tiles<NT, HH == 1>(a.gy, C, row, row_end, m, q, [&](const int nt) { return make_float4(gyv[nt][0], gyv[nt][1], gyv[nt][2], gyv[nt][3]); });
                     }
                 } else {
                     // The loads run in the ROW-CONTIGUOUS lane mapping (LPR lanes x 16 bytes = one row, RPI rows per instruction): the texture path
@@ -722,19 +710,10 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
                             ga[1][nt][e] *= so_gf;
                             gv[nt][e] = ch_tanh(ch_dot2(gxv[nt][e], ga[0][nt][e], gyv[nt][e], ga[1][nt][e]));
                         }
-                    if (live && a.g) {
-                        float* og = a.g + row * C + 4 * q;
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) ch_st4(og + 16 * nt, make_float4(gv[nt][0], gv[nt][1], gv[nt][2], gv[nt][3]));
-                    }
-                    if (live && a.bre) {
-                        float* o0 = a.bre + row * C + 4 * q;
-                        float* o1 = a.bim + row * C + 4 * q;
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            ch_st4(o0 + 16 * nt, make_float4(ga[0][nt][0], ga[0][nt][1], ga[0][nt][2], ga[0][nt][3]));
-                            ch_st4(o1 + 16 * nt, make_float4(ga[1][nt][0], ga[1][nt][1], ga[1][nt][2], ga[1][nt][3]));
-                        }
+                    if (a.g) ch_st_tiles<NT, HH == 1>(a.g, C, row, row_end, m, q, [&](const int nt) { return make_float4(gv[nt][0], gv[nt][1], gv[nt][2], gv[nt][3]); });
+                    if (a.bre) {
+                        ch_st_tiles<NT, HH == 1>(a.bre, C, row, row_end, m, q, [&](const int nt) { return make_float4(ga[0][nt][0], ga[0][nt][1], ga[0][nt][2], ga[0][nt][3]); });
+                        ch_st_tiles<NT, HH == 1>(a.bim, C, row, row_end, m, q, [&](const int nt) { return make_float4(ga[1][nt][0], ga[1][nt][1], ga[1][nt][2], ga[1][nt][3]); });
                     }
 #pragma unroll
                     for (int T = 0; T < NK; ++T) ch_split8(gv[2 * T], gv[2 * T + 1], s_in, gfh[hh][T], gfl[hh][T]);
@@ -905,12 +884,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
                 if (hj) {
 #pragma unroll
                     for (int hh = 0; hh < HH; ++hh)
-                        if (liveh[hh]) {
-                            float* oh = hj + (long long)rowh[hh] * C + 4 * q;
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-                                ch_st4(oh + 16 * nt, make_float4(acc[hh][nt][0], acc[hh][nt][1], acc[hh][nt][2], acc[hh][nt][3]));
-                        }
+                        ch_st_tiles<NT, HH == 1>(hj, C, rowh[hh], row_end, m, q, [&](const int nt) { return make_float4(acc[hh][nt][0], acc[hh][nt][1], acc[hh][nt][2], acc[hh][nt][3]); });
                 }
                 wm = ch_wave_max(wm);
 #pragma unroll
@@ -961,6 +935,17 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
                     float4 r[NT];
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) r[nt] = *reinterpret_cast<const float4*>(px + 16 * nt);
+#if DN_CH_LINES_WIDE
+                    (void)oo;
+                    ch_st_tiles<NT, true>(a.out, C, rowh[hh], row_end, m, q, [&](const int nt) {
+                        float4 y;
+                        y.x = acc[hh][nt][0] * so + r[nt].x;
+                        y.y = acc[hh][nt][1] * so + r[nt].y;
+                        y.z = acc[hh][nt][2] * so + r[nt].z;
+                        y.w = acc[hh][nt][3] * so + r[nt].w;
+                        omax = dn_f4_amax(omax, y);
+                        return y; });
+#else
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         float4 y;
@@ -971,6 +956,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
                         omax = dn_f4_amax(omax, y);
                         if (liveh[hh]) ch_st4(oo + 16 * nt, y);
                     }
+#endif
                 }
             } else {
                 float4 r4[HH][NT];
@@ -995,11 +981,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(C >= 256 ? 1 : 2) void cha
                     }
 #pragma unroll
                 for (int hh = 0; hh < HH; ++hh)
-                    if (liveh[hh]) {
-                        float* oo = a.out + (long long)rowh[hh] * C + 4 * q;
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) ch_st4(oo + 16 * nt, r4[hh][nt]);
-                    }
+                    ch_st_tiles<NT, HH == 1>(a.out, C, rowh[hh], row_end, m, q, [&](const int nt) { return r4[hh][nt]; });
             }
             CH_TR();
         }

@@ -166,11 +166,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
             float* dj = a.d_a[j - 1];
 #pragma unroll
             for (int hh = 0; hh < HH; ++hh)
-                if (liveh[hh]) {
-                    float* o = dj + (long long)rowh[hh] * C + 4 * q;
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) ch_st4(o + 16 * nt, make_float4(acc[hh][nt][0], acc[hh][nt][1], acc[hh][nt][2], acc[hh][nt][3]));
-                }
+                ch_st_tiles<NT>(dj, C, rowh[hh], a.V, m, q, [&](const int nt) { return make_float4(acc[hh][nt][0], acc[hh][nt][1], acc[hh][nt][2], acc[hh][nt][3]); });
             s_act = ch_uniform(dn_pow2_scale(ch_wave_max(wm)));
             CH_PACK(acc, s_act, fh, fl);
         }
@@ -193,13 +189,9 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
             }
 #pragma unroll
             for (int hh = 0; hh < HH; ++hh)
-                if (liveh[hh]) {
-                    float* o = a.d_xacc + (long long)rowh[hh] * C + 4 * q;
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        ch_st4(o + 16 * nt, make_float4(acc[hh][nt][0] * so0 + r4[hh][nt].x, acc[hh][nt][1] * so0 + r4[hh][nt].y,
-                                                                              acc[hh][nt][2] * so0 + r4[hh][nt].z, acc[hh][nt][3] * so0 + r4[hh][nt].w));
-                }
+                ch_st_tiles<NT>(a.d_xacc, C, rowh[hh], a.V, m, q, [&](const int nt) {
+                    return make_float4(acc[hh][nt][0] * so0 + r4[hh][nt].x, acc[hh][nt][1] * so0 + r4[hh][nt].y,
+                                       acc[hh][nt][2] * so0 + r4[hh][nt].z, acc[hh][nt][3] * so0 + r4[hh][nt].w); });
         }
         {   // xd group
             CH_ZERO(acc);
@@ -211,12 +203,8 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
             }
 #pragma unroll
             for (int hh = 0; hh < HH; ++hh)
-                if (liveh[hh]) {
-                    float* o = a.d_xd + (long long)rowh[hh] * C + 4 * q;
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        ch_st4(o + 16 * nt, make_float4(acc[hh][nt][0] * so0, acc[hh][nt][1] * so0, acc[hh][nt][2] * so0, acc[hh][nt][3] * so0));
-                }
+                ch_st_tiles<NT>(a.d_xd, C, rowh[hh], a.V, m, q, [&](const int nt) {
+                    return make_float4(acc[hh][nt][0] * so0, acc[hh][nt][1] * so0, acc[hh][nt][2] * so0, acc[hh][nt][3] * so0); });
         }
         if (a.with_grad) {
             // g group: d_dots = (d_a0 W_0[:, 2C:]) * (1 - g^2)   (kept in the accumulator registers for the gradient-feature stage)
@@ -246,11 +234,7 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
                     }
 #pragma unroll
                 for (int hh = 0; hh < HH; ++hh)
-                    if (liveh[hh]) {
-                        float* o = a.d_dots + (long long)rowh[hh] * C + 4 * q;
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) ch_st4(o + 16 * nt, make_float4(acc[hh][nt][0], acc[hh][nt][1], acc[hh][nt][2], acc[hh][nt][3]));
-                    }
+                    ch_st_tiles<NT>(a.d_dots, C, rowh[hh], a.V, m, q, [&](const int nt) { return make_float4(acc[hh][nt][0], acc[hh][nt][1], acc[hh][nt][2], acc[hh][nt][3]); });
             }
             // ---- gradient features backward, one 16-row half at a time:
             //      d_gx = d_dots * Bre + (d_dots gx) A_re + (d_dots gy) A_im ;  d_gy = d_dots * Bim - (d_dots gx) A_im + (d_dots gy) A_re
@@ -311,17 +295,12 @@ __global__ __launch_bounds__(64 * NW) DN_WAVES_PER_EU(2) void chain_bwd_kernel(C
                     float4 br[NT], bi[NT];
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) { br[nt] = ch_ld4(pr + 16 * nt); bi[nt] = ch_ld4(pi + 16 * nt); }
-                    if (live) {
-                        float* ox = a.d_gx + (long long)row * C + 4 * q;
-                        float* oy = a.d_gy + (long long)row * C + 4 * q;
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            ch_st4(ox + 16 * nt, make_float4(ag[0][nt][0] * sog + dd[nt][0] * br[nt].x, ag[0][nt][1] * sog + dd[nt][1] * br[nt].y,
-                                                                                   ag[0][nt][2] * sog + dd[nt][2] * br[nt].z, ag[0][nt][3] * sog + dd[nt][3] * br[nt].w));
-                            ch_st4(oy + 16 * nt, make_float4(ag[1][nt][0] * sog + dd[nt][0] * bi[nt].x, ag[1][nt][1] * sog + dd[nt][1] * bi[nt].y,
-                                                                                   ag[1][nt][2] * sog + dd[nt][2] * bi[nt].z, ag[1][nt][3] * sog + dd[nt][3] * bi[nt].w));
-                        }
-                    }
+                    ch_st_tiles<NT>(a.d_gx, C, row, a.V, m, q, [&](const int nt) {
+                        return make_float4(ag[0][nt][0] * sog + dd[nt][0] * br[nt].x, ag[0][nt][1] * sog + dd[nt][1] * br[nt].y,
+                                           ag[0][nt][2] * sog + dd[nt][2] * br[nt].z, ag[0][nt][3] * sog + dd[nt][3] * br[nt].w); });
+                    ch_st_tiles<NT>(a.d_gy, C, row, a.V, m, q, [&](const int nt) {
+                        return make_float4(ag[1][nt][0] * sog + dd[nt][0] * bi[nt].x, ag[1][nt][1] * sog + dd[nt][1] * bi[nt].y,
+                                           ag[1][nt][2] * sog + dd[nt][2] * bi[nt].z, ag[1][nt][3] * sog + dd[nt][3] * bi[nt].w); });
                 }
             };
             half(0);

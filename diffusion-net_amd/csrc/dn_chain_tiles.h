@@ -93,6 +93,51 @@ __device__ __forceinline__ void ch_st4(float* p, const float4 v) {
     *reinterpret_cast<float4*>(p) = v;
 #endif
 }
+// ---- whole-line stores of accumulator-layout tiles.  Lane (m, q) of a wave holds channels 16 nt + 4 q .. + 3 of row m: a store of tile nt
+// writes 64 contiguous bytes per row -- half a 128-byte line; the other half comes with the store of tile nt + 1.  As streaming stores
+// those halves reach memory separately often enough to cost 19-27 % more written bytes than the arrays hold (WRITE_SIZE of the chained
+// kernels: 772 / 719 MB for 649 / 568 MB; plain stores are exact but displace the gathered rows from the L2 and measure slower,
+// profiles/r06_line_stores.txt).  Here the two tiles are exchanged between rows m and m + 8 (DPP row_ror:8: one v_mov per register) so
+// that ONE instruction writes tiles nt, nt + 1 of rows 0..7 and the next one of rows 8..15: every row segment written by an
+// instruction is a whole line.  base: the array; row: this lane's row; v_end: rows below it exist.
+#ifndef DN_CH_LINES
+#define DN_CH_LINES 1
+#endif
+__device__ __forceinline__ float ch_rot8(float v) {      // the value lane (m + 8) % 16 of the same 16-lane row holds
+#ifdef DN_EMULATE
+    const int l_ = (int)(threadIdx.x & 63);
+    return __shfl(v, (l_ & 48) | ((l_ + 8) & 15), 64);
+#else
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+#endif
+}
+// (tile: a callable nt -> float4, evaluated pair by pair: two tiles and their rotated copies are alive at a time)
+// LINES = false: the plain form, one 64-byte segment per row and instruction (kernels at the register limit: the exchange costs ~16 registers)
+template <int NT, bool LINES = true, typename F>
+__device__ __forceinline__ void ch_st_tiles(float* base, const int C, const long long row, const int v_end, const int m, const int q, F&& tile) {
+  if constexpr (LINES && DN_CH_LINES != 0) {
+    static_assert(NT % 2 == 0, "tile pairs");
+    const bool hi = m >= 8;
+    const long long r0 = hi ? row - 8 : row, r1 = hi ? row : row + 8;      // rows this lane writes in the first / second instruction of a pair
+    float* p0 = base + r0 * C + 4 * q + (hi ? 16 : 0);
+    float* p1 = base + r1 * C + 4 * q + (hi ? 16 : 0);
+    const bool ok0 = r0 < v_end, ok1 = r1 < v_end;
+#pragma unroll
+    for (int np = 0; np < NT; np += 2) {
+        const float4 a = tile(np), b = tile(np + 1);
+        const float4 ra = make_float4(ch_rot8(a.x), ch_rot8(a.y), ch_rot8(a.z), ch_rot8(a.w));
+        const float4 rb = make_float4(ch_rot8(b.x), ch_rot8(b.y), ch_rot8(b.z), ch_rot8(b.w));
+        if (ok0) ch_st4(p0 + 16 * np, hi ? rb : a);
+        if (ok1) ch_st4(p1 + 16 * np, hi ? b : ra);
+    }
+  } else {
+    if (row < v_end) {
+        float* o = base + row * C + 4 * q;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) ch_st4(o + 16 * nt, tile(nt));
+    }
+  }
+}
 __device__ __forceinline__ float4 ch_ld4(const float* p) {
 #if DN_CH_STREAM
     return dn_ld4_stream(p);
