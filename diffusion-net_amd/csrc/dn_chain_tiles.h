@@ -82,7 +82,7 @@ __device__ __forceinline__ int ch_uniform_i(int v) {
 #endif
 }
 // Streaming global accesses of the chained kernels (dn_common.h): every activation tile is written exactly once per launch and consumed by
-// a LATER kernel; the single-use tiles of the backward are read the same way.  Build with -DDN_CH_STREAM=0 for plain accesses (A/B).
+// a LATER kernel.  Build with -DDN_CH_STREAM=0 for plain stores (A/B).
 #ifndef DN_CH_STREAM
 #define DN_CH_STREAM 1
 #endif
@@ -138,8 +138,13 @@ __device__ __forceinline__ void ch_st_tiles(float* base, const int C, const long
     }
   }
 }
+// (the LOADS of the backward's single-use tiles are plain since round 6: a 64-byte request per row is half a line, the other half comes with the next
+// tile's request, and a streaming line is often gone by then -- FETCH_SIZE 387 -> 375 k KiB, block backward 851-858 -> 842-846 us; -DDN_CH_STREAM_LD=1: A/B)
+#ifndef DN_CH_STREAM_LD
+#define DN_CH_STREAM_LD 0
+#endif
 __device__ __forceinline__ float4 ch_ld4(const float* p) {
-#if DN_CH_STREAM
+#if DN_CH_STREAM_LD
     return dn_ld4_stream(p);
 #else
     return *reinterpret_cast<const float4*>(p);
