@@ -79,6 +79,23 @@ __global__ __launch_bounds__(1024) void chain_prep_kernel(ChainPrepArgs a) {
     }
     const ChainPrepPiece pc = a.pc[blockIdx.x];
     uint4* out = a.out + (size_t)blockIdx.x * (2 * NT * 64);
+    // this thread's eight elements of the piece are requested FIRST (they do not depend on the matrix's magnitude, only their split does): their
+    // latency passes under the magnitude sweep below (round 6: 6.1 -> ~5 us per launch, eight launches per training step)
+    static_assert(NT * 64 <= NTHR, "one piece element group per thread");
+    float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tid < NT * 64) {
+        const int nt = tid >> 6, lane = tid & 63;
+        const int n = 16 * nt + (lane & 15), q = lane >> 4;
+        if (pc.transposed) {     // rows of the piece = columns of W (backward products)
+            const float* src = pc.W + (long long)(pc.col0 + 4 * q) * pc.ld + pc.row0 + n;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { va[t] = src[(long long)t * pc.ld]; vb[t] = src[(long long)(16 + t) * pc.ld]; }
+        } else {
+            const float* src = pc.W + (long long)n * pc.ld + pc.col0 + 4 * q;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { va[t] = src[t]; vb[t] = src[16 + t]; }
+        }
+    }
     // largest magnitude of the whole matrix (every piece's workgroup measures it: a few tens of KB out of L2)
     float mx = 0.f;
     {
@@ -97,32 +114,20 @@ __global__ __launch_bounds__(1024) void chain_prep_kernel(ChainPrepArgs a) {
             for (int u = 0; u < 4; ++u) { mx = dn_f4_amax(mx, v[u]); mx = dn_f4_amax(mx, w[u]); }
         }
     }
-    red[tid] = mx;
+    // wave maxima (DPP), then the sixteen waves' words through LDS: two barriers instead of ten
+    mx = ch_wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
     __syncthreads();
-    for (int d = NTHR / 2; d > 0; d >>= 1) {
-        if (tid < d) red[tid] = red[tid + d] > red[tid] ? red[tid + d] : red[tid];
-        __syncthreads();
-    }
-    mx = red[0];
+    mx = 0.f;
+#pragma unroll
+    for (int w = 0; w < NTHR / 64; ++w) mx = red[w] > mx ? red[w] : mx;
     if (tid == 0 && pc.amax) *pc.amax = mx;
     const float s = dn_pow2_scale(mx);
-    for (int e = tid; e < NT * 64; e += NTHR) {
-        const int nt = e >> 6, lane = e & 63;
-        const int n = 16 * nt + (lane & 15), q = lane >> 4;
-        float va[4], vb[4];
-        if (pc.transposed) {     // rows of the piece = columns of W (backward products)
-            const float* src = pc.W + (long long)(pc.col0 + 4 * q) * pc.ld + pc.row0 + n;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { va[t] = src[(long long)t * pc.ld]; vb[t] = src[(long long)(16 + t) * pc.ld]; }
-        } else {
-            const float* src = pc.W + (long long)n * pc.ld + pc.col0 + 4 * q;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { va[t] = src[t]; vb[t] = src[16 + t]; }
-        }
+    if (tid < NT * 64) {
         uint4 hi, lo;
         ch_split8(va, vb, s, hi, lo);
-        out[e] = hi;
-        out[NT * 64 + e] = lo;
+        out[tid] = hi;
+        out[NT * 64 + tid] = lo;
     }
 }
 
