@@ -22,6 +22,22 @@ def _free_port():
     return p
 
 
+def _json_objects(text):
+    """Every JSON object in the ranks' shared stdout (N processes write one pipe: two objects may land on one line)."""
+    import json
+    dec, out, i = json.JSONDecoder(), [], 0
+    while True:
+        i = text.find("{", i)
+        if i < 0:
+            return out
+        try:
+            o, j = dec.raw_decode(text, i)
+            out.append(o)
+            i = j
+        except ValueError:
+            i += 1
+
+
 def test_shard_by_cost_balances():
     from diffusion_net.dist import shard_by_cost
     costs = [9000, 12000, 7000, 11000, 10000, 8000, 10500, 9500]
@@ -124,8 +140,7 @@ def test_bench_gpus_n_launches_n_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    import json
-    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    lines = [o for o in _json_objects(r.stdout) if isinstance(o, dict) and "rank" in o]
     assert sorted(l["rank"] for l in lines) == [0, 1], r.stdout
     assert all(l["world"] == 2 and l["master"] == "127.0.0.1" for l in lines), lines
 
@@ -137,10 +152,11 @@ def test_bench_gpus_8_launches_8_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["DN_BENCH_LAUNCH_CHECK"] = "1"
     import json
+
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    lines = [o for o in _json_objects(r.stdout) if isinstance(o, dict) and "rank" in o]
     assert sorted(l["rank"] for l in lines) == list(range(8)), r.stdout
     assert sorted(l["local_rank"] for l in lines) == list(range(8)), r.stdout
     assert all(l["world"] == 8 and l["master"] == "127.0.0.1" for l in lines), lines
@@ -148,5 +164,5 @@ def test_bench_gpus_8_launches_8_ranks():
                         "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    lines = [o for o in _json_objects(r.stdout) if isinstance(o, dict) and "rank" in o]
     assert sorted(l["rank"] for l in lines) == list(range(8)), r.stdout
